@@ -1,0 +1,260 @@
+"""autograd bridge between the nn.Module API and the HIP kernels (bcos_hip.ops).
+
+Forward = ONE fused launch per B-cos layer (contraction + patch norm + |cos|^(B-1) scaling;
+reference bcosconv2d.py:153-194 issues 9 ATen launches for the same thing).
+Backward is implemented for *explanation mode* (`detach=True`): the dynamic scale is a constant, so
+d out / d x = conv_transpose(g * s, W) -- the "dynamic linear weights" W(x) of bcos/common.py:177-181.
+The training-mode backward (extra d s terms, weight gradients) is SURVEY.md section 8(f) row N4 and is not
+built; asking for it raises instead of silently producing explanation-mode gradients.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from bcos_hip import ops
+from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_NORM_ONLY, BCOS_LINEAR_EPS, BCOS_NONE,
+                          BcosHipError)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def require_hip(t: torch.Tensor, who: str):
+    if not t.is_cuda:
+        raise BcosHipError(
+            f"{who}: input is on {t.device}; this package only implements the B-cos hot path as HIP kernels "
+            "for gfx950 and has no CPU fallback (move the model and input to 'cuda').")
+    if t.dtype != torch.float32:
+        raise BcosHipError(f"{who}: the hot path is fp32 end to end (got {t.dtype})")
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """logical [N,C,H,W] (any strides) -> dense [N,H,W,C]; free when x is channels_last."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def from_nhwc(y: torch.Tensor) -> torch.Tensor:
+    """dense [N,H,W,C] -> logical [N,C,H,W] view with channels_last strides."""
+    return y.permute(0, 3, 1, 2)
+
+
+def empty_cl(n, c, h, w, device):
+    """(logical [N,C,H,W] channels_last tensor, its dense [N,H,W,C] view).  autograd Functions must return the
+    base tensor, not a view of it (in-place ReLU on a view of a custom Function's output is forbidden)."""
+    t = torch.empty((n, c, h, w), device=device, dtype=torch.float32, memory_format=torch.channels_last)
+    return t, t.permute(0, 2, 3, 1)
+
+
+def _pad_last(t: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    c = t.shape[-1]
+    r = (-c) % mult
+    return t if r == 0 else F.pad(t, (0, r))
+
+
+class WeightCache:
+    """Kernel-layout copies of a module's weight ([Cout,kh,kw,Cin_pad], dgrad sub-kernels), rebuilt when
+    the parameter changes (data_ptr / in-place version)."""
+
+    def __init__(self):
+        self._key = None
+        self._fwd = None
+        self._dgrad = {}
+
+    def _sync(self, w):
+        key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
+        if key != self._key:
+            self._key, self._fwd, self._dgrad = key, None, {}
+
+    def fwd(self, w_eff, src):
+        """w_eff: effective OIHW (or [O,I]) weight actually used (after unit-norm projection if any)."""
+        self._sync(src)
+        if self._fwd is None:
+            w4 = w_eff if w_eff.dim() == 4 else w_eff[:, :, None, None]
+            self._fwd = _pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous()
+        return self._fwd
+
+    def dgrad(self, w_eff, src, stride, padding, dilation, groups):
+        self._sync(src)
+        k = (stride, padding, dilation, groups)
+        if k not in self._dgrad:
+            w4 = w_eff.detach() if w_eff.dim() == 4 else w_eff.detach()[:, :, None, None]
+            cout = w4.shape[0]
+            plans = []
+            for g in range(groups):
+                wg = w4[g * (cout // groups):(g + 1) * (cout // groups)]
+                # pad Cout (the dgrad K dimension) to a multiple of 4 with zero filters
+                r = (-wg.shape[0]) % 4
+                if r:
+                    wg = torch.cat([wg, wg.new_zeros((r,) + tuple(wg.shape[1:]))], 0)
+                plans.append(ops.DgradPlan(wg, stride, padding, dilation))
+            self._dgrad[k] = plans
+        return self._dgrad[k]
+
+
+class BcosConv2dFn(Function):
+    """y = bcos_conv(x): see module docstring.  cfg keys: stride, padding, dilation, groups, b, max_out,
+    detach, cache (WeightCache), w_src (the parameter the cache is keyed on)."""
+
+    @staticmethod
+    def forward(ctx, x, w_eff, bias, cfg):
+        require_hip(x, "BcosConv2d")
+        stride, padding, dilation = cfg["stride"], cfg["padding"], cfg["dilation"]
+        groups, b, max_out = cfg["groups"], float(cfg["b"]), cfg["max_out"]
+        need_grad = ctx.needs_input_grad[0]
+        N, Cin, H, W = x.shape
+        Cout_all = w_eff.shape[0]
+        kh, kw = w_eff.shape[2], w_eff.shape[3]
+        xh = to_nhwc(x)
+        wk = cfg["cache"].fwd(w_eff, cfg["w_src"])                     # [Cout_all,kh,kw,Cin_g_pad]
+        Ho = ops.conv_out_size(H, kh, stride[0], padding[0], dilation[0])
+        Wo = ops.conv_out_size(W, kw, stride[1], padding[1], dilation[1])
+        cin_g = Cin // groups
+        if groups == 1:
+            xh = _pad_last(xh)
+        elif cin_g % 4 != 0:
+            raise BcosHipError(f"grouped B-cos conv needs in_channels/groups % 4 == 0 (got {cin_g})")
+        want_scale = bool(need_grad and b != 1.0)
+        fused = max_out == 1
+        y_cl, y = empty_cl(N, Cout_all, Ho, Wo, x.device)
+        scale = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if (want_scale and fused) else None
+        norm = None if fused or b == 1.0 else torch.empty((N, Ho, Wo, groups), device=x.device, dtype=torch.float32)
+        mode = BCOS_NONE if b == 1.0 else BCOS_CONV_EPS
+        cout_g = Cout_all // groups
+        for g in range(groups):
+            geom = ops.fwd_geom(N, H, W, wk.shape[3], cout_g, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                                dilation[0], dilation[1])
+            a = xh
+            if groups > 1:
+                geom.update(a_pitch=Cin, out_pitch=Cout_all, norm_pitch=groups)
+                a = xh[..., g * cin_g:]
+            ops.tapconv(a, wk[g * cout_g:(g + 1) * cout_g], geom,
+                        out=y[..., g * cout_g:] if groups > 1 else y,
+                        scale_out=(scale[..., g * cout_g:] if groups > 1 else scale) if scale is not None else None,
+                        norm_out=(norm[..., g:] if norm is not None else None),
+                        bias=(bias[g * cout_g:(g + 1) * cout_g] if bias is not None else None),
+                        bcos_mode=mode, b=b,
+                        flags=(0 if fused else BCOS_EPI_NORM_ONLY) | (BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0))
+        argmax = None
+        if not fused:
+            Cout = Cout_all // max_out
+            y_cl, y2 = empty_cl(N, Cout, Ho, Wo, x.device)
+            _, scale, argmax = ops.maxout_scale(y.reshape(-1, Cout_all), norm.view(-1, groups) if norm is not None else None,
+                                                Cout, max_out, b, groups=groups, want_scale=want_scale,
+                                                want_argmax=need_grad, out=y2.view(-1, Cout))
+            if scale is not None:
+                scale = scale.view(N, Ho, Wo, Cout)
+        ctx.cfg = cfg
+        ctx.in_shape = (N, Cin, H, W)
+        ctx.w_eff = w_eff
+        ctx.detached = bool(cfg["detach"]) or b == 1.0
+        ctx.save_for_backward(*(t for t in (scale, argmax) if t is not None))
+        ctx.has = (scale is not None, argmax is not None)
+        return y_cl
+
+    @staticmethod
+    def backward(ctx, gy):
+        cfg = ctx.cfg
+        if not ctx.detached:
+            raise NotImplementedError(
+                "BcosConv2d backward outside explanation mode (training-mode gradients through the dynamic "
+                "scale, weight gradients) is not implemented in the MI355X build: wrap the call in "
+                "model.explanation_mode() (SURVEY.md section 8(f) N4).")
+        saved = list(ctx.saved_tensors)
+        scale = saved.pop(0) if ctx.has[0] else None
+        argmax = saved.pop(0) if ctx.has[1] else None
+        N, Cin, H, W = ctx.in_shape
+        groups, max_out = cfg["groups"], cfg["max_out"]
+        g = to_nhwc(gy)
+        glin = ops.mul(g, scale) if scale is not None else g
+        if argmax is not None:   # MaxOut: route the gradient to the winning filter of each unit
+            full = torch.zeros(glin.shape[:3] + (glin.shape[3] * max_out,), device=glin.device, dtype=torch.float32)
+            idx = (torch.arange(glin.shape[3], device=glin.device) * max_out) + argmax.view(glin.shape).long()
+            full.scatter_(3, idx, glin)
+            glin = full
+        plans = cfg["cache"].dgrad(ctx.w_eff, cfg["w_src"], cfg["stride"], cfg["padding"], cfg["dilation"], groups)
+        cout_g = glin.shape[3] // groups
+        cin_g = Cin // groups
+        gx_cl, gx = empty_cl(N, Cin, H, W, gy.device)
+        for gi, plan in enumerate(plans):
+            gl = glin[..., gi * cout_g:(gi + 1) * cout_g]
+            gl = _pad_last(gl).contiguous() if (groups > 1 or cout_g % 4) else gl
+            if groups == 1:
+                plan.run(gl, H, W, out=gx)
+            else:
+                gx[..., gi * cin_g:(gi + 1) * cin_g] = plan.run(gl, H, W)
+        return gx_cl, None, None, None
+
+
+class BcosLinearFn(Function):
+    """y = bcos_linear(x) over the last dimension.  cfg keys: b, max_out, detach, cache, w_src."""
+
+    @staticmethod
+    def forward(ctx, x, w_eff, bias, cfg):
+        require_hip(x, "BcosLinear")
+        b, max_out = float(cfg["b"]), cfg["max_out"]
+        need_grad = ctx.needs_input_grad[0]
+        Cin = x.shape[-1]
+        x2 = x.reshape(-1, Cin)
+        x2 = _pad_last(x2 if x2.is_contiguous() else x2.contiguous())
+        wk = cfg["cache"].fwd(w_eff, cfg["w_src"]).view(w_eff.shape[0], -1)
+        want_scale = bool(need_grad and b != 1.0)
+        Cout_all = w_eff.shape[0]
+        argmax = None
+        if max_out == 1:
+            y, scale, _ = ops.linear_fwd(x2, wk, bias=bias, b=b, want_scale=want_scale,
+                                         flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0)
+        else:
+            rows = x2.shape[0]
+            lin = torch.empty((rows, Cout_all), device=x.device, dtype=torch.float32)
+            norm = torch.empty((rows,), device=x.device, dtype=torch.float32) if b != 1.0 else None
+            g = dict(N=1, H=1, W=rows, C=x2.shape[1], P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
+                     TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout_all)
+            ops.tapconv(x2, wk, g, out=lin, norm_out=norm, bias=bias,
+                        bcos_mode=BCOS_NONE if b == 1.0 else BCOS_LINEAR_EPS, b=b, flags=BCOS_EPI_NORM_ONLY)
+            y, scale, argmax = ops.maxout_scale(lin, norm, Cout_all // max_out, max_out, b, want_scale=want_scale,
+                                                want_argmax=need_grad)
+        ctx.cfg = cfg
+        ctx.w_eff = w_eff
+        ctx.in_shape = tuple(x.shape)
+        ctx.detached = bool(cfg["detach"]) or b == 1.0
+        ctx.save_for_backward(*(t for t in (scale, argmax) if t is not None))
+        ctx.has = (scale is not None, argmax is not None)
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        cfg = ctx.cfg
+        if not ctx.detached:
+            raise NotImplementedError(
+                "BcosLinear backward outside explanation mode is not implemented in the MI355X build: wrap the "
+                "call in model.explanation_mode() (SURVEY.md section 8(f) N4).")
+        saved = list(ctx.saved_tensors)
+        scale = saved.pop(0) if ctx.has[0] else None
+        argmax = saved.pop(0) if ctx.has[1] else None
+        max_out = cfg["max_out"]
+        g2 = gy.reshape(-1, gy.shape[-1])
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        glin = ops.mul(g2, scale) if scale is not None else g2
+        if argmax is not None:
+            full = torch.zeros((glin.shape[0], glin.shape[1] * max_out), device=glin.device, dtype=torch.float32)
+            idx = (torch.arange(glin.shape[1], device=glin.device) * max_out) + argmax.long()
+            full.scatter_(1, idx, glin)
+            glin = full
+        plan = cfg["cache"].dgrad(ctx.w_eff, cfg["w_src"], (1, 1), (0, 0), (1, 1), 1)[0]
+        rows = glin.shape[0]
+        glin = _pad_last(glin).contiguous()
+        gx = plan.run(glin.view(1, 1, rows, glin.shape[1]), 1, rows)      # [1,1,rows,Cin]
+        return gx.view(ctx.in_shape), None, None, None
+
+
+def plain_conv2d(x, w_eff, bias, stride, padding, dilation, groups, cache, w_src):
+    """Un-scaled convolution on the same kernel (NormedConv2d called on its own)."""
+    cfg = dict(stride=stride, padding=padding, dilation=dilation, groups=groups, b=1, max_out=1, detach=True,
+               cache=cache, w_src=w_src)
+    return BcosConv2dFn.apply(x, w_eff, bias, cfg)
+
+
+def plain_linear(x, w_eff, bias, cache, w_src):
+    cfg = dict(b=1, max_out=1, detach=True, cache=cache, w_src=w_src)
+    return BcosLinearFn.apply(x, w_eff, bias, cfg)

@@ -1,0 +1,98 @@
+"""BcosifyConv2d: the B-cos transform on top of a *plain* nn.Conv2d (no weight normalisation, optional bias)
+-- what `bcosify.py` turns every nn.Conv2d of a pretrained network into.
+
+API-compatible with the reference's bcos/modules/bcosifyconv2d.py:7-182 (constructor kwargs `clamping`,
+`b_loss`, the `weight` property, `from_standard_module`, `from_standard_module_linear`, and the
+`model_config` keys they read).
+"""
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _hipfn
+from .bcosconv2d import BcosConv2d
+
+__all__ = ["BcosifyConv2d"]
+
+
+def _read_config(model_config):
+    args = model_config["bcosify_args"]
+    return dict(clamping=args.get("clamping", False), b_loss=args.get("learn_b", False),
+                b=model_config["bcos_args"].get("b", 1))   # b defaults to 1 (= identity) like the reference (:127)
+
+
+class BcosifyConv2d(BcosConv2d):
+    def __init__(self, *args, clamping: bool = False, b_loss: bool = False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.clamping = clamping
+        self.b_loss = b_loss
+        # swap the unit-norm convolution for a standard one; `self.bias` is None unless
+        # from_standard_module attaches one afterwards (reference :18-31)
+        self.linear = nn.Conv2d(
+            in_channels=self.in_channels,
+            out_channels=self.out_channels * self.max_out,
+            kernel_size=self.kernel_size,
+            stride=self.stride,
+            padding=self.padding,
+            dilation=self.dilation,
+            groups=self.groups,
+            bias=self.bias,
+            padding_mode=self.padding_mode,
+            device=self.device,
+            dtype=self.dtype,
+        )
+
+    @property
+    def weight(self) -> Tensor:
+        # CLIP's ModifiedResNet reads conv1.weight.dtype (CLIP/clip/model.py:146)
+        return self.linear.weight
+
+    def _b_value(self) -> float:
+        b = self.b
+        if self.clamping:       # learnable B kept >= 1 (reference :60-61)
+            b = b.clamp(1 + 1e-6)
+        if self.b_loss:         # "b = -1 + weight decay" parametrisation (reference :64-65)
+            b = self.b + 2
+        return float(b.detach().item()) if isinstance(b, torch.Tensor) else float(b)
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        return self.forward_impl(in_tensor)
+
+    def forward_impl(self, in_tensor: Tensor) -> Tensor:
+        lin = self.linear
+        if lin.padding_mode != "zeros":
+            raise NotImplementedError("only zero padding is implemented by the HIP kernels")
+        b = self._b_value()
+        if not self.b_loss and not self.clamping:
+            plain_b = self.b.detach().item() if isinstance(self.b, torch.Tensor) else self.b
+            if plain_b == 1:
+                b = 1.0
+        cfg = dict(stride=tuple(lin.stride), padding=tuple(lin.padding), dilation=tuple(lin.dilation),
+                   groups=lin.groups, b=b, max_out=self.max_out, detach=self.detach, cache=self._wcache,
+                   w_src=lin.weight, force_pow=bool(self.b_loss))
+        return _hipfn.BcosConv2dFn.apply(in_tensor, lin.weight, lin.bias, cfg)
+
+    @classmethod
+    def _from(cls, model_config, weight, bias, **geometry):
+        cfgd = _read_config(model_config)
+        new = cls(bias=bias is not None, **geometry, **cfgd)
+        if model_config.get("weights", None) is not None:
+            new.linear.weight.data = weight.data.view_as(new.linear.weight.data)
+            if bias is not None:
+                new.linear.bias = nn.Parameter(bias.data)
+        return new
+
+    @classmethod
+    def from_standard_module(cls, mod, model_config):
+        """nn.Conv2d -> BcosifyConv2d, copying weight (and bias) when model_config['weights'] is set."""
+        return cls._from(model_config, mod.weight, mod.bias, in_channels=mod.in_channels,
+                         out_channels=mod.out_channels, kernel_size=mod.kernel_size, stride=mod.stride,
+                         padding=mod.padding, dilation=mod.dilation, groups=mod.groups,
+                         padding_mode=mod.padding_mode)
+
+    @classmethod
+    def from_standard_module_linear(cls, mod, model_config):
+        """nn.Linear classifier -> 1x1 BcosifyConv2d (applied before global average pooling)."""
+        return cls._from(model_config, mod.weight, mod.bias, in_channels=mod.in_features,
+                         out_channels=mod.out_features, kernel_size=1, stride=1, padding=0, dilation=1,
+                         groups=1, padding_mode="zeros")

@@ -1,0 +1,269 @@
+"""Fused forward / explanation engine for B-cosified ResNets (torchvision topology).
+
+The nn.Module graph stays the single source of truth for parameters (state dicts load into it unchanged);
+`attach(net)` compiles it into a flat launch plan in which
+  * every BcosifyConv2d + BatchNormUncentered2d (+ residual add) (+ ReLU) is ONE fused implicit-GEMM launch
+    (reference: 9 + 3 + 1 + 1 ATen launches, bcosifyconv2d.py:68-101, batchnorm_uncentered.py:46-60),
+  * AddInverse + Normalize + NCHW->NHWC is one streaming kernel, AdaptiveAvgPool + LogitLayer another,
+  * the explanation pass (bcos/common.py:163-181) is one input-gradient launch per layer whose epilogue
+    already multiplies by the stored scale of the layer below, adds the shortcut gradient and applies the
+    ReLU gate, so each gradient tensor is written once and read once,
+  * the last kernel turns the gradient w.r.t. the normalised NHWC input into W(x) [N,6,H,W] and the
+    contribution map [N,H,W].
+Activations are NHWC fp32; the stem's 6 input channels are zero-padded to 8.
+
+What is stored between forward and backward (explanation mode), per B-cos layer: t = s * bn_scale * relu_gate,
+the derivative of the layer's (post-BN, post-ReLU) output w.r.t. its pre-scale contraction `lin` with the
+dynamic scale s = |lin| / ||patch|| held constant -- exactly what `.detach()` does in the reference.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import BCOS_CONV_EPS, BCOS_NONE, BcosHipError
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+class _Conv:
+    """Kernel-side view of one BcosifyConv2d (+ the BatchNormUncentered2d that follows it)."""
+
+    def __init__(self, conv, bn, cin_pad_to=4):
+        from bcos.modules.bcosconv2d import BcosConv2d
+        if not isinstance(conv, BcosConv2d):
+            raise BcosHipError(f"engine: expected a B-cos conv, got {type(conv).__name__}")
+        lin = conv.linear
+        if lin.groups != 1 or conv.max_out != 1:
+            raise BcosHipError("engine: groups > 1 / max_out > 1 layers run through the module path only")
+        if lin.padding_mode != "zeros":
+            raise BcosHipError("engine: only zero padding")
+        self.module, self.bn = conv, bn
+        self.stride, self.padding, self.dilation = tuple(lin.stride), tuple(lin.padding), tuple(lin.dilation)
+        self.k = tuple(lin.kernel_size)
+        self.cin, self.cout = lin.in_channels, lin.out_channels
+        self.refresh()
+
+    def refresh(self):
+        conv, bn = self.module, self.bn
+        w, bias = conv._effective_weight_and_bias()
+        w = w.detach()
+        self.b = conv._b_value()
+        cin_pad = (-self.cin) % 4
+        wk = w.permute(0, 2, 3, 1)
+        if cin_pad:
+            wk = torch.nn.functional.pad(wk, (0, cin_pad))
+        self.w_fwd = wk.contiguous()
+        self.bias = bias.detach().contiguous() if bias is not None else None
+        self.dgrad = ops.DgradPlan(w, self.stride, self.padding, self.dilation)
+        if bn is not None:
+            if bn.training:
+                raise BcosHipError("engine: BatchNormUncentered2d must be in eval mode (call model.eval())")
+            self.ch_scale, self.ch_shift = bn.channel_scale_shift()
+        else:
+            self.ch_scale = self.ch_shift = None
+
+    def out_hw(self, H, W):
+        return (ops.conv_out_size(H, self.k[0], self.stride[0], self.padding[0], self.dilation[0]),
+                ops.conv_out_size(W, self.k[1], self.stride[1], self.padding[1], self.dilation[1]))
+
+    def fwd(self, x, *, addend=None, relu=False, want_scale=False):
+        y, t, _ = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
+                                 bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
+                                 ch_shift=self.ch_shift, addend=addend, relu=relu, want_scale=want_scale)
+        return y, t
+
+
+class _Block:
+    def __init__(self, block):
+        names = [n for n in ("conv1", "conv2", "conv3") if hasattr(block, n)]
+        self.convs = [_Conv(getattr(block, n), getattr(block, n.replace("conv", "bn"))) for n in names]
+        self.relu = isinstance(block.relu, nn.ReLU)
+        ds = block.downsample
+        self.shortcut = None
+        if ds is not None:
+            mods = list(ds.children())
+            if len(mods) != 2:
+                raise BcosHipError("engine: downsample must be (conv, norm)")
+            self.shortcut = _Conv(mods[0], mods[1])
+
+    def refresh(self):
+        for c in self.convs:
+            c.refresh()
+        if self.shortcut is not None:
+            self.shortcut.refresh()
+
+
+class ResNetEngine:
+    """Launch plan for `BcosifyNetwork(ResNetBcos(...))` (bcosify.py:22-53 + standard_models.py:36-54)."""
+
+    def __init__(self, net):
+        m = net.model
+        for attr in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "fc", "avgpool"):
+            if not hasattr(m, attr):
+                raise BcosHipError(f"engine: {type(m).__name__} has no `{attr}`: not a torchvision-style ResNet")
+        if not isinstance(m.maxpool, nn.AvgPool2d):
+            raise BcosHipError("engine: the stem pool must be nn.AvgPool2d (the B-cosification recipe swaps MaxPool for "
+                               "AvgPool2d(3,2,1): bcosification/experiment_parameters.py:99)")
+        pool = m.maxpool
+        self.pool = (_pair(pool.kernel_size)[0], _pair(pool.stride)[0], _pair(pool.padding)[0])
+        if pool.ceil_mode or not pool.count_include_pad or pool.divisor_override is not None:
+            raise BcosHipError("engine: unsupported AvgPool2d options")
+        self.net = net
+        self.stem = _Conv(m.conv1, m.bn1)
+        self.stem_relu = isinstance(m.relu, nn.ReLU)
+        self.blocks: List[_Block] = []
+        for li in range(1, 5):
+            for blk in getattr(m, f"layer{li}").children():
+                self.blocks.append(_Block(blk))
+        self.head = _Conv(m.fc, None)
+        norm = net.bcosifynormalize
+        self._mean, self._std = tuple(norm.mean), tuple(norm.std)
+        self._dev_consts = {}
+        ll = net.logit_layer
+        self.logit_bias = ll.logit_bias if ll is not None else None
+        self.logit_temperature = ll.logit_temperature if ll is not None else None
+
+    def refresh(self):
+        """Re-read parameters after they changed (load_state_dict, calibration, ...)."""
+        self.stem.refresh()
+        self.head.refresh()
+        for b in self.blocks:
+            b.refresh()
+
+    def _consts(self, device):
+        key = str(device)
+        if key not in self._dev_consts:
+            self._dev_consts[key] = (torch.tensor(self._mean, dtype=torch.float32, device=device),
+                                     torch.tensor(self._std, dtype=torch.float32, device=device))
+        return self._dev_consts[key]
+
+    # ------------------------------------------------------------------------------------------------
+    def _run_forward(self, x: torch.Tensor, keep: bool):
+        if x.dim() != 4 or x.shape[1] not in (3, 6):
+            raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise BcosHipError("engine: input must be a HIP tensor (no CPU fallback)")
+        x = x.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        mean, std = self._consts(x.device)
+        add_inverse = x.shape[1] == 3
+        xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse)
+        st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3]) if keep else None
+        a0, t0 = self.stem.fwd(xn, relu=self.stem_relu, want_scale=keep)
+        k, s, p = self.pool
+        cur = ops.avgpool2d_fwd(a0, k, s, p)
+        if keep:
+            st.update(t0=t0, a0_hw=(a0.shape[1], a0.shape[2]), blocks=[])
+        del a0
+        for blk in self.blocks:
+            inp = cur
+            rec = dict(in_hw=(inp.shape[1], inp.shape[2])) if keep else None
+            h = inp
+            ts, hws = [], []
+            for c in blk.convs[:-1]:
+                hws.append((h.shape[1], h.shape[2]))
+                h, t = c.fwd(h, relu=blk.relu, want_scale=keep)
+                ts.append(t)
+            if blk.shortcut is not None:
+                idn, td = blk.shortcut.fwd(inp, relu=False, want_scale=keep)
+            else:
+                idn, td = inp, None
+            hws.append((h.shape[1], h.shape[2]))
+            out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep)
+            ts.append(t)
+            if keep:
+                rec.update(ts=ts, td=td, out=out if blk.relu else None, hws=hws)
+                st["blocks"].append(rec)
+            cur = out
+        f, tf = self.head.fwd(cur, relu=False, want_scale=keep)
+        logits = ops.global_avgpool_logits(f, self.logit_temperature, self.logit_bias)
+        if keep:
+            st.update(tf=tf, feat_hw=(cur.shape[1], cur.shape[2]))
+        return logits, st
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run_forward(x, keep=False)[0]
+
+    @torch.no_grad()
+    def explain(self, x: torch.Tensor, targets: Optional[torch.Tensor] = None, want_weights: bool = True) -> Dict[str, torch.Tensor]:
+        """Forward in explanation mode + input-gradient pass of the explained logit of every image
+        (batched bcos/common.py:163-181).  `targets` [N] int64 selects the logits (default: arg-max)."""
+        logits, st = self._run_forward(x, keep=True)
+        pred, _ = ops.argmax_rows(logits)
+        cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
+        # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale
+        g_head = ops.head_onehot_grad(cls, st["tf"], self.logit_temperature)
+        st["tf"] = None
+        # A "consumer" owns the g_lin tensors of the layers that read some activation X and can therefore
+        # finish d logit / d X; its epilogue applies the multipliers of the block that PRODUCED X.
+        consumer = _Consumer(self.head, g_head, None, None)
+        nb = len(self.blocks)
+        for bi in range(nb - 1, -1, -1):
+            blk, rec = self.blocks[bi], st["blocks"][bi]
+            H, W = st["blocks"][bi + 1]["in_hw"] if bi + 1 < nb else st["feat_hw"]
+            # v = d logit / d out_b;  G_main = v * t_last (bn scale, ReLU gate and s of the block's last conv),
+            # G_sc = v * gate(out_b) [* t_d]  for the shortcut
+            G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gate=rec["out"])
+            rec["ts"][-1] = rec["td"] = rec["out"] = None
+            gl = G_main
+            convs = blk.convs
+            for ci in range(len(convs) - 1, 0, -1):
+                h, w = rec["hws"][ci]
+                gl = convs[ci].dgrad.run(gl, h, w, mul=rec["ts"][ci - 1])
+                rec["ts"][ci - 1] = None
+            consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc)
+        # block 0 reads the stem pool output: raw gradient, then pool backward (* t0), then the stem
+        H0, W0 = st["blocks"][0]["in_hw"]
+        g_pool, _ = consumer.run(H0, W0, t_main=None, td=None, gate=None)
+        k, s, p = self.pool
+        a_h, a_w = st["a0_hw"]
+        g0 = ops.avgpool2d_bwd(g_pool, a_h, a_w, k, s, p, mul=st["t0"])
+        st["t0"] = None
+        gxn = torch.empty((x.shape[0], st["H"], st["W"], 8), device=x.device, dtype=torch.float32)
+        self.stem.dgrad.run(g0, st["H"], st["W"], out=gxn)           # channels 0..5 of the padded buffer
+        _, std = self._consts(x.device)
+        wts, contrib = ops.finalize_explanation(gxn, st["x"], std, add_inverse=st["add_inverse"],
+                                                want_weights=want_weights, want_contrib=True)
+        return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
+                    contribution_map=contrib)
+
+
+class _Consumer:
+    """The layers reading one activation X: a main conv (with its g_lin) and optionally a shortcut -- either a
+    conv (g_sc = its g_lin) or the identity (g_sc = gradient added as is)."""
+
+    def __init__(self, conv, g_main, shortcut_conv, g_sc):
+        self.conv, self.g_main, self.shortcut_conv, self.g_sc = conv, g_main, shortcut_conv, g_sc
+
+    def run(self, H, W, t_main, td, gate):
+        """-> (v * t_main, v * gate [* td]) with v = d logit / d X; both v when t_main is None."""
+        g = self.g_main
+        kw, out2 = {}, None
+        if t_main is not None:
+            out2 = torch.empty((g.shape[0], H, W, self.conv.cin), device=g.device, dtype=torch.float32)
+            kw = dict(mul=t_main, out2=out2, mul2=td, gate2=gate)
+        if self.shortcut_conv is not None:
+            addend = self.shortcut_conv.dgrad.run(self.g_sc, H, W)
+        else:
+            addend = self.g_sc
+        out = self.conv.dgrad.run(g, H, W, addend=addend, **kw)
+        return out, (out2 if out2 is not None else out)
+
+
+def attach(net) -> ResNetEngine:
+    """Compile `net` (a BcosifyNetwork around a torchvision-style ResNet) and make `net(x)` (under no_grad) and
+    `net.explain_batch(x)` use the fused plan.  Call `net._bcos_engine.refresh()` after changing parameters."""
+    eng = ResNetEngine(net)
+    object.__setattr__(net, "_bcos_engine", eng)
+    return eng
+
+
+def detach(net):
+    if hasattr(net, "_bcos_engine"):
+        object.__delattr__(net, "_bcos_engine")

@@ -1,0 +1,112 @@
+"""ctypes binding of libbcos_hip.so (the C ABI declared in include/bcos_hip.h).
+
+This is the only place that touches the shared library.  There is deliberately NO CPU
+fallback: if the library is missing, or a kernel is asked to run on a non-HIP tensor,
+the call fails loudly (the CPU restatement lives in oracle/ and is test infrastructure).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+PKG_ROOT = Path(__file__).resolve().parent.parent          # b-cosification_amd/
+REPO_ROOT = PKG_ROOT.parent
+LIB_PATH = PKG_ROOT / "lib" / "libbcos_hip.so"
+CSRC = PKG_ROOT / "csrc"
+INCLUDE = REPO_ROOT / "include"
+SOURCES = ["bcos_tapconv.hip", "bcos_elementwise.hip", "bcos_abi.hip"]
+
+BCOS_NONE, BCOS_CONV_EPS, BCOS_LINEAR_EPS = 0, 1, 2
+BCOS_EPI_NORM_ONLY = 1
+BCOS_EPI_FORCE_POW = 2
+ABI_VERSION = 1
+
+
+class BcosHipError(RuntimeError):
+    pass
+
+
+class TapconvGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "C", "P", "Q", "in_sh", "in_sw", "dh0", "dw0", "dstep_h", "dstep_w",
+        "TH", "TW", "OH", "OW", "out_sh", "out_sw", "out_h0", "out_w0", "Cout",
+        "a_pitch", "out_pitch", "norm_pitch")]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2",
+        "out", "out2", "scale_out", "norm_out")] + [
+        ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/bcos_hip.h one to one
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "bcos_version": (C.c_int, []),
+    "bcos_last_error_string": (C.c_char_p, []),
+    "bcos_tapconv": (C.c_int, [_P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
+    "bcos_conv2d_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P] + [_I] * 13 + [_F, _P]),
+    "bcos_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
+    "bcos_conv2d_dgrad_s1": (C.c_int, [_P, _P, _P] + [_I] * 9 + [_P]),
+    "bcos_linear_dgrad": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
+    "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
+    "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
+    "bcos_maxout_scale": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
+    "bcos_prep_input": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bcos_finalize_explanation": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bcos_contrib_map": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "bcos_avgpool2d_fwd": (C.c_int, [_P, _P] + [_I] * 9 + [_P]),
+    "bcos_avgpool2d_bwd": (C.c_int, [_P, _P, _P] + [_I] * 9 + [_P]),
+    "bcos_global_avgpool_logits": (C.c_int, [_P, _P, _I, _I, _I, _F, _F, _P]),
+    "bcos_head_onehot_grad": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "bcos_argmax_rows": (C.c_int, [_P, _P, _P, _I, _I, _P]),
+    "bcos_channel_affine": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 into lib/libbcos_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + [CSRC / "bcos_internal.h", INCLUDE / "bcos_hip.h"]
+    if LIB_PATH.exists() and not force:
+        if all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+            return LIB_PATH
+    LIB_PATH.parent.mkdir(parents=True, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           f"-I{INCLUDE}", f"-I{CSRC}"] + [str(s) for s in srcs] + ["-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and type every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise BcosHipError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the B-cos hot path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.bcos_version()
+    if v != ABI_VERSION:
+        raise BcosHipError(f"libbcos_hip.so ABI version {v}, bindings expect {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().bcos_last_error_string().decode()
+        raise BcosHipError(f"{what} failed with code {code}: {msg}")

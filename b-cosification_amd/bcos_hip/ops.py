@@ -1,0 +1,328 @@
+"""Tensor-level wrappers over the C ABI: torch is used only for device memory and streams.
+
+All activation tensors here are *physically* NHWC float32 HIP tensors of shape [N,H,W,C]
+(i.e. `x_nchw_channels_last.permute(0,2,3,1)`), weights are [Cout,kh,kw,Cin].
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as _l
+from .lib import BCOS_CONV_EPS, BCOS_LINEAR_EPS, BCOS_NONE, BcosHipError, Epilogue, TapconvGeom
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: Optional[torch.Tensor], what: str, contiguous: bool = True):
+    """Device pointer of `t` (None -> NULL) after checking it is something the kernels accept."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BcosHipError(
+            f"{what}: expected a HIP device tensor, got device={t.device}. The B-cos hot path has no "
+            "CPU implementation in this package (the CPU restatement is oracle/, test-only).")
+    if t.dtype != torch.float32:
+        raise BcosHipError(f"{what}: expected float32, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise BcosHipError(f"{what}: expected a contiguous tensor, got strides {t.stride()}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def conv_out_size(size, k, s, p, d=1):
+    return (size + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
+            norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
+            gate2=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0):
+    """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv)."""
+    lib = _l.load()
+    g = TapconvGeom()
+    for k in ("a_pitch", "out_pitch", "norm_pitch"):
+        setattr(g, k, 0)
+    for k, v in geom.items():
+        setattr(g, k, int(v))
+    e = Epilogue()
+    tensors = dict(bias=bias, ch_scale=ch_scale, ch_shift=ch_shift, addend=addend, mul=mul, mul2=mul2,
+                   gate2=gate2, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out)
+    for k, t in tensors.items():
+        p = _dev(t, f"tapconv.{k}", contiguous=False)
+        setattr(e, k, p.value if p is not None else None)
+    e.bcos_mode = int(bcos_mode)
+    e.relu = int(bool(relu))
+    e.b = float(b)
+    e.flags = int(flags)
+    code = lib.bcos_tapconv(_dev(a, "tapconv.a", contiguous=False), _dev(wt, "tapconv.wt"), C.byref(g), C.byref(e), _stream())
+    _l.check(code, "bcos_tapconv")
+
+
+def fwd_geom(N, H, W, Cin, Cout, kh, kw, sh, sw, ph, pw, dh=1, dw=1):
+    Ho, Wo = conv_out_size(H, kh, sh, ph, dh), conv_out_size(W, kw, sw, pw, dw)
+    return dict(N=N, H=H, W=W, C=Cin, P=Ho, Q=Wo, in_sh=sh, in_sw=sw, dh0=-ph, dw0=-pw, dstep_h=dh,
+                dstep_w=dw, TH=kh, TW=kw, OH=Ho, OW=Wo, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout)
+
+
+def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=None, b=2.0, mode=BCOS_CONV_EPS,
+               ch_scale=None, ch_shift=None, addend=None, relu=False, want_scale=False, want_norm=False,
+               out=None, scale_out=None):
+    """Fused B-cos convolution.  x [N,H,W,Cin], w [Cout,kh,kw,Cin] -> y [N,Ho,Wo,Cout] (+ scale, norm)."""
+    N, H, W, Cin = x.shape
+    Cout, kh, kw, Cin_w = w.shape
+    if Cin_w != Cin:
+        raise BcosHipError(f"conv2d_fwd: weight has {Cin_w} input channels, activation has {Cin}")
+    g = fwd_geom(N, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1])
+    if out is None:
+        out = torch.empty((N, g["P"], g["Q"], Cout), device=x.device, dtype=torch.float32)
+    if want_scale and scale_out is None:
+        scale_out = torch.empty_like(out)
+    norm = torch.empty((N, g["P"], g["Q"]), device=x.device, dtype=torch.float32) if want_norm else None
+    if float(b) == 1.0:
+        mode = BCOS_NONE
+    tapconv(x, w, g, out=out, scale_out=scale_out, norm_out=norm, bias=bias, ch_scale=ch_scale,
+            ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu)
+    return out, scale_out, norm
+
+
+def linear_fwd(x2d, w, *, bias=None, b=2.0, want_scale=False, want_norm=False, mode=BCOS_LINEAR_EPS,
+               addend=None, out=None, flags=0):
+    """Fused B-cos linear.  x2d [rows,Cin], w [Cout,Cin] -> y [rows,Cout]."""
+    rows, Cin = x2d.shape
+    Cout = w.shape[0]
+    g = dict(N=1, H=1, W=rows, C=Cin, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
+             TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout)
+    if out is None:
+        out = torch.empty((rows, Cout), device=x2d.device, dtype=torch.float32)
+    scale = torch.empty_like(out) if want_scale else None
+    norm = torch.empty((rows,), device=x2d.device, dtype=torch.float32) if want_norm else None
+    if float(b) == 1.0:
+        mode = BCOS_NONE
+    tapconv(x2d, w, g, out=out, scale_out=scale, norm_out=norm, bias=bias, addend=addend, bcos_mode=mode, b=b,
+            flags=flags)
+    return out, scale, norm
+
+
+def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None):
+    """Plain fp32 GEMM on the same kernel: out[rows,N] = a2d[rows,K] @ bt[N,K]^T (no B-cos scaling)."""
+    rows, K = a2d.shape
+    Nn = bt.shape[0]
+    g = dict(N=1, H=1, W=rows, C=K, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
+             TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Nn)
+    if out is None:
+        out = torch.empty((rows, Nn), device=a2d.device, dtype=torch.float32)
+    tapconv(a2d, bt, g, out=out, addend=addend, mul=mul)
+    return out
+
+
+class DgradPlan:
+    """Input-gradient launches of one convolution: one tapconv per output parity class.
+
+    For y = conv(x, w; stride s, padding p)   gx[h] = sum_r g[(h + p - r) / s] w[r]  over the r with
+    (h + p - r) % s == 0.  Rows h = s*i + rho of parity class rho use the taps r = r0 + s*u,
+    r0 = (rho + p) % s; with th = U-1-u the gathered g coordinate is i + dh0 + th, dh0 = (rho+p-r0)/s - U + 1.
+    """
+
+    def __init__(self, w_oihw: torch.Tensor, stride, padding, dilation=(1, 1)):
+        Cout, Cin, kh, kw = w_oihw.shape
+        sh, sw = stride
+        ph, pw = padding
+        if (dilation[0] != 1 or dilation[1] != 1) and (sh != 1 or sw != 1):
+            raise BcosHipError("dgrad with dilation > 1 and stride > 1 is not supported")
+        self.stride, self.padding, self.dilation = (sh, sw), (ph, pw), tuple(dilation)
+        self.Cin, self.Cout, self.k = Cin, Cout, (kh, kw)
+        self.classes = []     # (rho_h, rho_w, TH, TW, dh0, dw0, weight [Cin,TH,TW,Cout] or None)
+        for rh in range(sh):
+            rs_h, dh0, step_h = self._taps(rh, sh, ph, kh, dilation[0])
+            for rw in range(sw):
+                rs_w, dw0, step_w = self._taps(rw, sw, pw, kw, dilation[1])
+                if len(rs_h) == 0 or len(rs_w) == 0:
+                    self.classes.append((rh, rw, 0, 0, 0, 0, 1, 1, None))
+                    continue
+                sub = w_oihw[:, :, rs_h][:, :, :, rs_w]                    # [Cout,Cin,TH,TW]
+                wt = sub.permute(1, 2, 3, 0).contiguous()                   # [Cin,TH,TW,Cout]
+                self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
+        self.has_empty = any(c[8] is None for c in self.classes)
+
+    @staticmethod
+    def _taps(rho, s, p, k, d):
+        if s == 1:
+            # gx[h] = sum_r g[h + p - r*d] w[r]; th = k-1-r -> offset = p - (k-1)*d + th*d
+            return list(range(k - 1, -1, -1)), p - (k - 1) * d, d
+        r0 = (rho + p) % s
+        rs = list(range(r0, k, s))
+        U = len(rs)
+        if U == 0:
+            return [], 0, 1
+        e = (rho + p - r0) // s
+        return rs[::-1], e - U + 1, 1
+
+    def run(self, glin, H, W, *, out=None, **epi):
+        """glin [N,Ho,Wo,Cout] -> gx [N,H,W,Cin]; **epi are tapconv epilogue tensors indexed like gx.
+        `out` may be wider than Cin (padded channel pitch); only the first Cin channels are written."""
+        N, Ho, Wo, Cout = glin.shape
+        epi = {k: v for k, v in epi.items() if v is not None}
+        zero_filled = False
+        if out is None:
+            if self.has_empty and not epi:
+                out = torch.zeros((N, H, W, self.Cin), device=glin.device, dtype=torch.float32)
+                zero_filled = True
+            else:
+                out = torch.empty((N, H, W, self.Cin), device=glin.device, dtype=torch.float32)
+        pitch = out.shape[-1]
+        sh, sw = self.stride
+        for (rh, rw, TH, TW, dh0, dw0, step_h, step_w, wt) in self.classes:
+            P = (H - rh + sh - 1) // sh
+            Q = (W - rw + sw - 1) // sw
+            if P <= 0 or Q <= 0:
+                continue
+            if wt is None:
+                # no tap reaches this parity class: the gradient there is whatever the epilogue adds to 0
+                if not zero_filled:
+                    self._empty_class(out, N, H, W, rh, rw, P, Q, epi)
+                continue
+            g = dict(N=N, H=Ho, W=Wo, C=Cout, P=P, Q=Q, in_sh=1, in_sw=1, dh0=dh0, dw0=dw0, dstep_h=step_h,
+                     dstep_w=step_w, TH=TH, TW=TW, OH=H, OW=W, out_sh=sh, out_sw=sw, out_h0=rh, out_w0=rw,
+                     Cout=self.Cin, out_pitch=pitch)
+            tapconv(glin, wt, g, out=out, **epi)
+        return out
+
+    def _empty_class(self, out, N, H, W, rh, rw, P, Q, epi):
+        sh, sw = self.stride
+        view = out[:, rh::sh, rw::sw, :self.Cin]
+        addend, mul = epi.get("addend"), epi.get("mul")
+        if addend is None:
+            view.zero_()
+        else:
+            v = addend[:, rh::sh, rw::sw, :]
+            view.copy_(v if mul is None else v * mul[:, rh::sh, rw::sw, :])
+        for k in ("out2", "scale_out", "mul2", "gate2"):
+            if epi.get(k) is not None:
+                raise BcosHipError(f"dgrad parity class without taps does not support epilogue field {k}")
+        if epi.get("relu"):
+            raise BcosHipError("dgrad parity class without taps does not support relu")
+
+
+def weight_rownorm_scale(w2d, gain=None):
+    lib = _l.load()
+    out = torch.empty_like(w2d)
+    rows, cols = w2d.shape[0], w2d[0].numel()
+    _l.check(lib.bcos_weight_rownorm_scale(_dev(w2d, "w"), _dev(gain, "gain"), _dev(out, "out"), rows, cols, _stream()),
+             "bcos_weight_rownorm_scale")
+    return out
+
+
+def mul(a, b, out=None):
+    lib = _l.load()
+    if out is None:
+        out = torch.empty_like(a)
+    _l.check(lib.bcos_mul(_dev(a, "a"), _dev(b, "b"), _dev(out, "out"), a.numel(), _stream()), "bcos_mul")
+    return out
+
+
+def maxout_scale(lin2d, norm, Cout, max_out, b, groups=1, want_scale=False, want_argmax=False, out=None):
+    lib = _l.load()
+    rows = lin2d.shape[0]
+    y = out if out is not None else torch.empty((rows, Cout), device=lin2d.device, dtype=torch.float32)
+    scale = torch.empty((rows, Cout), device=lin2d.device, dtype=torch.float32) if want_scale else None
+    arg = torch.empty((rows, Cout), device=lin2d.device, dtype=torch.int32) if want_argmax else None
+    argp = C.c_void_p(arg.data_ptr()) if arg is not None else None
+    _l.check(lib.bcos_maxout_scale(_dev(lin2d, "lin"), _dev(norm, "norm"), _dev(y, "y"), _dev(scale, "scale"), argp,
+                                   rows, Cout, max_out, groups, float(b), _stream()), "bcos_maxout_scale")
+    return y, scale, arg
+
+
+def prep_input(x_nchw, mean6, std6, cpad=8, add_inverse=False):
+    lib = _l.load()
+    N, Cx, H, W = x_nchw.shape
+    out = torch.empty((N, H, W, cpad), device=x_nchw.device, dtype=torch.float32)
+    _l.check(lib.bcos_prep_input(_dev(x_nchw, "x"), _dev(out, "out"), _dev(mean6, "mean"), _dev(std6, "std"), N, Cx, H, W,
+                                 cpad, int(add_inverse), _stream()), "bcos_prep_input")
+    return out
+
+
+def finalize_explanation(gxn, x_nchw, std6, add_inverse=False, want_weights=True, want_contrib=True):
+    lib = _l.load()
+    N, H, W, cpad = gxn.shape
+    Cx = x_nchw.shape[1]
+    wout = torch.empty((N, 6, H, W), device=gxn.device, dtype=torch.float32) if want_weights else None
+    cout = torch.empty((N, H, W), device=gxn.device, dtype=torch.float32) if want_contrib else None
+    _l.check(lib.bcos_finalize_explanation(_dev(gxn, "gxn"), _dev(x_nchw, "x"), _dev(std6, "std"), _dev(wout, "w"),
+                                           _dev(cout, "c"), N, Cx, H, W, cpad, int(add_inverse), _stream()),
+             "bcos_finalize_explanation")
+    return wout, cout
+
+
+def contrib_map(x_nchw, gx_nchw):
+    lib = _l.load()
+    N, Cc, H, W = x_nchw.shape
+    out = torch.empty((N, H, W), device=x_nchw.device, dtype=torch.float32)
+    _l.check(lib.bcos_contrib_map(_dev(x_nchw, "x"), _dev(gx_nchw, "gx"), _dev(out, "out"), N, Cc, H, W, _stream()),
+             "bcos_contrib_map")
+    return out
+
+
+def avgpool2d_fwd(x, k, s, p, out=None):
+    lib = _l.load()
+    N, H, W, Cc = x.shape
+    OH, OW = conv_out_size(H, k, s, p), conv_out_size(W, k, s, p)
+    y = out if out is not None else torch.empty((N, OH, OW, Cc), device=x.device, dtype=torch.float32)
+    _l.check(lib.bcos_avgpool2d_fwd(_dev(x, "x"), _dev(y, "y"), N, H, W, Cc, k, s, p, OH, OW, _stream()), "bcos_avgpool2d_fwd")
+    return y
+
+
+def avgpool2d_bwd(gy, H, W, k, s, p, mul=None, out=None):
+    lib = _l.load()
+    N, OH, OW, Cc = gy.shape
+    if out is None:
+        out = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
+    _l.check(lib.bcos_avgpool2d_bwd(_dev(gy, "gy"), _dev(mul, "mul"), _dev(out, "gx"), N, H, W, Cc, k, s, p, OH, OW, _stream()),
+             "bcos_avgpool2d_bwd")
+    return out
+
+
+def global_avgpool_logits(x, temperature=None, bias=None):
+    lib = _l.load()
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
+    inv_t = 1.0 if temperature is None else 1.0 / float(temperature)
+    _l.check(lib.bcos_global_avgpool_logits(_dev(x, "x"), _dev(y, "y"), N, H * W, Cc, inv_t, 0.0 if bias is None else float(bias),
+                                            _stream()), "bcos_global_avgpool_logits")
+    return y
+
+
+def head_onehot_grad(cls, scale, temperature=None, out=None):
+    lib = _l.load()
+    N, H, W, Cc = scale.shape
+    if cls.dtype != torch.int64 or not cls.is_cuda:
+        raise BcosHipError("head_onehot_grad: cls must be an int64 HIP tensor")
+    if out is None:
+        out = torch.empty_like(scale)
+    inv_t = 1.0 if temperature is None else 1.0 / float(temperature)
+    _l.check(lib.bcos_head_onehot_grad(C.c_void_p(cls.data_ptr()), _dev(scale, "scale"), _dev(out, "glin"), N, H * W, Cc, inv_t,
+                                       _stream()), "bcos_head_onehot_grad")
+    return out
+
+
+def argmax_rows(x2d):
+    lib = _l.load()
+    N, Cc = x2d.shape
+    idx = torch.empty((N,), device=x2d.device, dtype=torch.int64)
+    val = torch.empty((N,), device=x2d.device, dtype=torch.float32)
+    _l.check(lib.bcos_argmax_rows(_dev(x2d, "x"), C.c_void_p(idx.data_ptr()), _dev(val, "val"), N, Cc, _stream()), "bcos_argmax_rows")
+    return idx, val
+
+
+def channel_affine(x, scale, shift=None, relu=False, out=None):
+    lib = _l.load()
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _l.check(lib.bcos_channel_affine(_dev(x, "x"), _dev(scale, "scale"), _dev(shift, "shift"), _dev(out, "y"), x.numel() // Cc, Cc,
+                                     int(bool(relu)), _stream()), "bcos_channel_affine")
+    return out

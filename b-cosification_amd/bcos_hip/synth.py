@@ -1,0 +1,164 @@
+"""Synthetic, *calibrated* B-cosified networks for benchmarks and parity tests.
+
+There is no network access for pretrained weights, and a B-cos net with default random init collapses to
+~1e-12 activations after a few layers, which would make every parity check vacuous.
+Recipe (deterministic given the seeds and the torch version of the image):
+  1. torch.manual_seed(seed); standard topology with default init;
+  2. BatchNorm statistics / affine parameters randomised BEFORE conversion so the BnUncV2 fold is exercised;
+  3. conversion with the reference's config keys (bcosification/experiment_parameters.py:86-100), MaxPool ->
+     AvgPool2d(3,2,1), all biases set to None (bcosification/model.py:45-55);
+  4. calibration in execution order on a seed batch: every B-cos conv's weight is scaled by rms(y)^-1/2
+     (y is quadratic in W) so that rms(y) = 1, every uncentered BN gets running_var <- var(input).
+Step 4 is either executed (`calibrate`, on whatever device / module implementation the net lives on) or
+replayed from recorded numbers (`apply_calibration`), which is how the golden fixtures pin identical weights
+in the build container (reference modules, CPU) and on the GPU box (HIP modules).
+"""
+import math
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+
+def resnet_model_config(arch: str = "resnet50") -> dict:
+    """The `model` section of CONFIGS['resnet_50'] / ['resnet_18'] (bcosification/experiment_parameters.py:41-106)."""
+    return dict(
+        is_bcos=True,
+        name=arch,
+        last_layer_name="fc",
+        weights="synthetic",     # truthy: the converters copy the weights of the standard modules
+        args=dict(num_classes=1000, logit_bias=-math.log(1000 - 1)),
+        bcos_args=dict(b=2, max_out=1),
+        bcosify_args=dict(fix_b=True, use_bias=False, norm_layer="BnUncV2", manual_optim=False, gap=True,
+                          act_layer=True),
+        standard_changes={"maxpool": nn.AvgPool2d(kernel_size=3, stride=2, padding=1)},
+    )
+
+
+def randomize_batchnorm(model: nn.Module, gen: torch.Generator):
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            c = m.num_features
+            m.running_mean.copy_(torch.randn(c, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(c, generator=gen) + 0.5)
+            m.weight.data.copy_(torch.rand(c, generator=gen) + 0.5)
+            m.bias.data.copy_(torch.randn(c, generator=gen) * 0.1)
+
+
+def standard_resnet(arch: str, seed: int = 0, resnet_cls=None, blocks=None):
+    """Step 1-2.  `resnet_cls` / `blocks` let the golden generator pass the reference's own ResNetBcos."""
+    if resnet_cls is None:
+        from bcos.models.standard_models import BasicBlock, Bottleneck, ResNetBcos
+        resnet_cls, blocks = ResNetBcos, dict(basic=BasicBlock, bottleneck=Bottleneck)
+    spec = {"resnet18": ("basic", [2, 2, 2, 2]), "resnet34": ("basic", [3, 4, 6, 3]),
+            "resnet50": ("bottleneck", [3, 4, 6, 3])}[arch]
+    torch.manual_seed(seed)
+    net = resnet_cls(blocks[spec[0]], spec[1])
+    gen = torch.Generator().manual_seed(seed + 1)
+    randomize_batchnorm(net, gen)
+    return net
+
+
+def finish_conversion(model: nn.Module, model_config: dict, hip_pools: bool = True):
+    """bcosification/model.py:44-55: apply `standard_changes`, then null every bias.  `hip_pools` swaps plain
+    nn.AvgPool2d modules for the HIP-backed subclass (bcos/modules/pooling.py) -- pass False when the modules
+    are the reference's own (golden generation on CPU)."""
+    for k, v in (model_config.get("standard_changes") or {}).items():
+        setattr(model.model, k, v)
+    if hip_pools:
+        from bcos.modules.pooling import use_hip_pools
+        use_hip_pools(model)
+    for mod in model.modules():
+        if hasattr(mod, "bias") and mod.bias is not None:
+            mod.bias = None
+    return model
+
+
+def build_bcosified_resnet(arch: str = "resnet50", seed: int = 0):
+    """Steps 1-3 with this package's modules (CPU tensors; move with .to('cuda') afterwards)."""
+    from bcosify import BcosifyNetwork
+    cfg = resnet_model_config(arch)
+    net = BcosifyNetwork(standard_resnet(arch, seed), cfg, add_channels=True, logit_layer=True)
+    finish_conversion(net, cfg)
+    return net.eval()
+
+
+def synthetic_images(n: int, seed: int = 123, size: int = 224, smooth: bool = True) -> torch.Tensor:
+    """[n,6,size,size] AddInverse-encoded images in [0,1].  `smooth`: bilinearly upsampled 14x14 noise plus a
+    per-image colour offset (pure pixel noise makes every image predict the same class)."""
+    gen = torch.Generator().manual_seed(seed)
+    if smooth:
+        low = torch.rand(n, 3, 14, 14, generator=gen)
+        x3 = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=False)
+        x3 = (0.7 * x3 + 0.3 * torch.rand(n, 3, 1, 1, generator=gen)).clamp(0, 1)
+    else:
+        x3 = torch.rand(n, 3, size, size, generator=gen)
+    return torch.cat([x3, 1 - x3], dim=1).contiguous()
+
+
+def _is_bcos_conv(m) -> bool:
+    return hasattr(m, "linear") and hasattr(m, "b") and isinstance(getattr(m, "linear", None), nn.Conv2d)
+
+
+def _is_bnu(m) -> bool:
+    return type(m).__name__.startswith("BatchNormUncentered2d")
+
+
+@torch.no_grad()
+def calibrate(net: nn.Module, x: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+    """Step 4, executed: returns the record {module name: conv gain (0-d) | bn running_var [C]}."""
+    record: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    names = {m: n for n, m in net.named_modules()}
+    hooks = []
+
+    def conv_pre(mod, args):
+        y = mod(*args)          # re-entrancy guarded below
+        gain = y.pow(2).mean().sqrt().clamp_min(1e-30).pow(-0.5)
+        mod.linear.weight.mul_(gain)    # in place on the Parameter (bumps its version: kernel-layout caches refresh)
+        record[names[mod]] = gain.detach().cpu()
+
+    def bn_pre(mod, args):
+        var = args[0].var(dim=(0, 2, 3), unbiased=False)
+        mod.running_var.copy_(var)
+        record[names[mod]] = var.detach().cpu()
+
+    busy = set()
+
+    def guard(fn):
+        def wrapped(mod, args):
+            if mod in busy:
+                return None
+            busy.add(mod)
+            try:
+                fn(mod, args)
+            finally:
+                busy.discard(mod)
+            return None
+        return wrapped
+
+    for m in net.modules():
+        if _is_bcos_conv(m):
+            hooks.append(m.register_forward_pre_hook(guard(conv_pre)))
+        elif _is_bnu(m):
+            hooks.append(m.register_forward_pre_hook(guard(bn_pre)))
+    try:
+        net(x)
+    finally:
+        for h in hooks:
+            h.remove()
+    return record
+
+
+@torch.no_grad()
+def apply_calibration(net: nn.Module, record: Dict[str, torch.Tensor]):
+    """Step 4, replayed from a record produced by `calibrate` (possibly with another implementation)."""
+    mods = dict(net.named_modules())
+    for name, val in record.items():
+        m = mods[name]
+        val = torch.as_tensor(val)
+        if _is_bcos_conv(m):
+            m.linear.weight.mul_(val.to(m.linear.weight.device, m.linear.weight.dtype))
+        else:
+            m.running_var.copy_(val.to(m.running_var.device))
+    return net

@@ -1,0 +1,414 @@
+// bcos_elementwise.hip -- the HBM-bound kernels of the B-cos forward / explanation path on
+// gfx950: input preparation, pooling, the classification head, the end of the explanation
+// pass and the unit-norm weight projection.  All are streaming kernels: 16-byte accesses
+// where the layout allows, 256-thread blocks, grid-stride loops capped at 256 CUs x 8 blocks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bcos_hip.h"
+#include "bcos_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int64_t MAX_BLOCKS = 256 * 8;
+
+inline unsigned grid_for(int64_t work_items) {
+    int64_t b = (work_items + TPB - 1) / TPB;
+    if (b < 1) b = 1;
+    if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+    return (unsigned)b;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error(what, err);
+    return BCOS_OK;
+}
+
+// ---- unit-norm weight projection: one wavefront per row --------------------------------
+__global__ __launch_bounds__(TPB) void weight_rownorm_kernel(const float* __restrict__ w,
+                                                             const float* __restrict__ gain,
+                                                             float* __restrict__ out, int rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * TPB) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float* src = w + (int64_t)r * cols;
+        float ss = 0.f;
+        for (int64_t c = lane; c < cols; c += 64) ss = fmaf(src[c], src[c], ss);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float nrm = sqrtf(ss);
+        const float gn = gain ? gain[r] : 1.f;
+        float* dst = out + (int64_t)r * cols;
+        for (int64_t c = lane; c < cols; c += 64) {
+            float v = src[c] / nrm;
+            dst[c] = gain ? gn * v : v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, int64_t n4, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += stride) {
+        f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+        f32x4 y = reinterpret_cast<const f32x4*>(b)[i];
+        reinterpret_cast<f32x4*>(out)[i] = x * y;
+    }
+    // tail
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) out[i] = a[i] * b[i];
+}
+
+__device__ inline float bcos_scale_of(float lin, float nrm, float b) {
+    if (b == 2.0f) return fabsf(lin) / nrm;
+    return powf(fabsf(lin / nrm) + 1e-6f, b - 1.0f);
+}
+
+// ---- MaxOut + scaling, general path ----------------------------------------------------------
+__global__ __launch_bounds__(TPB) void maxout_scale_kernel(const float* __restrict__ lin,
+                                                           const float* __restrict__ norm, float* __restrict__ y,
+                                                           float* __restrict__ scale_out,
+                                                           int32_t* __restrict__ argmax_out, int64_t rows, int Cout,
+                                                           int max_out, int norm_stride, float b) {
+    const int64_t total = rows * Cout;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    const int per_group = Cout / norm_stride;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / Cout;
+        const int c = (int)(i - r * Cout);
+        const float* src = lin + r * (int64_t)Cout * max_out + (int64_t)c * max_out;
+        float best = src[0];
+        int arg = 0;
+        for (int m = 1; m < max_out; ++m) {
+            const float v = src[m];
+            if (v > best) { best = v; arg = m; }
+        }
+        float s = 1.f;
+        if (norm) {
+            const float nrm = norm[r * norm_stride + c / per_group];
+            s = bcos_scale_of(best, nrm, b);
+        }
+        y[i] = s * best;
+        if (scale_out) scale_out[i] = s;
+        if (argmax_out) argmax_out[i] = arg;
+    }
+}
+
+// ---- network input: AddInverse + Normalize + NCHW -> NHWC (padded) -----------------------------
+__global__ __launch_bounds__(TPB) void prep_input_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         const float* __restrict__ mean6,
+                                                         const float* __restrict__ std6, int N, int Cx, int HW,
+                                                         int Cpad, int add_inverse) {
+    const int64_t total = (int64_t)N * HW;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    float mu[6], sd[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { mu[c] = mean6[c]; sd[c] = std6[c]; }
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / HW;
+        const int64_t hw = i - n * HW;
+        const float* src = x + n * (int64_t)Cx * HW + hw;
+        float v[6];
+        if (add_inverse) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { v[c] = src[(int64_t)c * HW]; v[c + 3] = 1.0f - v[c]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = src[(int64_t)c * HW];
+        }
+        float* dst = out + i * Cpad;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst[c] = (v[c] - mu[c]) / sd[c];
+        for (int c = 6; c < Cpad; ++c) dst[c] = 0.f;
+    }
+}
+
+// ---- end of the explanation pass -----------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void finalize_expl_kernel(const float* __restrict__ gxn,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ std6,
+                                                            float* __restrict__ wout, float* __restrict__ cout,
+                                                            int N, int Cx, int HW, int Cpad, int add_inverse) {
+    const int64_t total = (int64_t)N * HW;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    float sd[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sd[c] = std6[c];
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / HW;
+        const int64_t hw = i - n * HW;
+        const float* g = gxn + i * Cpad;
+        const float* src = x + n * (int64_t)Cx * HW + hw;
+        float contrib = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float wv = g[c] / sd[c];
+            float xv;
+            if (add_inverse) xv = c < 3 ? src[(int64_t)c * HW] : 1.0f - src[(int64_t)(c - 3) * HW];
+            else xv = src[(int64_t)c * HW];
+            if (wout) wout[(n * 6 + c) * (int64_t)HW + hw] = wv;
+            contrib += xv * wv;   // same order as torch .sum(1) over 6 channels is not guaranteed; 6 terms
+        }
+        if (cout) cout[i] = contrib;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void contrib_map_kernel(const float* __restrict__ x, const float* __restrict__ gx,
+                                                          float* __restrict__ out, int N, int C, int HW) {
+    const int64_t total = (int64_t)N * HW;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / HW;
+        const int64_t hw = i - n * HW;
+        const int64_t base = n * (int64_t)C * HW + hw;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += x[base + (int64_t)c * HW] * gx[base + (int64_t)c * HW];
+        out[i] = acc;
+    }
+}
+
+// ---- AvgPool2d (count_include_pad=True), NHWC, 4 channels per thread -------------------------------
+__global__ __launch_bounds__(TPB) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                          int H, int W, int C4, int k, int s, int p, int OH,
+                                                          int OW) {
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int64_t n = t / OH;
+        int hs = oh * s - p, ws = ow * s - p;
+        int he = min(hs + k, H + p), we = min(ws + k, W + p);
+        const float pool = (float)((he - hs) * (we - ws));
+        hs = max(hs, 0); ws = max(ws, 0); he = min(he, H); we = min(we, W);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w)
+                acc += reinterpret_cast<const f32x4*>(x)[((n * H + h) * W + w) * C4 + c4];
+        reinterpret_cast<f32x4*>(y)[i] = acc / pool;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mul,
+                                                          float* __restrict__ gx, int N, int H, int W, int C4,
+                                                          int k, int s, int p, int OH, int OW) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int64_t n = t / H;
+        // windows oh with oh*s - p <= h < oh*s - p + k
+        int oh_lo = (h + p - k + s) / s;  // ceil((h+p-k+1)/s) for non-negative numerator
+        if (h + p - k + 1 <= 0) oh_lo = 0;
+        int ow_lo = (w + p - k + s) / s;
+        if (w + p - k + 1 <= 0) ow_lo = 0;
+        const int oh_hi = min((h + p) / s, OH - 1);
+        const int ow_hi = min((w + p) / s, OW - 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            const int hs = oh * s - p;
+            const int he = min(hs + k, H + p);
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int ws = ow * s - p;
+                const int we = min(ws + k, W + p);
+                const float pool = (float)((he - hs) * (we - ws));
+                acc += reinterpret_cast<const f32x4*>(gy)[((n * OH + oh) * OW + ow) * C4 + c4] / pool;
+            }
+        }
+        if (mul) acc *= reinterpret_cast<const f32x4*>(mul)[i];
+        reinterpret_cast<f32x4*>(gx)[i] = acc;
+    }
+}
+
+// ---- head: global average pool + logit layer -----------------------------------------------------
+__global__ __launch_bounds__(TPB) void gap_logits_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                         int HW, int C, float inv_t, float bias) {
+    const int64_t total = (int64_t)N * C;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / C;
+        const int c = (int)(i - n * C);
+        const float* src = x + n * (int64_t)HW * C + c;
+        float acc = 0.f;
+        for (int hw = 0; hw < HW; ++hw) acc += src[(int64_t)hw * C];
+        float v = acc / (float)HW;
+        if (inv_t != 1.0f) v *= inv_t;
+        y[i] = v + bias;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void head_onehot_kernel(const int64_t* __restrict__ cls,
+                                                          const float* __restrict__ scale, float* __restrict__ glin,
+                                                          int N, int HW, int C, float coef) {
+    const int64_t total = (int64_t)N * HW * C;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const int64_t n = i / ((int64_t)HW * C);
+        glin[i] = (c == (int)cls[n]) ? scale[i] * coef : 0.f;
+    }
+}
+
+// one wavefront per row; ties -> lowest index
+__global__ __launch_bounds__(TPB) void argmax_rows_kernel(const float* __restrict__ x, int64_t* __restrict__ idx,
+                                                          float* __restrict__ val, int N, int C) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * TPB) >> 6;
+    for (int r = wave; r < N; r += nwaves) {
+        const float* src = x + (int64_t)r * C;
+        float best = -INFINITY;
+        int arg = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = src[c];
+            if (v > best || (v == best && c < arg)) { best = v; arg = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oa = __shfl_xor(arg, o);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        if (lane == 0) {
+            if (idx) idx[r] = arg;
+            if (val) val[r] = best;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void channel_affine_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ y,
+                                                             int64_t total4, int C4, int relu) {
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total4; i += stride) {
+        const int c4 = (int)(i % C4);
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * reinterpret_cast<const f32x4*>(scale)[c4];
+        if (shift) v += reinterpret_cast<const f32x4*>(shift)[c4];
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int bcos_weight_rownorm_scale(const float* w, const float* gain, float* w_out, int rows, int64_t cols,
+                                         void* stream) {
+    if (!w || !w_out || rows <= 0 || cols <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_weight_rownorm_scale: bad argument");
+    const unsigned grid = grid_for((int64_t)rows * 64);
+    hipLaunchKernelGGL(weight_rownorm_kernel, dim3(grid), dim3(TPB), 0, STREAM(stream), w, gain, w_out, rows, cols);
+    return check_launch("weight_rownorm_kernel");
+}
+
+extern "C" int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n < 0) return bcos_set_error(BCOS_E_INVAL, "bcos_mul: bad argument");
+    if (n == 0) return BCOS_OK;
+    int64_t n4 = n / 4;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) n4 = 0;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n4 > 0 ? n4 : n)), dim3(TPB), 0, STREAM(stream), a, b, out, n4, n);
+    return check_launch("mul_kernel");
+}
+
+extern "C" int bcos_maxout_scale(const float* lin, const float* norm, float* y, float* scale_out,
+                                 int32_t* argmax_out, int64_t rows, int Cout, int max_out, int norm_stride, float b,
+                                 void* stream) {
+    if (!lin || !y || rows <= 0 || Cout <= 0 || max_out <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_maxout_scale: bad argument");
+    if (norm_stride <= 0 || Cout % norm_stride != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_maxout_scale: Cout % groups != 0");
+    hipLaunchKernelGGL(maxout_scale_kernel, dim3(grid_for(rows * Cout)), dim3(TPB), 0, STREAM(stream), lin, norm, y,
+                       scale_out, argmax_out, rows, Cout, max_out, norm_stride, b);
+    return check_launch("maxout_scale_kernel");
+}
+
+extern "C" int bcos_prep_input(const float* x, float* out, const float* mean6, const float* std6, int N, int Cx,
+                               int H, int W, int Cpad, int add_inverse, void* stream) {
+    if (!x || !out || !mean6 || !std6 || N <= 0 || H <= 0 || W <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: bad argument");
+    if (Cx != (add_inverse ? 3 : 6)) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: Cx must be 3 (add_inverse) or 6");
+    if (Cpad < 6) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: Cpad < 6");
+    hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), x, out,
+                       mean6, std6, N, Cx, H * W, Cpad, add_inverse);
+    return check_launch("prep_input_kernel");
+}
+
+extern "C" int bcos_finalize_explanation(const float* gxn, const float* x, const float* std6, float* weights_out,
+                                         float* contrib_out, int N, int Cx, int H, int W, int Cpad, int add_inverse,
+                                         void* stream) {
+    if (!gxn || !x || !std6 || (!weights_out && !contrib_out) || N <= 0 || H <= 0 || W <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_finalize_explanation: bad argument");
+    if (Cx != (add_inverse ? 3 : 6) || Cpad < 6) return bcos_set_error(BCOS_E_INVAL, "bcos_finalize_explanation: bad channels");
+    hipLaunchKernelGGL(finalize_expl_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), gxn, x,
+                       std6, weights_out, contrib_out, N, Cx, H * W, Cpad, add_inverse);
+    return check_launch("finalize_expl_kernel");
+}
+
+extern "C" int bcos_contrib_map(const float* x, const float* gx, float* out, int N, int C, int H, int W,
+                                void* stream) {
+    if (!x || !gx || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_contrib_map: bad argument");
+    hipLaunchKernelGGL(contrib_map_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), x, gx, out,
+                       N, C, H * W);
+    return check_launch("contrib_map_kernel");
+}
+
+static int pool_args_ok(int N, int H, int W, int C, int k, int s, int p, int OH, int OW) {
+    return N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && s > 0 && p >= 0 && 2 * p <= k && OH > 0 && OW > 0;
+}
+
+extern "C" int bcos_avgpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, int k, int s, int p, int OH,
+                                  int OW, void* stream) {
+    if (!x || !y || !pool_args_ok(N, H, W, C, k, s, p, OH, OW)) return bcos_set_error(BCOS_E_INVAL, "bcos_avgpool2d_fwd: bad argument");
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((int64_t)N * OH * OW * (C / 4))), dim3(TPB), 0, STREAM(stream),
+                       x, y, N, H, W, C / 4, k, s, p, OH, OW);
+    return check_launch("avgpool_fwd_kernel");
+}
+
+extern "C" int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, int N, int H, int W, int C, int k,
+                                  int s, int p, int OH, int OW, void* stream) {
+    if (!gy || !gx || !pool_args_ok(N, H, W, C, k, s, p, OH, OW)) return bcos_set_error(BCOS_E_INVAL, "bcos_avgpool2d_bwd: bad argument");
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(TPB), 0, STREAM(stream), gy,
+                       mul, gx, N, H, W, C / 4, k, s, p, OH, OW);
+    return check_launch("avgpool_bwd_kernel");
+}
+
+extern "C" int bcos_global_avgpool_logits(const float* x, float* y, int N, int HW, int C, float inv_temperature,
+                                          float logit_bias, void* stream) {
+    if (!x || !y || N <= 0 || HW <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_global_avgpool_logits: bad argument");
+    hipLaunchKernelGGL(gap_logits_kernel, dim3(grid_for((int64_t)N * C)), dim3(TPB), 0, STREAM(stream), x, y, N, HW, C,
+                       inv_temperature, logit_bias);
+    return check_launch("gap_logits_kernel");
+}
+
+extern "C" int bcos_head_onehot_grad(const int64_t* cls, const float* scale, float* glin, int N, int HW, int C,
+                                     float inv_temperature, void* stream) {
+    if (!cls || !scale || !glin || N <= 0 || HW <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_head_onehot_grad: bad argument");
+    const float coef = inv_temperature / (float)HW;
+    hipLaunchKernelGGL(head_onehot_kernel, dim3(grid_for((int64_t)N * HW * C)), dim3(TPB), 0, STREAM(stream), cls, scale,
+                       glin, N, HW, C, coef);
+    return check_launch("head_onehot_kernel");
+}
+
+extern "C" int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N, int C, void* stream) {
+    if (!x || (!idx && !val) || N <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_argmax_rows: bad argument");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(grid_for((int64_t)N * 64)), dim3(TPB), 0, STREAM(stream), x, idx, val, N, C);
+    return check_launch("argmax_rows_kernel");
+}
+
+extern "C" int bcos_channel_affine(const float* x, const float* scale, const float* shift, float* y, int64_t pixels,
+                                   int C, int relu, void* stream) {
+    if (!x || !scale || !y || pixels <= 0 || C <= 0 || C % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_channel_affine: bad argument (C % 4)");
+    const int64_t total4 = pixels * (C / 4);
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(grid_for(total4)), dim3(TPB), 0, STREAM(stream), x, scale, shift, y,
+                       total4, C / 4, relu);
+    return check_launch("channel_affine_kernel");
+}

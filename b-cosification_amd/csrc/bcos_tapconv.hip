@@ -1,0 +1,364 @@
+// bcos_tapconv.hip -- fused implicit-GEMM "tap convolution" for gfx950 (MI355X, CDNA4).
+//
+// One kernel family serves BcosConv2d / BcosifyConv2d forward (reference
+// bcos/modules/bcosconv2d.py:153-231, bcosifyconv2d.py:50-102), BcosLinear / BcosifyLinear
+// forward (bcoslinear.py:88-130, bcosifylinear.py:42-95) and the explanation-mode input
+// gradients (the autograd convolution_backward behind bcos/common.py:177).
+//
+// Structure (written for CDNA4, not translated from anything):
+//   * GEMM view: rows m = output pixels (n,i,j), cols = Cout, K = taps x Cin, NHWC activations
+//     and [Cout][taps][Cin] weights so that both operands are K-contiguous.
+//   * 256 threads = 4 wavefronts of 64; block tile BM x BN x 32, each wave owns TM x TN
+//     tiles of 32x32 computed with v_mfma_f32_32x32x2_f32 (exact fp32, 16 acc VGPRs per tile).
+//   * operands are staged global -> VGPR -> LDS (padded rows, 36 floats, conflict-free
+//     ds_read_b128) so that out-of-image taps are zero-filled in registers; the loads for
+//     K-step k+1 are issued before the MFMAs of step k and written to the other LDS
+//     buffer after them (one barrier per K-step).
+//   * each lane feeds 4 MFMAs from one ds_read_b128 per operand: lanes 0-31 hold
+//     k = 8q..8q+3 and lanes 32-63 k = 8q+4..8q+7 of their row, so MFMA c consumes the
+//     k-pair (8q+c, 8q+4+c) -- a permutation of K applied identically to A and B.
+//   * the per-row patch norm sum_k A[m,k]^2 is accumulated from the A fragments already in
+//     registers (8 FMAs per 16 MFMAs) and finished with one cross-half shuffle.
+//   * the fused epilogue (include/bcos_hip.h: bcos_epilogue) runs on the accumulators.
+//   * block -> tile mapping is XCD-aware: the 8 XCDs (private L2s) each get a contiguous
+//     range of tiles, n-tile fastest, so blocks sharing an A row-panel share an L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bcos_hip.h"
+#include "bcos_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;            // K floats per step
+constexpr int LDS_LD = BK + 4;    // padded LDS row (floats): 144 B, 16 rows hit 16 distinct 16-B slots
+constexpr int NTHREADS = 256;
+constexpr int NXCD = 8;
+
+struct KArgs {
+    const float* a;
+    const float* wt;
+    bcos_tapconv_geom g;
+    bcos_epilogue e;
+    int M;          // N*P*Q
+    int PQ;
+    int Ktot;       // taps*C
+    int cpt;        // 16-byte chunks per tap = C/4
+    int nchunks;    // Ktot/4
+    int nk;         // K steps
+    int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+__global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32;   // float4 loads per thread per K-step
+    constexpr int BUF = (BM + BN) * LDS_LD;          // floats per LDS buffer
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // ---- XCD-aware tile id -----------------------------------------------------------
+    const int nt = p.tiles_m * p.tiles_n;
+    int tile;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid % NXCD, idx = bid / NXCD;
+        const int q = nt / NXCD, r = nt % NXCD;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile = base + idx;
+    }
+    const int tile_m = tile / p.tiles_n;
+    const int tile_n = tile - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int chunk = tid & 7;      // 16-B chunk within the 32-float K-step
+    const int r0 = tid >> 3;        // staging row 0..31 (+32 per pass)
+
+    const bcos_tapconv_geom& g = p.g;
+    const int H = g.H, W = g.W;
+    const int a_pitch = g.a_pitch;
+
+    // ---- per-thread staging rows (fixed over the K loop) -------------------------------
+    int64_t a_nbase[A_LD];
+    int a_ih0[A_LD], a_iw0[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = m0 + r0 + 32 * j;
+        if (m < p.M) {
+            const int n = m / p.PQ;
+            const int rem = m - n * p.PQ;
+            const int i = rem / g.Q;
+            const int jj = rem - i * g.Q;
+            a_nbase[j] = (int64_t)n * H * W * a_pitch;
+            a_ih0[j] = i * g.in_sh + g.dh0;
+            a_iw0[j] = jj * g.in_sw + g.dw0;
+        } else {
+            a_nbase[j] = 0;
+            a_ih0[j] = -(1 << 28);   // fails every bounds check -> zero rows
+            a_iw0[j] = -(1 << 28);
+        }
+    }
+    int64_t b_off[B_LD];
+    bool b_ok[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int co = n0 + r0 + 32 * j;
+        b_ok[j] = co < g.Cout;
+        b_off[j] = (int64_t)(b_ok[j] ? co : 0) * p.Ktot;
+    }
+
+    f32x4 ra[A_LD], rb[B_LD];
+    auto load_step = [&](int ks) {
+        const int q = ks * 8 + chunk;
+        const bool kvalid = q < p.nchunks;
+        const int tap = q / p.cpt;
+        const int cc = q - tap * p.cpt;
+        const int th = tap / g.TW;
+        const int tw = tap - th * g.TW;
+        const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+            const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float* src = p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4;
+                v = *reinterpret_cast<const f32x4*>(src);
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kvalid && b_ok[j]) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[j] + (int64_t)q * 4);
+            rb[j] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+        float* sA = smem + buf * BUF;
+        float* sB = sA + BM * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j)
+            *reinterpret_cast<f32x4*>(sA + (r0 + 32 * j) * LDS_LD + chunk * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            *reinterpret_cast<f32x4*>(sB + (r0 + 32 * j) * LDS_LD + chunk * 4) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float ss[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ss[i] = 0.f;
+
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    const int a_frag = (wave_m * WM + frag_row) * LDS_LD + frag_half * 4;
+    const int b_frag = BM * LDS_LD + (wave_n * WN + frag_row) * LDS_LD + frag_half * 4;
+
+    // ---- main loop ------------------------------------------------------------------------
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int ks = 0; ks < p.nk; ++ks) {
+        const int cur = ks & 1;
+        const bool more = ks + 1 < p.nk;
+        if (more) load_step(ks + 1);
+        const float* sbuf = smem + cur * BUF;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(sbuf + a_frag + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(sbuf + b_frag + j * 32 * LDS_LD + kk * 8);
+            if (NORM) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ss[i] = fmaf(af[i][0], af[i][0], ss[i]);
+                    ss[i] = fmaf(af[i][1], af[i][1], ss[i]);
+                    ss[i] = fmaf(af[i][2], af[i][2], ss[i]);
+                    ss[i] = fmaf(af[i][3], af[i][3], ss[i]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_step(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: row bookkeeping through LDS ------------------------------------------
+    // (all waves are past the last barrier: the tile buffers are free)
+    int64_t* sPix = reinterpret_cast<int64_t*>(smem);            // [BM] output pixel index or -1
+    float* sNorm = reinterpret_cast<float*>(sPix + BM);          // [BM] patch norm
+    float* sRinv = sNorm + BM;                                   // [BM] 1 / norm
+    const bcos_epilogue& e = p.e;
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int64_t pix = -1;
+        if (m < p.M) {
+            const int n = m / p.PQ;
+            const int rem = m - n * p.PQ;
+            const int i = rem / g.Q;
+            const int jj = rem - i * g.Q;
+            pix = ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+        }
+        sPix[tid] = pix;
+    }
+    if (NORM) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float t = ss[i] + __shfl_xor(ss[i], 32);
+            if (wave_n == 0 && lane < 32) {
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
+                const int row = wave_m * WM + i * 32 + lane;
+                sNorm[row] = nrm;
+                sRinv[row] = 1.0f / nrm;
+            }
+        }
+    }
+    __syncthreads();
+    if (NORM && e.norm_out != nullptr && tile_n == 0 && tid < BM) {
+        const int64_t pix = sPix[tid];
+        if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[tid];
+    }
+
+    const bool b_is_2 = e.b == 2.0f && !(e.flags & BCOS_EPI_FORCE_POW);
+    const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
+    const float bm1 = e.b - 1.0f;
+    const int Cout = g.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wave_n * WN + j * 32 + (lane & 31);
+        const bool col_ok = col < Cout;
+        const int colc = col_ok ? col : 0;
+        const float bias = e.bias ? e.bias[colc] : 0.f;
+        const float csc = e.ch_scale ? e.ch_scale[colc] : 1.f;
+        const float csh = e.ch_shift ? e.ch_shift[colc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t pix = sPix[row];
+                if (pix < 0 || !col_ok) continue;
+                const int64_t idx = pix * g.out_pitch + col;
+                float v = acc[i][j][r] + bias;
+                float s = 1.f;
+                if (NORM && !norm_only) {
+                    if (b_is_2) {
+                        s = fabsf(v) * sRinv[row];
+                    } else {
+                        s = powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
+                    }
+                    v *= s;
+                }
+                v = v * csc + csh;   // csc==1, csh==0 when absent: exact
+                s *= csc;
+                if (e.addend) v += e.addend[idx];
+                if (e.relu) {
+                    s = v > 0.f ? s : 0.f;
+                    v = fmaxf(v, 0.f);
+                }
+                if (e.out) e.out[idx] = e.mul ? v * e.mul[idx] : v;
+                if (e.out2) {
+                    float o2 = v;
+                    if (e.mul2) o2 *= e.mul2[idx];
+                    if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
+                    e.out2[idx] = o2;
+                }
+                if (e.scale_out) e.scale_out[idx] = s;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
+    KArgs p = base;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.g.Cout + BN - 1) / BN;
+    const size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHREADS);
+    hipError_t err;
+    if (norm) {
+        auto k = tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true>;
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
+        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+    } else {
+        auto k = tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false>;
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
+        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+    }
+    err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);
+    return BCOS_OK;
+}
+
+}  // namespace
+
+extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
+                            const bcos_epilogue* epi, void* stream) {
+    if (!a || !wt || !geom || !epi) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: NULL argument");
+    const bcos_tapconv_geom& g = *geom;
+    if (g.N <= 0 || g.H <= 0 || g.W <= 0 || g.C <= 0 || g.P <= 0 || g.Q <= 0 || g.TH <= 0 || g.TW <= 0 ||
+        g.Cout <= 0 || g.OH <= 0 || g.OW <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: non-positive dimension");
+    if (g.C % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: C must be a multiple of 4");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(wt)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: operands must be 16-byte aligned");
+    const int64_t M64 = (int64_t)g.N * g.P * g.Q;
+    if (M64 >= (int64_t)1 << 31) return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: more than 2^31 rows");
+    if (!epi->out && !epi->out2 && !epi->scale_out)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: no output buffer");
+    // the last row/col written must be inside the output tensor
+    if ((g.P - 1) * g.out_sh + g.out_h0 >= g.OH || (g.Q - 1) * g.out_sw + g.out_w0 >= g.OW || g.out_h0 < 0 ||
+        g.out_w0 < 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: output mapping outside [OH,OW]");
+
+    KArgs p;
+    p.a = a;
+    p.wt = wt;
+    p.g = g;
+    if (p.g.a_pitch == 0) p.g.a_pitch = g.C;
+    if (p.g.out_pitch == 0) p.g.out_pitch = g.Cout;
+    if (p.g.norm_pitch == 0) p.g.norm_pitch = 1;
+    if (p.g.a_pitch % 4 != 0 || p.g.a_pitch < g.C) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad a_pitch");
+    if (p.g.out_pitch < g.Cout) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad out_pitch");
+    p.e = *epi;
+    p.M = (int)M64;
+    p.PQ = g.P * g.Q;
+    p.Ktot = g.TH * g.TW * g.C;
+    p.cpt = g.C / 4;
+    p.nchunks = p.Ktot / 4;
+    p.nk = (p.nchunks + 7) / 8;
+    p.tiles_m = p.tiles_n = 0;
+    const bool norm = epi->bcos_mode != BCOS_NONE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g.Cout > 64) return launch_cfg<128, 128, 2, 2>(p, norm, s);
+    if (g.Cout > 32) return launch_cfg<128, 64, 2, 2>(p, norm, s);
+    return launch_cfg<128, 32, 4, 1>(p, norm, s);
+}

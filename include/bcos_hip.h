@@ -1,0 +1,251 @@
+/*
+ * bcos_hip.h -- C ABI of the MI355X (gfx950) B-cos forward / explanation hot path.
+ *
+ * The reference (shrebox/B-cosification) has no FFI for this path: the boundary is the
+ * Python nn.Module API of bcos/modules.  Every entry point below
+ * therefore names the reference *function* whose ATen launch sequence it replaces
+ * (paths relative to the reference root), and the Python host layer in
+ * b-cosification_amd/bcos/ binds them with ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer to fp32 data unless the name says otherwise;
+ *     the caller owns every buffer; the library never allocates or frees device memory.
+ *   - all work is enqueued on the hipStream_t passed as `void* stream` (NULL = default
+ *     stream); calls are asynchronous and re-entrant, no global mutable state except the
+ *     thread-local last-error string.
+ *   - return value: 0 = ok, negative = error (BCOS_E_*); never throws.
+ *   - activations are NHWC ("channels-last": pixel-major, channels contiguous).  The
+ *     logical NCHW shape of the reference is kept by the Python layer through
+ *     torch.channels_last strides, so no copies are involved.
+ *   - weights are [Cout][taps][Cin] (K-contiguous, "KRSC"); Cin must be a multiple of 4.
+ */
+#ifndef BCOS_HIP_H
+#define BCOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCOS_ABI_VERSION 1
+
+enum {
+    BCOS_OK = 0,
+    BCOS_E_INVAL = -22,   /* bad shape / alignment / NULL where required */
+    BCOS_E_NOSUP = -95,   /* combination not supported by the kernels   */
+    BCOS_E_LAUNCH = -5    /* hip launch error (see bcos_last_error_string) */
+};
+
+/* B-cos scaling flavour applied to the contraction result `lin` of one output row.
+ *   BCOS_NONE        y = lin                                (b == 1: bcosconv2d.py:172-174)
+ *   BCOS_CONV_EPS    norm = sqrt(sum_patch x^2 + 1e-6)       (bcosconv2d.py:212-221)
+ *   BCOS_LINEAR_EPS  norm = sqrt(sum x^2) + 1e-12            (bcoslinear.py:113)
+ * with  b == 2 : s = |lin| / norm                            (bcosconv2d.py:186-187)
+ *       b != 2 : s = (|lin / norm| + 1e-6)^(b-1)             (bcosconv2d.py:188-190)
+ * and   y = s * lin.                                                                  */
+enum { BCOS_NONE = 0, BCOS_CONV_EPS = 1, BCOS_LINEAR_EPS = 2 };
+
+/*
+ * Generic "tap convolution" descriptor: one implicit GEMM
+ *     acc[m, co] = sum_{t < TH*TW} sum_{c < C} A[n, i*in_sh + dh(t), j*in_sw + dw(t), c] * Wt[co, t, c]
+ * over rows m = (n, i, j), n < N, i < P, j < Q, with dh(t) = dh0 + (t / TW) * dstep_h,
+ * dw(t) = dw0 + (t % TW) * dstep_w, taps outside [0,H)x[0,W) contributing zero
+ * (zero padding).  Row m is written to pixel (n, i*out_sh + out_h0, j*out_sw + out_w0)
+ * of an NHWC tensor [N, OH, OW, Cout].
+ *
+ * A forward convolution (stride s, padding p, dilation d) is
+ *     in_s = s, dh0 = -p, dstep = d, TH x TW = kernel, P x Q = OH x OW, out_s = 1, out_0 = 0.
+ * The input-gradient ("dgrad") of a strided convolution is one launch per output parity
+ * class with the matching sub-kernel, in_s = 1 and out_s = stride (see bcos_hip/conv.py).
+ */
+typedef struct bcos_tapconv_geom {
+    int32_t N, H, W, C;          /* A operand: NHWC, C % 4 == 0                      */
+    int32_t P, Q;                /* row grid per image                              */
+    int32_t in_sh, in_sw;        /* input coordinate step per row-grid step         */
+    int32_t dh0, dw0;            /* first tap offset                                */
+    int32_t dstep_h, dstep_w;    /* tap-to-tap offset (dilation)                    */
+    int32_t TH, TW;              /* tap grid                                        */
+    int32_t OH, OW;              /* output tensor spatial size                      */
+    int32_t out_sh, out_sw;      /* output pixel step per row-grid step             */
+    int32_t out_h0, out_w0;      /* output pixel offset                             */
+    int32_t Cout;                /* GEMM N; output channel count                    */
+    int32_t a_pitch;             /* floats between consecutive pixels of A (0 = C): lets a launch
+                                    read a channel slice (grouped convolution)      */
+    int32_t out_pitch;           /* floats between consecutive output pixels (0 = Cout); every
+                                    per-element epilogue tensor uses the same pitch  */
+    int32_t norm_pitch;          /* floats between consecutive pixels of norm_out (0 = 1) */
+} bcos_tapconv_geom;
+
+/*
+ * Fused epilogue, applied per output element (row m -> output pixel index `pix`,
+ * channel c, idx = pix*out_pitch + c).  NULL pointers / zero flags switch a stage off.
+ * Stages run in this order:
+ *     v = acc
+ *     v += bias[c]                                   nn.Conv2d bias (bcosifyconv2d.py:18-31)
+ *     s = bcos_scale(v, norm[m]); v *= s             B-cos transform (bcos_mode, b)
+ *     v *= ch_scale[c]; s *= ch_scale[c]             BatchNormUncentered2d eval: weight/sqrt(var+eps)
+ *                                                    (batchnorm_uncentered.py:46-60)
+ *     v += ch_shift[c]                               ... its bias
+ *     v += addend[idx]                               residual add (fwd) / gradient accumulation (dgrad)
+ *     relu: s = v > 0 ? s : 0; v = max(v, 0)
+ *     out [idx] = mul  ? v * mul [idx] : v           dgrad: multiply by the stored scale of the layer below
+ *     out2[idx] = v [* mul2[idx]] [* (gate2[idx] > 0)]   second product of the same v (shortcut gradient)
+ *     scale_out[idx] = s                             d out / d lin with the dynamic scale detached
+ *                                                    (explanation mode: bcosconv2d.py:181-184)
+ *     norm_out[pix] = norm[m]                        (only written by blocks of the first Cout tile)
+ */
+typedef struct bcos_epilogue {
+    const float* bias;
+    const float* ch_scale;
+    const float* ch_shift;
+    const float* addend;
+    const float* mul;
+    const float* mul2;
+    const float* gate2;
+    float* out;
+    float* out2;
+    float* scale_out;
+    float* norm_out;
+    int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
+    int32_t relu;
+    float b;                /* the B-cos exponent B (2 = fast path)       */
+    int32_t flags;          /* BCOS_EPI_* bits                            */
+} bcos_epilogue;
+
+/* compute the patch norms (norm_out) but leave v unscaled: used by the MaxOut / grouped
+ * general path, where bcos_maxout_scale applies the scaling afterwards. */
+#define BCOS_EPI_NORM_ONLY 1
+/* use the general (|lin/norm| + 1e-6)^(b-1) form even when b == 2: the reference takes that branch for
+ * its learnable-B variants (bcosifyconv2d.py:91-98 with b_loss). */
+#define BCOS_EPI_FORCE_POW 2
+
+/* -- library -------------------------------------------------------------------------- */
+
+/* ABI version (BCOS_ABI_VERSION of the build). */
+int bcos_version(void);
+
+/* Human-readable description of the last error on this thread ("" if none). */
+const char* bcos_last_error_string(void);
+
+/* -- contraction kernels (fp32 MFMA v_mfma_f32_32x32x2_f32, LDS-tiled implicit GEMM) ----- */
+
+/* The generic fused implicit GEMM every entry point below lowers to. */
+int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
+                 const bcos_epilogue* epi, void* stream);
+
+/*
+ * Replaces BcosConv2d.forward_impl (bcos/modules/bcosconv2d.py:153-194) and
+ * BcosifyConv2d.forward_impl (bcos/modules/bcosifyconv2d.py:50-102) for groups == 1,
+ * max_out == 1: conv2d + calc_patch_norms (bcosconv2d.py:196-231) + |cos|^(B-1) scaling in
+ * one pass.  x [N,H,W,Cin] NHWC, w [Cout,kh,kw,Cin], y [N,Ho,Wo,Cout] NHWC.
+ * `bias` may be NULL.  `scale_out` (NULL or [N,Ho,Wo,Cout]) receives the detached dynamic
+ * scale s = dy/dlin used by the explanation pass; `norm_out` (NULL or [N,Ho,Wo]) the patch
+ * norms.  Unit-norm weights (NormedConv2d, bcosconv2d.py:26-35) are obtained by running
+ * bcos_weight_rownorm_scale on `w` first (the projection is input independent).
+ */
+int bcos_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                    float* scale_out, float* norm_out,
+                    int N, int Cin, int H, int W, int Cout, int kh, int kw,
+                    int sh, int sw, int ph, int pw, int dh, int dw,
+                    float b, void* stream);
+
+/*
+ * Replaces BcosLinear.forward (bcos/modules/bcoslinear.py:88-130) and BcosifyLinear.forward
+ * (bcos/modules/bcosifylinear.py:42-95), max_out == 1.  x [rows,Cin], w [Cout,Cin],
+ * y [rows,Cout].
+ */
+int bcos_linear_fwd(const float* x, const float* w, const float* bias, float* y,
+                    float* scale_out, float* norm_out,
+                    int64_t rows, int Cin, int Cout, float b, void* stream);
+
+/*
+ * Input gradient of bcos_conv2d_fwd in explanation mode (scale detached): replaces the
+ * autograd convolution_backward + mul of bcos/common.py:177.
+ *     gx = conv_transpose(gy * s, w)
+ * gy, s: [N,Ho,Wo,Cout]; wT: [Cin,kh,kw,Cout] = w with the spatial taps flipped and
+ * Cout/Cin swapped (stride 1) -- produced by bcos_hip.conv.prepare_dgrad_weights; for
+ * stride > 1 the Python layer issues one bcos_tapconv per parity class instead.
+ * `gylin` is gy*s precomputed by the caller (bcos_mul) or fused into the producer.
+ */
+int bcos_conv2d_dgrad_s1(const float* gylin, const float* wT, float* gx,
+                         int N, int Cin, int H, int W, int Cout, int kh, int kw,
+                         int ph, int pw, void* stream);
+
+/* Input gradient of bcos_linear_fwd in explanation mode: gx[rows,Cin] = gylin[rows,Cout] @ w. */
+int bcos_linear_dgrad(const float* gylin, const float* wT, float* gx,
+                      int64_t rows, int Cin, int Cout, void* stream);
+
+/* -- HBM-bound helper kernels ---------------------------------------------------------- */
+
+/* w[r,:] *= gain[r] / ||w[r,:]||_2  (gain NULL = 1): NormedConv2d / NormedLinear unit-norm
+ * projection (bcosconv2d.py:28-35, bcoslinear.py:25-27).  One wavefront per row. */
+int bcos_weight_rownorm_scale(const float* w, const float* gain, float* w_out,
+                              int rows, int64_t cols, void* stream);
+
+/* out[i] = a[i] * b[i] */
+int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* MaxOut + B-cos scaling for the non-fused general path (max_out > 1, groups > 1):
+ * lin [rows, Cout*max_out] -> y [rows, Cout] with per-row norms given (bcosconv2d.py:166-194). */
+int bcos_maxout_scale(const float* lin, const float* norm, float* y, float* scale_out,
+                      int32_t* argmax_out, int64_t rows, int Cout, int max_out,
+                      int norm_stride, float b, void* stream);
+
+/*
+ * Network input: AddInverse (bcos/data/transforms.py:54-55, if add_inverse) + the 6-channel
+ * Normalize of BcosifyNetwork (bcosify.py:38-43) + NCHW -> NHWC with channel padding.
+ * x: [N,Cx,H,W] NCHW with Cx = 3 (add_inverse) or 6; out: [N,H,W,Cpad], channels >= 6 zero.
+ */
+int bcos_prep_input(const float* x, float* out, const float* mean6, const float* std6,
+                    int N, int Cx, int H, int W, int Cpad, int add_inverse, void* stream);
+
+/*
+ * End of the explanation pass (bcos/common.py:180-181): from the gradient w.r.t. the
+ * normalised NHWC input gxn [N,H,W,Cpad] produce the dynamic linear weights
+ * W(x) = d logit / d x  [N,6,H,W] NCHW (chain rule through Normalize: / std) and the
+ * contribution map sum_c x_c * W_c  [N,H,W].  x6 is the 6-channel network input
+ * ([N,6,H,W], or [N,3,H,W] with add_inverse).
+ */
+int bcos_finalize_explanation(const float* gxn, const float* x, const float* std6,
+                              float* weights_out, float* contrib_out,
+                              int N, int Cx, int H, int W, int Cpad, int add_inverse,
+                              void* stream);
+
+/* (x * gx).sum(channel) for NCHW tensors: bcos/common.py:181. */
+int bcos_contrib_map(const float* x, const float* gx, float* out,
+                     int N, int C, int H, int W, void* stream);
+
+/* AvgPool2d(k, s, p), count_include_pad = True (torchvision maxpool swapped for
+ * nn.AvgPool2d(3,2,1): bcosification/experiment_parameters.py:99), NHWC. */
+int bcos_avgpool2d_fwd(const float* x, float* y, int N, int H, int W, int C,
+                       int k, int s, int p, int OH, int OW, void* stream);
+/* ... its input gradient, optionally multiplied elementwise by `mul` ([N,H,W,C]). */
+int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, int N, int H, int W, int C,
+                       int k, int s, int p, int OH, int OW, void* stream);
+
+/* AdaptiveAvgPool2d(1) + flatten + LogitLayer (bcos/modules/logitlayer.py:22-27):
+ * y[n,c] = mean_hw x[n,hw,c] / T + bias. */
+int bcos_global_avgpool_logits(const float* x, float* y, int N, int HW, int C,
+                               float inv_temperature, float logit_bias, void* stream);
+
+/* Start of the explanation backward for a GAP head: for every image n with explained class
+ * cls[n],  glin[n,hw,c] = (c == cls[n]) * scale[n,hw,c] * inv_temperature / HW
+ * (the gradient of logit cls[n] w.r.t. the head's `lin`, bcos/common.py:166-177). */
+int bcos_head_onehot_grad(const int64_t* cls, const float* scale, float* glin,
+                          int N, int HW, int C, float inv_temperature, void* stream);
+
+/* Row-wise arg-max over logits [N,C] -> idx [N] (int64), val [N]; ties -> lowest index
+ * (torch.max semantics used at bcos/common.py:166). */
+int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N, int C, void* stream);
+
+/* BatchNormUncentered2d eval as a standalone op (module API path), NHWC:
+ * y = x * scale[c] + shift[c] (shift may be NULL) (batchnorm_uncentered.py:46-60). */
+int bcos_channel_affine(const float* x, const float* scale, const float* shift, float* y,
+                        int64_t pixels, int C, int relu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCOS_HIP_H */

@@ -1,0 +1,279 @@
+"""CPU oracle for the B-cos forward / explanation hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch-fp32-CPU restatement of the reference's
+algorithm (shrebox/B-cosification, paths relative to the reference root).  Only tests/,
+__graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import it -- as the checker or as the
+timed CPU baseline, never as part of the product path (b-cosification_amd/ fails loudly without its
+HIP library instead of falling back to this).
+
+Parity pinning: the reference ships NO tests / golden vectors for this path, so
+this restatement is pinned against outputs of the reference itself, imported in the build
+container by oracle/refimport.py; tests/golden/make_golden.py records those outputs (and the
+oracle-vs-reference differences it measured) as fixtures under tests/golden/.
+
+Everything is functional and works on state dicts with the reference's key layout
+(SURVEY.md section 8 T3), so the same state dict drives the oracle and the HIP product.
+"""
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# bcosify.py:15-20
+IMAGENET_MEAN_ADDINVERSE = (0.485, 0.456, 0.406, 0.515, 0.544, 0.594)
+IMAGENET_STD_ADDINVERSE = (0.229, 0.224, 0.225, 0.229, 0.224, 0.225)
+CLIP_MEAN_ADDINVERSE = (0.48145466, 0.4578275, 0.40821073, 0.51854534, 0.5421725, 0.59178927)
+CLIP_MEAN_ZERO = (0.0,) * 6
+CLIP_STD_ADDINVERSE = (0.26862954, 0.26130258, 0.27577711, 0.26862954, 0.26130258, 0.27577711)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+# ----------------------------------------------------------------------------------------------
+# layer level
+# ----------------------------------------------------------------------------------------------
+def add_inverse(x: torch.Tensor) -> torch.Tensor:
+    """bcos/data/transforms.py:54-55"""
+    return torch.cat([x, 1 - x], dim=-3)
+
+
+def normalize6(x: torch.Tensor, mean: Sequence[float], std: Sequence[float]) -> torch.Tensor:
+    """torchvision.transforms.Normalize as used at bcosify.py:38-43,51-53 (clone, sub_, div_)."""
+    m = torch.tensor(mean, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+    s = torch.tensor(std, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+    return (x - m) / s
+
+
+def unit_norm_weight(w: torch.Tensor) -> torch.Tensor:
+    """NormedConv2d / NormedLinear: bcosconv2d.py:28-29, bcoslinear.py:26."""
+    dims = tuple(range(1, w.dim()))
+    return w / torch.linalg.vector_norm(w, dim=dims, keepdim=True)
+
+
+def patch_norm(x, kernel_size, stride, padding, groups=1, out_channels=None):
+    """BcosConv2d.calc_patch_norms, bcosconv2d.py:196-231 (dilation 1)."""
+    sq = x * x
+    if groups == 1:
+        sq = sq.sum(1, keepdim=True)
+    else:
+        sq = sq.unflatten(1, (groups, x.shape[1] // groups)).sum(2)
+    n = (F.avg_pool2d(sq, kernel_size, padding=padding, stride=stride, divisor_override=1) + 1e-6).sqrt()
+    if groups > 1:
+        n = torch.repeat_interleave(n, repeats=out_channels // groups, dim=1)
+    return n
+
+
+def patch_norm_slow(x, weight_shape, stride, padding, dilation, groups):
+    """BcosConv2d._calc_patch_norms_slow, bcosconv2d.py:233-250 (any dilation)."""
+    ones = torch.ones(weight_shape, dtype=x.dtype, device=x.device)
+    return (F.conv2d(x * x, ones, None, stride, padding, dilation, groups) + 1e-6).sqrt()
+
+
+def _scale_and_apply(out, norm, b, detach):
+    """bcosconv2d.py:176-194 / bcoslinear.py:115-130."""
+    src = out.detach() if detach else out
+    if detach:
+        norm = norm.detach()
+    if b == 2:
+        s = src.abs() / norm
+    else:
+        s = ((src / norm).abs() + 1e-6).pow(b - 1)
+    return s * out, s
+
+
+def _maxout(out, max_out, dim):
+    if max_out > 1:
+        out = out.unflatten(dim, (out.shape[dim] // max_out, max_out)).max(dim=dim + 1 if dim >= 0 else -1).values
+    return out
+
+
+def bcos_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, b=2, max_out=1,
+                detach=False, normalize_weight=False, weight_gain=None, return_scale=False):
+    """BcosConv2d.forward_impl (bcosconv2d.py:153-194) / BcosifyConv2d.forward_impl (bcosifyconv2d.py:50-102).
+
+    normalize_weight=True  -> native BcosConv2d (NormedConv2d unit-norm weights, optional `scale`, bcosconv2d.py:26-35)
+    normalize_weight=False -> BcosifyConv2d (plain nn.Conv2d with optional bias)
+    """
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    w = weight
+    if normalize_weight:
+        w = unit_norm_weight(w)
+        if weight_gain is not None:
+            w = weight_gain * w
+    out = F.conv2d(x, w, bias, stride, padding, dilation, groups)
+    if max_out > 1:
+        out = out.unflatten(1, (out.shape[1] // max_out, max_out)).max(dim=2).values
+    if b == 1:
+        return (out, None) if return_scale else out
+    kh, kw = weight.shape[2], weight.shape[3]
+    if any(d > 1 for d in dilation):
+        norm = patch_norm_slow(x, weight.shape, stride, padding, dilation, groups)
+        if max_out > 1:  # ones-kernel conv gives Cout*max_out identical maps per group
+            norm = norm[:, ::max_out]
+    else:
+        norm = patch_norm(x, (kh, kw), stride, padding, groups, out.shape[1])
+    y, s = _scale_and_apply(out, norm, b, detach)
+    return (y, s) if return_scale else y
+
+
+def bcos_linear(x, weight, bias=None, b=2, max_out=1, detach=False, normalize_weight=False, return_scale=False):
+    """BcosLinear.forward (bcoslinear.py:88-130) / BcosifyLinear.forward (bcosifylinear.py:42-95)."""
+    w = unit_norm_weight(weight) if normalize_weight else weight
+    out = F.linear(x, w, bias)
+    if max_out > 1:
+        out = out.unflatten(-1, (out.shape[-1] // max_out, max_out)).max(dim=-1).values
+    if b == 1:
+        return (out, None) if return_scale else out
+    norm = torch.linalg.vector_norm(x, dim=-1, keepdim=True) + 1e-12
+    y, s = _scale_and_apply(out, norm, b, detach)
+    return (y, s) if return_scale else y
+
+
+def bn_uncentered_eval(x, running_var, weight=None, bias=None, eps=1e-5):
+    """batch_norm_uncentered_2d, eval branch: batchnorm_uncentered.py:46-60."""
+    std = (running_var + eps).sqrt()[None, :, None, None]
+    r = x / std
+    if weight is not None:
+        r = weight[None, :, None, None] * r
+    if bias is not None:
+        r = r + bias[None, :, None, None]
+    return r.type(x.dtype)
+
+
+def bn_uncentered_fold(bn_weight, bn_bias, running_mean, running_var, eps, norm_layer="BnUncV2"):
+    """BatchNormUncentered2d.from_standard_module: batchnorm_uncentered.py:117-141 (returns weight, bias)."""
+    if bn_bias is not None and norm_layer == "BnUncV2":
+        std = (running_var + eps).sqrt()
+        return bn_weight, bn_bias - (running_mean / std) * bn_weight
+    return bn_weight, bn_bias
+
+
+def layer_norm_detachable(x, normalized_shape, weight, bias, eps=1e-5, detach=False):
+    """DetachableLayerNorm.forward: centered_norms.py:197-224."""
+    if not detach:
+        return F.layer_norm(x, normalized_shape, weight, bias, eps)
+    d = len(normalized_shape)
+    var, mean = torch.var_mean(x, dim=tuple(range(-d, 0)), unbiased=False, keepdim=True)
+    std = (var.detach() + eps).sqrt()
+    y = (x - mean) / std
+    if weight is not None:
+        y = weight * y
+    if bias is not None:
+        y = y + bias
+    return y
+
+
+def gelu_detachable(x, detach=False):
+    """MyGELU.forward: bcosify_vit.py:27-32."""
+    gate = 0.5 * (1 + torch.erf(x / np.sqrt(2)))
+    if detach:
+        gate = gate.detach()
+    return gate * x
+
+
+def logit_layer(x, temperature=None, bias=None):
+    """LogitLayer.forward: bcos/modules/logitlayer.py:22-27."""
+    if temperature is not None:
+        x = x / temperature
+    if bias is not None:
+        x = x + bias
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# B-cosified ResNet (torchvision topology, classifier before GAP: bcos/models/standard_models.py:36-54,
+# conversion bcosify.py:74-114, factory bcos/experiments/ImageNet/bcosification/model.py:15-57)
+# ----------------------------------------------------------------------------------------------
+RESNET_SPECS = {
+    "resnet18": ("basic", [2, 2, 2, 2]),
+    "resnet34": ("basic", [3, 4, 6, 3]),
+    "resnet50": ("bottleneck", [3, 4, 6, 3]),
+}
+
+
+def _bnu(sd, prefix, x):
+    return bn_uncentered_eval(x, sd[prefix + ".running_var"], sd.get(prefix + ".weight"), sd.get(prefix + ".bias"),
+                              eps=1e-5)
+
+
+def _bconv(sd, prefix, x, stride, padding, b, detach):
+    return bcos_conv2d(x, sd[prefix + ".linear.weight"], sd.get(prefix + ".linear.bias"), stride=stride,
+                       padding=padding, b=b, detach=detach)
+
+
+def resnet_features(sd: Dict[str, torch.Tensor], xn: torch.Tensor, arch: str, b=2, detach=False, prefix="model.",
+                    stem_pool="avg", taps: Optional[dict] = None):
+    """Body of ResNetBcos._forward_impl up to and including `fc` (a 1x1 B-cos conv), on the normalised input."""
+    kind, blocks = RESNET_SPECS[arch]
+    x = _bconv(sd, prefix + "conv1", xn, 2, 3, b, detach)
+    x = F.relu(_bnu(sd, prefix + "bn1", x))
+    if stem_pool == "avg":   # standard_changes: maxpool -> nn.AvgPool2d(3, 2, 1)   (experiment_parameters.py:99)
+        x = F.avg_pool2d(x, kernel_size=3, stride=2, padding=1)
+    else:
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li, nblocks in enumerate(blocks, start=1):
+        for bi in range(nblocks):
+            p = f"{prefix}layer{li}.{bi}."
+            stride = 2 if (li > 1 and bi == 0) else 1
+            identity = x
+            if kind == "basic":
+                out = F.relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, stride, 1, b, detach)))
+                out = _bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, 1, 1, b, detach))
+            else:  # torchvision v1.5: stride on the 3x3
+                out = F.relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, 1, 0, b, detach)))
+                out = F.relu(_bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, stride, 1, b, detach)))
+                out = _bnu(sd, p + "bn3", _bconv(sd, p + "conv3", out, 1, 0, b, detach))
+            if (p + "downsample.0.linear.weight") in sd:
+                identity = _bnu(sd, p + "downsample.1", _bconv(sd, p + "downsample.0", x, stride, 0, b, detach))
+            x = F.relu(out + identity)
+            if taps is not None:
+                taps[f"layer{li}.{bi}"] = x
+    x = _bconv(sd, prefix + "fc", x, 1, 0, b, detach)
+    return x
+
+
+def resnet_logits(sd, x6, arch, b=2, detach=False, mean=IMAGENET_MEAN_ADDINVERSE, std=IMAGENET_STD_ADDINVERSE,
+                  logit_bias=-math.log(1000 - 1), logit_temperature=None, stem_pool="avg"):
+    """BcosifyNetwork.forward (bcosify.py:50-53) for a B-cosified torchvision ResNet with logit layer."""
+    xn = normalize6(x6, mean, std)
+    f = resnet_features(sd, xn, arch, b=b, detach=detach, stem_pool=stem_pool)
+    logits = F.adaptive_avg_pool2d(f, 1).flatten(1)
+    return logit_layer(logits, logit_temperature, logit_bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# explanation (bcos/common.py:92-188, 280-317; interpretability/explanation_methods/explainers/captum.py:29-32)
+# ----------------------------------------------------------------------------------------------
+def explain_batch(forward_fn, x: torch.Tensor, targets: Optional[torch.Tensor] = None):
+    """Batched form of BcosUtilMixin.explain: forward in explanation mode, backward of the chosen logit.
+
+    forward_fn(x, detach=True) -> logits [N,K].  Returns dict(logits, prediction, explained_class_idx,
+    dynamic_linear_weights [N,C,H,W], contribution_map [N,H,W]).  Samples are independent in eval mode,
+    so back-propagating the sum of the selected logits equals N separate explain() calls."""
+    x = x.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        logits = forward_fn(x, detach=True)
+        pred = logits.max(1)
+        idx = pred.indices if targets is None else targets
+        sel = logits.gather(1, idx.view(-1, 1)).sum()
+        (grad,) = torch.autograd.grad(sel, x)
+    return dict(logits=logits.detach(), prediction=pred.indices, explained_class_idx=idx,
+                dynamic_linear_weights=grad, contribution_map=(x.detach() * grad).sum(1))
+
+
+def gradient_to_image(image, linear_mapping, smooth=15, alpha_percentile=99.5):
+    """bcos/common.py:387-436 -> RGBA [H,W,4] numpy."""
+    contribs = (image * linear_mapping).sum(0, keepdim=True)
+    rgb = linear_mapping / (linear_mapping.abs().max(0, keepdim=True).values + 1e-12)
+    rgb = rgb.clamp(min=0)
+    rgb = rgb[:3] / (rgb[:3] + rgb[3:] + 1e-12)
+    alpha = linear_mapping.norm(p=2, dim=0, keepdim=True)
+    alpha = torch.where(contribs < 0, 1e-12, alpha)
+    if smooth:
+        alpha = F.avg_pool2d(alpha, smooth, stride=1, padding=(smooth - 1) // 2)
+    alpha = (alpha / torch.quantile(alpha, q=alpha_percentile / 100)).clip(0, 1)
+    return torch.cat([rgb, alpha], dim=0).permute(1, 2, 0).detach().cpu().numpy()
