@@ -71,10 +71,13 @@ class _Conv:
         return (ops.conv_out_size(H, self.k[0], self.stride[0], self.padding[0], self.dilation[0]),
                 ops.conv_out_size(W, self.k[1], self.stride[1], self.padding[1], self.dilation[1]))
 
-    def fwd(self, x, *, addend=None, relu=False, want_scale=False):
+    def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None):
+        gate = gates.pop(0) if (relu and gates is not None) else None
         y, t, _ = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
                                  bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
-                                 ch_shift=self.ch_shift, addend=addend, relu=relu, want_scale=want_scale)
+                                 ch_shift=self.ch_shift, addend=addend, relu=relu, relu_gate=gate,
+                                 want_scale=want_scale)
+        self.last_gate = gate       # the replayed gate tensor, if any (else the output itself encodes the gate)
         return y, t
 
 
@@ -143,18 +146,18 @@ class ResNetEngine:
         return self._dev_consts[key]
 
     # ------------------------------------------------------------------------------------------------
-    def _run_forward(self, x: torch.Tensor, keep: bool):
+    def _run_forward(self, x: torch.Tensor, keep: bool, gates=None):
         if x.dim() != 4 or x.shape[1] not in (3, 6):
             raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
-        if not x.is_cuda:
-            raise BcosHipError("engine: input must be a HIP tensor (no CPU fallback)")
+        ops.require_device(x, "bcos_hip.engine")
         x = x.detach()
         x = x if x.is_contiguous() else x.contiguous()
         mean, std = self._consts(x.device)
         add_inverse = x.shape[1] == 3
         xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse)
         st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3]) if keep else None
-        a0, t0 = self.stem.fwd(xn, relu=self.stem_relu, want_scale=keep)
+        gates = list(gates) if gates is not None else None
+        a0, t0 = self.stem.fwd(xn, relu=self.stem_relu, want_scale=keep, gates=gates)
         k, s, p = self.pool
         cur = ops.avgpool2d_fwd(a0, k, s, p)
         if keep:
@@ -167,17 +170,19 @@ class ResNetEngine:
             ts, hws = [], []
             for c in blk.convs[:-1]:
                 hws.append((h.shape[1], h.shape[2]))
-                h, t = c.fwd(h, relu=blk.relu, want_scale=keep)
+                h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates)
                 ts.append(t)
             if blk.shortcut is not None:
                 idn, td = blk.shortcut.fwd(inp, relu=False, want_scale=keep)
             else:
                 idn, td = inp, None
             hws.append((h.shape[1], h.shape[2]))
-            out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep)
+            out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates)
             ts.append(t)
             if keep:
-                rec.update(ts=ts, td=td, out=out if blk.relu else None, hws=hws)
+                # `out` doubles as the gate of the shortcut gradient: with replayed gates a closed gate stores exactly 0
+                pinned = blk.convs[-1].last_gate
+                rec.update(ts=ts, td=td, out=(pinned if pinned is not None else out) if blk.relu else None, hws=hws)
                 st["blocks"].append(rec)
             cur = out
         f, tf = self.head.fwd(cur, relu=False, want_scale=keep)
@@ -191,10 +196,13 @@ class ResNetEngine:
         return self._run_forward(x, keep=False)[0]
 
     @torch.no_grad()
-    def explain(self, x: torch.Tensor, targets: Optional[torch.Tensor] = None, want_weights: bool = True) -> Dict[str, torch.Tensor]:
+    def explain(self, x: torch.Tensor, targets: Optional[torch.Tensor] = None, want_weights: bool = True,
+                gates=None) -> Dict[str, torch.Tensor]:
         """Forward in explanation mode + input-gradient pass of the explained logit of every image
-        (batched bcos/common.py:163-181).  `targets` [N] int64 selects the logits (default: arg-max)."""
-        logits, st = self._run_forward(x, keep=True)
+        (batched bcos/common.py:163-181).  `targets` [N] int64 selects the logits (default: arg-max).
+        `gates`: optional list of NHWC 0/1 tensors, one per ReLU in execution order, that REPLACE the v > 0
+        decisions (replay of gates recorded elsewhere; used by the gate-pinned parity test)."""
+        logits, st = self._run_forward(x, keep=True, gates=gates)
         pred, _ = ops.argmax_rows(logits)
         cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
         # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale

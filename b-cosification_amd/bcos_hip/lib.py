@@ -10,6 +10,9 @@ import subprocess
 import sys
 from pathlib import Path
 
+import torch  # noqa: F401  -- MUST precede CDLL: torch ships its own libamdhip64; loading ours first would bring a
+#                      second HIP runtime (/opt/rocm) into the process and torch then finds no device
+
 PKG_ROOT = Path(__file__).resolve().parent.parent          # b-cosification_amd/
 REPO_ROOT = PKG_ROOT.parent
 LIB_PATH = PKG_ROOT / "lib" / "libbcos_hip.so"
@@ -36,7 +39,7 @@ class TapconvGeom(C.Structure):
 
 class Epilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2",
+        "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2", "relu_gate",
         "out", "out2", "scale_out", "norm_out")] + [
         ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32)]
 

@@ -31,8 +31,13 @@ def _dev(t: Optional[torch.Tensor], what: str, contiguous: bool = True):
     return C.c_void_p(t.data_ptr())
 
 
-def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+def require_device(t: torch.Tensor, who: str = "bcos_hip"):
+    """Fail loudly on anything that is not an fp32 HIP tensor: there is no CPU fallback."""
+    if not t.is_cuda:
+        raise BcosHipError(f"{who}: input is on {t.device}; the B-cos hot path only exists as HIP kernels for "
+                           "gfx950 (no CPU fallback) -- move the model and the input to 'cuda'")
+    if t.dtype != torch.float32:
+        raise BcosHipError(f"{who}: the hot path is fp32 end to end (got {t.dtype})")
 
 
 def conv_out_size(size, k, s, p, d=1):
@@ -41,7 +46,7 @@ def conv_out_size(size, k, s, p, d=1):
 
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
-            gate2=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0):
+            gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0):
     """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv)."""
     lib = _l.load()
     g = TapconvGeom()
@@ -51,7 +56,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         setattr(g, k, int(v))
     e = Epilogue()
     tensors = dict(bias=bias, ch_scale=ch_scale, ch_shift=ch_shift, addend=addend, mul=mul, mul2=mul2,
-                   gate2=gate2, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out)
+                   gate2=gate2, relu_gate=relu_gate, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out)
     for k, t in tensors.items():
         p = _dev(t, f"tapconv.{k}", contiguous=False)
         setattr(e, k, p.value if p is not None else None)
@@ -70,8 +75,8 @@ def fwd_geom(N, H, W, Cin, Cout, kh, kw, sh, sw, ph, pw, dh=1, dw=1):
 
 
 def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=None, b=2.0, mode=BCOS_CONV_EPS,
-               ch_scale=None, ch_shift=None, addend=None, relu=False, want_scale=False, want_norm=False,
-               out=None, scale_out=None):
+               ch_scale=None, ch_shift=None, addend=None, relu=False, relu_gate=None, want_scale=False,
+               want_norm=False, out=None, scale_out=None):
     """Fused B-cos convolution.  x [N,H,W,Cin], w [Cout,kh,kw,Cin] -> y [N,Ho,Wo,Cout] (+ scale, norm)."""
     N, H, W, Cin = x.shape
     Cout, kh, kw, Cin_w = w.shape
@@ -86,7 +91,7 @@ def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=Non
     if float(b) == 1.0:
         mode = BCOS_NONE
     tapconv(x, w, g, out=out, scale_out=scale_out, norm_out=norm, bias=bias, ch_scale=ch_scale,
-            ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu)
+            ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu, relu_gate=relu_gate)
     return out, scale_out, norm
 
 

@@ -278,8 +278,9 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
                 s *= csc;
                 if (e.addend) v += e.addend[idx];
                 if (e.relu) {
-                    s = v > 0.f ? s : 0.f;
-                    v = fmaxf(v, 0.f);
+                    const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
+                    s = open_gate ? s : 0.f;
+                    v = open_gate ? v : 0.f;
                 }
                 if (e.out) e.out[idx] = e.mul ? v * e.mul[idx] : v;
                 if (e.out2) {

@@ -89,7 +89,8 @@ typedef struct bcos_tapconv_geom {
  *                                                    (batchnorm_uncentered.py:46-60)
  *     v += ch_shift[c]                               ... its bias
  *     v += addend[idx]                               residual add (fwd) / gradient accumulation (dgrad)
- *     relu: s = v > 0 ? s : 0; v = max(v, 0)
+ *     relu: s = v > 0 ? s : 0; v = max(v, 0)         (relu_gate != NULL: the decision is relu_gate[idx] > 0 instead of
+ *                                                    v > 0 -- replay of recorded gates, see tests/ gate-pinned parity)
  *     out [idx] = mul  ? v * mul [idx] : v           dgrad: multiply by the stored scale of the layer below
  *     out2[idx] = v [* mul2[idx]] [* (gate2[idx] > 0)]   second product of the same v (shortcut gradient)
  *     scale_out[idx] = s                             d out / d lin with the dynamic scale detached
@@ -104,6 +105,7 @@ typedef struct bcos_epilogue {
     const float* mul;
     const float* mul2;
     const float* gate2;
+    const float* relu_gate;
     float* out;
     float* out2;
     float* scale_out;

@@ -85,12 +85,6 @@ def _scale_and_apply(out, norm, b, detach):
     return s * out, s
 
 
-def _maxout(out, max_out, dim):
-    if max_out > 1:
-        out = out.unflatten(dim, (out.shape[dim] // max_out, max_out)).max(dim=dim + 1 if dim >= 0 else -1).values
-    return out
-
-
 def bcos_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, b=2, max_out=1,
                 detach=False, normalize_weight=False, weight_gain=None, return_scale=False):
     """BcosConv2d.forward_impl (bcosconv2d.py:153-194) / BcosifyConv2d.forward_impl (bcosifyconv2d.py:50-102).
@@ -206,11 +200,18 @@ def _bconv(sd, prefix, x, stride, padding, b, detach):
 
 
 def resnet_features(sd: Dict[str, torch.Tensor], xn: torch.Tensor, arch: str, b=2, detach=False, prefix="model.",
-                    stem_pool="avg", taps: Optional[dict] = None):
-    """Body of ResNetBcos._forward_impl up to and including `fc` (a 1x1 B-cos conv), on the normalised input."""
+                    stem_pool="avg", taps: Optional[dict] = None, gate_log: Optional[list] = None):
+    """Body of ResNetBcos._forward_impl up to and including `fc` (a 1x1 B-cos conv), on the normalised input.
+    `gate_log`, if given, receives the pre-activation of every ReLU in execution order."""
     kind, blocks = RESNET_SPECS[arch]
+
+    def relu(t):
+        if gate_log is not None:
+            gate_log.append(t.detach())
+        return F.relu(t)
+
     x = _bconv(sd, prefix + "conv1", xn, 2, 3, b, detach)
-    x = F.relu(_bnu(sd, prefix + "bn1", x))
+    x = relu(_bnu(sd, prefix + "bn1", x))
     if stem_pool == "avg":   # standard_changes: maxpool -> nn.AvgPool2d(3, 2, 1)   (experiment_parameters.py:99)
         x = F.avg_pool2d(x, kernel_size=3, stride=2, padding=1)
     else:
@@ -221,15 +222,15 @@ def resnet_features(sd: Dict[str, torch.Tensor], xn: torch.Tensor, arch: str, b=
             stride = 2 if (li > 1 and bi == 0) else 1
             identity = x
             if kind == "basic":
-                out = F.relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, stride, 1, b, detach)))
+                out = relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, stride, 1, b, detach)))
                 out = _bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, 1, 1, b, detach))
             else:  # torchvision v1.5: stride on the 3x3
-                out = F.relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, 1, 0, b, detach)))
-                out = F.relu(_bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, stride, 1, b, detach)))
+                out = relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, 1, 0, b, detach)))
+                out = relu(_bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, stride, 1, b, detach)))
                 out = _bnu(sd, p + "bn3", _bconv(sd, p + "conv3", out, 1, 0, b, detach))
             if (p + "downsample.0.linear.weight") in sd:
                 identity = _bnu(sd, p + "downsample.1", _bconv(sd, p + "downsample.0", x, stride, 0, b, detach))
-            x = F.relu(out + identity)
+            x = relu(out + identity)
             if taps is not None:
                 taps[f"layer{li}.{bi}"] = x
     x = _bconv(sd, prefix + "fc", x, 1, 0, b, detach)
@@ -237,10 +238,10 @@ def resnet_features(sd: Dict[str, torch.Tensor], xn: torch.Tensor, arch: str, b=
 
 
 def resnet_logits(sd, x6, arch, b=2, detach=False, mean=IMAGENET_MEAN_ADDINVERSE, std=IMAGENET_STD_ADDINVERSE,
-                  logit_bias=-math.log(1000 - 1), logit_temperature=None, stem_pool="avg"):
+                  logit_bias=-math.log(1000 - 1), logit_temperature=None, stem_pool="avg", gate_log=None):
     """BcosifyNetwork.forward (bcosify.py:50-53) for a B-cosified torchvision ResNet with logit layer."""
     xn = normalize6(x6, mean, std)
-    f = resnet_features(sd, xn, arch, b=b, detach=detach, stem_pool=stem_pool)
+    f = resnet_features(sd, xn, arch, b=b, detach=detach, stem_pool=stem_pool, gate_log=gate_log)
     logits = F.adaptive_avg_pool2d(f, 1).flatten(1)
     return logit_layer(logits, logit_temperature, logit_bias)
 

@@ -1,0 +1,210 @@
+"""CPU emulation of the C-ABI *semantics* for host-logic tests (TEST INFRASTRUCTURE, `-m "not gpu"` only).
+
+The product has no CPU path.  To test the host side (launch descriptors, parity-class decomposition of strided
+input gradients, the fused engine's forward/backward plan, sharding) without a GPU, the tests monkeypatch the
+thin wrappers in `bcos_hip.ops` with the pure-torch interpreters below, which implement exactly what
+include/bcos_hip.h documents for each entry point.  Nothing here is reachable from the product.
+"""
+import torch
+import torch.nn.functional as F
+
+from bcos_hip.lib import BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_NORM_ONLY, BCOS_LINEAR_EPS, BCOS_NONE
+
+
+def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
+            ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
+            b=2.0, relu=False, flags=0):
+    g = dict(a_pitch=0, out_pitch=0, norm_pitch=0)
+    g.update(geom)
+    N, H, W, C = g["N"], g["H"], g["W"], g["C"]
+    P, Q, TH, TW, Cout = g["P"], g["Q"], g["TH"], g["TW"], g["Cout"]
+    a4 = (a if a.dim() == 4 else a.view(N, H, W, -1))[..., :C]
+    w = wt.reshape(Cout, TH, TW, C)
+    acc = torch.zeros(N, P, Q, Cout, dtype=torch.float64)
+    ss = torch.zeros(N, P, Q, dtype=torch.float64)
+    ii = torch.arange(P) * g["in_sh"]
+    jj = torch.arange(Q) * g["in_sw"]
+    for th in range(TH):
+        for tw in range(TW):
+            ih = ii + g["dh0"] + th * g["dstep_h"]
+            iw = jj + g["dw0"] + tw * g["dstep_w"]
+            vh = (ih >= 0) & (ih < H)
+            vw = (iw >= 0) & (iw < W)
+            patch = a4[:, ih.clamp(0, H - 1)][:, :, iw.clamp(0, W - 1)].double()
+            patch = patch * (vh[:, None] & vw[None, :])[None, :, :, None]
+            acc += torch.einsum("npqc,oc->npqo", patch, w[:, th, tw].double())
+            ss += (patch * patch).sum(-1)
+    v = acc
+    if bias is not None:
+        v = v + bias.double()
+    s = torch.ones_like(v)
+    nrm = None
+    if bcos_mode != BCOS_NONE:
+        nrm = ss.sqrt() + 1e-12 if bcos_mode == BCOS_LINEAR_EPS else (ss + 1e-6).sqrt()
+        if not (flags & BCOS_EPI_NORM_ONLY):
+            if b == 2.0 and not (flags & BCOS_EPI_FORCE_POW):
+                s = v.abs() / nrm[..., None]
+            else:
+                s = ((v / nrm[..., None]).abs() + 1e-6).pow(b - 1)
+            v = v * s
+    if ch_scale is not None:
+        v = v * ch_scale.double()
+        s = s * ch_scale.double()
+    if ch_shift is not None:
+        v = v + ch_shift.double()
+    oh = torch.arange(P) * g["out_sh"] + g["out_h0"]
+    ow = torch.arange(Q) * g["out_sw"] + g["out_w0"]
+
+    def v4(t):
+        return t if t.dim() == 4 else t.view(N, g["OH"], g["OW"], -1)
+
+    def rd(t):
+        return v4(t)[:, oh][:, :, ow][..., :Cout].double()
+
+    def wr(t, val):
+        v4(t)[:, oh[:, None], ow[None, :], :Cout] = val.to(t.dtype)
+
+    if addend is not None:
+        v = v + rd(addend)
+    if relu:
+        open_gate = (rd(relu_gate) > 0) if relu_gate is not None else (v > 0)
+        s = torch.where(open_gate, s, torch.zeros_like(s))
+        v = torch.where(open_gate, v, torch.zeros_like(v))
+    if out is not None:
+        wr(out, v * rd(mul) if mul is not None else v)
+    if out2 is not None:
+        o2 = v
+        if mul2 is not None:
+            o2 = o2 * rd(mul2)
+        if gate2 is not None:
+            o2 = torch.where(rd(gate2) > 0, o2, torch.zeros_like(o2))
+        wr(out2, o2)
+    if scale_out is not None:
+        wr(scale_out, s)
+    if norm_out is not None and nrm is not None:
+        no = norm_out if norm_out.dim() == 4 else norm_out.view(N, g["OH"], g["OW"], 1)
+        no[:, oh[:, None], ow[None, :], 0] = nrm.to(no.dtype)
+
+
+def prep_input(x, mean6, std6, cpad=8, add_inverse=False):
+    if add_inverse:
+        x = torch.cat([x, 1 - x], 1)
+    xn = (x - mean6.view(1, 6, 1, 1)) / std6.view(1, 6, 1, 1)
+    return F.pad(xn.permute(0, 2, 3, 1), (0, cpad - 6)).contiguous()
+
+
+def finalize_explanation(gxn, x, std6, add_inverse=False, want_weights=True, want_contrib=True):
+    if add_inverse:
+        x = torch.cat([x, 1 - x], 1)
+    w = gxn[..., :6].permute(0, 3, 1, 2) / std6.view(1, 6, 1, 1)
+    return (w.contiguous() if want_weights else None), ((x * w).sum(1) if want_contrib else None)
+
+
+def avgpool2d_fwd(x, k, s, p, out=None):
+    y = F.avg_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def avgpool2d_bwd(gy, H, W, k, s, p, mul=None, out=None):
+    with torch.enable_grad():
+        x = torch.zeros(gy.shape[0], gy.shape[3], H, W, requires_grad=True)
+        y = F.avg_pool2d(x, k, s, p)
+        (gx,) = torch.autograd.grad(y, x, gy.permute(0, 3, 1, 2))
+    gx = gx.permute(0, 2, 3, 1).contiguous()
+    if mul is not None:
+        gx = gx * mul
+    if out is not None:
+        out.copy_(gx)
+        return out
+    return gx
+
+
+def global_avgpool_logits(x, temperature=None, bias=None):
+    y = x.mean((1, 2))
+    if temperature is not None:
+        y = y / temperature
+    if bias is not None:
+        y = y + bias
+    return y
+
+
+def head_onehot_grad(cls, scale, temperature=None, out=None):
+    N, H, W, C = scale.shape
+    coef = (1.0 if temperature is None else 1.0 / temperature) / (H * W)
+    onehot = F.one_hot(cls, C).to(scale.dtype).view(N, 1, 1, C)
+    return onehot * scale * coef
+
+
+def argmax_rows(x2d):
+    v, i = x2d.max(1)
+    return i, v
+
+
+def mul(a, b, out=None):
+    return a * b
+
+
+def channel_affine(x, scale, shift=None, relu=False, out=None):
+    y = x * scale
+    if shift is not None:
+        y = y + shift
+    if relu:
+        y = y.clamp_min(0)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def weight_rownorm_scale(w2d, gain=None):
+    flat = w2d.reshape(w2d.shape[0], -1)
+    out = flat / flat.norm(dim=1, keepdim=True)
+    if gain is not None:
+        out = gain.view(-1, 1) * out
+    return out.view_as(w2d)
+
+
+def contrib_map(x, gx):
+    return (x * gx).sum(1)
+
+
+def install(monkeypatch):
+    """Patch bcos_hip.ops with the emulators (pytest monkeypatch fixture) and lift the HIP-device checks."""
+    from bcos_hip import ops
+    for name in ("tapconv", "prep_input", "finalize_explanation", "avgpool2d_fwd", "avgpool2d_bwd",
+                 "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
+                 "weight_rownorm_scale", "contrib_map", "maxout_scale"):
+        monkeypatch.setattr(ops, name, globals()[name])
+    monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
+    from bcos.modules import _hipfn
+    monkeypatch.setattr(_hipfn, "require_hip", lambda t, who="": None)
+
+
+def maxout_scale(lin2d, norm, Cout, max_out, b, groups=1, want_scale=False, want_argmax=False, out=None):
+    rows = lin2d.shape[0]
+    u = lin2d.view(rows, Cout, max_out)
+    best, arg = u.max(-1)
+    s = torch.ones_like(best)
+    if norm is not None:
+        nrm = norm.view(rows, groups).repeat_interleave(Cout // groups, dim=1)
+        s = best.abs() / nrm if b == 2.0 else ((best / nrm).abs() + 1e-6).pow(b - 1)
+    y = s * best
+    if out is not None:
+        out.copy_(y)
+        y = out
+    return y, (s if want_scale else None), (arg.to(torch.int32) if want_argmax else None)
+
+
+class _Setter:
+    """Stand-in for pytest's monkeypatch in spawned worker processes (no undo needed there)."""
+
+    @staticmethod
+    def setattr(obj, name, value):
+        setattr(obj, name, value)
+
+
+def install_permanent():
+    install(_Setter)

@@ -1,0 +1,312 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (/root/reference) on CPU.
+
+Run in the build container only:   python tests/golden/make_golden.py
+(needs /root/reference; see oracle/refimport.py for how the reference is imported without its third-party
+dependencies).  The fixtures are data -- seeded inputs, the reference's outputs, and the calibration record that
+pins the synthetic weights -- never reference source.  While generating, the script also checks the CPU oracle
+(oracle/bcos_oracle.py) against the live reference and writes the differences it measured to
+tests/golden/oracle_vs_reference.json, which is what "oracle pinned" means in DESIGN.md.
+"""
+import json
+import math
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from oracle import refimport  # noqa: E402
+
+refimport.setup()
+sys.path.append(os.path.join(REPO, "b-cosification_amd"))   # AFTER the reference: only `bcos_hip.synth` is used
+
+from bcos_hip import synth  # noqa: E402
+from oracle import bcos_oracle as O  # noqa: E402
+
+R = refimport.modules()
+torch.set_num_threads(8)
+REPORT = {}
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300)), float((a - b).abs().max())
+
+
+def t2n(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+# --------------------------------------------------------------------------------------------------------
+# F1: per-layer cases (BcosConv2d / BcosifyConv2d / BcosLinear / BcosifyLinear), explanation mode
+# --------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name,            kind,      cin, cout, k, s, p, d, g, b,   max_out, bias,  H,  W
+    ("c1x1",          "bcosify",  16,  24,  1, 1, 0, 1, 1, 2,   1, False, 9, 7),
+    ("c3x3",          "bcosify",  16,  20,  3, 1, 1, 1, 1, 2,   1, False, 9, 7),
+    ("c3x3_s2",       "bcosify",  16,  20,  3, 2, 1, 1, 1, 2,   1, False, 10, 9),
+    ("c1x1_s2",       "bcosify",  16,  32,  1, 2, 0, 1, 1, 2,   1, False, 10, 9),
+    ("c7x7_s2_stem",  "bcosify",   6,  16,  7, 2, 3, 1, 1, 2,   1, False, 20, 18),
+    ("c3x3_bias",     "bcosify",  12,  20,  3, 1, 1, 1, 1, 2,   1, True,  8, 8),
+    ("c3x3_b1",       "bcosify",  12,  20,  3, 1, 1, 1, 1, 1,   1, False, 8, 8),
+    ("c3x3_b1p5",     "bcosify",  12,  20,  3, 1, 1, 1, 1, 1.5, 1, False, 8, 8),
+    ("native_c3x3",   "bcos",     12,  20,  3, 1, 1, 1, 1, 2,   1, False, 8, 8),
+    ("native_maxout", "bcos",     12,  10,  3, 1, 1, 1, 1, 2,   2, False, 8, 8),
+    ("native_groups", "bcos",     16,  24,  3, 1, 1, 1, 2, 2,   1, False, 8, 8),
+    ("native_dil2",   "bcos",     12,  20,  3, 1, 2, 2, 1, 2,   1, False, 9, 9),
+    ("native_b2p5",   "bcos",      8,  12,  3, 2, 1, 1, 1, 2.5, 1, False, 9, 9),
+]
+LINEAR_CASES = [
+    # name,          kind,     cin, cout, b, max_out, bias, lead shape
+    ("l_bcosify",   "bcosify", 48,  40,  2,   1, False, (3, 7)),
+    ("l_bias",      "bcosify", 48,  40,  2,   1, True,  (3, 7)),
+    ("l_native",    "bcos",    48,  40,  2,   1, False, (5,)),
+    ("l_maxout",    "bcos",    32,  12,  2,   2, False, (5,)),
+    ("l_b1p5",      "bcos",    32,  24,  1.5, 1, False, (2, 3)),
+    ("l_odd",       "bcosify", 30,  10,  2,   1, False, (6,)),
+]
+
+
+def layer_cases():
+    out = {}
+    import warnings
+    warnings.simplefilter("ignore")
+    g = torch.Generator().manual_seed(2024)
+    for (name, kind, cin, cout, k, s, p, d, groups, b, mo, bias, H, W) in CONV_CASES:
+        if kind == "bcos":
+            mod = R.bcos_modules.BcosConv2d(cin, cout, k, s, p, d, groups, b=b, max_out=mo)
+        else:
+            mod = R.bcosifyconv2d.BcosifyConv2d(cin, cout, k, s, p, d, groups, b=b, max_out=mo, bias=bias)
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+            if getattr(mod.linear, "bias", None) is not None:
+                mod.linear.bias.copy_(torch.randn(mod.linear.bias.shape, generator=g) * 0.1)
+        x = torch.randn(2, cin, H, W, generator=g)
+        mod.eval()
+        y_plain = mod(x).detach()
+        mod.set_explanation_mode(True)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, xr, gy)
+        case = dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=gx)
+        if getattr(mod.linear, "bias", None) is not None:
+            case["bias"] = mod.linear.bias.detach()
+        assert torch.equal(y.detach(), y_plain)
+        # oracle check
+        xo = x.clone().requires_grad_(True)
+        yo = O.bcos_conv2d(xo, case["weight"], case.get("bias"), s, p, d, groups, b, mo, detach=True,
+                           normalize_weight=(kind == "bcos"))
+        (gxo,) = torch.autograd.grad(yo, xo, gy)
+        REPORT[f"layer/{name}"] = dict(y=rel(yo, y), gx=rel(gxo, gx))
+        for kk, vv in case.items():
+            out[f"{name}/{kk}"] = vv
+    for (name, kind, cin, cout, b, mo, bias, lead) in LINEAR_CASES:
+        if kind == "bcos":
+            mod = R.bcos_modules.BcosLinear(cin, cout, b=b, max_out=mo)
+        else:
+            mod = R.bcosifylinear.BcosifyLinear(cin, cout, b=b, max_out=mo, bias=bias)
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+            if getattr(mod.linear, "bias", None) is not None:
+                mod.linear.bias.copy_(torch.randn(mod.linear.bias.shape, generator=g) * 0.1)
+        x = torch.randn(*lead, cin, generator=g)
+        mod.set_explanation_mode(True)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, xr, gy)
+        case = dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=gx)
+        if getattr(mod.linear, "bias", None) is not None:
+            case["bias"] = mod.linear.bias.detach()
+        xo = x.clone().requires_grad_(True)
+        yo = O.bcos_linear(xo, case["weight"], case.get("bias"), b, mo, detach=True, normalize_weight=(kind == "bcos"))
+        (gxo,) = torch.autograd.grad(yo, xo, gy)
+        REPORT[f"layer/{name}"] = dict(y=rel(yo, y), gx=rel(gxo, gx))
+        for kk, vv in case.items():
+            out[f"{name}/{kk}"] = vv
+    meta = dict(conv=[dict(zip(("name", "kind", "cin", "cout", "k", "s", "p", "d", "groups", "b", "max_out", "bias", "H", "W"), c))
+                      for c in CONV_CASES],
+                linear=[dict(zip(("name", "kind", "cin", "cout", "b", "max_out", "bias", "lead"), c)) for c in LINEAR_CASES])
+    np.savez_compressed(os.path.join(HERE, "layers.npz"), **t2n(out))
+    with open(os.path.join(HERE, "layers.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+# --------------------------------------------------------------------------------------------------------
+# F2-F5: patch norms fast vs slow, BNU fold, add_channels, scale invariance
+# --------------------------------------------------------------------------------------------------------
+def small_invariants():
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    mod = R.bcos_modules.BcosConv2d(8, 12, 3, 2, 1, groups=2)
+    x = torch.randn(2, 8, 9, 9, generator=g)
+    fast = mod.calc_patch_norms(x)
+    slow = mod._calc_patch_norms_slow(x)
+    REPORT["patch_norm_fast_vs_slow"] = rel(fast, slow)
+    out.update({"pn/x": x, "pn/norm": fast})
+    REPORT["oracle_patch_norm"] = rel(O.patch_norm(x, 3, 2, 1, 2, 12), fast)
+    # BNU fold
+    bn = nn.BatchNorm2d(8)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(8, generator=g)); bn.running_var.copy_(torch.rand(8, generator=g) + 0.5)
+        bn.weight.copy_(torch.rand(8, generator=g) + 0.5); bn.bias.copy_(torch.randn(8, generator=g))
+    cfg = synth.resnet_model_config("resnet18")
+    bnu = R.bcos_modules.norms.BatchNormUncentered2d.from_standard_module(bn, cfg).eval()
+    xb = torch.randn(2, 8, 5, 5, generator=g)
+    out.update({"bnu/x": xb, "bnu/y": bnu(xb).detach(), "bnu/y_standard_bn": bn.eval()(xb).detach(),
+                "bnu/weight": bnu.weight.detach(), "bnu/bias": bnu.bias.detach(), "bnu/running_var": bnu.running_var,
+                "bnu/running_mean": bnu.running_mean, "bnu/src_weight": bn.weight.detach(), "bnu/src_bias": bn.bias.detach()})
+    REPORT["bnu_fold_equals_bn"] = rel(bnu(xb), bn(xb))
+    REPORT["oracle_bnu"] = rel(O.bn_uncentered_eval(xb, bnu.running_var, bnu.weight, bnu.bias, bnu.eps), bnu(xb))
+    # add_channels (CNN)
+    conv = nn.Conv2d(3, 4, 3, bias=False)
+    holder = nn.Sequential(conv)
+    w0 = conv.weight.detach().clone()
+    R.bcosify.BcosifyNetwork.add_channels(holder)
+    out.update({"addch/w_before": w0, "addch/w_after": conv.weight.detach()})
+    # scale invariance of normed layers
+    m1 = R.bcos_modules.BcosConv2d(8, 6, 3, 1, 1)
+    xs = torch.randn(1, 8, 6, 6, generator=g)
+    y1 = m1(xs).detach()
+    with torch.no_grad():
+        m1.linear.weight.mul_(3.7)
+    REPORT["normed_scale_invariance"] = rel(m1(xs), y1)
+    np.savez_compressed(os.path.join(HERE, "invariants.npz"), **t2n(out))
+
+
+# --------------------------------------------------------------------------------------------------------
+# F6/F7: B-cosified ResNet-18 end to end (config 1: 8 images @224), reference modules on CPU
+# --------------------------------------------------------------------------------------------------------
+def reference_resnet(arch, seed=0):
+    cfg = synth.resnet_model_config(arch)
+    std = synth.standard_resnet(arch, seed, resnet_cls=R.standard_models.ResNetBcos,
+                                blocks=dict(basic=R.tv_resnet.BasicBlock, bottleneck=R.tv_resnet.Bottleneck))
+    net = R.bcosify.BcosifyNetwork(std, cfg, add_channels=True, logit_layer=True)
+    synth.finish_conversion(net, cfg, hip_pools=False)
+    return net.eval()
+
+
+def state_checksum(sd):
+    return {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items() if v.dtype.is_floating_point}
+
+
+def resnet18_end_to_end():
+    arch = "resnet18"
+    net = reference_resnet(arch)
+    x = synth.synthetic_images(8)
+    record = synth.calibrate(net, x[:4])
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    # reference explanation, one image at a time exactly like BcosUtilMixin.explain
+    logits, wts, contribs, preds = [], [], [], []
+    for i in range(8):
+        xi = x[i:i + 1].clone().requires_grad_(True)
+        res = net.explain(xi)
+        with torch.no_grad():
+            logits.append(net(x[i:i + 1]))
+        wts.append(res["dynamic_linear_weights"].detach())
+        contribs.append(res["contribution_map"].detach())
+        preds.append(res["prediction"])
+        if i == 0:
+            rgba = res["explanation"]
+    logits = torch.cat(logits); wts = torch.cat(wts); contribs = torch.cat(contribs)
+    # completeness: sum (x - mean_c) * W(x) == logit - logit_bias   
+    mean = torch.tensor(O.IMAGENET_MEAN_ADDINVERSE).view(1, 6, 1, 1)
+    compl = ((x - mean) * wts).sum((1, 2, 3)) - (logits[torch.arange(8), torch.tensor(preds)] + math.log(999))
+    REPORT["r18/completeness_residual_max"] = float(compl.abs().max())
+    # the reference against itself with oneDNN off (summation order floor)
+    with torch.backends.mkldnn.flags(enabled=False):
+        l2 = torch.cat([net(x[i:i + 1]).detach() for i in range(2)])
+        w2 = []
+        for i in range(2):
+            xi = x[i:i + 1].clone().requires_grad_(True)
+            w2.append(net.explain(xi)["dynamic_linear_weights"].detach())
+        w2 = torch.cat(w2)
+    REPORT["r18/reference_self_floor_logits"] = rel(l2, logits[:2])
+    REPORT["r18/reference_self_floor_weights"] = rel(w2, wts[:2])
+    # oracle vs reference
+    fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
+    oe = O.explain_batch(fwd, x)
+    REPORT["r18/oracle_logits"] = rel(oe["logits"], logits)
+    REPORT["r18/oracle_weights"] = rel(oe["dynamic_linear_weights"], wts)
+    REPORT["r18/oracle_contrib"] = rel(oe["contribution_map"], contribs)
+    REPORT["r18/oracle_argmax_equal"] = bool((oe["prediction"] == torch.tensor(preds)).all())
+    rgba_o = O.gradient_to_image(x[0], wts[0])
+    REPORT["r18/oracle_rgba_maxdiff"] = float(np.abs(rgba_o - rgba).max())
+    # ReLU gates of images 0-1 (NHWC order, bit-packed), recorded with the oracle whose forward is bit-identical
+    # to the reference's on this host (r18/oracle_logits == 0): lets the GPU test replay the reference's gates
+    log = []
+    with torch.no_grad():
+        lg = O.resnet_logits(sd, x[:2], arch, detach=True, gate_log=log)
+    assert torch.equal(lg, logits[:2])
+    gate_np = {f"gate/{i:02d}": np.packbits((p > 0).permute(0, 2, 3, 1).contiguous().numpy().reshape(-1)) for i, p in enumerate(log)}
+    gate_shapes = [list(p.permute(0, 2, 3, 1).shape) for p in log]
+    rec_np = {f"calib/{k}": v.numpy() for k, v in record.items()}
+    rec_np.update(gate_np)
+    np.savez_compressed(os.path.join(HERE, "resnet18_e2e.npz"), logits=logits.numpy(), prediction=np.array(preds),
+                        contribution_map=contribs.numpy(), weights_01=wts[:2].numpy(), rgba_0=rgba,
+                        completeness=compl.numpy(), **rec_np)
+    with open(os.path.join(HERE, "resnet18_e2e.json"), "w") as f:
+        json.dump(dict(arch=arch, weight_seed=0, image_seed=123, n_images=8, calib_images=4,
+                       calib_order=list(record.keys()), state_checksum=state_checksum(sd), gate_shapes=gate_shapes,
+                       torch_version=torch.__version__), f, indent=1)
+
+
+def resnet50_logits_small():
+    """Config-2 topology at 2 images (logits + argmax only: the maps of a 54-layer ReLU net are below the
+    reference's own reproducibility floor)."""
+    arch = "resnet50"
+    net = reference_resnet(arch)
+    x = synth.synthetic_images(4)
+    record = synth.calibrate(net, x)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        logits = net(x[:2])
+    wts = []
+    for i in range(2):
+        xi = x[i:i + 1].clone().requires_grad_(True)
+        wts.append(net.explain(xi)["dynamic_linear_weights"].detach())
+    wts = torch.cat(wts)
+    with torch.backends.mkldnn.flags(enabled=False):
+        w2 = []
+        for i in range(2):
+            xi = x[i:i + 1].clone().requires_grad_(True)
+            w2.append(net.explain(xi)["dynamic_linear_weights"].detach())
+        REPORT["r50/reference_self_floor_weights"] = rel(torch.cat(w2), wts)
+        REPORT["r50/reference_self_floor_logits"] = rel(net(x[:2]).detach(), logits)
+    fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
+    oe = O.explain_batch(fwd, x[:2])
+    REPORT["r50/oracle_logits"] = rel(oe["logits"], logits)
+    REPORT["r50/oracle_weights"] = rel(oe["dynamic_linear_weights"], wts)
+    contrib = (x[:2] * wts).sum(1)
+    rec_np = {f"calib/{k}": v.numpy() for k, v in record.items()}
+    np.savez_compressed(os.path.join(HERE, "resnet50_small.npz"), logits=logits.numpy(),
+                        prediction=logits.argmax(1).numpy(), contribution_map=contrib.numpy(), **rec_np)
+    with open(os.path.join(HERE, "resnet50_small.json"), "w") as f:
+        json.dump(dict(arch=arch, weight_seed=0, image_seed=123, n_images=2, calib_images=4,
+                       calib_order=list(record.keys()), state_checksum=state_checksum(sd),
+                       torch_version=torch.__version__), f, indent=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["layers", "inv", "r18", "r50"]
+    rep_path = os.path.join(HERE, "oracle_vs_reference.json")
+    if os.path.exists(rep_path):
+        REPORT.update(json.load(open(rep_path)))
+    if "layers" in which:
+        layer_cases()
+    if "inv" in which:
+        small_invariants()
+    if "r18" in which:
+        resnet18_end_to_end()
+    if "r50" in which:
+        resnet50_logits_small()
+    with open(rep_path, "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+    for k in sorted(REPORT):
+        print(k, REPORT[k])

