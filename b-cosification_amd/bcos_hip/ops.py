@@ -12,6 +12,11 @@ from . import lib as _l
 from .lib import BCOS_CONV_EPS, BCOS_LINEAR_EPS, BCOS_NONE, BcosHipError, Epilogue, TapconvGeom
 
 
+# bench.py sets this to a list to collect (start, end) HIP events recorded on the launch stream around every
+# contraction launch (the roofline's live per-kernel timing); None = off, no overhead.
+KERNEL_TIMING = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -64,7 +69,14 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     e.relu = int(bool(relu))
     e.b = float(b)
     e.flags = int(flags)
+    timing = KERNEL_TIMING
+    if timing is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     code = lib.bcos_tapconv(_dev(a, "tapconv.a", contiguous=False), _dev(wt, "tapconv.wt"), C.byref(g), C.byref(e), _stream())
+    if timing is not None:
+        ev1.record()
+        timing.append((ev0, ev1))
     _l.check(code, "bcos_tapconv")
 
 

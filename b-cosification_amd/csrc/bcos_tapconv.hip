@@ -49,6 +49,7 @@ struct KArgs {
     int nchunks;    // Ktot/4
     int nk;         // K steps
     int tiles_m, tiles_n;
+    int vec_ok;     // every per-element epilogue tensor is 16-byte addressable (pitch % 4 == 0, aligned bases)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
@@ -208,12 +209,28 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: row bookkeeping through LDS ------------------------------------------
-    // (all waves are past the last barrier: the tile buffers are free)
-    int64_t* sPix = reinterpret_cast<int64_t*>(smem);            // [BM] output pixel index or -1
-    float* sNorm = reinterpret_cast<float*>(sPix + BM);          // [BM] patch norm
-    float* sRinv = sNorm + BM;                                   // [BM] 1 / norm
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // (all waves are past the last barrier: the staging buffers are free)
+    // 1. accumulators -> LDS tile sC[BM][BN+4] (MFMA layout: lane = column, 16 rows per lane);
+    // 2. every thread then owns 16-byte column chunks of whole rows: wave-wide accesses are 2..8 full rows of
+    //    BN*4 contiguous bytes, all epilogue tensors move as dwordx4, and the loads of a group of EPI_G chunks are
+    //    issued together before any of them is consumed (the streaming layers 64<->256 @56^2 are HBM-bound here).
+    constexpr int LDC = BN + 4;
+    float* sC = smem;
+    int64_t* sPix = reinterpret_cast<int64_t*>(smem + BM * LDC);   // [BM] output pixel index or -1
+    float* sNorm = reinterpret_cast<float*>(sPix + BM);            // [BM] patch norm
+    float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
     const bcos_epilogue& e = p.e;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int colt = wave_n * WN + j * 32 + (lane & 31);
+                sC[row * LDC + colt] = acc[i][j][r];
+            }
     if (tid < BM) {
         const int m = m0 + tid;
         int64_t pix = -1;
@@ -248,34 +265,99 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
     const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
     const float bm1 = e.b - 1.0f;
     const int Cout = g.Cout;
+    constexpr int CPR = BN / 4;              // 16-byte chunks per tile row
+    constexpr int RPP = NTHREADS / CPR;      // rows per pass
+    constexpr int PASSES = BM / RPP;
+    constexpr int EPI_G = 4;                 // chunks whose loads are in flight together
+    static_assert(PASSES % EPI_G == 0, "epilogue grouping");
+    const int cq = tid % CPR;
+    const int rbase = tid / CPR;
+    const int col = n0 + cq * 4;
+    const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wave_n * WN + j * 32 + (lane & 31);
-        const bool col_ok = col < Cout;
-        const int colc = col_ok ? col : 0;
-        const float bias = e.bias ? e.bias[colc] : 0.f;
-        const float csc = e.ch_scale ? e.ch_scale[colc] : 1.f;
-        const float csh = e.ch_shift ? e.ch_shift[colc] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const int c = col + q < Cout ? col + q : 0;
+        if (e.bias) bias4[q] = e.bias[c];
+        if (e.ch_scale) csc4[q] = e.ch_scale[c];
+        if (e.ch_shift) csh4[q] = e.ch_shift[c];
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    if (vec) {
+#pragma unroll 1
+        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
+            f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
+            int64_t idx[EPI_G];
+            bool ok[EPI_G];
+            float rinv[EPI_G], nrm[EPI_G];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int u = 0; u < EPI_G; ++u) {
+                const int row = rbase + (p0 + u) * RPP;
                 const int64_t pix = sPix[row];
-                if (pix < 0 || !col_ok) continue;
-                const int64_t idx = pix * g.out_pitch + col;
-                float v = acc[i][j][r] + bias;
+                ok[u] = pix >= 0;
+                idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
+                v[u] = *reinterpret_cast<const f32x4*>(sC + row * LDC + cq * 4);
+                rinv[u] = NORM ? sRinv[row] : 1.f;
+                nrm[u] = NORM ? sNorm[row] : 1.f;
+                ad[u] = e.addend ? *reinterpret_cast<const f32x4*>(e.addend + idx[u]) : zero4;
+                rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
+                m1[u] = e.mul ? *reinterpret_cast<const f32x4*>(e.mul + idx[u]) : zero4;
+                m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
+                g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                f32x4 val = v[u] + bias4;
+                f32x4 s = {1.f, 1.f, 1.f, 1.f};
+                if (NORM && !norm_only) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        s[q] = b_is_2 ? fabsf(val[q]) * rinv[u] : powf(fabsf(val[q] / nrm[u]) + 1e-6f, bm1);
+                    val *= s;
+                }
+                val = val * csc4 + csh4;
+                s *= csc4;
+                if (e.addend) val += ad[u];
+                if (e.relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
+                        s[q] = open_gate ? s[q] : 0.f;
+                        val[q] = open_gate ? val[q] : 0.f;
+                    }
+                }
+                if (ok[u]) {
+                    if (e.out) *reinterpret_cast<f32x4*>(e.out + idx[u]) = e.mul ? val * m1[u] : val;
+                    if (e.out2) {
+                        f32x4 o2 = val;
+                        if (e.mul2) o2 *= m2[u];
+                        if (e.gate2) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(e.out2 + idx[u]) = o2;
+                    }
+                    if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + idx[u]) = s;
+                }
+            }
+        }
+    } else if (col < Cout) {
+        // ragged right edge (Cout % 4 != 0) or unaligned tensors: same math, element by element
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = rbase + ps * RPP;
+            const int64_t pix = sPix[row];
+            if (pix < 0) continue;
+            for (int q = 0; q < 4 && col + q < Cout; ++q) {
+                const int64_t idx = pix * g.out_pitch + col + q;
+                float v = sC[row * LDC + cq * 4 + q] + bias4[q];
                 float s = 1.f;
                 if (NORM && !norm_only) {
-                    if (b_is_2) {
-                        s = fabsf(v) * sRinv[row];
-                    } else {
-                        s = powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
-                    }
+                    s = b_is_2 ? fabsf(v) * sRinv[row] : powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
                     v *= s;
                 }
-                v = v * csc + csh;   // csc==1, csh==0 when absent: exact
-                s *= csc;
+                v = v * csc4[q] + csh4[q];
+                s *= csc4[q];
                 if (e.addend) v += e.addend[idx];
                 if (e.relu) {
                     const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
@@ -300,7 +382,9 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     KArgs p = base;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.g.Cout + BN - 1) / BN;
-    const size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float) + (size_t)BM * 16;
+    if (lds_epi > lds) lds = lds_epi;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHREADS);
     hipError_t err;
     if (norm) {
@@ -357,6 +441,12 @@ extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_
     p.nchunks = p.Ktot / 4;
     p.nk = (p.nchunks + 7) / 8;
     p.tiles_m = p.tiles_n = 0;
+    {
+        uintptr_t bits = 0;
+        const void* ptrs[] = {epi->addend, epi->mul, epi->mul2, epi->gate2, epi->relu_gate, epi->out, epi->out2, epi->scale_out};
+        for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);
+        p.vec_ok = ((bits & 15) == 0 && p.g.out_pitch % 4 == 0) ? 1 : 0;
+    }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g.Cout > 64) return launch_cfg<128, 128, 2, 2>(p, norm, s);

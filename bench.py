@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: images/s, forward + explanation, B-cosified ResNet-50 @224, batch 256 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one pass of the hot path over one batch of 256 synthetic 224x224 images per GPU: input
+preparation, 54 fused B-cos conv launches, head, arg-max, 54 layers of input-gradient launches, W(x) and
+contribution maps -- followed (N > 1) by the single all-gather of per-rank logits and maps.  Inputs and
+weights are resident in HBM before the timed region.  Weak scaling: every rank processes its own 256 images.
+
+Besides the contract fields the JSON line carries
+  roofline      fp32-MFMA roofline of the dominant kernel family (tapconv_kernel): algorithmic FLOP of the B-cos
+                contractions of one step (17.22 GFLOP/image) / the time spent in those launches,
+                measured live with HIP events on the launch stream inside the timed region;
+  cpu_baseline  the CPU oracle (the PyTorch-CPU restatement of the reference's path) timed on this host's cores on
+                a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "b-cosification_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GFLOP_FWD_PER_IMAGE = 8.611        # 2*MAC of the 54 B-cos convs of ResNet-50 @224
+GFLOP_PER_IMAGE = 2 * GFLOP_FWD_PER_IMAGE   # + one input-gradient contraction per layer
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
+    ap.add_argument("--forward-only", action="store_true", help="diagnostic: time the forward pass only")
+    return ap.parse_args()
+
+
+def cpu_baseline(net, arch, n_images):
+    """The oracle (kind 'port': PyTorch-CPU restatement of the reference path, pinned by tests/golden) on the
+    host cores: forward + explanation of `n_images` images, 1 warm-up + 2 timed passes."""
+    from bcos_hip import synth
+    from oracle import bcos_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    x = synth.synthetic_images(n_images, seed=321)
+    fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
+    O.explain_batch(fwd, x[:2])                     # warm-up (oneDNN primitive creation)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        O.explain_batch(fwd, x)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return dict(value=round(n_images / best, 3), unit="images/s", cores=cores, kind="port",
+                sample=f"forward+explanation of {n_images} images (1 batch), best of 2 after warm-up, "
+                       f"torch {torch.__version__} CPU fp32, {cores} threads")
+
+
+def main():
+    args = parse()
+    from bcos_hip import dist as bdist, engine, lib, ops, synth
+    lib.load()      # fails loudly if the HIP library was not built
+    rank, local_rank, world = bdist.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # -- model + data, resident in HBM --------------------------------------------------------------------------
+    net = synth.build_bcosified_resnet(args.arch, seed=0).to(dev)
+    calib = synth.synthetic_images(8, seed=123).to(dev)
+    with torch.no_grad():
+        synth.calibrate(net, calib)            # identical on every rank (same seeds, deterministic kernels)
+    eng = engine.attach(net)
+    x = synth.synthetic_images(args.batch, seed=1000 + rank).to(dev)
+    torch.cuda.synchronize()
+
+    gathered = {}
+
+    def step():
+        if args.forward_only:
+            out = dict(logits=eng.forward(x))
+            keys = ("logits",)
+        else:
+            out = eng.explain(x, want_weights=True)
+            keys = ("logits", "contribution_map")
+        if world > 1:       # the single collective of the path: all-gather of per-rank results over RCCL/xGMI
+            for k in keys:
+                buf = gathered.get(k)
+                if buf is None:
+                    buf = gathered[k] = torch.empty((world * out[k].shape[0],) + tuple(out[k].shape[1:]),
+                                                    device=dev, dtype=out[k].dtype)
+                dist.all_gather_into_tensor(buf, out[k].contiguous())
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.KERNEL_TIMING = []          # (start, end) HIP events on the launch stream around every tapconv launch
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    images = args.batch * world * args.steps
+    value = images / elapsed
+
+    kernel_ms = sum(s.elapsed_time(e) for s, e in events)            # all tapconv launches of this rank
+    launches = len(events)
+    gflop_step = (GFLOP_FWD_PER_IMAGE if args.forward_only else GFLOP_PER_IMAGE) * args.batch
+    achieved = gflop_step * args.steps / kernel_ms if kernel_ms > 0 else 0.0     # GFLOP/ms == TFLOP/s
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", "traffic_latest.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                    kernel="tapconv_kernel (all instantiations)", launches_per_step=launches // max(args.steps, 1),
+                    avg_launch_us=round(1e3 * kernel_ms / max(launches, 1), 2),
+                    kernel_ms_per_step=round(kernel_ms / max(args.steps, 1), 3),
+                    algorithmic_gflop_per_step=round(gflop_step, 1))
+
+    result = {
+        "metric": "images/sec (fwd+explanation) B-cos ResNet-50 @224, batch 256, 1/2/4/8 MI355X",
+        "value": round(value, 2),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"B-cosified {args.arch} {'forward' if args.forward_only else 'forward+explanation'}, "
+                               f"batch {args.batch} per GPU, 224x224x6 (AddInverse), calibrated random-init weights",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "collective": "all_gather(logits, contribution maps)" if world > 1 else "none"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(net, args.arch, args.cpu_sample)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
