@@ -18,7 +18,7 @@ REPO_ROOT = PKG_ROOT.parent
 LIB_PATH = PKG_ROOT / "lib" / "libbcos_hip.so"
 CSRC = PKG_ROOT / "csrc"
 INCLUDE = REPO_ROOT / "include"
-SOURCES = ["bcos_tapconv.hip", "bcos_elementwise.hip", "bcos_abi.hip"]
+SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_abi.hip"]
 
 BCOS_NONE, BCOS_CONV_EPS, BCOS_LINEAR_EPS = 0, 1, 2
 BCOS_EPI_NORM_ONLY = 1

@@ -8,4 +8,11 @@ int bcos_set_error(int code, const char* msg);
 // record a HIP runtime error; returns BCOS_E_LAUNCH
 int bcos_set_hip_error(const char* what, hipError_t err);
 
+
+struct bcos_tapconv_geom;
+struct bcos_epilogue;
+// narrow-output (Cout <= 8) path, bcos_skinny.hip: 1 = handled, 0 = not applicable, < 0 = error
+int bcos_try_skinny(const float* a, const float* wt, const bcos_tapconv_geom& g, const bcos_epilogue& e, int M,
+                    hipStream_t stream);
+
 #endif

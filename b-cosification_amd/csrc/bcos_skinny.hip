@@ -1,0 +1,170 @@
+// bcos_skinny.hip -- direct convolution for very narrow outputs (Cout <= 8) on gfx950.
+//
+// The last input-gradient of a B-cosified CNN (stem dgrad: 7x7/2 conv 6->64, explanation pass of
+// bcos/common.py:177) produces only 6 channels per pixel.  On the 32x32 MFMA tile of bcos_tapconv.hip
+// 26 of 32 output columns are padding, and -- worse -- with so few columns per row the im2col expansion of the
+// A operand (every input pixel re-read once per tap, 13 GB per launch from L2) is what bounds the kernel, not
+// the matrix pipe (measured: 2.3 ms per parity class either way).  This kernel removes both:
+//   * a workgroup owns a 16x16 patch of output pixels; the (16+TH-1)x(16+TW-1) input pixels it touches are
+//     loaded ONCE (coalesced 16-byte loads, zero-filled outside the image) into LDS as [pixel][C+4] and every
+//     tap then reads its operands from there: HBM/L2 traffic drops ~10x to about the unique input size;
+//   * the contraction runs on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks per instruction, block b =
+//     lanes 4b..4b+3.  Lane l supplies A = its own output pixel and B = weight column l%4, so one instruction
+//     advances 64 pixels x 4 channels by one k; two accumulators cover 8 channels (75 % useful for Cout = 6).
+//     D: lane l, register r = (pixel of lane 4*(l/4)+r, channel l%4 [+4])   (layout verified on hardware);
+//   * the whole [8][Ktot] weight panel sits in LDS (rows padded by 4 floats so that the four distinct
+//     addresses of a ds_read_b128 fall on different bank quads).
+// Requirements (else bcos_tapconv falls back to the generic kernel): unit input stride and tap step (true for
+// every dgrad parity class), C % 4 == 0, LDS footprint <= 160 KB, plain / addend / mul epilogue.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bcos_hip.h"
+#include "bcos_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SK_THREADS = 256;     // 4 wavefronts x 64 pixels = 16 x 16 output pixels
+constexpr int SK_T = 16;
+
+struct SkArgs {
+    const float* a;
+    const float* wt;        // [Cout][taps][C]
+    float* out;
+    const float* addend;    // optional, indexed like out
+    const float* mul;       // optional, indexed like out
+    bcos_tapconv_geom g;
+    int Ktot, ldw;          // Ktot = taps * C; ldw = taps * CH + 4: one channel slice of the weight panel
+    int CH;                 // channels per pass (C is processed in C / CH slices so that 2 workgroups fit a CU)
+    int ldp;                // LDS floats per input pixel = CH + 4
+    int PH, PW;             // input patch extent = 16 + TH - 1, 16 + TW - 1
+    int tiles_i, tiles_j;
+};
+
+__global__ __launch_bounds__(SK_THREADS) void skinny_kernel(const SkArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;                               // [8][ldw] weight panel
+    float* sX = smem + 8 * p.ldw;                   // [PH*PW][ldp] input patch
+    const bcos_tapconv_geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = blockIdx.x;
+    const int tj = b % p.tiles_j; b /= p.tiles_j;
+    const int ti = b % p.tiles_i;
+    const int n = b / p.tiles_i;
+    const int i_base = ti * SK_T, j_base = tj * SK_T;
+
+    const int pi = wave * 4 + (lane >> 4), pj = lane & 15;      // this lane's output pixel inside the tile
+    const float* w0 = sW + (lane & 3) * p.ldw;                  // channel l%4
+    const float* w1 = sW + ((lane & 3) + 4) * p.ldw;            // channel l%4 + 4
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int C = g.C, CH = p.CH, ntaps = g.TH * g.TW;
+    const int cps = CH / 4;                         // 16-byte chunks per pixel per slice
+    const float* abase = p.a + (int64_t)n * g.H * g.W * g.a_pitch;
+    for (int c0 = 0; c0 < C; c0 += CH) {
+        if (c0) __syncthreads();                    // everyone is done reading the previous slice
+        // weight slice: sW[r][tap*CH + c] = wt[r][tap][c0 + c]   (rows >= Cout are zero)
+        for (int i = tid; i < 8 * ntaps * cps; i += SK_THREADS) {
+            const int r = i / (ntaps * cps);
+            const int rem = i - r * (ntaps * cps);
+            const int tap = rem / cps, c4 = rem - tap * cps;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < g.Cout) v = *reinterpret_cast<const f32x4*>(p.wt + (int64_t)r * p.Ktot + tap * C + c0 + c4 * 4);
+            *reinterpret_cast<f32x4*>(sW + r * p.ldw + tap * CH + c4 * 4) = v;
+        }
+        // input patch slice: pixel (ph, pw) of the patch = input (i_base + dh0 + ph, j_base + dw0 + pw)
+        for (int i = tid; i < p.PH * p.PW * cps; i += SK_THREADS) {
+            const int px = i / cps, c4 = i - px * cps;
+            const int ph = px / p.PW, pw = px - ph * p.PW;
+            const int ih = i_base + g.dh0 + ph, iw = j_base + g.dw0 + pw;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+                v = *reinterpret_cast<const f32x4*>(abase + ((int64_t)ih * g.W + iw) * g.a_pitch + c0 + c4 * 4);
+            *reinterpret_cast<f32x4*>(sX + px * p.ldp + c4 * 4) = v;
+        }
+        __syncthreads();
+        for (int th = 0; th < g.TH; ++th) {
+            for (int tw = 0; tw < g.TW; ++tw) {
+                const float* xs = sX + ((pi + th) * p.PW + (pj + tw)) * p.ldp;
+                const int kb = (th * g.TW + tw) * CH;
+#pragma unroll 4
+                for (int c = 0; c < CH; c += 4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(xs + c);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(w0 + kb + c);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(w1 + kb + c);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q], b0[q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q], b1[q], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // D: lane l, reg r -> the pixel of lane (l & ~3) + r, channel l%4 (+4): 4 consecutive pj of one tile row
+    const int ch = lane & 3;
+    const int oi = i_base + pi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oj = j_base + (pj & ~3) + r;
+        if (oi >= g.P || oj >= g.Q) continue;
+        const int64_t px = ((int64_t)n * g.OH + (oi * g.out_sh + g.out_h0)) * g.OW + (oj * g.out_sw + g.out_w0);
+        const int64_t base = px * g.out_pitch;
+        if (ch < g.Cout) {
+            float v = acc0[r];
+            if (p.addend) v += p.addend[base + ch];
+            if (p.mul) v *= p.mul[base + ch];
+            p.out[base + ch] = v;
+        }
+        if (ch + 4 < g.Cout) {
+            float v = acc1[r];
+            if (p.addend) v += p.addend[base + ch + 4];
+            if (p.mul) v *= p.mul[base + ch + 4];
+            p.out[base + ch + 4] = v;
+        }
+    }
+}
+
+}  // namespace
+
+// Returns 1 if the launch was handled here, 0 if the caller should use the generic kernel, < 0 on error.
+int bcos_try_skinny(const float* a, const float* wt, const bcos_tapconv_geom& g, const bcos_epilogue& e, int M,
+                    hipStream_t stream) {
+    (void)M;
+    if (g.Cout > 8) return 0;
+    if (e.bcos_mode != BCOS_NONE || e.bias || e.ch_scale || e.ch_shift || e.relu || e.out2 || e.scale_out ||
+        e.norm_out || e.mul2 || e.gate2 || !e.out)
+        return 0;
+    if (g.in_sh != 1 || g.in_sw != 1 || g.dstep_h != 1 || g.dstep_w != 1) return 0;
+    SkArgs p;
+    p.a = a; p.wt = wt; p.out = e.out; p.addend = e.addend; p.mul = e.mul;
+    p.g = g;
+    p.Ktot = g.TH * g.TW * g.C;
+    p.PH = SK_T + g.TH - 1;
+    p.PW = SK_T + g.TW - 1;
+    p.tiles_i = (g.P + SK_T - 1) / SK_T;
+    p.tiles_j = (g.Q + SK_T - 1) / SK_T;
+    // channels per pass: the largest slice (C, C/2, C/4, ... multiple of 4) whose footprint lets two workgroups
+    // share a CU (one stages its slice while the other computes); fall back to whatever fits 160 KB
+    size_t lds = 0;
+    p.CH = 0;
+    for (int ch = g.C; ch >= 4 && ch % 4 == 0; ch /= 2) {
+        const size_t need = ((size_t)8 * (g.TH * g.TW * ch + 4) + (size_t)p.PH * p.PW * (ch + 4)) * sizeof(float);
+        if (need <= 160 * 1024 && p.CH == 0) { p.CH = ch; lds = need; }
+        if (need <= 80 * 1024) { p.CH = ch; lds = need; break; }
+        if (g.C % (ch / 2) != 0 || (ch / 2) % 4 != 0) break;
+    }
+    if (p.CH == 0) return 0;
+    p.ldw = g.TH * g.TW * p.CH + 4;
+    p.ldp = p.CH + 4;
+    const int64_t blocks = (int64_t)g.N * p.tiles_i * p.tiles_j;
+    if (blocks >= ((int64_t)1 << 31)) return 0;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute(skinny)", err);
+    hipLaunchKernelGGL(skinny_kernel, dim3((unsigned)blocks), dim3(SK_THREADS), lds, stream, p);
+    err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("skinny launch", err);
+    return 1;
+}

@@ -449,6 +449,10 @@ extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_
     }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g.Cout <= 8) {
+        const int handled = bcos_try_skinny(a, wt, p.g, p.e, p.M, s);
+        if (handled != 0) return handled < 0 ? handled : BCOS_OK;
+    }
     if (g.Cout > 64) return launch_cfg<128, 128, 2, 2>(p, norm, s);
     if (g.Cout > 32) return launch_cfg<128, 64, 2, 2>(p, norm, s);
     return launch_cfg<128, 32, 4, 1>(p, norm, s);

@@ -1,0 +1,21 @@
+"""GEMM micro-benchmark of the tapconv kernel in linear mode (development aid)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "b-cosification_amd")); sys.path.insert(0, ROOT)
+import torch
+from bcos_hip import ops
+dev = "cuda"
+def bench(M, K, N, bcos=False, iters=10):
+    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
+    out = torch.empty(M, N, device=dev)
+    f = (lambda: ops.linear_fwd(a, w, out=out)) if bcos else (lambda: ops.matmul_nt(a, w, out=out))
+    for _ in range(3): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"M{M} K{K} N{N} bcos={bcos}: {ms:.3f} ms  {2.0*M*K*N/ms/1e9:.1f} TF/s")
+for (M, K, N) in [(4096, 4096, 4096), (8192, 8192, 8192), (65536, 2304, 256), (65536, 1024, 1024), (50176, 2304, 256), (12544, 4608, 512), (802816, 576, 64)]:
+    bench(M, K, N)
+bench(8192, 8192, 8192, bcos=True)
