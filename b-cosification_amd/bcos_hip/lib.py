@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- MUST precede CDLL: torch ships its own libamdhip6
 
 PKG_ROOT = Path(__file__).resolve().parent.parent          # b-cosification_amd/
 REPO_ROOT = PKG_ROOT.parent
-LIB_PATH = PKG_ROOT / "lib" / "libbcos_hip.so"
+LIB_PATH = Path(os.environ["BCOS_HIP_LIB"]) if os.environ.get("BCOS_HIP_LIB") else PKG_ROOT / "lib" / "libbcos_hip.so"
 CSRC = PKG_ROOT / "csrc"
 INCLUDE = REPO_ROOT / "include"
 SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_abi.hip"]

@@ -24,11 +24,22 @@
 //     range of tiles, n-tile fastest, so blocks sharing an A row-panel share an L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "bcos_hip.h"
 #include "bcos_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef OPT_PREFETCH
+#define OPT_PREFETCH 0
+#endif
+#ifndef OPT_BRANCHFREE
+#define OPT_BRANCHFREE 0
+#endif
+#ifndef OPT_LOADFIRST
+#define OPT_LOADFIRST 0
+#endif
 
 namespace {
 
@@ -48,34 +59,23 @@ struct KArgs {
     int cpt;        // 16-byte chunks per tap = C/4
     int nchunks;    // Ktot/4
     int nk;         // K steps
-    int tiles_m, tiles_n;
+    int tiles_n;            // column tiles
+    int n_big, n_small;     // tiles of BM rows, then tiles of BM/2 rows (tail of the launch)
+    int rows_big;           // rows covered by the BM-row tiles
+    int uniform_tap; // C % 32 == 0: every K-step lies inside one tap
     int vec_ok;     // every per-element epilogue tensor is 16-byte addressable (pitch % 4 == 0, aligned bases)
 };
 
+// One output tile [m0, m0+BM) x [n0, n0+BN): main loop + epilogue.  `tile_n` only tells whether this block is the one
+// that writes the per-row norms.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
-__global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
+__device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_LD = BM / 32, B_LD = BN / 32;   // float4 loads per thread per K-step
     constexpr int BUF = (BM + BN) * LDS_LD;          // floats per LDS buffer
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     static_assert(TM >= 1 && TN >= 1, "wave tile");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    // ---- XCD-aware tile id -----------------------------------------------------------
-    const int nt = p.tiles_m * p.tiles_n;
-    int tile;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid % NXCD, idx = bid / NXCD;
-        const int q = nt / NXCD, r = nt % NXCD;
-        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        tile = base + idx;
-    }
-    const int tile_m = tile / p.tiles_n;
-    const int tile_n = tile - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,30 +118,61 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
     }
 
     f32x4 ra[A_LD], rb[B_LD];
+    // Position of the NEXT K-step to load inside the (tap, channel) space.  When C % 32 == 0 a K-step lies inside
+    // one tap, so the position is wave-uniform and advanced incrementally (scalar registers, no divisions);
+    // otherwise (the 6->8 channel stem) every lane derives its own tap from its chunk index.
+    int s_cc = 0, s_th = 0, s_tw = 0;      // uniform mode: chunk offset inside the tap, tap coordinates
     auto load_step = [&](int ks) {
+        int cc, dh, dw;
+        bool kvalid;
         const int q = ks * 8 + chunk;
-        const bool kvalid = q < p.nchunks;
-        const int tap = q / p.cpt;
-        const int cc = q - tap * p.cpt;
-        const int th = tap / g.TW;
-        const int tw = tap - th * g.TW;
-        const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+        if (p.uniform_tap) {
+            cc = s_cc + chunk;
+            dh = s_th * g.dstep_h;
+            dw = s_tw * g.dstep_w;
+            kvalid = true;
+            s_cc += 8;
+            if (s_cc == p.cpt) {
+                s_cc = 0;
+                if (++s_tw == g.TW) { s_tw = 0; ++s_th; }
+            }
+        } else {
+            kvalid = q < p.nchunks;
+            const int tap = q / p.cpt;
+            cc = q - tap * p.cpt;
+            const int th = tap / g.TW;
+            const int tw = tap - th * g.TW;
+            dh = th * g.dstep_h;
+            dw = tw * g.dstep_w;
+        }
+        // branch-free: out-of-image taps / rows beyond M load a valid dummy address and are zeroed afterwards
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
             const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#if OPT_BRANCHFREE
+            const int64_t off = ok ? a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4 : 0;
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.a + off);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[j] = ok ? v : z;
+#else
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const float* src = p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4;
-                v = *reinterpret_cast<const f32x4*>(src);
-            }
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
             ra[j] = v;
+#endif
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
+            const bool ok = kvalid && b_ok[j];
+#if OPT_BRANCHFREE
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.wt + (ok ? b_off[j] + (int64_t)q * 4 : 0));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rb[j] = ok ? v : z;
+#else
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kvalid && b_ok[j]) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[j] + (int64_t)q * 4);
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[j] + (int64_t)q * 4);
             rb[j] = v;
+#endif
         }
     };
     auto store_step = [&](int buf) {
@@ -171,14 +202,55 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
     const int b_frag = BM * LDS_LD + (wave_n * WN + frag_row) * LDS_LD + frag_half * 4;
 
     // ---- main loop ------------------------------------------------------------------------
+    // per K-step: fragments of sub-step kk+1 are read from LDS while the 4*TM*TN MFMAs of kk execute (two
+    // register sets), the global loads of K-step ks+1 are issued behind the first fragment reads and land in
+    // the other LDS buffer after the MFMAs; one barrier per K-step.
     load_step(0);
     store_step(0);
     __syncthreads();
     for (int ks = 0; ks < p.nk; ++ks) {
         const int cur = ks & 1;
         const bool more = ks + 1 < p.nk;
-        if (more) load_step(ks + 1);
         const float* sbuf = smem + cur * BUF;
+#if OPT_PREFETCH
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(sbuf + a_frag + i * 32 * LDS_LD);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(sbuf + b_frag + j * 32 * LDS_LD);
+        if (more) load_step(ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int cs = kk & 1, ns = cs ^ 1;
+            if (kk + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[ns][i] = *reinterpret_cast<const f32x4*>(sbuf + a_frag + i * 32 * LDS_LD + (kk + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[ns][j] = *reinterpret_cast<const f32x4*>(sbuf + b_frag + j * 32 * LDS_LD + (kk + 1) * 8);
+            }
+            if (NORM) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ss[i] = fmaf(af[cs][i][0], af[cs][i][0], ss[i]);
+                    ss[i] = fmaf(af[cs][i][1], af[cs][i][1], ss[i]);
+                    ss[i] = fmaf(af[cs][i][2], af[cs][i][2], ss[i]);
+                    ss[i] = fmaf(af[cs][i][3], af[cs][i][3], ss[i]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cs][i][c], bf[cs][j][c], acc[i][j], 0, 0, 0);
+        }
+#else
+#if OPT_LOADFIRST
+        if (more) load_step(ks + 1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 af[TM], bf[TN];
@@ -188,6 +260,9 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[j] = *reinterpret_cast<const f32x4*>(sbuf + b_frag + j * 32 * LDS_LD + kk * 8);
+#if !OPT_LOADFIRST
+            if (kk == 0 && more) load_step(ks + 1);
+#endif
             if (NORM) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -205,6 +280,7 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
+#endif
         if (more) store_step(cur ^ 1);
         __syncthreads();
     }
@@ -377,15 +453,66 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
     }
 }
 
+// XCD-aware id remap: the 8 XCDs (private L2s) each get a contiguous range of `nt` work items (bijective for any nt)
+__device__ __forceinline__ int xcd_remap(int bid, int nt) {
+    const int xcd = bid % NXCD, idx = bid / NXCD;
+    const int q = nt / NXCD, r = nt % NXCD;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// Grid = n_big tiles of BM rows followed by n_small tiles of BM/2 rows covering the remaining rows.  Workgroups are
+// dispatched in blockIdx order, so the half-height tiles fill the tail of the launch: with a few hundred equal
+// tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
+// = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+__global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    if (bid < p.n_big) {
+        const int tile = xcd_remap(bid, p.n_big);
+        const int tile_m = tile / p.tiles_n;
+        const int tile_n = tile - tile_m * p.tiles_n;
+        tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+    } else {
+        constexpr int BMS = BM / 2;
+        constexpr int WMS = (BMS / 32 >= WAVES_M) ? WAVES_M : BMS / 32;    // waves along M of the small tile
+        constexpr int WNS = 4 / WMS;
+        if constexpr (BN / WNS >= 32) {
+            const int tile = xcd_remap(bid - p.n_big, p.n_small);
+            const int tile_m = tile / p.tiles_n;
+            const int tile_n = tile - tile_m * p.tiles_n;
+            tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+        }
+    }
+}
+
+constexpr int SLOTS = 512;   // 256 CUs x 2 resident workgroups (LDS- and VGPR-limited)
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     KArgs p = base;
-    p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.g.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int64_t total = (int64_t)tiles_m * p.tiles_n;
+    // how many BM-row tiles to keep at full height: whole "rounds" of SLOTS (of 256 when there is less than one round)
+    constexpr bool can_split = (BM / 2 >= 32) && (BN / (4 / ((BM / 64 >= WAVES_M) ? WAVES_M : BM / 64)) >= 32);
+    int m_big = tiles_m;
+    if (can_split && total < 8 * SLOTS && !getenv("BCOS_NO_TAIL_SPLIT")) {
+        const int64_t unit = total >= SLOTS ? SLOTS : SLOTS / 2;
+        const int64_t full = (total / unit) * unit;
+        const int64_t rem = total - full;
+        if (rem > 0 && rem < (unit * 9) / 10) m_big = (int)(full / p.tiles_n);
+    }
+    p.rows_big = m_big * BM;
+    if (p.rows_big > p.M) p.rows_big = p.M;
+    p.n_big = m_big * p.tiles_n;
+    const int rows_small = p.M - p.rows_big;
+    p.n_small = rows_small > 0 ? ((rows_small + BM / 2 - 1) / (BM / 2)) * p.tiles_n : 0;
     size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float) + (size_t)BM * 16;
     if (lds_epi > lds) lds = lds_epi;
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHREADS);
+    const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
     hipError_t err;
     if (norm) {
         auto k = tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true>;
@@ -440,7 +567,8 @@ extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_
     p.cpt = g.C / 4;
     p.nchunks = p.Ktot / 4;
     p.nk = (p.nchunks + 7) / 8;
-    p.tiles_m = p.tiles_n = 0;
+    p.tiles_n = p.n_big = p.n_small = p.rows_big = 0;
+    p.uniform_tap = (g.C % BK == 0) ? 1 : 0;
     {
         uintptr_t bits = 0;
         const void* ptrs[] = {epi->addend, epi->mul, epi->mul2, epi->gate2, epi->relu_gate, epi->out, epi->out2, epi->scale_out};
