@@ -53,21 +53,32 @@ def cpu_baseline(net, arch, n_images):
     host cores: forward + explanation of `n_images` images, 1 warm-up + 2 timed passes."""
     from bcos_hip import synth
     from oracle import bcos_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("BCOS_CPU_BASELINE_THREADS", "32"))))   # oneDNN stops scaling (and
+    torch.set_num_threads(cores)                                       # oversubscribes badly) far below 256 threads
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     x = synth.synthetic_images(n_images, seed=321)
     fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
-    O.explain_batch(fwd, x[:2])                     # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    O.explain_batch(fwd, x[:2])                     # warm-up (oneDNN primitive creation) + cost probe
+    probe = time.perf_counter() - t0
+    # bounded sample: keep the whole baseline leg within ~30 s of CPU work
+    n_images = max(2, min(n_images, int(12.0 / max(probe / 2, 1e-3))))
+    x = x[:n_images]
     times = []
     for _ in range(2):
         t0 = time.perf_counter()
         O.explain_batch(fwd, x)
         times.append(time.perf_counter() - t0)
+        if sum(times) > 25.0:
+            break
     best = min(times)
     return dict(value=round(n_images / best, 3), unit="images/s", cores=cores, kind="port",
-                sample=f"forward+explanation of {n_images} images (1 batch), best of 2 after warm-up, "
-                       f"torch {torch.__version__} CPU fp32, {cores} threads")
+                sample=f"forward+explanation of {n_images} images (1 batch), best of {len(times)} after warm-up, "
+                       f"torch {torch.__version__} CPU fp32, {cores} of {avail} hardware threads")
 
 
 def main():
