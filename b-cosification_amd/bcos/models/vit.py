@@ -1,0 +1,194 @@
+"""SimpleViT topology (Beyer et al., "Better plain ViT baselines for ImageNet-1k") with the reference's module and
+state-dict names (bcos/models/vit.py:230-339): `to_patch_embedding.linear`, `transformer.encoder_N.attn.{norm,to_qkv,
+to_out}`, `transformer.encoder_N.ff.net.{norm,linear1,act,linear2}`, `linear_head.{norm,linear}`; sin-cos positional
+embedding (:64-86); optional classifier-before-mean ordering `gap_reorder` (:331-338).
+
+`Attention` (:118-158) is the one piece that needs MI355X code of its own: q and k are detached in explanation mode, so
+the softmax matrix is a constant and only v carries gradient; forward and that gradient are LDS-resident HIP kernels
+(bcos_attention_fwd / _bwd_v), the plain `to_qkv` projection runs on the same fp32-MFMA GEMM as the B-cos layers.
+"""
+from collections import OrderedDict
+from typing import Any, Callable, List, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from bcos.modules import _hipfn
+from bcos.modules.common import DetachableModule
+from bcos_hip import ops
+
+__all__ = ["SimpleViT", "Attention", "PosEmbSinCos2d", "simple_vit_ti_patch16_224", "simple_vit_s_patch16_224",
+           "simple_vit_b_patch16_224", "simple_vit_l_patch16_224"]
+
+
+def pair(t: Any) -> Tuple[Any, Any]:
+    return t if isinstance(t, tuple) else (t, t)
+
+
+class PatchRearrange(nn.Module):
+    """'b c (h p1) (w p2) -> b h w (p1 p2 c)' (einops Rearrange in the reference, :290-294)."""
+
+    def __init__(self, p1: int, p2: int):
+        super().__init__()
+        self.p1, self.p2 = p1, p2
+
+    def forward(self, x: Tensor) -> Tensor:
+        b, c, hh, ww = x.shape
+        h, w = hh // self.p1, ww // self.p2
+        x = x.reshape(b, c, h, self.p1, w, self.p2).permute(0, 2, 4, 3, 5, 1)
+        return x.reshape(b, h, w, self.p1 * self.p2 * c)
+
+
+class PosEmbSinCos2d(nn.Module):
+    def __init__(self, temperature: Union[int, float] = 10_000):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, patches: Tensor) -> Tensor:
+        h, w, dim = patches.shape[-3:]
+        device, dtype = patches.device, patches.dtype
+        y, x = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+        assert (dim % 4) == 0, "feature dimension must be multiple of 4 for sincos emb"
+        omega = torch.arange(dim // 4, device=device) / (dim // 4 - 1)
+        omega = 1.0 / (self.temperature**omega)
+        y = y.flatten()[:, None] * omega[None, :]
+        x = x.flatten()[:, None] * omega[None, :]
+        return torch.cat((x.sin(), x.cos(), y.sin(), y.cos()), dim=1).type(dtype)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, linear_layer=None, norm_layer=None, act_layer=None):
+        assert linear_layer is not None and norm_layer is not None and act_layer is not None
+        super().__init__()
+        self.net = nn.Sequential(OrderedDict(norm=norm_layer(dim), linear1=linear_layer(dim, hidden_dim), act=act_layer(),
+                                             linear2=linear_layer(hidden_dim, dim)))
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.net(x)
+
+
+class _AttentionCoreFn(Function):
+    """softmax(q k^T scale) v on packed qkv [B,T,3*inner]; explanation-mode backward feeds v only."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale, detach):
+        _hipfn.require_hip(qkv, "Attention")
+        qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        need = ctx.needs_input_grad[0]
+        out, stats = ops.attention_fwd(qkv, heads, scale, want_stats=need)
+        ctx.cfg = (heads, scale, detach)
+        if need:
+            ctx.save_for_backward(qkv, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        heads, scale, detach = ctx.cfg
+        if not detach:
+            raise NotImplementedError("attention backward outside explanation mode is not implemented in the MI355X build")
+        qkv, stats = ctx.saved_tensors
+        gv = ops.attention_bwd_v(qkv, stats, gout if gout.is_contiguous() else gout.contiguous(), heads, scale)
+        gqkv = torch.zeros_like(qkv)
+        inner = gv.shape[-1]
+        gqkv[..., 2 * inner:] = gv
+        return gqkv, None, None, None
+
+
+class Attention(DetachableModule):
+    def __init__(self, dim, heads=8, dim_head=64, linear_layer=None, norm_layer=None):
+        assert linear_layer is not None and norm_layer is not None
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.scale = dim_head**-0.5
+        self.norm = norm_layer(dim)
+        self.attend = nn.Softmax(dim=-1)
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = linear_layer(inner_dim, dim, bias=False)
+        self._qkv_cache = _hipfn.WeightCache()
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.norm(x)
+        qkv = _hipfn.plain_linear(x, self.to_qkv.weight, self.to_qkv.bias, self._qkv_cache, self.to_qkv.weight)
+        out = _AttentionCoreFn.apply(qkv, self.heads, self.scale, self.detach)
+        return self.to_out(out)
+
+
+class Encoder(nn.Module):
+    def __init__(self, dim, heads, dim_head, mlp_dim, linear_layer=None, norm_layer=None, act_layer=None):
+        super().__init__()
+        self.attn = Attention(dim, heads=heads, dim_head=dim_head, linear_layer=linear_layer, norm_layer=norm_layer)
+        self.ff = FeedForward(dim, mlp_dim, linear_layer=linear_layer, norm_layer=norm_layer, act_layer=act_layer)
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.attn(x) + x
+        x = self.ff(x) + x
+        return x
+
+
+class Transformer(nn.Sequential):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, linear_layer=None, norm_layer=None, act_layer=None):
+        layers = OrderedDict()
+        for i in range(depth):
+            layers[f"encoder_{i}"] = Encoder(dim=dim, heads=heads, dim_head=dim_head, mlp_dim=mlp_dim,
+                                             linear_layer=linear_layer, norm_layer=norm_layer, act_layer=act_layer)
+        super().__init__(layers)
+
+
+class SimpleViT(nn.Module):
+    def __init__(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, channels: int = 6,
+                 linear_layer: Callable[..., nn.Module] = None, norm_layer: Callable[..., nn.Module] = None,
+                 act_layer: Callable[..., nn.Module] = None, norm2d_layer=None, conv2d_layer=None,
+                 conv_stem: List[int] = None, gap_reorder: bool = False, **kwargs):
+        super().__init__()
+        _ = kwargs
+        image_height, image_width = pair(image_size)
+        patch_height, patch_width = pair(patch_size)
+        assert linear_layer is not None and norm_layer is not None and act_layer is not None
+        if conv_stem:
+            raise NotImplementedError("conv-stem ViTs (vitc_*) are outside the MI355X hot path")
+        assert image_height % patch_height == 0 and image_width % patch_width == 0, \
+            "Image dimensions must be divisible by the patch size."
+        self.image_size, self.patch_size = (image_height, image_width), (patch_height, patch_width)
+        self.num_patches = (image_height // patch_height) * (image_width // patch_width)
+        self.patch_dim = channels * patch_height * patch_width
+        self.to_patch_embedding = nn.Sequential(OrderedDict(rearrage=PatchRearrange(patch_height, patch_width),
+                                                            linear=linear_layer(self.patch_dim, dim)))
+        self.positional_embedding = PosEmbSinCos2d()
+        dim_head = dim // heads
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, linear_layer=linear_layer,
+                                       norm_layer=norm_layer, act_layer=act_layer)
+        self.to_latent = nn.Identity()
+        self.linear_head = nn.Sequential(OrderedDict(norm=norm_layer(dim), linear=linear_layer(dim, num_classes)))
+        self.gap_reorder = gap_reorder
+
+    def forward(self, img):
+        x = self.to_patch_embedding(img)
+        pe = self.positional_embedding(x)
+        x = x.flatten(1, -2) + pe
+        x = self.transformer(x)
+        if self.gap_reorder:
+            return self.linear_head(self.to_latent(x)).mean(dim=1)
+        return self.linear_head(self.to_latent(x.mean(dim=1)))
+
+
+def _simple_vit(dim, depth, heads, mlp_dim, **kwargs):
+    kwargs.setdefault("num_classes", 1_000)
+    return SimpleViT(image_size=224, patch_size=16, dim=dim, depth=depth, heads=heads, mlp_dim=mlp_dim, **kwargs)
+
+
+def simple_vit_ti_patch16_224(**kwargs):
+    return _simple_vit(192, 12, 3, 768, **kwargs)
+
+
+def simple_vit_s_patch16_224(**kwargs):
+    return _simple_vit(384, 12, 6, 1536, **kwargs)
+
+
+def simple_vit_b_patch16_224(**kwargs):
+    return _simple_vit(768, 12, 12, 3072, **kwargs)
+
+
+def simple_vit_l_patch16_224(**kwargs):
+    return _simple_vit(1024, 14, 16, 4096, **kwargs)

@@ -1,0 +1,96 @@
+"""Detachable (centred) norms for B-cos transformers on MI355X.
+
+Reference: bcos/modules/norms/centered_norms.py -- `DetachableLayerNorm` :187-245 is the one the B-cosified ViTs use
+(SURVEY.md a10).  In explanation mode its variance is a constant while the mean stays differentiable, so
+    y = w (x - mean(x)) / std (+ b),    d y / d x  applied to g:   h - mean(h),  h = g w / std.
+Forward and that input gradient are one-wavefront-per-row HIP kernels (bcos_layernorm_fwd / _bwd_detached).
+The 2-D group-norm variants (`DetachableGroupNorm2d`, ViT-C conv stems only) are not part of any benchmarked
+configuration and are declared but not implemented.
+"""
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.autograd import Function
+
+from bcos_hip import ops
+
+from bcos.modules import _hipfn
+from bcos.modules.common import DetachableModule
+
+__all__ = ["DetachableLayerNorm", "DetachableGroupNorm2d", "DetachableGNLayerNorm2d"]
+
+
+class _LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, detach):
+        _hipfn.require_hip(x, "DetachableLayerNorm")
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        w = weight.detach().contiguous() if weight is not None else None
+        b = bias.detach().contiguous() if bias is not None else None
+        y, rstd = ops.layernorm_fwd(x2, w, b, eps, want_rstd=ctx.needs_input_grad[0])
+        ctx.detach_mode = detach
+        ctx.w = w
+        if rstd is not None:
+            ctx.save_for_backward(rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.detach_mode:
+            raise NotImplementedError("LayerNorm backward outside explanation mode is not implemented in the MI355X "
+                                      "build (SURVEY.md section 8(f) N4): use model.explanation_mode()")
+        (rstd,) = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1])
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        gx, _ = ops.layernorm_bwd_detached(g2, ctx.w, rstd)
+        return gx.view(gy.shape), None, None, None, None
+
+
+class DetachableLayerNorm(nn.LayerNorm, DetachableModule):
+    """nn.LayerNorm over the last dimension whose variance is detached in explanation mode (reference :187-245)."""
+
+    def __init__(self, *args, **kwargs):
+        DetachableModule.__init__(self)
+        super().__init__(*args, **kwargs)
+
+    def forward(self, input: Tensor) -> Tensor:
+        if len(self.normalized_shape) != 1:
+            raise NotImplementedError("the HIP LayerNorm normalises over the last dimension only")
+        return _LayerNormFn.apply(input, self.weight, self.bias, self.eps, self.detach)
+
+    @classmethod
+    def from_standard_module(cls, standard_module: nn.LayerNorm, model_config: dict):
+        new = cls(normalized_shape=standard_module.normalized_shape, eps=standard_module.eps,
+                  elementwise_affine=standard_module.elementwise_affine)
+        if model_config.get("weights", None) is not None:
+            new.weight.data = standard_module.weight.data
+            if standard_module.bias is not None:
+                new.bias.data = standard_module.bias.data
+        return new
+
+
+class DetachableGroupNorm2d(nn.GroupNorm, DetachableModule):
+    """ViT-C conv-stem norm (reference :93-160): declared for import compatibility, not implemented (no benchmarked
+    configuration uses the conv-stem ViTs)."""
+
+    def __init__(self, *args, **kwargs):
+        DetachableModule.__init__(self)
+        super().__init__(*args, **kwargs)
+
+    def forward(self, input):
+        raise NotImplementedError("DetachableGroupNorm2d (ViT-C conv stems) is outside the MI355X hot path")
+
+    @classmethod
+    def from_standard_module(cls, mod: nn.GroupNorm, model_config: dict):
+        new = cls(mod.num_groups, mod.num_channels, eps=mod.eps, affine=mod.affine)
+        if model_config.get("weights", None) is not None and mod.affine:
+            new.weight.data = mod.weight.data
+            new.bias.data = mod.bias.data
+        return new
+
+
+class DetachableGNLayerNorm2d(DetachableGroupNorm2d):
+    def __init__(self, num_channels: int, *args, **kwargs):
+        super().__init__(1, num_channels, *args, **kwargs)

@@ -18,7 +18,7 @@ REPO_ROOT = PKG_ROOT.parent
 LIB_PATH = Path(os.environ["BCOS_HIP_LIB"]) if os.environ.get("BCOS_HIP_LIB") else PKG_ROOT / "lib" / "libbcos_hip.so"
 CSRC = PKG_ROOT / "csrc"
 INCLUDE = REPO_ROOT / "include"
-SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_abi.hip"]
+SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_vit.hip", "bcos_abi.hip"]
 
 BCOS_NONE, BCOS_CONV_EPS, BCOS_LINEAR_EPS = 0, 1, 2
 BCOS_EPI_NORM_ONLY = 1
@@ -66,6 +66,13 @@ SIGNATURES = {
     "bcos_head_onehot_grad": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "bcos_argmax_rows": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "bcos_channel_affine": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "bcos_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "bcos_layernorm_bwd_detached": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "bcos_gelu_gate": (C.c_int, [_P, _P, _P, _L, _P]),
+    "bcos_add_rows_bcast": (C.c_int, [_P, _P, _L, _L, _P]),
+    "bcos_attention_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "bcos_attention_bwd_v": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "bcos_finalize_explanation_patches": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

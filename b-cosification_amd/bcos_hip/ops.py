@@ -66,7 +66,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         p = _dev(t, f"tapconv.{k}", contiguous=False)
         setattr(e, k, p.value if p is not None else None)
     e.bcos_mode = int(bcos_mode)
-    e.relu = int(bool(relu))
+    e.relu = int(relu)          # 0 none, 1 ReLU, 2 GELU with constant gate
     e.b = float(b)
     e.flags = int(flags)
     timing = KERNEL_TIMING
@@ -343,3 +343,74 @@ def channel_affine(x, scale, shift=None, relu=False, out=None):
     _l.check(lib.bcos_channel_affine(_dev(x, "x"), _dev(scale, "scale"), _dev(shift, "shift"), _dev(out, "y"), x.numel() // Cc, Cc,
                                      int(bool(relu)), _stream()), "bcos_channel_affine")
     return out
+
+
+# ---- transformer pieces (csrc/bcos_vit.hip) ----------------------------------------------------------------
+def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None):
+    lib = _l.load()
+    rows, D = x2d.shape
+    y = out if out is not None else torch.empty_like(x2d)
+    rstd = torch.empty((rows,), device=x2d.device, dtype=torch.float32) if want_rstd else None
+    _l.check(lib.bcos_layernorm_fwd(_dev(x2d, "x"), _dev(weight, "w"), _dev(bias, "b"), _dev(y, "y"), _dev(rstd, "rstd"), rows, D,
+                                    float(eps), _stream()), "bcos_layernorm_fwd")
+    return y, rstd
+
+
+def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None):
+    lib = _l.load()
+    rows, D = gy2d.shape
+    o = (out if out is not None else torch.empty_like(gy2d)) if want_out else None
+    o2 = torch.empty_like(gy2d) if want_out2 else None
+    _l.check(lib.bcos_layernorm_bwd_detached(_dev(gy2d, "gy"), _dev(weight, "w"), _dev(rstd, "rstd"), _dev(addend, "addend"),
+                                             _dev(mul2, "mul2"), _dev(o, "out"), _dev(o2, "out2"), rows, D, _stream()),
+             "bcos_layernorm_bwd_detached")
+    return o, o2
+
+
+def gelu_gate(x, want_gate=False, out=None):
+    lib = _l.load()
+    y = out if out is not None else torch.empty_like(x)
+    gate = torch.empty_like(x) if want_gate else None
+    _l.check(lib.bcos_gelu_gate(_dev(x, "x"), _dev(y, "y"), _dev(gate, "gate"), x.numel(), _stream()), "bcos_gelu_gate")
+    return y, gate
+
+
+def add_rows_bcast(x, pe):
+    lib = _l.load()
+    _l.check(lib.bcos_add_rows_bcast(_dev(x, "x"), _dev(pe, "pe"), x.numel(), pe.numel(), _stream()), "bcos_add_rows_bcast")
+    return x
+
+
+def attention_fwd(qkv, heads, scale, want_stats=False):
+    """qkv [B,T,3*H*64] -> out [B,T,H*64] (+ stats [B,H,T,2])."""
+    lib = _l.load()
+    B, T, three_inner = qkv.shape
+    inner = three_inner // 3
+    out = torch.empty((B, T, inner), device=qkv.device, dtype=torch.float32)
+    stats = torch.empty((B, heads, T, 2), device=qkv.device, dtype=torch.float32) if want_stats else None
+    _l.check(lib.bcos_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), _dev(stats, "stats"), B, T, heads, inner // heads,
+                                    float(scale), _stream()), "bcos_attention_fwd")
+    return out, stats
+
+
+def attention_bwd_v(qkv, stats, gout, heads, scale):
+    lib = _l.load()
+    B, T, three_inner = qkv.shape
+    inner = three_inner // 3
+    gv = torch.empty((B, T, inner), device=qkv.device, dtype=torch.float32)
+    _l.check(lib.bcos_attention_bwd_v(_dev(qkv, "qkv"), _dev(stats, "stats"), _dev(gout, "gout"), _dev(gv, "gv"), B, T, heads,
+                                      inner // heads, float(scale), _stream()), "bcos_attention_bwd_v")
+    return gv
+
+
+def finalize_explanation_patches(gp, x_nchw, std6, patch, add_inverse=False, want_weights=True, want_contrib=True):
+    """gp [N*gh*gw, patch*patch*Cpad] (patch-major input gradient) -> W(x) [N,6,H,W], contribution map [N,H,W]."""
+    lib = _l.load()
+    N, Cx, H, W = x_nchw.shape
+    cpad = gp.shape[-1] // (patch * patch)
+    wout = torch.empty((N, 6, H, W), device=gp.device, dtype=torch.float32) if want_weights else None
+    cout = torch.empty((N, H, W), device=gp.device, dtype=torch.float32) if want_contrib else None
+    _l.check(lib.bcos_finalize_explanation_patches(_dev(gp, "gp"), _dev(x_nchw, "x"), _dev(std6, "std"), _dev(wout, "w"),
+                                                   _dev(cout, "c"), N, Cx, H, W, patch, cpad, int(add_inverse), _stream()),
+             "bcos_finalize_explanation_patches")
+    return wout, cout

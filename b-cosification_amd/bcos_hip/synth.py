@@ -98,7 +98,8 @@ def synthetic_images(n: int, seed: int = 123, size: int = 224, smooth: bool = Tr
 
 
 def _is_bcos_conv(m) -> bool:
-    return hasattr(m, "linear") and hasattr(m, "b") and isinstance(getattr(m, "linear", None), nn.Conv2d)
+    """a B-cos conv or linear layer of either implementation (duck-typed: `.linear` + `.b`)"""
+    return hasattr(m, "linear") and hasattr(m, "b") and isinstance(getattr(m, "linear", None), (nn.Conv2d, nn.Linear))
 
 
 def _is_bnu(m) -> bool:
@@ -162,3 +163,46 @@ def apply_calibration(net: nn.Module, record: Dict[str, torch.Tensor]):
         else:
             m.running_var.copy_(val.to(m.running_var.device))
     return net
+
+
+# ---- SimpleViT (BASELINE.json configs[2]) -------------------------------------------------------------------
+def vit_model_config(arch: str = "simple_vit_ti_patch16_224") -> dict:
+    """CONFIGS['bcosifyv2_<arch>_..._gapReorder'] model section (vit_bcosification/experiment_parameters.py:129-215)."""
+    return dict(
+        is_bcos=True,
+        name=arch,
+        weights="pretrained",
+        args=dict(num_classes=1000, channels=6, gap_reorder=True),
+        bcos_args=dict(b=2, max_out=1),
+        bcosify_args=dict(fix_b=True, use_bias=False),
+        logit_layer=True,
+        act_layer=True,
+        logit_bias=math.log(1 / (1000 - 1)),
+    )
+
+
+def standard_vit(arch: str, seed: int = 0, vit_module=None):
+    """The standard (non-B-cos) SimpleViT that the recipe starts from (vit_final/model.py:21-46 with nn.Linear,
+    nn.LayerNorm, nn.GELU, 3 input channels).  `vit_module` lets the golden generator pass the reference's module."""
+    if vit_module is None:
+        from bcos.models import vit as vit_module
+    torch.manual_seed(seed)
+    return getattr(vit_module, arch)(channels=3, linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU)
+
+
+def finish_vit_conversion(model: nn.Module, model_config: dict):
+    """vit_bcosification/model.py:19-29: null the biases unless use_bias, set gap_reorder."""
+    if not model_config.get("bcosify_args", {}).get("use_bias", False):
+        for mod in model.modules():
+            if hasattr(mod, "bias") and mod.bias is not None:
+                mod.bias = None
+    if model_config["args"].get("gap_reorder", False):
+        model.model.gap_reorder = True
+    return model
+
+
+def build_bcosified_vit(arch: str = "simple_vit_ti_patch16_224", seed: int = 0):
+    from bcosify_vit import BcosifyNetwork
+    cfg = vit_model_config(arch)
+    net = BcosifyNetwork(standard_vit(arch, seed), cfg, add_channels=True, logit_layer=cfg["logit_layer"])
+    return finish_vit_conversion(net, cfg).eval()

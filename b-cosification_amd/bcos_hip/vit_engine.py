@@ -1,0 +1,257 @@
+"""Fused forward / explanation engine for B-cosified SimpleViT models (BASELINE.json configs[2]).
+
+Per encoder block the launch plan is
+    LN -> to_qkv GEMM -> attention -> to_out B-cos GEMM (+ residual in the epilogue)
+    LN -> linear1 B-cos GEMM (+ GELU gate in the epilogue) -> linear2 B-cos GEMM (+ residual in the epilogue)
+i.e. 3 fused B-cos launches, 1 plain GEMM, 2 LayerNorm and 1 attention kernel (reference: ~45 ATen launches,
+bcos/models/vit.py:143-228 + bcosifylinear.py:61-94).  The patch embedding is run as a stride-16 16x16 B-cos
+"convolution" over the NHWC input (identical to Rearrange + BcosifyLinear, vit.py:290-296), the classifier with
+`gap_reorder` as a per-token B-cos GEMM followed by the mean + logit-bias kernel.
+
+Explanation pass (explanation mode of bcos/common.py:163-181): LayerNorm variance, GELU gate, softmax matrix and the
+B-cos scales are constants, so the backward is: per B-cos layer one GEMM with the stored scale applied in the
+producer's epilogue, LayerNorm input-gradients (which also add the residual gradient and pre-multiply by the next
+scale), and the attention v-gradient kernel.  The last GEMM yields the patch-major input gradient which one kernel turns
+into W(x) [N,6,H,W] and the contribution map.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import BCOS_LINEAR_EPS, BcosHipError
+
+
+class _Lin:
+    """Kernel-side view of one BcosifyLinear / BcosLinear."""
+
+    def __init__(self, mod):
+        from bcos.modules.bcoslinear import BcosLinear
+        if not isinstance(mod, BcosLinear) or mod.max_out != 1:
+            raise BcosHipError(f"vit engine: expected a B-cos linear with max_out == 1, got {type(mod).__name__}")
+        self.module = mod
+        self.refresh()
+
+    def refresh(self):
+        w, bias = self.module._effective_weight_and_bias()
+        w = w.detach()
+        self.b = self.module._b_value()
+        self.w = w.contiguous()                        # [Cout, Cin]
+        self.wt = w.t().contiguous()                   # [Cin, Cout] for the input gradient
+        self.bias = bias.detach().contiguous() if bias is not None else None
+        self.cin, self.cout = w.shape[1], w.shape[0]
+
+    def fwd(self, x2d, *, addend=None, act=0, want_scale=False):
+        rows = x2d.shape[0]
+        g = dict(N=1, H=1, W=rows, C=self.cin, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1, TH=1,
+                 TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=self.cout)
+        y = torch.empty((rows, self.cout), device=x2d.device, dtype=torch.float32)
+        t = torch.empty_like(y) if want_scale else None
+        ops.tapconv(x2d, self.w, g, out=y, scale_out=t, bias=self.bias, addend=addend,
+                    bcos_mode=BCOS_LINEAR_EPS if self.b != 1.0 else 0, b=self.b, relu=act)
+        return y, t
+
+    def dgrad(self, glin, *, mul=None):
+        return ops.matmul_nt(glin, self.wt, mul=mul)
+
+
+class _LN:
+    def __init__(self, mod):
+        from bcos.modules.norms.centered_norms import DetachableLayerNorm
+        if not isinstance(mod, DetachableLayerNorm):
+            raise BcosHipError(f"vit engine: expected DetachableLayerNorm, got {type(mod).__name__}")
+        self.module = mod
+        self.refresh()
+
+    def refresh(self):
+        m = self.module
+        self.w = m.weight.detach().contiguous() if m.weight is not None else None
+        self.bias = m.bias.detach().contiguous() if m.bias is not None else None
+        self.eps = m.eps
+
+    def fwd(self, x2d, keep):
+        return ops.layernorm_fwd(x2d, self.w, self.bias, self.eps, want_rstd=keep)
+
+    def bwd(self, gy, rstd, *, addend=None, mul2=None, want_out=True, want_out2=False):
+        return ops.layernorm_bwd_detached(gy, self.w, rstd, addend=addend, mul2=mul2, want_out=want_out, want_out2=want_out2)
+
+
+class ViTEngine:
+    """Launch plan for `bcosify_vit.BcosifyNetwork(SimpleViT(...))`."""
+
+    def __init__(self, net):
+        from bcos.models.vit import SimpleViT
+        from bcosify_vit import MyGELU
+        m = net.model
+        if not isinstance(m, SimpleViT):
+            raise BcosHipError(f"vit engine: {type(m).__name__} is not a SimpleViT")
+        self.net = net
+        self.patch = m.patch_size[0]
+        if m.patch_size[0] != m.patch_size[1]:
+            raise BcosHipError("vit engine: square patches only")
+        self.embed_mod = m.to_patch_embedding.linear
+        self.blocks = []
+        for enc in m.transformer.children():
+            act = enc.ff.net.act
+            if isinstance(act, MyGELU):
+                act_mode = 2
+            elif isinstance(act, nn.Identity):
+                act_mode = 0
+            else:
+                raise BcosHipError(f"vit engine: unsupported activation {type(act).__name__}")
+            if enc.attn.to_qkv.bias is not None:
+                raise BcosHipError("vit engine: to_qkv with bias is not supported")
+            self.blocks.append(dict(ln1=_LN(enc.attn.norm), qkv=enc.attn.to_qkv, heads=enc.attn.heads,
+                                    scale=enc.attn.scale, out=_Lin(enc.attn.to_out), ln2=_LN(enc.ff.net.norm),
+                                    l1=_Lin(enc.ff.net.linear1), act=act_mode, l2=_Lin(enc.ff.net.linear2)))
+        self.head_ln = _LN(m.linear_head.norm)
+        self.head = _Lin(m.linear_head.linear)
+        self.gap_reorder = bool(m.gap_reorder)
+        norm = net.bcosifynormalize
+        self._mean, self._std = tuple(norm.mean), tuple(norm.std)
+        self._dev = {}
+        ll = net.logit_layer
+        self.logit_bias = ll.logit_bias if ll is not None else None
+        self.logit_temperature = ll.logit_temperature if ll is not None else None
+        self.refresh()
+
+    def refresh(self):
+        from bcos.modules.bcoslinear import BcosLinear
+        e = self.embed_mod
+        if not isinstance(e, BcosLinear) or e.max_out != 1:
+            raise BcosHipError("vit engine: patch embedding must be a B-cos linear")
+        w, bias = e._effective_weight_and_bias()
+        p = self.patch
+        dim = w.shape[0]
+        if w.shape[1] != p * p * 6:
+            raise BcosHipError("vit engine: patch embedding must take 6-channel patches")
+        w4 = torch.nn.functional.pad(w.detach().view(dim, p, p, 6), (0, 2))           # [dim, p, p, 8]
+        self.embed_w = w4.contiguous()
+        self.embed_wt = w4.reshape(dim, p * p * 8).t().contiguous()                   # [p*p*8, dim]
+        self.embed_bias = bias.detach().contiguous() if bias is not None else None
+        self.embed_b = e._b_value()
+        self.dim = dim
+        for blk in self.blocks:
+            for k in ("ln1", "out", "ln2", "l1", "l2"):
+                blk[k].refresh()
+            wq = blk["qkv"].weight.detach()
+            inner = wq.shape[0] // 3
+            blk["wqkv"] = wq.contiguous()                                            # [3*inner, dim]
+            blk["wv_t"] = wq[2 * inner:].t().contiguous()                            # [dim, inner]: gx = gv @ Wv
+            blk["inner"] = inner
+        self.head_ln.refresh()
+        self.head.refresh()
+        self._pe = {}
+
+    def _consts(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.tensor(self._mean, dtype=torch.float32, device=device),
+                              torch.tensor(self._std, dtype=torch.float32, device=device))
+        return self._dev[key]
+
+    def _posemb(self, gh, gw, device):
+        key = (gh, gw, str(device))
+        if key not in self._pe:
+            pe = self.net.model.positional_embedding(torch.empty((1, gh, gw, self.dim), device=device))
+            self._pe[key] = pe.contiguous()
+        return self._pe[key]
+
+    # --------------------------------------------------------------------------------------------------------
+    def _run_forward(self, x, keep):
+        if x.dim() != 4 or x.shape[1] not in (3, 6):
+            raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
+        ops.require_device(x, "bcos_hip.vit_engine")
+        x = x.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        N, _, H, W = x.shape
+        p = self.patch
+        gh, gw = H // p, W // p
+        T = gh * gw
+        mean, std = self._consts(x.device)
+        add_inverse = x.shape[1] == 3
+        xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse)
+        # patch embedding = 16x16 / stride 16 B-cos conv with the linear layer's epsilon placement
+        geom = ops.fwd_geom(N, H, W, 8, self.dim, p, p, p, p, 0, 0)
+        tok = torch.empty((N * T, self.dim), device=x.device, dtype=torch.float32)
+        t_embed = torch.empty_like(tok) if keep else None
+        ops.tapconv(xn, self.embed_w, geom, out=tok, scale_out=t_embed, bias=self.embed_bias,
+                    bcos_mode=BCOS_LINEAR_EPS if self.embed_b != 1.0 else 0, b=self.embed_b)
+        ops.add_rows_bcast(tok, self._posemb(gh, gw, x.device))
+        st = dict(x=x, add_inverse=add_inverse, N=N, T=T, t_embed=t_embed, blocks=[]) if keep else None
+        cur = tok
+        for blk in self.blocks:
+            h, rstd1 = blk["ln1"].fwd(cur, keep)
+            qkv = ops.matmul_nt(h, blk["wqkv"])
+            a, stats = ops.attention_fwd(qkv.view(N, T, -1), blk["heads"], blk["scale"], want_stats=keep)
+            x1, t_out = blk["out"].fwd(a.view(N * T, -1), addend=cur, want_scale=keep)
+            h2, rstd2 = blk["ln2"].fwd(x1, keep)
+            z, t1 = blk["l1"].fwd(h2, act=blk["act"], want_scale=keep)
+            x2, t2 = blk["l2"].fwd(z, addend=x1, want_scale=keep)
+            if keep:
+                st["blocks"].append(dict(rstd1=rstd1, qkv=qkv, stats=stats, t_out=t_out, rstd2=rstd2, t1=t1, t2=t2))
+            cur = x2
+        if self.gap_reorder:
+            hN, rstd_h = self.head_ln.fwd(cur, keep)
+            f, t_head = self.head.fwd(hN, want_scale=keep)
+            logits = ops.global_avgpool_logits(f.view(N, T, 1, -1), self.logit_temperature, self.logit_bias)
+        else:
+            pooled = ops.global_avgpool_logits(cur.view(N, T, 1, -1), None, None)
+            hN, rstd_h = self.head_ln.fwd(pooled, keep)
+            f, t_head = self.head.fwd(hN, want_scale=keep)
+            logits = f
+            if self.logit_temperature is not None:
+                logits = logits / self.logit_temperature
+            if self.logit_bias is not None:
+                logits = logits + self.logit_bias
+        if keep:
+            st.update(rstd_h=rstd_h, t_head=t_head)
+        return logits, st
+
+    @torch.no_grad()
+    def forward(self, x):
+        return self._run_forward(x, keep=False)[0]
+
+    @torch.no_grad()
+    def explain(self, x, targets: Optional[torch.Tensor] = None, want_weights: bool = True) -> Dict[str, torch.Tensor]:
+        logits, st = self._run_forward(x, keep=True)
+        N, T = st["N"], st["T"]
+        pred, _ = ops.argmax_rows(logits)
+        cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
+        nb = len(self.blocks)
+        t_last = st["blocks"][-1]["t2"] if nb else st["t_embed"]
+        if self.gap_reorder:
+            g_head = ops.head_onehot_grad(cls, st["t_head"].view(N, T, 1, -1), self.logit_temperature)     # [N,T,1,K]
+            g_hN = self.head.dgrad(g_head.view(N * T, -1))
+            g_x, g_lin = self.head_ln.bwd(g_hN, st["rstd_h"], mul2=t_last, want_out=True, want_out2=True)
+        else:
+            g_head = ops.head_onehot_grad(cls, st["t_head"].view(N, 1, 1, -1), self.logit_temperature)     # [N,1,1,K]
+            g_hN = self.head.dgrad(g_head.view(N, -1))
+            g_pool, _ = self.head_ln.bwd(g_hN, st["rstd_h"])
+            g_x = (g_pool / T).repeat_interleave(T, dim=0).contiguous()          # gradient of the token mean
+            g_lin = ops.mul(g_x, t_last)
+        # invariant at the top of each block iteration: g_x = d logit / d (block output), g_lin = g_x * t2 of the block
+        for bi in range(nb - 1, -1, -1):
+            blk, rec = self.blocks[bi], st["blocks"][bi]
+            g_z = blk["l2"].dgrad(g_lin, mul=rec["t1"])                         # = g_lin of linear1 (GELU gate inside t1)
+            g_h2 = blk["l1"].dgrad(g_z)
+            g_x1, g_lin_out = blk["ln2"].bwd(g_h2, rec["rstd2"], addend=g_x, mul2=rec["t_out"], want_out2=True)
+            g_a = blk["out"].dgrad(g_lin_out)
+            g_v = ops.attention_bwd_v(rec["qkv"].view(N, T, -1), rec["stats"], g_a.view(N, T, -1), blk["heads"], blk["scale"])
+            g_h = ops.matmul_nt(g_v.view(N * T, -1), blk["wv_t"])
+            t_prev = st["blocks"][bi - 1]["t2"] if bi > 0 else st["t_embed"]
+            g_x, g_lin = blk["ln1"].bwd(g_h, rec["rstd1"], addend=g_x1, mul2=t_prev, want_out=bi > 0, want_out2=True)
+            st["blocks"][bi] = None
+        gp = ops.matmul_nt(g_lin, self.embed_wt)                                # [N*T, p*p*8] patch-major input gradient
+        _, std = self._consts(x.device)
+        wts, contrib = ops.finalize_explanation_patches(gp, st["x"], std, self.patch, add_inverse=st["add_inverse"],
+                                                        want_weights=want_weights, want_contrib=True)
+        return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
+                    contribution_map=contrib)
+
+
+def attach(net) -> ViTEngine:
+    eng = ViTEngine(net)
+    object.__setattr__(net, "_bcos_engine", eng)
+    return eng

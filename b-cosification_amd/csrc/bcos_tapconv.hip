@@ -395,12 +395,19 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
                 val = val * csc4 + csh4;
                 s *= csc4;
                 if (e.addend) val += ad[u];
-                if (e.relu) {
+                if (e.relu == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
                         s[q] = open_gate ? s[q] : 0.f;
                         val[q] = open_gate ? val[q] : 0.f;
+                    }
+                } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
+                        s[q] *= gate;
+                        val[q] *= gate;
                     }
                 }
                 if (ok[u]) {
@@ -435,10 +442,14 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
                 v = v * csc4[q] + csh4[q];
                 s *= csc4[q];
                 if (e.addend) v += e.addend[idx];
-                if (e.relu) {
+                if (e.relu == 1) {
                     const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
                     s = open_gate ? s : 0.f;
                     v = open_gate ? v : 0.f;
+                } else if (e.relu == 2) {
+                    const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
+                    s *= gate;
+                    v *= gate;
                 }
                 if (e.out) e.out[idx] = e.mul ? v * e.mul[idx] : v;
                 if (e.out2) {

@@ -89,7 +89,8 @@ typedef struct bcos_tapconv_geom {
  *                                                    (batchnorm_uncentered.py:46-60)
  *     v += ch_shift[c]                               ... its bias
  *     v += addend[idx]                               residual add (fwd) / gradient accumulation (dgrad)
- *     relu: s = v > 0 ? s : 0; v = max(v, 0)         (relu_gate != NULL: the decision is relu_gate[idx] > 0 instead of
+ *     relu == 2: gate = 0.5 (1 + erf(v / sqrt 2)); s *= gate; v *= gate   (MyGELU, bcosify_vit.py:27-32)
+ *     relu == 1: s = v > 0 ? s : 0; v = max(v, 0)    (relu_gate != NULL: the decision is relu_gate[idx] > 0 instead of
  *                                                    v > 0 -- replay of recorded gates, see tests/ gate-pinned parity)
  *     out [idx] = mul  ? v * mul [idx] : v           dgrad: multiply by the stored scale of the layer below
  *     out2[idx] = v [* mul2[idx]] [* (gate2[idx] > 0)]   second product of the same v (shortcut gradient)
@@ -111,7 +112,7 @@ typedef struct bcos_epilogue {
     float* scale_out;
     float* norm_out;
     int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
-    int32_t relu;
+    int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */
     int32_t flags;          /* BCOS_EPI_* bits                            */
 } bcos_epilogue;
@@ -246,6 +247,41 @@ int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N, int C, voi
  * y = x * scale[c] + shift[c] (shift may be NULL) (batchnorm_uncentered.py:46-60). */
 int bcos_channel_affine(const float* x, const float* scale, const float* shift, float* y,
                         int64_t pixels, int C, int relu, void* stream);
+
+/* -- transformer pieces (bcos_vit.hip) ---------------------------------------------------- */
+
+/* LayerNorm over the last dimension D of x [rows, D] (weight / bias may be NULL); rstd_out (NULL or [rows]) keeps
+ * 1/sqrt(var+eps) for the backward.  Forward of DetachableLayerNorm (bcos/modules/norms/centered_norms.py:197-224;
+ * the value does not depend on explanation mode). */
+int bcos_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_out,
+                       int64_t rows, int D, float eps, void* stream);
+
+/* Input gradient of DetachableLayerNorm in explanation mode (variance constant, mean differentiable,
+ * centered_norms.py:204-215):  g = gy * weight * rstd - mean_D(gy * weight * rstd)  (+ addend);
+ * out = g, out2 = g * mul2 (either may be NULL; mul2 NULL -> out2 = g). */
+int bcos_layernorm_bwd_detached(const float* gy, const float* weight, const float* rstd, const float* addend,
+                                const float* mul2, float* out, float* out2, int64_t rows, int D, void* stream);
+
+/* MyGELU (bcosify_vit.py:27-32): y = gate * x with gate = 0.5 (1 + erf(x / sqrt 2)); gate_out may be NULL. */
+int bcos_gelu_gate(const float* x, float* y, float* gate_out, int64_t n, void* stream);
+
+/* x[i] += pe[i % period]: sin-cos positional embedding added to the tokens (bcos/models/vit.py:324-326). */
+int bcos_add_rows_bcast(float* x, const float* pe, int64_t total, int64_t period, void* stream);
+
+/* softmax(q k^T * scale) v per (batch, head), head dim 64.  qkv [B, T, 3*H*64] ordered (q | k | v) x (h d) like
+ * vit.py:145-146; out [B, T, H*64]; stats (NULL or [B, H, T, 2]) = (row max, 1 / row sum) for the backward. */
+int bcos_attention_fwd(const float* qkv, float* out, float* stats, int B, int T, int H, int Dh, float scale, void* stream);
+
+/* Gradient w.r.t. v with q, k detached (vit.py:148-151, bcosattnpool.py:37-39): gv = attn^T gout, attn recomputed from
+ * qkv and stats. gout, gv: [B, T, H*64]. */
+int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout, float* gv, int B, int T, int H, int Dh,
+                         float scale, void* stream);
+
+/* End of the ViT explanation pass: gp [N, H/p, W/p, p, p, Cpad] (input gradient of the patch embedding, one row per
+ * patch in the "(p1 p2 c)" order of vit.py:291) -> W(x) [N,6,H,W] (/ std) and contribution map [N,H,W]. */
+int bcos_finalize_explanation_patches(const float* gp, const float* x, const float* std6, float* weights_out,
+                                      float* contrib_out, int N, int Cx, int H, int W, int patch, int Cpad,
+                                      int add_inverse, void* stream);
 
 #ifdef __cplusplus
 }

@@ -278,3 +278,71 @@ def gradient_to_image(image, linear_mapping, smooth=15, alpha_percentile=99.5):
         alpha = F.avg_pool2d(alpha, smooth, stride=1, padding=(smooth - 1) // 2)
     alpha = (alpha / torch.quantile(alpha, q=alpha_percentile / 100)).clip(0, 1)
     return torch.cat([rgb, alpha], dim=0).permute(1, 2, 0).detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# B-cosified SimpleViT (bcos/models/vit.py:230-339 converted by bcosify_vit.py:45-154; factory
+# bcos/experiments/ImageNet/vit_bcosification/model.py:7-31)
+# ----------------------------------------------------------------------------------------------
+def posemb_sincos_2d(h, w, dim, temperature=10_000, dtype=torch.float32):
+    """PosEmbSinCos2d.forward: vit.py:69-86."""
+    y, x = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    omega = torch.arange(dim // 4) / (dim // 4 - 1)
+    omega = 1.0 / (temperature ** omega)
+    y = y.flatten()[:, None] * omega[None, :]
+    x = x.flatten()[:, None] * omega[None, :]
+    return torch.cat((x.sin(), x.cos(), y.sin(), y.cos()), dim=1).type(dtype)
+
+
+def vit_attention(sd, p, x, heads, b, detach):
+    """Attention.forward: vit.py:143-158 (q, k detached in explanation mode; to_qkv is a plain Linear)."""
+    dim = x.shape[-1]
+    h = layer_norm_detachable(x, (dim,), sd[p + "norm.weight"], sd.get(p + "norm.bias"), 1e-5, detach)
+    qkv = F.linear(h, sd[p + "to_qkv.weight"]).chunk(3, dim=-1)
+    B, T, inner = qkv[0].shape
+    q, k, v = (t.view(B, T, heads, inner // heads).transpose(1, 2) for t in qkv)
+    if detach:
+        q, k = q.detach(), k.detach()
+    dots = torch.matmul(q, k.transpose(-1, -2)) * (inner // heads) ** -0.5
+    out = torch.matmul(dots.softmax(dim=-1), v).transpose(1, 2).reshape(B, T, inner)
+    return bcos_linear(out, sd[p + "to_out.linear.weight"], sd.get(p + "to_out.linear.bias"), b=b, detach=detach)
+
+
+def vit_feedforward(sd, p, x, b, detach, gelu=True):
+    dim = x.shape[-1]
+    h = layer_norm_detachable(x, (dim,), sd[p + "norm.weight"], sd.get(p + "norm.bias"), 1e-5, detach)
+    h = bcos_linear(h, sd[p + "linear1.linear.weight"], sd.get(p + "linear1.linear.bias"), b=b, detach=detach)
+    if gelu:
+        h = gelu_detachable(h, detach)
+    return bcos_linear(h, sd[p + "linear2.linear.weight"], sd.get(p + "linear2.linear.bias"), b=b, detach=detach)
+
+
+def simple_vit_logits(sd, x6, patch=16, heads=3, b=2, detach=False, gap_reorder=True, gelu=True,
+                      mean=IMAGENET_MEAN_ADDINVERSE, std=IMAGENET_STD_ADDINVERSE, logit_bias=-math.log(1000 - 1),
+                      logit_temperature=None, prefix="model."):
+    """bcosify_vit.BcosifyNetwork.forward (bcosify_vit.py:80-83) around SimpleViT.forward (vit.py:322-339)."""
+    xn = normalize6(x6, mean, std)
+    B, C, H, W = xn.shape
+    gh, gw = H // patch, W // patch
+    # Rearrange 'b c (h p1) (w p2) -> b h w (p1 p2 c)'  (vit.py:290-294)
+    tok = xn.reshape(B, C, gh, patch, gw, patch).permute(0, 2, 4, 3, 5, 1).reshape(B, gh, gw, patch * patch * C)
+    x = bcos_linear(tok, sd[prefix + "to_patch_embedding.linear.linear.weight"],
+                    sd.get(prefix + "to_patch_embedding.linear.linear.bias"), b=b, detach=detach)
+    dim = x.shape[-1]
+    x = x.reshape(B, gh * gw, dim) + posemb_sincos_2d(gh, gw, dim, dtype=x.dtype)
+    depth = 0
+    while (prefix + f"transformer.encoder_{depth}.attn.to_qkv.weight") in sd:
+        depth += 1
+    for i in range(depth):
+        p = prefix + f"transformer.encoder_{i}."
+        x = vit_attention(sd, p + "attn.", x, heads, b, detach) + x
+        x = vit_feedforward(sd, p + "ff.net.", x, b, detach, gelu) + x
+
+    def head(t):
+        t = layer_norm_detachable(t, (dim,), sd[prefix + "linear_head.norm.weight"], sd.get(prefix + "linear_head.norm.bias"),
+                                  1e-5, detach)
+        return bcos_linear(t, sd[prefix + "linear_head.linear.linear.weight"], sd.get(prefix + "linear_head.linear.linear.bias"),
+                           b=b, detach=detach)
+
+    out = head(x).mean(dim=1) if gap_reorder else head(x.mean(dim=1))
+    return logit_layer(out, logit_temperature, logit_bias)

@@ -66,7 +66,11 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
 
     if addend is not None:
         v = v + rd(addend)
-    if relu:
+    if relu == 2:
+        gate = 0.5 * (1 + torch.erf(v / 2 ** 0.5))
+        s = s * gate
+        v = v * gate
+    elif relu:
         open_gate = (rd(relu_gate) > 0) if relu_gate is not None else (v > 0)
         s = torch.where(open_gate, s, torch.zeros_like(s))
         v = torch.where(open_gate, v, torch.zeros_like(v))
@@ -176,7 +180,8 @@ def install(monkeypatch):
     from bcos_hip import ops
     for name in ("tapconv", "prep_input", "finalize_explanation", "avgpool2d_fwd", "avgpool2d_bwd",
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
-                 "weight_rownorm_scale", "contrib_map", "maxout_scale"):
+                 "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
+                 "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn
@@ -196,6 +201,68 @@ def maxout_scale(lin2d, norm, Cout, max_out, b, groups=1, want_scale=False, want
         out.copy_(y)
         y = out
     return y, (s if want_scale else None), (arg.to(torch.int32) if want_argmax else None)
+
+
+def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None):
+    var, mean = torch.var_mean(x2d.double(), dim=-1, unbiased=False, keepdim=True)
+    sd = (var + eps).sqrt()
+    y = (x2d.double() - mean) / sd
+    if weight is not None:
+        y = y * weight.double()
+    if bias is not None:
+        y = y + bias.double()
+    return y.float(), ((1 / sd).float().view(-1) if want_rstd else None)
+
+
+def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None):
+    h = gy2d.double() * (weight.double() if weight is not None else 1.0) * rstd.double().view(-1, 1)
+    g = h - h.mean(-1, keepdim=True)
+    if addend is not None:
+        g = g + addend.double()
+    o2 = (g * mul2.double() if mul2 is not None else g).float() if want_out2 else None
+    return (g.float() if want_out else None), o2
+
+
+def gelu_gate(x, want_gate=False, out=None):
+    gate = 0.5 * (1 + torch.erf(x / 2 ** 0.5))
+    return gate * x, (gate if want_gate else None)
+
+
+def add_rows_bcast(x, pe):
+    x.view(-1, pe.numel()).add_(pe.reshape(1, -1))
+    return x
+
+
+def _attn_probs(qkv, heads, scale):
+    B, T, three = qkv.shape
+    inner = three // 3
+    q, k, v = (t.view(B, T, heads, inner // heads).transpose(1, 2).double() for t in qkv.split(inner, dim=-1))
+    return torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1), v, inner
+
+
+def attention_fwd(qkv, heads, scale, want_stats=False):
+    p, v, inner = _attn_probs(qkv, heads, scale)
+    B, T, _ = qkv.shape
+    out = (p @ v).transpose(1, 2).reshape(B, T, inner).float()
+    return out, (torch.zeros(B, heads, T, 2) if want_stats else None)
+
+
+def attention_bwd_v(qkv, stats, gout, heads, scale):
+    p, v, inner = _attn_probs(qkv, heads, scale)
+    B, T, _ = qkv.shape
+    g = gout.view(B, T, heads, inner // heads).transpose(1, 2).double()
+    return (p.transpose(-1, -2) @ g).transpose(1, 2).reshape(B, T, inner).float()
+
+
+def finalize_explanation_patches(gp, x, std6, patch, add_inverse=False, want_weights=True, want_contrib=True):
+    if add_inverse:
+        x = torch.cat([x, 1 - x], 1)
+    N, _, H, W = x.shape
+    gh, gw = H // patch, W // patch
+    cpad = gp.shape[-1] // (patch * patch)
+    g = gp.view(N, gh, gw, patch, patch, cpad)[..., :6].permute(0, 5, 1, 3, 2, 4).reshape(N, 6, H, W)
+    w = g / std6.view(1, 6, 1, 1)
+    return (w.contiguous() if want_weights else None), ((x * w).sum(1) if want_contrib else None)
 
 
 class _Setter:

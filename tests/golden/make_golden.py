@@ -293,8 +293,55 @@ def resnet50_logits_small():
                        torch_version=torch.__version__), f, indent=1)
 
 
+def vit_ti_end_to_end():
+    """BASELINE.json configs[2] topology (B-cosified simple_vit_ti_patch16_224, gap_reorder) on 4 images: logits, class
+    indices, W(x) and contribution maps.  No ReLU gates here (erf-GELU, softmax): maps are smooth in the weights."""
+    import importlib
+    ref_vit = importlib.import_module("bcos.models.vit")
+    ref_bvit = importlib.import_module("bcosify_vit")
+    import warnings
+    warnings.simplefilter("ignore")
+    arch = "simple_vit_ti_patch16_224"
+    cfg = synth.vit_model_config(arch)
+    std = synth.standard_vit(arch, 0, vit_module=ref_vit)
+    net = ref_bvit.BcosifyNetwork(std, cfg, add_channels=True, logit_layer=cfg["logit_layer"])
+    synth.finish_vit_conversion(net, cfg)
+    net.eval()
+    x = synth.synthetic_images(4)
+    record = synth.calibrate(net, x)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    logits, wts, contribs, preds = [], [], [], []
+    for i in range(4):
+        xi = x[i:i + 1].clone().requires_grad_(True)
+        res = net.explain(xi)
+        with torch.no_grad():
+            logits.append(net(x[i:i + 1]))
+        wts.append(res["dynamic_linear_weights"].detach())
+        contribs.append(res["contribution_map"].detach())
+        preds.append(res["prediction"])
+    logits = torch.cat(logits); wts = torch.cat(wts); contribs = torch.cat(contribs)
+    oe = O.explain_batch(lambda xx, detach: O.simple_vit_logits(sd, xx, detach=detach), x)
+    REPORT["vit/oracle_logits"] = rel(oe["logits"], logits)
+    REPORT["vit/oracle_weights"] = rel(oe["dynamic_linear_weights"], wts)
+    REPORT["vit/oracle_contrib"] = rel(oe["contribution_map"], contribs)
+    REPORT["vit/oracle_argmax_equal"] = bool((oe["prediction"] == torch.tensor(preds)).all())
+    with torch.backends.mkldnn.flags(enabled=False):
+        w2 = []
+        for i in range(2):
+            xi = x[i:i + 1].clone().requires_grad_(True)
+            w2.append(net.explain(xi)["dynamic_linear_weights"].detach())
+        REPORT["vit/reference_self_floor_weights"] = rel(torch.cat(w2), wts[:2])
+    rec_np = {f"calib/{k}": v.numpy() for k, v in record.items()}
+    np.savez_compressed(os.path.join(HERE, "vit_ti_e2e.npz"), logits=logits.numpy(), prediction=np.array(preds),
+                        contribution_map=contribs.numpy(), weights_0=wts[:1].numpy(), **rec_np)
+    with open(os.path.join(HERE, "vit_ti_e2e.json"), "w") as f:
+        json.dump(dict(arch=arch, weight_seed=0, image_seed=123, n_images=4, calib_images=4,
+                       calib_order=list(record.keys()), state_checksum=state_checksum(sd),
+                       torch_version=torch.__version__), f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "inv", "r18", "r50"]
+    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -306,6 +353,8 @@ if __name__ == "__main__":
         resnet18_end_to_end()
     if "r50" in which:
         resnet50_logits_small()
+    if "vit" in which:
+        vit_ti_end_to_end()
     with open(rep_path, "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     for k in sorted(REPORT):

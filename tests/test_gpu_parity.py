@@ -378,3 +378,90 @@ def test_resnet50_batch256_properties(lib):
     ref = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, "resnet50", detach=detach), x[100:102].cpu())
     assert rel(sub["logits"], ref["logits"]) <= 1e-4
     assert torch.equal(sub["prediction"].cpu(), ref["prediction"])
+
+
+# ------------------------------------------------------------------------------------------ transformer pieces
+def test_vit_kernels(lib):
+    """DetachableLayerNorm / MyGELU / attention kernels against their oracle forms (explanation-mode gradients)."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(50, 192, generator=g) * 2 + 0.3
+    w, b = torch.rand(192, generator=g) + 0.5, torch.randn(192, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True)
+    y_ref = O.layer_norm_detachable(xr, (192,), w, b, 1e-5, detach=True)
+    gy = torch.randn(y_ref.shape, generator=g)
+    (gx_ref,) = torch.autograd.grad(y_ref, xr, gy)
+    y, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, want_rstd=True)
+    assert rel(y, y_ref) <= 1e-6
+    add, m2 = torch.randn(50, 192, generator=g), torch.randn(50, 192, generator=g)
+    o, o2 = ops.layernorm_bwd_detached(gy.to(DEV), w.to(DEV), rstd, addend=add.to(DEV), mul2=m2.to(DEV), want_out2=True)
+    assert rel(o, gx_ref + add) <= 1e-5 and rel(o2, (gx_ref + add) * m2) <= 1e-5
+    z = torch.randn(1000, generator=g) * 2
+    yg, gate = ops.gelu_gate(z.to(DEV), want_gate=True)
+    assert rel(yg, O.gelu_detachable(z)) <= 1e-6 and rel(gate, 0.5 * (1 + torch.erf(z / 2 ** 0.5))) <= 1e-6
+    for (B, T, H) in ((3, 196, 3), (2, 50, 32), (1, 17, 1)):
+        qkv = torch.randn(B, T, 3 * H * 64, generator=g)
+        inner = H * 64
+        q, k, v = (t.view(B, T, H, 64).transpose(1, 2) for t in qkv.split(inner, dim=-1))
+        vr = v.clone().requires_grad_(True)
+        out_ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ vr).transpose(1, 2).reshape(B, T, inner)
+        go = torch.randn(out_ref.shape, generator=g)
+        (gv_ref,) = torch.autograd.grad(out_ref, vr, go)
+        out, stats = ops.attention_fwd(qkv.to(DEV), H, 0.125, want_stats=True)
+        assert rel(out, out_ref) <= 1e-5, (B, T, H)
+        gv = ops.attention_bwd_v(qkv.to(DEV), stats, go.to(DEV), H, 0.125)
+        assert rel(gv, gv_ref.transpose(1, 2).reshape(B, T, inner)) <= 1e-5, (B, T, H)
+
+
+def _golden_vit(golden_dir):
+    from bcos_hip import synth
+    meta = json.load(open(os.path.join(golden_dir, "vit_ti_e2e.json")))
+    data = np.load(os.path.join(golden_dir, "vit_ti_e2e.npz"))
+    net = synth.build_bcosified_vit(meta["arch"], seed=meta["weight_seed"])
+    synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
+    sd = net.state_dict()
+    for k, (s1, s2) in meta["state_checksum"].items():
+        assert abs(float(sd[k].double().sum()) - s1) <= 1e-6 * max(1.0, s2), k
+    return net.to(DEV), meta, data
+
+
+def test_vit_ti_against_reference_golden(lib, golden_dir):
+    """BASELINE.json configs[2] topology: B-cosified simple_vit_ti_patch16_224.  No ReLU gates => the maps are held to
+    1e-4 against the reference's recorded outputs directly."""
+    from bcos_hip import synth, vit_engine
+    net, meta, data = _golden_vit(golden_dir)
+    x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+    out_m = net.explain_batch(x[:2])                       # nn.Module path: autograd over per-layer HIP kernels
+    assert rel(out_m["logits"], data["logits"][:2]) <= 1e-4
+    assert rel(out_m["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
+    eng = vit_engine.attach(net)
+    out = net.explain_batch(x)
+    assert rel(out["logits"], data["logits"]) <= 1e-4
+    assert np.array_equal(out["prediction"].cpu().numpy(), data["prediction"])
+    assert rel(out["contribution_map"], data["contribution_map"]) <= 1e-4
+    assert rel(out["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
+    with torch.no_grad():
+        assert rel(net(x), data["logits"]) <= 1e-4         # forward through the engine
+    again = eng.explain(x)
+    assert torch.equal(again["dynamic_linear_weights"], out["dynamic_linear_weights"])     # deterministic
+
+
+def test_vit_ti_batch512_properties(lib):
+    """BASELINE.json configs[2] at full size: batch 512 on one GPU; a sub-batch reproduces bit-identically and agrees
+    with the CPU oracle."""
+    from bcos_hip import synth, vit_engine
+    net = synth.build_bcosified_vit("simple_vit_ti_patch16_224").to(DEV)
+    x = synth.synthetic_images(512).to(DEV)
+    with torch.no_grad():
+        synth.calibrate(net, x[:8])
+    eng = vit_engine.attach(net)
+    out = eng.explain(x)
+    assert out["logits"].shape == (512, 1000) and torch.isfinite(out["dynamic_linear_weights"]).all()
+    assert len(set(out["prediction"].tolist())) > 1
+    sub = eng.explain(x[300:302])
+    assert torch.equal(sub["logits"], out["logits"][300:302])
+    assert torch.equal(sub["contribution_map"], out["contribution_map"][300:302])
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = O.explain_batch(lambda xx, detach: O.simple_vit_logits(sd, xx, detach=detach), x[300:302].cpu())
+    assert rel(sub["logits"], ref["logits"]) <= 1e-4 and torch.equal(sub["prediction"].cpu(), ref["prediction"])
+    assert rel(sub["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4

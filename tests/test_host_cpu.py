@@ -283,3 +283,55 @@ def test_shard_bounds_cover_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_vit_conversion_layout_and_engine_plan(monkeypatch):
+    """bcosify_vit conversion (75 tensors / 5.80 M for ViT-Ti, interleaved 6-channel patch embedding) and the fused ViT
+    plan (patch-embedding-as-conv, LN / attention / GELU-epilogue launches, explanation backward) on emulated kernels."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import synth, vit_engine
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    from bcos.modules.norms import DetachableLayerNorm
+    from bcosify_vit import MyGELU
+    net = synth.build_bcosified_vit("simple_vit_ti_patch16_224")
+    sd = net.state_dict()
+    assert len(sd) == 75 and sum(v.numel() for v in sd.values()) == 5_800_128
+    assert sd["model.to_patch_embedding.linear.linear.weight"].shape == (192, 1536)
+    assert sd["model.transformer.encoder_3.attn.to_qkv.weight"].shape == (576, 192)
+    assert not any(k.endswith("bias") for k in sd)
+    enc = net.model.transformer.encoder_0
+    assert isinstance(enc.attn.to_out, BcosifyLinear) and type(enc.attn.to_qkv) is nn.Linear
+    assert isinstance(enc.ff.net.act, MyGELU) and isinstance(enc.attn.norm, DetachableLayerNorm)
+    # add_channels interleave: columns (p, c) with c in (r,g,b,-r,-g,-b)/2
+    w = sd["model.to_patch_embedding.linear.linear.weight"].view(192, 256, 6)
+    assert torch.equal(w[..., 3:], -w[..., :3])
+    x = synth.synthetic_images(2, size=64)
+    # a 64x64 input has 16 tokens: build a small-image twin sharing the weights
+    from bcos.models import vit as vitmod
+    small = vitmod.SimpleViT(image_size=64, patch_size=16, num_classes=1000, dim=192, depth=12, heads=3, mlp_dim=768,
+                             channels=3, linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU)
+    from bcosify_vit import BcosifyNetwork
+    cfg = synth.vit_model_config()
+    net64 = synth.finish_vit_conversion(BcosifyNetwork(small, cfg, add_channels=True, logit_layer=True), cfg).eval()
+    net64.load_state_dict(sd)
+    sd = {k: v.detach() for k, v in sd.items()}
+    eng = vit_engine.ViTEngine(net64)
+    out = eng.explain(x)
+    ref = O.explain_batch(lambda xx, detach: O.simple_vit_logits(sd, xx, detach=detach), x)
+    assert rel(out["logits"], ref["logits"]) <= 1e-5
+    assert torch.equal(out["prediction"], ref["prediction"])
+    assert rel(out["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
+    assert rel(out["contribution_map"], ref["contribution_map"]) <= 1e-4
+    assert rel(eng.forward(x), ref["logits"]) <= 1e-5
+    # classifier after the token mean (gap_reorder = False)
+    net64.model.gap_reorder = False
+    eng2 = vit_engine.ViTEngine(net64)
+    out2 = eng2.explain(x)
+    ref2 = O.explain_batch(lambda xx, detach: O.simple_vit_logits(sd, xx, detach=detach, gap_reorder=False), x)
+    assert rel(out2["logits"], ref2["logits"]) <= 1e-5
+    assert rel(out2["dynamic_linear_weights"], ref2["dynamic_linear_weights"]) <= 1e-4
+    # module path (autograd over the HIP-backed modules) agrees as well
+    net64.model.gap_reorder = True
+    out_m = net64.explain_batch(x)
+    assert rel(out_m["logits"], ref["logits"]) <= 1e-5
+    assert rel(out_m["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
