@@ -99,7 +99,7 @@ class BcosUtilMixin:
         Uses the fused engine when one is attached (`bcos_hip.engine.attach`), else autograd over the modules.
         """
         engine = getattr(self, "_bcos_engine", None)
-        if engine is not None:
+        if engine is not None and getattr(engine, "supports_explain", True):
             return engine.explain(images, targets)
         x = images.detach().clone().requires_grad_(True)
         with torch.enable_grad(), self.explanation_mode():

@@ -41,14 +41,14 @@ class _AvgPoolFn(Function):
 class AvgPool2d(nn.AvgPool2d):
     def _hip_ok(self, x):
         k, s, p = _hipfn._pair(self.kernel_size), _hipfn._pair(self.stride), _hipfn._pair(self.padding)
-        return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0
-                and k[0] == k[1] and s[0] == s[1] and p[0] == p[1] and not self.ceil_mode
-                and self.count_include_pad and self.divisor_override is None)
+        return (x.dim() == 4 and x.shape[1] % 4 == 0 and k[0] == k[1] and s[0] == s[1] and p[0] == p[1]
+                and not self.ceil_mode and self.count_include_pad and self.divisor_override is None)
 
     def forward(self, input):
+        _hipfn.require_hip(input, "bcos.modules.pooling.AvgPool2d")
         if not self._hip_ok(input):
             raise _hipfn.BcosHipError(
-                "bcos.modules.pooling.AvgPool2d: needs a 4-d fp32 HIP tensor with C % 4 == 0 and square, "
+                "bcos.modules.pooling.AvgPool2d: needs a 4-d tensor with C % 4 == 0 and square, "
                 "count_include_pad pooling without ceil_mode / divisor_override")
         return _AvgPoolFn.apply(input, _hipfn._pair(self.kernel_size)[0], _hipfn._pair(self.stride)[0],
                                 _hipfn._pair(self.padding)[0])

@@ -82,16 +82,31 @@ class _Conv:
 
 
 class _Block:
+    """A residual block: main-path convs (each followed by its norm; ReLU after all but possibly the last, which adds the
+    shortcut first), an optional shortcut conv, and -- CLIP's anti-aliased variant (CLIP/clip/model.py:25,36-40) -- an
+    AvgPool2d(stride) in front of the last main conv and in front of the shortcut conv."""
+
     def __init__(self, block):
         names = [n for n in ("conv1", "conv2", "conv3") if hasattr(block, n)]
         self.convs = [_Conv(getattr(block, n), getattr(block, n.replace("conv", "bn"))) for n in names]
-        self.relu = isinstance(block.relu, nn.ReLU)
+        relus = [getattr(block, r) for r in ("relu", "relu1", "relu2", "relu3") if hasattr(block, r)]
+        self.relu = all(isinstance(r, nn.ReLU) for r in relus)
+        if not self.relu and not all(isinstance(r, nn.Identity) for r in relus):
+            raise BcosHipError("engine: mixed activations inside a block")
+        self.pool = 0
+        ap = getattr(block, "avgpool", None)
+        if isinstance(ap, nn.AvgPool2d):
+            self.pool = _pool_stride(ap)
         ds = block.downsample
         self.shortcut = None
+        self.shortcut_pool = 0
         if ds is not None:
             mods = list(ds.children())
+            if len(mods) == 3 and isinstance(mods[0], nn.AvgPool2d):
+                self.shortcut_pool = _pool_stride(mods[0])
+                mods = mods[1:]
             if len(mods) != 2:
-                raise BcosHipError("engine: downsample must be (conv, norm)")
+                raise BcosHipError("engine: downsample must be ([AvgPool2d,] conv, norm)")
             self.shortcut = _Conv(mods[0], mods[1])
 
     def refresh(self):
@@ -101,40 +116,74 @@ class _Block:
             self.shortcut.refresh()
 
 
+def _pool_stride(pool: nn.AvgPool2d) -> int:
+    k, s, p = _pair(pool.kernel_size), _pair(pool.stride), _pair(pool.padding)
+    if k != s or k[0] != k[1] or p != (0, 0) or pool.ceil_mode or pool.divisor_override is not None:
+        raise BcosHipError("engine: only AvgPool2d(stride) anti-aliasing pools are supported inside blocks")
+    return k[0]
+
+
 class ResNetEngine:
     """Launch plan for `BcosifyNetwork(ResNetBcos(...))` (bcosify.py:22-53 + standard_models.py:36-54)."""
 
     def __init__(self, net):
         m = net.model
-        for attr in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "fc", "avgpool"):
+        self.net = net
+        for attr in ("conv1", "bn1", "layer1", "layer2", "layer3", "layer4"):
             if not hasattr(m, attr):
-                raise BcosHipError(f"engine: {type(m).__name__} has no `{attr}`: not a torchvision-style ResNet")
-        if not isinstance(m.maxpool, nn.AvgPool2d):
+                raise BcosHipError(f"engine: {type(m).__name__} has no `{attr}`: not a ResNet-style network")
+        if hasattr(m, "attnpool"):
+            # CLIP ModifiedResNet (CLIP/clip/model.py:94-154): 3-conv stem + AvgPool2d(2), attention-pool head
+            self.stem = [(_Conv(getattr(m, f"conv{i}"), getattr(m, f"bn{i}")), isinstance(getattr(m, f"relu{i}"), nn.ReLU))
+                         for i in (1, 2, 3)]
+            pool = m.avgpool
+            self.head_kind = "attnpool"
+            self.head = None
+            self.attnpool = m.attnpool
+            if getattr(m.attnpool, "attn_unpool", False):
+                raise BcosHipError("engine: attn_unpool heads run through the module path only")
+        else:
+            for attr in ("relu", "maxpool", "fc", "avgpool"):
+                if not hasattr(m, attr):
+                    raise BcosHipError(f"engine: {type(m).__name__} has no `{attr}`: not a torchvision-style ResNet")
+            self.stem = [(_Conv(m.conv1, m.bn1), isinstance(m.relu, nn.ReLU))]
+            pool = m.maxpool
+            self.head_kind = "gap_fc"
+            self.head = _Conv(m.fc, None)
+        if not isinstance(pool, nn.AvgPool2d):
             raise BcosHipError("engine: the stem pool must be nn.AvgPool2d (the B-cosification recipe swaps MaxPool for "
                                "AvgPool2d(3,2,1): bcosification/experiment_parameters.py:99)")
-        pool = m.maxpool
         self.pool = (_pair(pool.kernel_size)[0], _pair(pool.stride)[0], _pair(pool.padding)[0])
         if pool.ceil_mode or not pool.count_include_pad or pool.divisor_override is not None:
             raise BcosHipError("engine: unsupported AvgPool2d options")
-        self.net = net
-        self.stem = _Conv(m.conv1, m.bn1)
-        self.stem_relu = isinstance(m.relu, nn.ReLU)
         self.blocks: List[_Block] = []
         for li in range(1, 5):
             for blk in getattr(m, f"layer{li}").children():
                 self.blocks.append(_Block(blk))
-        self.head = _Conv(m.fc, None)
         norm = net.bcosifynormalize
         self._mean, self._std = tuple(norm.mean), tuple(norm.std)
         self._dev_consts = {}
         ll = net.logit_layer
         self.logit_bias = ll.logit_bias if ll is not None else None
         self.logit_temperature = ll.logit_temperature if ll is not None else None
+        self.supports_explain = self.head_kind == "gap_fc"
+        if self.head_kind == "attnpool":
+            self._refresh_attnpool()
+
+    def _refresh_attnpool(self):
+        ap = self.attnpool
+        w = lambda lin: lin.weight.detach().contiguous()   # noqa: E731  (c_proj may be a BcosifyLinear: .weight property)
+        self.ap_w = dict(q=w(ap.q_proj), k=w(ap.k_proj), v=w(ap.v_proj), c=w(ap.c_proj))
+        self.ap_heads = ap.num_heads
 
     def refresh(self):
         """Re-read parameters after they changed (load_state_dict, calibration, ...)."""
-        self.stem.refresh()
-        self.head.refresh()
+        for c, _ in self.stem:
+            c.refresh()
+        if self.head is not None:
+            self.head.refresh()
+        else:
+            self._refresh_attnpool()
         for b in self.blocks:
             b.refresh()
 
@@ -155,14 +204,20 @@ class ResNetEngine:
         mean, std = self._consts(x.device)
         add_inverse = x.shape[1] == 3
         xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse)
-        st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3]) if keep else None
         gates = list(gates) if gates is not None else None
-        a0, t0 = self.stem.fwd(xn, relu=self.stem_relu, want_scale=keep, gates=gates)
+        st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3], stem_ts=[], stem_hws=[], blocks=[]) if keep else None
+        a = xn
+        for conv, relu in self.stem:
+            if keep:
+                st["stem_hws"].append((a.shape[1], a.shape[2]))
+            a, t = conv.fwd(a, relu=relu, want_scale=keep, gates=gates)
+            if keep:
+                st["stem_ts"].append(t)
         k, s, p = self.pool
-        cur = ops.avgpool2d_fwd(a0, k, s, p)
+        cur = ops.avgpool2d_fwd(a, k, s, p)
         if keep:
-            st.update(t0=t0, a0_hw=(a0.shape[1], a0.shape[2]), blocks=[])
-        del a0
+            st["a0_hw"] = (a.shape[1], a.shape[2])
+        del a
         for blk in self.blocks:
             inp = cur
             rec = dict(in_hw=(inp.shape[1], inp.shape[2])) if keep else None
@@ -172,24 +227,51 @@ class ResNetEngine:
                 hws.append((h.shape[1], h.shape[2]))
                 h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates)
                 ts.append(t)
+            pre_pool_hw = (h.shape[1], h.shape[2])
+            if blk.pool:
+                h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0)
             if blk.shortcut is not None:
-                idn, td = blk.shortcut.fwd(inp, relu=False, want_scale=keep)
+                sc_in = ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0) if blk.shortcut_pool else inp
+                idn, td = blk.shortcut.fwd(sc_in, relu=False, want_scale=keep)
             else:
                 idn, td = inp, None
             hws.append((h.shape[1], h.shape[2]))
             out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates)
             ts.append(t)
             if keep:
-                # `out` doubles as the gate of the shortcut gradient: with replayed gates a closed gate stores exactly 0
                 pinned = blk.convs[-1].last_gate
-                rec.update(ts=ts, td=td, out=(pinned if pinned is not None else out) if blk.relu else None, hws=hws)
+                rec.update(ts=ts, td=td, out=(pinned if pinned is not None else out) if blk.relu else None, hws=hws,
+                           pre_pool_hw=pre_pool_hw)
                 st["blocks"].append(rec)
             cur = out
+        if self.head_kind == "attnpool":
+            return self._attnpool_forward(cur), st
         f, tf = self.head.fwd(cur, relu=False, want_scale=keep)
         logits = ops.global_avgpool_logits(f, self.logit_temperature, self.logit_bias)
         if keep:
             st.update(tf=tf, feat_hw=(cur.shape[1], cur.shape[2]))
         return logits, st
+
+    def _attnpool_forward(self, feat):
+        """BcosAttentionPool2d.forward, pooled mode (bcosattnpool.py:33-59): tokens = [mean; HW positions], plain q/k/v
+        projections (no bias, no positional embedding), 32-head softmax attention of the mean token, plain c_proj."""
+        N, H, W, C = feat.shape
+        T = H * W + 1
+        tokens = torch.empty((N, T, C), device=feat.device, dtype=torch.float32)
+        tokens[:, 1:] = feat.view(N, H * W, C)
+        tokens[:, 0] = ops.global_avgpool_logits(feat, None, None)
+        flat = tokens.view(N * T, C)
+        qkv = torch.empty((N, T, 3 * C), device=feat.device, dtype=torch.float32)
+        for i, key in enumerate("qkv"):
+            ops.tapconv(flat, self.ap_w[key], _linear_geom(N * T, C, C, out_pitch=3 * C), out=qkv.view(N * T, 3 * C)[:, i * C:])
+        out, _ = ops.attention_fwd(qkv, self.ap_heads, (C // self.ap_heads) ** -0.5)
+        pooled = out[:, 0, :].contiguous()
+        emb = ops.matmul_nt(pooled, self.ap_w["c"])
+        if self.logit_temperature is not None:
+            emb = emb / self.logit_temperature
+        if self.logit_bias is not None:
+            emb = emb + self.logit_bias
+        return emb
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -202,6 +284,9 @@ class ResNetEngine:
         (batched bcos/common.py:163-181).  `targets` [N] int64 selects the logits (default: arg-max).
         `gates`: optional list of NHWC 0/1 tensors, one per ReLU in execution order, that REPLACE the v > 0
         decisions (replay of gates recorded elsewhere; used by the gate-pinned parity test)."""
+        if not self.supports_explain:
+            raise NotImplementedError("engine.explain: attention-pool (CLIP) heads are forward-only in the fused engine; "
+                                      "use the module path (net.explain_batch without an attached engine)")
         logits, st = self._run_forward(x, keep=True, gates=gates)
         pred, _ = ops.argmax_rows(logits)
         cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
@@ -210,7 +295,7 @@ class ResNetEngine:
         st["tf"] = None
         # A "consumer" owns the g_lin tensors of the layers that read some activation X and can therefore
         # finish d logit / d X; its epilogue applies the multipliers of the block that PRODUCED X.
-        consumer = _Consumer(self.head, g_head, None, None)
+        consumer = _Consumer(self.head, g_head, None, None, 0)
         nb = len(self.blocks)
         for bi in range(nb - 1, -1, -1):
             blk, rec = self.blocks[bi], st["blocks"][bi]
@@ -223,18 +308,30 @@ class ResNetEngine:
             convs = blk.convs
             for ci in range(len(convs) - 1, 0, -1):
                 h, w = rec["hws"][ci]
-                gl = convs[ci].dgrad.run(gl, h, w, mul=rec["ts"][ci - 1])
+                if blk.pool and ci == len(convs) - 1:
+                    # anti-aliasing pool between conv(ci-1) and conv(ci): gradient w.r.t. the pooled tensor, then
+                    # the pool's input gradient times the scale of conv(ci-1)
+                    gp = convs[ci].dgrad.run(gl, h, w)
+                    ph, pw = rec["pre_pool_hw"]
+                    gl = ops.avgpool2d_bwd(gp, ph, pw, blk.pool, blk.pool, 0, mul=rec["ts"][ci - 1])
+                else:
+                    gl = convs[ci].dgrad.run(gl, h, w, mul=rec["ts"][ci - 1])
                 rec["ts"][ci - 1] = None
-            consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc)
-        # block 0 reads the stem pool output: raw gradient, then pool backward (* t0), then the stem
+            consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc, blk.shortcut_pool)
+        # block 0 reads the stem pool output: raw gradient, pool backward (* t of the last stem conv), then the stem
         H0, W0 = st["blocks"][0]["in_hw"]
         g_pool, _ = consumer.run(H0, W0, t_main=None, td=None, gate=None)
         k, s, p = self.pool
         a_h, a_w = st["a0_hw"]
-        g0 = ops.avgpool2d_bwd(g_pool, a_h, a_w, k, s, p, mul=st["t0"])
-        st["t0"] = None
+        ts = st["stem_ts"]
+        gl = ops.avgpool2d_bwd(g_pool, a_h, a_w, k, s, p, mul=ts[-1])
+        ts[-1] = None
+        for si in range(len(self.stem) - 1, 0, -1):
+            h, w = st["stem_hws"][si]
+            gl = self.stem[si][0].dgrad.run(gl, h, w, mul=ts[si - 1])
+            ts[si - 1] = None
         gxn = torch.empty((x.shape[0], st["H"], st["W"], 8), device=x.device, dtype=torch.float32)
-        self.stem.dgrad.run(g0, st["H"], st["W"], out=gxn)           # channels 0..5 of the padded buffer
+        self.stem[0][0].dgrad.run(gl, st["H"], st["W"], out=gxn)     # channels 0..5 of the padded buffer
         _, std = self._consts(x.device)
         wts, contrib = ops.finalize_explanation(gxn, st["x"], std, add_inverse=st["add_inverse"],
                                                 want_weights=want_weights, want_contrib=True)
@@ -244,10 +341,11 @@ class ResNetEngine:
 
 class _Consumer:
     """The layers reading one activation X: a main conv (with its g_lin) and optionally a shortcut -- either a
-    conv (g_sc = its g_lin) or the identity (g_sc = gradient added as is)."""
+    conv (g_sc = its g_lin; preceded by an AvgPool2d(sc_pool) in CLIP's blocks) or the identity (g_sc = gradient added
+    as is)."""
 
-    def __init__(self, conv, g_main, shortcut_conv, g_sc):
-        self.conv, self.g_main, self.shortcut_conv, self.g_sc = conv, g_main, shortcut_conv, g_sc
+    def __init__(self, conv, g_main, shortcut_conv, g_sc, sc_pool):
+        self.conv, self.g_main, self.shortcut_conv, self.g_sc, self.sc_pool = conv, g_main, shortcut_conv, g_sc, sc_pool
 
     def run(self, H, W, t_main, td, gate):
         """-> (v * t_main, v * gate [* td]) with v = d logit / d X; both v when t_main is None."""
@@ -257,11 +355,20 @@ class _Consumer:
             out2 = torch.empty((g.shape[0], H, W, self.conv.cin), device=g.device, dtype=torch.float32)
             kw = dict(mul=t_main, out2=out2, mul2=td, gate2=gate)
         if self.shortcut_conv is not None:
-            addend = self.shortcut_conv.dgrad.run(self.g_sc, H, W)
+            if self.sc_pool:
+                pooled = self.shortcut_conv.dgrad.run(self.g_sc, H // self.sc_pool, W // self.sc_pool)
+                addend = ops.avgpool2d_bwd(pooled, H, W, self.sc_pool, self.sc_pool, 0)
+            else:
+                addend = self.shortcut_conv.dgrad.run(self.g_sc, H, W)
         else:
             addend = self.g_sc
         out = self.conv.dgrad.run(g, H, W, addend=addend, **kw)
         return out, (out2 if out2 is not None else out)
+
+
+def _linear_geom(rows, cin, cout, out_pitch=0):
+    return dict(N=1, H=1, W=rows, C=cin, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1, TH=1, TW=1,
+                OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=cout, out_pitch=out_pitch)
 
 
 def attach(net) -> ResNetEngine:

@@ -206,3 +206,47 @@ def build_bcosified_vit(arch: str = "simple_vit_ti_patch16_224", seed: int = 0):
     cfg = vit_model_config(arch)
     net = BcosifyNetwork(standard_vit(arch, seed), cfg, add_channels=True, logit_layer=cfg["logit_layer"])
     return finish_vit_conversion(net, cfg).eval()
+
+
+# ---- CLIP RN50 image encoder (BASELINE.json configs[3]) -------------------------------------------------------
+def clip_model_config() -> dict:
+    """CONFIGS['resnet_50_clip_b2_noBias_..._bcosification'] model section
+    (clip_bcosification/experiment_parameters.py:41-106)."""
+    return dict(
+        is_bcos=True,
+        name="resnet50clip",
+        weights="clip",
+        bcos_args=dict(b=2, max_out=1),
+        bcosify_args=dict(clip_kd=True, fix_b=True, norm_layer="BnUncV2", use_bias=False),
+    )
+
+
+def standard_clip_rn50(seed: int = 0, clip_module=None):
+    """CLIP RN50 vision tower (layers (3,4,6,3), width 64, 32 heads, 1024-d output) with default init and randomised
+    BatchNorm statistics; `clip_module` lets the golden generator pass the reference's CLIP/clip/model.py."""
+    if clip_module is None:
+        from CLIP.clip import model as clip_module
+    torch.manual_seed(seed)
+    net = clip_module.ModifiedResNet([3, 4, 6, 3], 1024, 32, input_resolution=224, width=64)
+    randomize_batchnorm(net, torch.Generator().manual_seed(seed + 1))
+    return net
+
+
+def finish_clip_conversion(model: nn.Module, hip_pools: bool = True):
+    """clip_bcosification/model.py:17-23: null every bias and the attention pool's positional embedding."""
+    for mod in model.modules():
+        if hasattr(mod, "bias") and mod.bias is not None:
+            mod.bias = None
+        if hasattr(mod, "positional_embedding") and mod.positional_embedding is not None:
+            mod.positional_embedding = None
+    if hip_pools:
+        from bcos.modules.pooling import use_hip_pools
+        use_hip_pools(model)
+    return model
+
+
+def build_bcosified_clip_rn50(seed: int = 0):
+    from bcosify import BcosifyNetwork
+    cfg = clip_model_config()
+    net = BcosifyNetwork(standard_clip_rn50(seed), cfg, add_channels=True, logit_layer=False)
+    return finish_clip_conversion(net).eval()

@@ -346,3 +346,57 @@ def simple_vit_logits(sd, x6, patch=16, heads=3, b=2, detach=False, gap_reorder=
 
     out = head(x).mean(dim=1) if gap_reorder else head(x.mean(dim=1))
     return logit_layer(out, logit_temperature, logit_bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# B-cosified CLIP RN50 image encoder (CLIP/clip/model.py:94-154 converted by bcosify.py with clip_kd;
+# factory bcos/experiments/ImageNet/clip_bcosification/model.py:8-25; head bcos/modules/bcosattnpool.py:22-59)
+# ----------------------------------------------------------------------------------------------
+CLIP_RN50_LAYERS = [3, 4, 6, 3]
+
+
+def bcos_attention_pool(sd, p, x, num_heads, detach=False):
+    """BcosAttentionPool2d.forward, pooled mode (bcosattnpool.py:33-59): no positional embedding, no biases, q and k
+    detached in explanation mode, output projection = c_proj.weight used as a plain linear."""
+    t = x.flatten(start_dim=2).permute(2, 0, 1)                       # (HW) N C
+    t = torch.cat([t.mean(dim=0, keepdim=True), t], dim=0)            # (HW+1) N C
+    q, k = t[:1], t
+    if detach:
+        q, k = q.detach(), k.detach()
+    out, _ = F.multi_head_attention_forward(
+        query=q, key=k, value=t, embed_dim_to_check=t.shape[-1], num_heads=num_heads,
+        q_proj_weight=sd[p + "q_proj.weight"], k_proj_weight=sd[p + "k_proj.weight"], v_proj_weight=sd[p + "v_proj.weight"],
+        in_proj_weight=None, in_proj_bias=None, bias_k=None, bias_v=None, add_zero_attn=False, dropout_p=0,
+        out_proj_weight=sd[p + "c_proj.linear.weight"], out_proj_bias=None, use_separate_proj_weight=True,
+        training=False, need_weights=False)
+    return out.squeeze(0)
+
+
+def clip_rn50_embed(sd, x6, b=2, detach=False, mean=CLIP_MEAN_ADDINVERSE, std=CLIP_STD_ADDINVERSE, num_heads=32,
+                    layers=CLIP_RN50_LAYERS, prefix="model."):
+    """bcosify.BcosifyNetwork.forward around ModifiedResNet.forward (CLIP/clip/model.py:139-154), B-cosified."""
+    x = normalize6(x6, mean, std)
+    for i, (stride, pad) in zip((1, 2, 3), ((2, 1), (1, 1), (1, 1))):
+        x = F.relu(_bnu(sd, f"{prefix}bn{i}", _bconv(sd, f"{prefix}conv{i}", x, stride, pad, b, detach)))
+    x = F.avg_pool2d(x, 2)
+    for li, nblocks in enumerate(layers, start=1):
+        for bi in range(nblocks):
+            p = f"{prefix}layer{li}.{bi}."
+            stride = 2 if (li > 1 and bi == 0) else 1
+            out = F.relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, 1, 0, b, detach)))
+            out = F.relu(_bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, 1, 1, b, detach)))
+            if stride > 1:
+                out = F.avg_pool2d(out, stride)
+            out = _bnu(sd, p + "bn3", _bconv(sd, p + "conv3", out, 1, 0, b, detach))
+            identity = x
+            if (p + "downsample.1.linear.weight") in sd:     # BcosSequential renumbers (AvgPool, conv, bn) -> 0, 1, 2
+                identity = F.avg_pool2d(x, stride) if stride > 1 else x
+                identity = _bnu(sd, p + "downsample.2", _bconv(sd, p + "downsample.1", identity, 1, 0, b, detach))
+            x = F.relu(out + identity)
+    return bcos_attention_pool(sd, prefix + "attnpool.", x, num_heads, detach)
+
+
+def zeroshot_logits(features, text_weights):
+    """clip_evaluate (bcos/training/trainer.py:112-118): L2-normalise the image features, 100 * f @ W_text."""
+    f = features / features.norm(dim=-1, keepdim=True)
+    return 100.0 * f @ text_weights

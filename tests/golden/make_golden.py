@@ -340,8 +340,44 @@ def vit_ti_end_to_end():
                        torch_version=torch.__version__), f, indent=1)
 
 
+def clip_rn50_embeddings():
+    """BASELINE.json configs[3] topology: B-cosified CLIP RN50 image encoder (clip_kd conversion, attention-pool head):
+    embeddings of 4 images + the zero-shot head of clip_evaluate on a seeded text matrix."""
+    import importlib
+    ref_clip = importlib.import_module("CLIP.clip.model")
+    cfg = synth.clip_model_config()
+    std = synth.standard_clip_rn50(0, clip_module=ref_clip)
+    net = R.bcosify.BcosifyNetwork(std, cfg, add_channels=True, logit_layer=False)
+    synth.finish_clip_conversion(net, hip_pools=False)
+    net.eval()
+    x = synth.synthetic_images(4)
+    record = synth.calibrate(net, x)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        emb = net(x)
+    REPORT["clip/oracle_embed"] = rel(O.clip_rn50_embed(sd, x), emb)
+    # explanation-mode gradient of one embedding coordinate (q, k detached)
+    xr = x[:1].clone().requires_grad_(True)
+    with net.explanation_mode():
+        (g,) = torch.autograd.grad(net(xr)[:, 7].sum(), xr)
+    xo = x[:1].clone().requires_grad_(True)
+    (go,) = torch.autograd.grad(O.clip_rn50_embed(sd, xo, detach=True)[:, 7].sum(), xo)
+    REPORT["clip/oracle_grad"] = rel(go, g)
+    wt = torch.randn(1024, 16, generator=torch.Generator().manual_seed(99))
+    f = emb / emb.norm(dim=-1, keepdim=True)
+    logits = 100.0 * f @ wt                                         # bcos/training/trainer.py:112-118
+    REPORT["clip/oracle_zeroshot"] = rel(O.zeroshot_logits(emb, wt), logits)
+    rec_np = {f"calib/{k}": v.numpy() for k, v in record.items()}
+    np.savez_compressed(os.path.join(HERE, "clip_rn50.npz"), embeddings=emb.numpy(), zeroshot_logits=logits.numpy(),
+                        grad_e7_image0=g.numpy(), **rec_np)
+    with open(os.path.join(HERE, "clip_rn50.json"), "w") as f_:
+        json.dump(dict(arch="clip_rn50", weight_seed=0, image_seed=123, n_images=4, calib_images=4, text_seed=99,
+                       calib_order=list(record.keys()), state_checksum=state_checksum(sd),
+                       torch_version=torch.__version__), f_, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit"]
+    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit", "clip"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -355,6 +391,8 @@ if __name__ == "__main__":
         resnet50_logits_small()
     if "vit" in which:
         vit_ti_end_to_end()
+    if "clip" in which:
+        clip_rn50_embeddings()
     with open(rep_path, "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     for k in sorted(REPORT):

@@ -256,7 +256,7 @@ def _gate_flips(net, eng, x, arch):
     """(#gates that differ between HIP and oracle, #gates, largest |oracle pre-activation| / rms among them)."""
     pre = _oracle_pre_activations(net, x, arch)
     _, st = eng._run_forward(x, keep=True)
-    ours = [st["t0"]] + [t for rec in st["blocks"] for t in rec["ts"]]
+    ours = list(st["stem_ts"]) + [t for rec in st["blocks"] for t in rec["ts"]]
     flips, total, worst = 0, 0, 0.0
     for p, t in zip(pre, ours):
         open_ref = (p > 0)
@@ -465,3 +465,59 @@ def test_vit_ti_batch512_properties(lib):
     ref = O.explain_batch(lambda xx, detach: O.simple_vit_logits(sd, xx, detach=detach), x[300:302].cpu())
     assert rel(sub["logits"], ref["logits"]) <= 1e-4 and torch.equal(sub["prediction"].cpu(), ref["prediction"])
     assert rel(sub["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------ CLIP RN50 image encoder
+def _golden_clip(golden_dir):
+    from bcos_hip import synth
+    meta = json.load(open(os.path.join(golden_dir, "clip_rn50.json")))
+    data = np.load(os.path.join(golden_dir, "clip_rn50.npz"))
+    net = synth.build_bcosified_clip_rn50(seed=meta["weight_seed"])
+    synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
+    sd = net.state_dict()
+    for k, (s1, s2) in meta["state_checksum"].items():
+        assert abs(float(sd[k].double().sum()) - s1) <= 1e-6 * max(1.0, s2), k
+    return net.to(DEV), meta, data
+
+
+def test_clip_rn50_against_reference_golden(lib, golden_dir):
+    """BASELINE.json configs[3] topology: B-cosified CLIP RN50 image encoder, zero-shot style forward."""
+    from bcos_hip import clip_head, engine, synth
+    net, meta, data = _golden_clip(golden_dir)
+    x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+    # nn.Module path: forward and the explanation-mode gradient of one embedding coordinate (q, k detached)
+    xr = x[:1].clone().requires_grad_(True)
+    with net.explanation_mode():
+        e = net(xr)
+        (g,) = torch.autograd.grad(e[:, 7].sum(), xr)
+    assert rel(e, data["embeddings"][:1]) <= 1e-4
+    assert rel(g, data["grad_e7_image0"]) <= 2e-3      # ReLU-gate floor of a 55-layer CNN (see the ResNet-50 test)
+    eng = engine.attach(net)
+    with torch.no_grad():
+        emb = net(x)                                    # fused plan
+    assert rel(emb, data["embeddings"]) <= 1e-4
+    wt = torch.randn(1024, 16, generator=torch.Generator().manual_seed(meta["text_seed"])).to(DEV)
+    logits = clip_head.zeroshot_logits(emb, wt)
+    assert rel(logits, data["zeroshot_logits"]) <= 1e-4
+    assert torch.equal(logits.argmax(1).cpu(), torch.from_numpy(data["zeroshot_logits"]).argmax(1))
+    assert torch.equal(eng.forward(x[1:3]), emb[1:3])   # batch independence, bit-exact
+
+
+def test_clip_rn50_batch256_forward(lib):
+    """configs[3] per-GPU shard (2048 images over 8 GPUs = 256 per rank): forward + zero-shot head at full shard size,
+    sub-batch agreement with the CPU oracle."""
+    from bcos_hip import clip_head, engine, synth
+    net = synth.build_bcosified_clip_rn50().to(DEV)
+    x = synth.synthetic_images(256).to(DEV)
+    with torch.no_grad():
+        synth.calibrate(net, x[:8])
+    eng = engine.attach(net)
+    emb = eng.forward(x)
+    assert emb.shape == (256, 1024) and torch.isfinite(emb).all()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = O.clip_rn50_embed(sd, x[40:42].cpu())
+    assert rel(emb[40:42], ref) <= 1e-4
+    wt = torch.randn(1024, 1000, generator=torch.Generator().manual_seed(5))
+    logits = clip_head.zeroshot_logits(emb, wt.to(DEV))
+    assert rel(logits[40:42], O.zeroshot_logits(ref, wt)) <= 1e-4
+    assert torch.equal(logits[40:42].argmax(1).cpu(), O.zeroshot_logits(ref, wt).argmax(1))

@@ -335,3 +335,42 @@ def test_vit_conversion_layout_and_engine_plan(monkeypatch):
     out_m = net64.explain_batch(x)
     assert rel(out_m["logits"], ref["logits"]) <= 1e-5
     assert rel(out_m["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
+
+
+def test_clip_rn50_conversion_and_engine(monkeypatch):
+    """clip_kd conversion (279 tensors / 38.23 M, renumbered downsample keys, attention-pool keys) and the generalised
+    CNN plan (3-conv stem, anti-aliasing pools, attention-pool head) on emulated kernels; module-path explanation."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import engine, synth
+    from bcos.modules import BcosAttentionPool2d
+    net = synth.build_bcosified_clip_rn50()
+    sd = net.state_dict()
+    assert len(sd) == 279 and sum(v.numel() for v in sd.values()) == 38_234_871
+    assert "model.layer2.0.downsample.1.linear.weight" in sd and "model.layer2.0.downsample.2.running_var" in sd
+    assert sd["model.attnpool.c_proj.linear.weight"].shape == (1024, 2048) and "model.attnpool.q_proj.weight" in sd
+    assert not any(k.endswith("bias") or "positional_embedding" in k for k in sd)
+    assert isinstance(net.model.attnpool, BcosAttentionPool2d)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "linear") and isinstance(m.linear, nn.Conv2d):
+                m.linear.weight.mul_(3.0)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    x = synth.synthetic_images(2, size=64)
+    ref = O.clip_rn50_embed(sd, x)
+    eng = engine.ResNetEngine(net)
+    assert not eng.supports_explain
+    emb = eng.forward(x)
+    assert rel(emb, ref) <= 1e-5
+    # nn.Module path incl. explanation-mode gradient of an embedding coordinate (q, k detached)
+    xr = x.clone().requires_grad_(True)
+    with net.explanation_mode():
+        e = net(xr)
+        (g,) = torch.autograd.grad(e[:, 7].sum(), xr)
+    xo = x.clone().requires_grad_(True)
+    eo = O.clip_rn50_embed(sd, xo, detach=True)
+    (go,) = torch.autograd.grad(eo[:, 7].sum(), xo)
+    assert rel(e, eo) <= 1e-5 and rel(g, go) <= 1e-4
+    # zero-shot head (clip_evaluate): normalise, 100 * f @ W_text
+    wt = torch.randn(1024, 10)
+    from bcos_hip import clip_head
+    assert rel(clip_head.zeroshot_logits(emb, wt), O.zeroshot_logits(ref, wt)) <= 1e-5
