@@ -374,3 +374,34 @@ def test_clip_rn50_conversion_and_engine(monkeypatch):
     wt = torch.randn(1024, 10)
     from bcos_hip import clip_head
     assert rel(clip_head.zeroshot_logits(emb, wt), O.zeroshot_logits(ref, wt)) <= 1e-5
+
+
+def test_explainer_registry_and_ixg_semantics(monkeypatch):
+    """get_explainer / Ours / IxG (captum InputXGradient semantics) and BcosUtilMixin.attribute(_selection)."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import engine, synth
+    from interpretability.explanation_methods import get_explainer
+    net = synth.build_bcosified_resnet("resnet18")
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "linear") and isinstance(m.linear, nn.Conv2d):
+                m.linear.weight.mul_(3.0)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    x = synth.synthetic_images(2, size=32)
+    tg = torch.tensor([5, 900])
+    ref = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, "resnet18", detach=detach), x, targets=tg)
+    ixg_ref = x * ref["dynamic_linear_weights"]
+    assert get_explainer(net, "Ours", "default") is net
+    att = net.attribute(x, tg)                               # explanation mode + IxG over the modules
+    assert rel(att, ixg_ref) <= 1e-4
+    engine.attach(net)
+    att_e = net.attribute(x, [5, 900])                       # same through the fused engine
+    assert rel(att_e, ixg_ref) <= 1e-4
+    sel = net.attribute_selection(x, [[5, 900], [900, 5]])
+    assert sel.shape == (4, 6, 32, 32) and rel(sel[:2], ixg_ref) <= 1e-4
+    ixg = get_explainer(net, "IxG", "default")
+    with net.explanation_mode():
+        multi = ixg.attribute_selection(x, [[5, 7], [900, 3]])
+    assert multi.shape == (4, 6, 32, 32) and rel(multi[0], ixg_ref[0]) <= 1e-4 and rel(multi[2], ixg_ref[1]) <= 1e-4
+    with pytest.raises(KeyError, match="out of scope"):
+        get_explainer(net, "RISE", "default")
