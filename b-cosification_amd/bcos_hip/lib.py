@@ -49,6 +49,8 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "bcos_version": (C.c_int, []),
     "bcos_last_error_string": (C.c_char_p, []),
+    "bcos_set_contraction_mode": (C.c_int, [_I]),
+    "bcos_get_contraction_mode": (C.c_int, []),
     "bcos_tapconv": (C.c_int, [_P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
     "bcos_conv2d_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P] + [_I] * 13 + [_F, _P]),
     "bcos_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
@@ -113,7 +115,22 @@ def load():
     if v != ABI_VERSION:
         raise BcosHipError(f"libbcos_hip.so ABI version {v}, bindings expect {ABI_VERSION}")
     _lib = lib
+    mode = os.environ.get("BCOS_CONTRACTION", "").lower()
+    if mode in ("f32", "fp32", "0"):
+        lib.bcos_set_contraction_mode(0)
+    elif mode in ("bf16x3", "1"):
+        lib.bcos_set_contraction_mode(1)
     return lib
+
+
+def get_contraction_mode() -> str:
+    return {0: "f32", 1: "bf16x3"}[load().bcos_get_contraction_mode()]
+
+
+def set_contraction_mode(mode: str):
+    """'f32' (v_mfma_f32_32x32x2_f32) or 'bf16x3' (exact 3-way bf16 split, 6 products; include/bcos_hip.h)."""
+    code = {"f32": 0, "bf16x3": 1}[mode]
+    check(load().bcos_set_contraction_mode(code), "bcos_set_contraction_mode")
 
 
 def check(code: int, what: str):

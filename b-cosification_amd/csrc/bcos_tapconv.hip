@@ -43,6 +43,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+int g_contraction_mode = 1;   // process-wide: 0 = v_mfma_f32_32x32x2_f32, 1 (default) = 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way splits
+
 constexpr int BK = 32;            // K floats per step
 constexpr int LDS_LD = BK + 4;    // padded LDS row (floats): 144 B, 16 rows hit 16 distinct 16-B slots
 constexpr int NTHREADS = 256;
@@ -62,9 +64,217 @@ struct KArgs {
     int tiles_n;            // column tiles
     int n_big, n_small;     // tiles of BM rows, then tiles of BM/2 rows (tail of the launch)
     int rows_big;           // rows covered by the BM-row tiles
+    int x3;          // contraction on split-bf16 MFMA (see tile_body_x3) instead of fp32 MFMA
     int uniform_tap; // C % 32 == 0: every K-step lies inside one tap
     int vec_ok;     // every per-element epilogue tensor is 16-byte addressable (pitch % 4 == 0, aligned bases)
 };
+
+// Fused epilogue of one tile (include/bcos_hip.h: bcos_epilogue), shared by the fp32 and the split-bf16 main loops.
+// `ss` = per-lane partial row sums in MFMA fragment layout, or `ROWSS` = partial row sums in staging layout.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+__device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
+                                              const float* ss, const float* ROWSS, const int m0, const int n0,
+                                              const int tile_n) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const bcos_tapconv_geom& g = p.g;
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // (all waves are past the last barrier: the staging buffers are free)
+    // 1. accumulators -> LDS tile sC[BM][BN+4] (MFMA layout: lane = column, 16 rows per lane);
+    // 2. every thread then owns 16-byte column chunks of whole rows: wave-wide accesses are 2..8 full rows of
+    //    BN*4 contiguous bytes, all epilogue tensors move as dwordx4, and the loads of a group of EPI_G chunks are
+    //    issued together before any of them is consumed (the streaming layers 64<->256 @56^2 are HBM-bound here).
+    constexpr int LDC = BN + 4;
+    float* sC = smem;
+    int64_t* sPix = reinterpret_cast<int64_t*>(smem + BM * LDC);   // [BM] output pixel index or -1
+    float* sNorm = reinterpret_cast<float*>(sPix + BM);            // [BM] patch norm
+    float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
+    const bcos_epilogue& e = p.e;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int colt = wave_n * WN + j * 32 + (lane & 31);
+                sC[row * LDC + colt] = acc[i][j][r];
+            }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int64_t pix = -1;
+        if (m < p.M) {
+            const int n = m / p.PQ;
+            const int rem = m - n * p.PQ;
+            const int i = rem / g.Q;
+            const int jj = rem - i * g.Q;
+            pix = ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+        }
+        sPix[tid] = pix;
+    }
+    if (NORM && ROWSS == nullptr) {
+        // row sums of squares in MFMA fragment layout (fp32 kernel): lane (row, k-half), two halves per row
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float t = ss[i] + __shfl_xor(ss[i], 32);
+            if (wave_n == 0 && lane < 32) {
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
+                const int row = wave_m * WM + i * 32 + lane;
+                sNorm[row] = nrm;
+                sRinv[row] = 1.0f / nrm;
+            }
+        }
+    } else if (NORM) {
+        // row sums of squares in staging layout (split kernel): thread (r0 + 64 j, chunk), 4 chunk-lanes per row
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j) {
+            float t = ROWSS[j];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            if ((tid & 3) == 0) {
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
+                const int row = (tid >> 2) + 64 * j;
+                sNorm[row] = nrm;
+                sRinv[row] = 1.0f / nrm;
+            }
+        }
+    }
+    __syncthreads();
+    if (NORM && e.norm_out != nullptr && tile_n == 0 && tid < BM) {
+        const int64_t pix = sPix[tid];
+        if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[tid];
+    }
+
+    const bool b_is_2 = e.b == 2.0f && !(e.flags & BCOS_EPI_FORCE_POW);
+    const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
+    const float bm1 = e.b - 1.0f;
+    const int Cout = g.Cout;
+    constexpr int CPR = BN / 4;              // 16-byte chunks per tile row
+    constexpr int RPP = NTHREADS / CPR;      // rows per pass
+    constexpr int PASSES = BM / RPP;
+    constexpr int EPI_G = 4;                 // chunks whose loads are in flight together
+    static_assert(PASSES % EPI_G == 0, "epilogue grouping");
+    const int cq = tid % CPR;
+    const int rbase = tid / CPR;
+    const int col = n0 + cq * 4;
+    const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = col + q < Cout ? col + q : 0;
+        if (e.bias) bias4[q] = e.bias[c];
+        if (e.ch_scale) csc4[q] = e.ch_scale[c];
+        if (e.ch_shift) csh4[q] = e.ch_shift[c];
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    if (vec) {
+#pragma unroll 1
+        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
+            f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
+            int64_t idx[EPI_G];
+            bool ok[EPI_G];
+            float rinv[EPI_G], nrm[EPI_G];
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                const int row = rbase + (p0 + u) * RPP;
+                const int64_t pix = sPix[row];
+                ok[u] = pix >= 0;
+                idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
+                v[u] = *reinterpret_cast<const f32x4*>(sC + row * LDC + cq * 4);
+                rinv[u] = NORM ? sRinv[row] : 1.f;
+                nrm[u] = NORM ? sNorm[row] : 1.f;
+                ad[u] = e.addend ? *reinterpret_cast<const f32x4*>(e.addend + idx[u]) : zero4;
+                rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
+                m1[u] = e.mul ? *reinterpret_cast<const f32x4*>(e.mul + idx[u]) : zero4;
+                m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
+                g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                f32x4 val = v[u] + bias4;
+                f32x4 s = {1.f, 1.f, 1.f, 1.f};
+                if (NORM && !norm_only) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        s[q] = b_is_2 ? fabsf(val[q]) * rinv[u] : powf(fabsf(val[q] / nrm[u]) + 1e-6f, bm1);
+                    val *= s;
+                }
+                val = val * csc4 + csh4;
+                s *= csc4;
+                if (e.addend) val += ad[u];
+                if (e.relu == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
+                        s[q] = open_gate ? s[q] : 0.f;
+                        val[q] = open_gate ? val[q] : 0.f;
+                    }
+                } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
+                        s[q] *= gate;
+                        val[q] *= gate;
+                    }
+                }
+                if (ok[u]) {
+                    if (e.out) *reinterpret_cast<f32x4*>(e.out + idx[u]) = e.mul ? val * m1[u] : val;
+                    if (e.out2) {
+                        f32x4 o2 = val;
+                        if (e.mul2) o2 *= m2[u];
+                        if (e.gate2) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(e.out2 + idx[u]) = o2;
+                    }
+                    if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + idx[u]) = s;
+                }
+            }
+        }
+    } else if (col < Cout) {
+        // ragged right edge (Cout % 4 != 0) or unaligned tensors: same math, element by element
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = rbase + ps * RPP;
+            const int64_t pix = sPix[row];
+            if (pix < 0) continue;
+            for (int q = 0; q < 4 && col + q < Cout; ++q) {
+                const int64_t idx = pix * g.out_pitch + col + q;
+                float v = sC[row * LDC + cq * 4 + q] + bias4[q];
+                float s = 1.f;
+                if (NORM && !norm_only) {
+                    s = b_is_2 ? fabsf(v) * sRinv[row] : powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
+                    v *= s;
+                }
+                v = v * csc4[q] + csh4[q];
+                s *= csc4[q];
+                if (e.addend) v += e.addend[idx];
+                if (e.relu == 1) {
+                    const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
+                    s = open_gate ? s : 0.f;
+                    v = open_gate ? v : 0.f;
+                } else if (e.relu == 2) {
+                    const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
+                    s *= gate;
+                    v *= gate;
+                }
+                if (e.out) e.out[idx] = e.mul ? v * e.mul[idx] : v;
+                if (e.out2) {
+                    float o2 = v;
+                    if (e.mul2) o2 *= e.mul2[idx];
+                    if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
+                    e.out2[idx] = o2;
+                }
+                if (e.scale_out) e.scale_out[idx] = s;
+            }
+        }
+    }
+}
 
 // One output tile [m0, m0+BM) x [n0, n0+BN): main loop + epilogue.  `tile_n` only tells whether this block is the one
 // that writes the per-row norms.
@@ -285,183 +495,214 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
         __syncthreads();
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // (all waves are past the last barrier: the staging buffers are free)
-    // 1. accumulators -> LDS tile sC[BM][BN+4] (MFMA layout: lane = column, 16 rows per lane);
-    // 2. every thread then owns 16-byte column chunks of whole rows: wave-wide accesses are 2..8 full rows of
-    //    BN*4 contiguous bytes, all epilogue tensors move as dwordx4, and the loads of a group of EPI_G chunks are
-    //    issued together before any of them is consumed (the streaming layers 64<->256 @56^2 are HBM-bound here).
-    constexpr int LDC = BN + 4;
-    float* sC = smem;
-    int64_t* sPix = reinterpret_cast<int64_t*>(smem + BM * LDC);   // [BM] output pixel index or -1
-    float* sNorm = reinterpret_cast<float*>(sPix + BM);            // [BM] patch norm
-    float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
-    const bcos_epilogue& e = p.e;
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, acc, ss, nullptr, m0, n0, tile_n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 main loop ("bf16x3"): every fp32 operand x is split EXACTLY into three bf16 numbers x = h + m + l (8 + 8 + 8
+// significand bits, bf16 has fp32's exponent range so no scaling is needed), and a*b is evaluated as
+//     a_h b_h + (a_h b_m + a_m b_h) + (a_m b_m + a_h b_l + a_l b_h)
+// i.e. 6 products on v_mfma_f32_32x32x16_bf16 (products of bf16 numbers are exact in fp32, accumulation is fp32).
+// The dropped terms (a_m b_l, a_l b_m, a_l b_l) are <= 2^-21 |a b|: fp32-rounding class, but 6 bf16 MFMAs cost 192
+// matrix-pipe cycles per 16 k against 512 for 8 fp32 MFMAs.  Same tiling / staging / epilogue as tile_body; the
+// splits are produced while the tile is written to LDS (one 16-byte global load -> three 8-byte LDS stores), LDS rows
+// are 16 bf16 = 32 B with an XOR swizzle of the two halves (conflict-free stores and ds_read_b128); K advances 16 per
+// step through two LDS buffers: while the 6*TM*TN MFMAs of step k run, step k+1 is converted and written to the
+// other buffer and the global loads of step k+2 are in flight (one barrier per step).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X3_BK = 16;      // k per step = one MFMA k-block; two LDS buffers
+constexpr int X3_ROW = 32;     // bytes per LDS row of one split: 16 bf16, unpadded; the two 16-B halves of a row are swapped
+                               // when bit 3 of the row index is set, which makes both the 8-byte staging stores (4 rows x 32 B
+                               // per 16-lane group) and the 16-byte fragment reads (16 rows per group) bank-conflict free
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+__device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM / 64, B_LD = BN / 64 > 0 ? BN / 64 : 1;     // float4 loads per thread per 16-k step
+    constexpr bool B_HALF = BN < 64;                                     // BN = 32: only half the threads stage B
+    char* lds = reinterpret_cast<char*>(smem);
+    constexpr int A_SPLIT = BM * X3_ROW, B_SPLIT = BN * X3_ROW, B_BASE = 3 * A_SPLIT;
+    constexpr int BUF = 3 * (A_SPLIT + B_SPLIT);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int chunk = tid & 3;       // 16-byte chunk (4 k) within the 16-k step
+    const int r0 = tid >> 2;         // staging row 0..63 (+64 per pass)
+    const bcos_tapconv_geom& g = p.g;
+    const int H = g.H, W = g.W;
+    const int a_pitch = g.a_pitch;
+
+    int64_t a_nbase[A_LD];
+    int a_ih0[A_LD], a_iw0[A_LD];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int colt = wave_n * WN + j * 32 + (lane & 31);
-                sC[row * LDC + colt] = acc[i][j][r];
-            }
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int64_t pix = -1;
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = m0 + r0 + 64 * j;
         if (m < p.M) {
             const int n = m / p.PQ;
             const int rem = m - n * p.PQ;
             const int i = rem / g.Q;
             const int jj = rem - i * g.Q;
-            pix = ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+            a_nbase[j] = (int64_t)n * H * W * a_pitch;
+            a_ih0[j] = i * g.in_sh + g.dh0;
+            a_iw0[j] = jj * g.in_sw + g.dw0;
+        } else {
+            a_nbase[j] = 0;
+            a_ih0[j] = -(1 << 28);
+            a_iw0[j] = -(1 << 28);
         }
-        sPix[tid] = pix;
     }
-    if (NORM) {
+    int64_t b_off[B_LD];
+    bool b_ok[B_LD];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float t = ss[i] + __shfl_xor(ss[i], 32);
-            if (wave_n == 0 && lane < 32) {
-                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
-                const int row = wave_m * WM + i * 32 + lane;
-                sNorm[row] = nrm;
-                sRinv[row] = 1.0f / nrm;
-            }
-        }
+    for (int j = 0; j < B_LD; ++j) {
+        const int co = n0 + r0 + 64 * j;
+        b_ok[j] = co < g.Cout && (!B_HALF || r0 < BN);
+        b_off[j] = (int64_t)(b_ok[j] ? co : 0) * p.Ktot;
     }
+
+    const int nk = (p.nchunks + 3) / 4;
+    const bool uniform = (g.C % X3_BK) == 0;
+    f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];     // two steps of global loads in flight
+    int s_cc = 0, s_th = 0, s_tw = 0;
+    auto load_step = [&](int ks, f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
+        int cc, dh, dw;
+        bool kvalid;
+        const int q = ks * 4 + chunk;
+        if (uniform) {
+            cc = s_cc + chunk;
+            dh = s_th * g.dstep_h;
+            dw = s_tw * g.dstep_w;
+            kvalid = true;
+            s_cc += 4;
+            if (s_cc == p.cpt) {
+                s_cc = 0;
+                if (++s_tw == g.TW) { s_tw = 0; ++s_th; }
+            }
+        } else {
+            kvalid = q < p.nchunks;
+            const int tap = q / p.cpt;
+            cc = q - tap * p.cpt;
+            const int th = tap / g.TW;
+            const int tw = tap - th * g.TW;
+            dh = th * g.dstep_h;
+            dw = tw * g.dstep_w;
+        }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+            const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kvalid && b_ok[j]) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[j] + (int64_t)q * 4);
+            rb[j] = v;
+        }
+    };
+    // x = h + m + l with h, m, l the three successive 8-bit significand slices (truncation; every step exact)
+    auto split_store = [&](const f32x4& v, char* dst, const int split_stride) {
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned u = __float_as_uint(v[q]);
+            h[q] = u & 0xffff0000u;
+            const float r1 = v[q] - __uint_as_float(h[q]);
+            m[q] = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(m[q]);
+            l[q] = __float_as_uint(r2);
+        }
+        uint2 ph, pm, pl;
+        ph.x = (h[0] >> 16) | h[1]; ph.y = (h[2] >> 16) | h[3];
+        pm.x = (m[0] >> 16) | m[1]; pm.y = (m[2] >> 16) | m[3];
+        pl.x = (l[0] >> 16) | (l[1] & 0xffff0000u); pl.y = (l[2] >> 16) | (l[3] & 0xffff0000u);
+        *reinterpret_cast<uint2*>(dst) = ph;
+        *reinterpret_cast<uint2*>(dst + split_stride) = pm;
+        *reinterpret_cast<uint2*>(dst + 2 * split_stride) = pl;
+    };
+    float rowss[BM / 32];            // only the first A_LD entries are used (tile_epilogue reads them in staging layout)
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) rowss[j] = 0.f;
+    auto store_step = [&](const f32x4 (&ra)[A_LD], const f32x4 (&rb)[B_LD], int buf) {
+        char* base = lds + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            if (NORM) {
+                rowss[j] = fmaf(ra[j][0], ra[j][0], rowss[j]);
+                rowss[j] = fmaf(ra[j][1], ra[j][1], rowss[j]);
+                rowss[j] = fmaf(ra[j][2], ra[j][2], rowss[j]);
+                rowss[j] = fmaf(ra[j][3], ra[j][3], rowss[j]);
+            }
+            split_store(ra[j], base + (r0 + 64 * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4)), A_SPLIT);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            if (!B_HALF || r0 < BN)
+                split_store(rb[j], base + B_BASE + (r0 + 64 * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4)), B_SPLIT);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    const int frag_off = (frag_half * 16) ^ (((frag_row >> 3) & 1) << 4);
+    const int a_frag = (wave_m * WM + frag_row) * X3_ROW + frag_off;
+    const int b_frag = B_BASE + (wave_n * WN + frag_row) * X3_ROW + frag_off;
+
+    auto mma_step = [&](int buf) {
+        const char* base = lds + buf * BUF;
+        bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[sp][i] = *reinterpret_cast<const bf16x8*>(base + a_frag + sp * A_SPLIT + i * 32 * X3_ROW);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[sp][j] = *reinterpret_cast<const bf16x8*>(base + b_frag + sp * B_SPLIT + j * 32 * X3_ROW);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // buf[ks & 1] holds step ks; the registers R[(ks+1) & 1] hold step ks+1; step ks+2 is loaded into R[ks & 1]
+    load_step(0, ra0, rb0);
+    if (nk > 1) load_step(1, ra1, rb1);
+    store_step(ra0, rb0, 0);
     __syncthreads();
-    if (NORM && e.norm_out != nullptr && tile_n == 0 && tid < BM) {
-        const int64_t pix = sPix[tid];
-        if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[tid];
-    }
-
-    const bool b_is_2 = e.b == 2.0f && !(e.flags & BCOS_EPI_FORCE_POW);
-    const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
-    const float bm1 = e.b - 1.0f;
-    const int Cout = g.Cout;
-    constexpr int CPR = BN / 4;              // 16-byte chunks per tile row
-    constexpr int RPP = NTHREADS / CPR;      // rows per pass
-    constexpr int PASSES = BM / RPP;
-    constexpr int EPI_G = 4;                 // chunks whose loads are in flight together
-    static_assert(PASSES % EPI_G == 0, "epilogue grouping");
-    const int cq = tid % CPR;
-    const int rbase = tid / CPR;
-    const int col = n0 + cq * 4;
-    const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = col + q < Cout ? col + q : 0;
-        if (e.bias) bias4[q] = e.bias[c];
-        if (e.ch_scale) csc4[q] = e.ch_scale[c];
-        if (e.ch_shift) csh4[q] = e.ch_shift[c];
-    }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    if (vec) {
-#pragma unroll 1
-        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
-            f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
-            int64_t idx[EPI_G];
-            bool ok[EPI_G];
-            float rinv[EPI_G], nrm[EPI_G];
-#pragma unroll
-            for (int u = 0; u < EPI_G; ++u) {
-                const int row = rbase + (p0 + u) * RPP;
-                const int64_t pix = sPix[row];
-                ok[u] = pix >= 0;
-                idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
-                v[u] = *reinterpret_cast<const f32x4*>(sC + row * LDC + cq * 4);
-                rinv[u] = NORM ? sRinv[row] : 1.f;
-                nrm[u] = NORM ? sNorm[row] : 1.f;
-                ad[u] = e.addend ? *reinterpret_cast<const f32x4*>(e.addend + idx[u]) : zero4;
-                rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
-                m1[u] = e.mul ? *reinterpret_cast<const f32x4*>(e.mul + idx[u]) : zero4;
-                m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
-                g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
-            }
-#pragma unroll
-            for (int u = 0; u < EPI_G; ++u) {
-                f32x4 val = v[u] + bias4;
-                f32x4 s = {1.f, 1.f, 1.f, 1.f};
-                if (NORM && !norm_only) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        s[q] = b_is_2 ? fabsf(val[q]) * rinv[u] : powf(fabsf(val[q] / nrm[u]) + 1e-6f, bm1);
-                    val *= s;
-                }
-                val = val * csc4 + csh4;
-                s *= csc4;
-                if (e.addend) val += ad[u];
-                if (e.relu == 1) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
-                        s[q] = open_gate ? s[q] : 0.f;
-                        val[q] = open_gate ? val[q] : 0.f;
-                    }
-                } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
-                        s[q] *= gate;
-                        val[q] *= gate;
-                    }
-                }
-                if (ok[u]) {
-                    if (e.out) *reinterpret_cast<f32x4*>(e.out + idx[u]) = e.mul ? val * m1[u] : val;
-                    if (e.out2) {
-                        f32x4 o2 = val;
-                        if (e.mul2) o2 *= m2[u];
-                        if (e.gate2) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
-                        }
-                        *reinterpret_cast<f32x4*>(e.out2 + idx[u]) = o2;
-                    }
-                    if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + idx[u]) = s;
-                }
-            }
-        }
-    } else if (col < Cout) {
-        // ragged right edge (Cout % 4 != 0) or unaligned tensors: same math, element by element
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int row = rbase + ps * RPP;
-            const int64_t pix = sPix[row];
-            if (pix < 0) continue;
-            for (int q = 0; q < 4 && col + q < Cout; ++q) {
-                const int64_t idx = pix * g.out_pitch + col + q;
-                float v = sC[row * LDC + cq * 4 + q] + bias4[q];
-                float s = 1.f;
-                if (NORM && !norm_only) {
-                    s = b_is_2 ? fabsf(v) * sRinv[row] : powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
-                    v *= s;
-                }
-                v = v * csc4[q] + csh4[q];
-                s *= csc4[q];
-                if (e.addend) v += e.addend[idx];
-                if (e.relu == 1) {
-                    const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
-                    s = open_gate ? s : 0.f;
-                    v = open_gate ? v : 0.f;
-                } else if (e.relu == 2) {
-                    const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
-                    s *= gate;
-                    v *= gate;
-                }
-                if (e.out) e.out[idx] = e.mul ? v * e.mul[idx] : v;
-                if (e.out2) {
-                    float o2 = v;
-                    if (e.mul2) o2 *= e.mul2[idx];
-                    if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
-                    e.out2[idx] = o2;
-                }
-                if (e.scale_out) e.scale_out[idx] = s;
-            }
+    for (int ks = 0; ks < nk; ks += 2) {
+        if (ks + 2 < nk) load_step(ks + 2, ra0, rb0);
+        mma_step(0);
+        if (ks + 1 < nk) store_step(ra1, rb1, 1);
+        __syncthreads();
+        if (ks + 1 < nk) {
+            if (ks + 3 < nk) load_step(ks + 3, ra1, rb1);
+            mma_step(1);
+            if (ks + 2 < nk) store_step(ra0, rb0, 0);
+            __syncthreads();
         }
     }
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, acc, nullptr, NORM ? rowss : nullptr, m0, n0, tile_n);
 }
 
 // XCD-aware id remap: the 8 XCDs (private L2s) each get a contiguous range of `nt` work items (bijective for any nt)
@@ -476,7 +717,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 // dispatched in blockIdx order, so the half-height tiles fill the tail of the launch: with a few hundred equal
 // tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
 // = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool X3>
 __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
@@ -484,7 +725,8 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
         const int tile = xcd_remap(bid, p.n_big);
         const int tile_m = tile / p.tiles_n;
         const int tile_n = tile - tile_m * p.tiles_n;
-        tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        if constexpr (X3) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        else tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
     } else {
         constexpr int BMS = BM / 2;
         constexpr int WMS = (BMS / 32 >= WAVES_M) ? WAVES_M : BMS / 32;    // waves along M of the small tile
@@ -493,7 +735,8 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
             const int tile = xcd_remap(bid - p.n_big, p.n_small);
             const int tile_m = tile / p.tiles_n;
             const int tile_n = tile - tile_m * p.tiles_n;
-            tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            if constexpr (X3) tile_body_x3<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            else tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
         }
     }
 }
@@ -525,23 +768,34 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     if (lds_epi > lds) lds = lds_epi;
     const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
     hipError_t err;
-    if (norm) {
-        auto k = tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true>;
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
+    const size_t lds_x3 = 2 * 3 * (size_t)(BM + BN) * X3_ROW;
+    if (p.x3 && lds_x3 > lds_epi) lds = lds_x3;
+    else if (p.x3) lds = lds_epi;
+    auto launch = [&](auto k) -> hipError_t {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(k, grid, block, lds, stream, p);
-    } else {
-        auto k = tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false>;
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
-        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
-    }
+        return hipSuccess;
+    };
+    if (p.x3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, true>)
+                         : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, true>);
+    else err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, false>)
+                    : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, false>);
+    if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
     err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);
     return BCOS_OK;
 }
 
 }  // namespace
+
+extern "C" int bcos_set_contraction_mode(int mode) {
+    if (mode != 0 && mode != 1) return bcos_set_error(BCOS_E_INVAL, "bcos_set_contraction_mode: 0 = fp32 MFMA, 1 = split-bf16 MFMA");
+    g_contraction_mode = mode;
+    return BCOS_OK;
+}
+
+extern "C" int bcos_get_contraction_mode(void) { return g_contraction_mode; }
 
 extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                             const bcos_epilogue* epi, void* stream) {
@@ -580,6 +834,7 @@ extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_
     p.nk = (p.nchunks + 7) / 8;
     p.tiles_n = p.n_big = p.n_small = p.rows_big = 0;
     p.uniform_tap = (g.C % BK == 0) ? 1 : 0;
+    p.x3 = g_contraction_mode == 1 ? 1 : 0;
     {
         uintptr_t bits = 0;
         const void* ptrs[] = {epi->addend, epi->mul, epi->mul2, epi->gate2, epi->relu_gate, epi->out, epi->out2, epi->scale_out};

@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time the forward pass only")
+    ap.add_argument("--contraction", choices=("bf16x3", "f32"), default=None,
+                    help="arithmetic of the contraction kernel (include/bcos_hip.h: bcos_set_contraction_mode); default: "
+                         "the library default (bf16x3 = exact 3-way bf16 split, 6 products, fp32 accumulation)")
     return ap.parse_args()
 
 
@@ -85,6 +88,9 @@ def main():
     args = parse()
     from bcos_hip import dist as bdist, engine, lib, ops, synth
     lib.load()      # fails loudly if the HIP library was not built
+    if args.contraction:
+        lib.set_contraction_mode(args.contraction)
+    contraction = lib.get_contraction_mode()
     rank, local_rank, world = bdist.init()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -173,11 +179,11 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if contraction == "f32" else "f32 (contraction: exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"B-cosified {args.arch} {'forward' if args.forward_only else 'forward+explanation'}, "
                                f"batch {args.batch} per GPU, 224x224x6 (AddInverse), calibrated random-init weights",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "contraction": contraction,
                    "collective": "all_gather(logits, contribution maps)" if world > 1 else "none"},
         "roofline": roofline,
     }

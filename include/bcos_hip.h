@@ -132,6 +132,17 @@ int bcos_version(void);
 /* Human-readable description of the last error on this thread ("" if none). */
 const char* bcos_last_error_string(void);
 
+/* Arithmetic of the contraction inside bcos_tapconv (process-wide; inputs, outputs and accumulation are fp32 in
+ * both modes):
+ *   0  v_mfma_f32_32x32x2_f32: exact fp32 FMA chain
+ *   1  "bf16x3" (default): every fp32 operand is split exactly into three bf16 slices (x = h + m + l, 3 x 8 significand
+ *      bits, fp32 exponent range) and a*b is evaluated with the 6 leading products on v_mfma_f32_32x32x16_bf16
+ *      (products of bf16 numbers are exact in fp32; dropped terms <= 2^-21 |a b|, i.e. fp32-rounding class -- the
+ *      "error-compensated split scheme" of SURVEY.md fact 10 / H2); ~2.7x fewer matrix-pipe cycles.  Measured against an
+ *      fp64 reference both modes give the same error (relL2 7.5e-7 vs 8.6e-7 at K = 2304). */
+int bcos_set_contraction_mode(int mode);
+int bcos_get_contraction_mode(void);
+
 /* -- contraction kernels (fp32 MFMA v_mfma_f32_32x32x2_f32, LDS-tiled implicit GEMM) ----- */
 
 /* The generic fused implicit GEMM every entry point below lowers to. */

@@ -311,7 +311,7 @@ def test_resnet18_config1_against_reference_golden(lib, golden_dir):
     res = net.explain(xi)
     assert set(res) == {"prediction", "explained_class_idx", "dynamic_linear_weights", "contribution_map", "explanation"}
     assert res["prediction"] == int(data["prediction"][0]) and res["explanation"].shape == (224, 224, 4)
-    assert rel(res["contribution_map"], data["contribution_map"][:1]) <= 1e-4
+    assert rel(res["contribution_map"], data["contribution_map"][:1]) <= 2e-3      # free gates (floor as above)
     # RGBA rendering (host-side gradient_to_image): alpha everywhere; colour where the explanation is visible (the
     # colour of a ~zero-weight pixel is a 0/0-type ratio and legitimately flips between 0 and 1)
     rgba, gold = res["explanation"], data["rgba_0"]
@@ -521,3 +521,51 @@ def test_clip_rn50_batch256_forward(lib):
     logits = clip_head.zeroshot_logits(emb, wt.to(DEV))
     assert rel(logits[40:42], O.zeroshot_logits(ref, wt)) <= 1e-4
     assert torch.equal(logits[40:42].argmax(1).cpu(), O.zeroshot_logits(ref, wt).argmax(1))
+
+
+# ------------------------------------------------------------------------------------------ both contraction modes
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_contraction_modes_parity(lib, golden_dir, mode):
+    """The contraction runs either on fp32 MFMA or on the exact 3-way bf16 split (6 bf16 MFMA products, fp32
+    accumulation; include/bcos_hip.h).  Both must meet the same tolerances: layers vs the oracle, error vs fp64 of the
+    same size class, ResNet-18 logits / class indices vs the reference fixture and gate-pinned maps <= 1e-4."""
+    from bcos_hip import engine, ops, synth
+    from bcos_hip import lib as blib
+    prev = blib.get_contraction_mode()
+    blib.set_contraction_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(3)
+        a = torch.randn(512, 2304, generator=g) * (torch.rand(512, 1, generator=g) * 3)
+        w = torch.randn(256, 2304, generator=g) / 48
+        ref64 = a.double() @ w.double().t()
+        err = rel(ops.matmul_nt(a.to(DEV), w.to(DEV)), ref64)
+        assert err <= 2e-6, (mode, err)                       # fp32-rounding class (measured ~8e-7 in both modes)
+        # tiny / huge magnitudes: the split needs no scaling (bf16 has fp32's exponent range)
+        for scale in (1e-20, 1e15):
+            out = ops.matmul_nt((a * scale).to(DEV), w.to(DEV))
+            assert rel(out, ref64 * scale) <= 2e-6, (mode, scale)
+        for geom in CONV_GEOMS[:8]:
+            N, Cin, H, W, Cout, k, s, p = geom
+            x = torch.randn(N, Cin, H, W, generator=g)
+            wt = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+            xr = x.clone().requires_grad_(True)
+            y_ref, s_ref = O.bcos_conv2d(xr, wt, stride=s, padding=p, detach=True, return_scale=True)
+            gy = torch.randn(y_ref.shape, generator=g)
+            (gx_ref,) = torch.autograd.grad(y_ref, xr, gy)
+            y, sc, _ = ops.conv2d_fwd(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                      stride=(s, s), padding=(p, p), want_scale=True)
+            gx = ops.DgradPlan(wt.to(DEV), (s, s), (p, p)).run(ops.mul(gy.permute(0, 2, 3, 1).contiguous().to(DEV), sc), H, W)
+            assert rel(y.permute(0, 3, 1, 2), y_ref) <= 1e-5 and rel(gx.permute(0, 3, 1, 2), gx_ref) <= 1e-5, (mode, geom)
+        net, meta, data = _golden_net(golden_dir, "resnet18_e2e")
+        x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+        eng = engine.attach(net)
+        out = eng.explain(x)
+        assert rel(out["logits"], data["logits"]) <= 1e-4
+        assert np.array_equal(out["prediction"].cpu().numpy(), data["prediction"])
+        gates = [torch.from_numpy(np.unpackbits(data[f"gate/{i:02d}"])[: int(np.prod(shp))].reshape(shp).astype(np.float32)).to(DEV)
+                 for i, shp in enumerate(meta["gate_shapes"])]
+        pinned = eng.explain(x[:2], gates=gates)
+        assert rel(pinned["contribution_map"], data["contribution_map"][:2]) <= 1e-4
+        assert rel(pinned["dynamic_linear_weights"], data["weights_01"]) <= 1e-4
+    finally:
+        blib.set_contraction_mode(prev)
