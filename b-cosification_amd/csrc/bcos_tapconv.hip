@@ -565,7 +565,7 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
 
     const int nk = (p.nchunks + 3) / 4;
     const bool uniform = (g.C % X3_BK) == 0;
-    f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];     // two steps of global loads in flight
+    f32x4 ra0[A_LD], rb0[B_LD];
     int s_cc = 0, s_th = 0, s_tw = 0;
     auto load_step = [&](int ks, f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
         int cc, dh, dw;
@@ -685,23 +685,35 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
             }
     };
 
-    // buf[ks & 1] holds step ks; the registers R[(ks+1) & 1] hold step ks+1; step ks+2 is loaded into R[ks & 1]
+    // buf[ks & 1] holds step ks.  Three-stage software pipeline over one MFMA site per iteration (two sites make the
+    // compiler keep the accumulators in VGPRs and shuttle 64 registers to the AGPRs and back around every step):
+    //   global loads of step ks+2 are issued into (na, nb); step ks+1 -- loaded one iteration ago into (ra0, rb0) -- is
+    //   split and written to the other LDS buffer next to the MFMAs of step ks; the register sets are rotated after
+    //   the barrier (by then the loads have had a whole MFMA phase to land).
+    f32x4 na[A_LD], nb[B_LD];
     load_step(0, ra0, rb0);
-    if (nk > 1) load_step(1, ra1, rb1);
     store_step(ra0, rb0, 0);
+    if (nk > 1) load_step(1, ra0, rb0);
     __syncthreads();
-    for (int ks = 0; ks < nk; ks += 2) {
-        if (ks + 2 < nk) load_step(ks + 2, ra0, rb0);
-        mma_step(0);
-        if (ks + 1 < nk) store_step(ra1, rb1, 1);
+    int ks = 0;
+    for (; ks + 2 < nk; ++ks) {          // steady state: no branches between the MFMAs and the split/stores
+        load_step(ks + 2, na, nb);
+        mma_step(ks & 1);
+        store_step(ra0, rb0, (ks + 1) & 1);
         __syncthreads();
-        if (ks + 1 < nk) {
-            if (ks + 3 < nk) load_step(ks + 3, ra1, rb1);
-            mma_step(1);
-            if (ks + 2 < nk) store_step(ra0, rb0, 0);
-            __syncthreads();
-        }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) ra0[j] = na[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) rb0[j] = nb[j];
     }
+    if (ks + 1 < nk) {                   // second to last step: nothing left to load
+        mma_step(ks & 1);
+        store_step(ra0, rb0, (ks + 1) & 1);
+        __syncthreads();
+        ++ks;
+    }
+    mma_step(ks & 1);                    // last step
+    __syncthreads();
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, acc, nullptr, NORM ? rowss : nullptr, m0, n0, tile_n);
 }
 
