@@ -567,42 +567,61 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     const bool uniform = (g.C % X3_BK) == 0;
     f32x4 ra0[A_LD], rb0[B_LD];
     int s_cc = 0, s_th = 0, s_tw = 0;
+    // Per-row source offset / validity of the CURRENT tap are cached and only recomputed when the K walk enters a new
+    // tap (uniform mode: C % 16 == 0); inside a tap a step just advances by 16 floats.  The weight rows advance by 16
+    // floats per step unconditionally.
+    int64_t a_cur[A_LD], b_cur[B_LD];
+    bool a_valid[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) { a_cur[j] = 0; a_valid[j] = false; }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) b_cur[j] = b_off[j] + chunk * 4;
     auto load_step = [&](int ks, f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
-        int cc, dh, dw;
-        bool kvalid;
-        const int q = ks * 4 + chunk;
+        bool kvalid = true;
         if (uniform) {
-            cc = s_cc + chunk;
-            dh = s_th * g.dstep_h;
-            dw = s_tw * g.dstep_w;
-            kvalid = true;
+            if (s_cc == 0) {
+                const int dh = s_th * g.dstep_h, dw = s_tw * g.dstep_w;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) {
+                    const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                    a_valid[j] = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    a_cur[j] = a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + chunk * 4;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_valid[j]) v = *reinterpret_cast<const f32x4*>(p.a + a_cur[j] + s_cc * 4);
+                ra[j] = v;
+            }
             s_cc += 4;
             if (s_cc == p.cpt) {
                 s_cc = 0;
                 if (++s_tw == g.TW) { s_tw = 0; ++s_th; }
             }
         } else {
+            const int q = ks * 4 + chunk;
             kvalid = q < p.nchunks;
             const int tap = q / p.cpt;
-            cc = q - tap * p.cpt;
+            const int cc = q - tap * p.cpt;
             const int th = tap / g.TW;
             const int tw = tap - th * g.TW;
-            dh = th * g.dstep_h;
-            dw = tw * g.dstep_w;
-        }
+            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
-            const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
-            ra[j] = v;
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
+                ra[j] = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kvalid && b_ok[j]) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[j] + (int64_t)q * 4);
+            if (kvalid && b_ok[j]) v = *reinterpret_cast<const f32x4*>(p.wt + b_cur[j]);
             rb[j] = v;
+            b_cur[j] += 16;
         }
     };
     // x = h + m + l with h, m, l the three successive 8-bit significand slices (truncation; every step exact)
