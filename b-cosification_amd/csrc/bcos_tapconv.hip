@@ -64,6 +64,7 @@ struct KArgs {
     int tiles_n;            // column tiles
     int n_big, n_small;     // tiles of BM rows, then tiles of BM/2 rows (tail of the launch)
     int rows_big;           // rows covered by the BM-row tiles
+    unsigned a_bytes, wt_bytes;   // operand sizes for the buffer descriptors of the split-bf16 path (< 2 GiB there)
     int x3;          // contraction on split-bf16 MFMA (see tile_body_x3) instead of fp32 MFMA
     int uniform_tap; // C % 32 == 0: every K-step lies inside one tap
     int vec_ok;     // every per-element epilogue tensor is 16-byte addressable (pitch % 4 == 0, aligned bases)
@@ -535,7 +536,14 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     const int H = g.H, W = g.W;
     const int a_pitch = g.a_pitch;
 
-    int64_t a_nbase[A_LD];
+    // Operands are fetched with raw buffer loads: a lane whose source is outside the image / past the last weight row
+    // carries the offset OOB (>= num_records, the host guarantees both operands are < 2 GiB) and the hardware returns
+    // zeros -- no exec-mask branches, no zero-filling moves, 32-bit offsets.  Inside a tap the K walk advances through
+    // the scalar offset operand, so a steady-state step issues its loads with no vector ALU work at all.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
+    unsigned a_nbase[A_LD];          // byte offset of the row's image (+ this lane's 16-byte chunk)
     int a_ih0[A_LD], a_iw0[A_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
@@ -545,7 +553,7 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
             const int rem = m - n * p.PQ;
             const int i = rem / g.Q;
             const int jj = rem - i * g.Q;
-            a_nbase[j] = (int64_t)n * H * W * a_pitch;
+            a_nbase[j] = ((unsigned)n * H * W * a_pitch + chunk * 4) * 4u;
             a_ih0[j] = i * g.in_sh + g.dh0;
             a_iw0[j] = jj * g.in_sw + g.dw0;
         } else {
@@ -554,54 +562,48 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
             a_iw0[j] = -(1 << 28);
         }
     }
-    int64_t b_off[B_LD];
-    bool b_ok[B_LD];
+    unsigned b_off[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int co = n0 + r0 + 64 * j;
-        b_ok[j] = co < g.Cout && (!B_HALF || r0 < BN);
-        b_off[j] = (int64_t)(b_ok[j] ? co : 0) * p.Ktot;
+        const bool ok = co < g.Cout && (!B_HALF || r0 < BN);
+        b_off[j] = ok ? ((unsigned)co * p.Ktot + chunk * 4) * 4u : OOB;
     }
 
     const int nk = (p.nchunks + 3) / 4;
     const bool uniform = (g.C % X3_BK) == 0;
-    f32x4 ra0[A_LD], rb0[B_LD];
     int s_cc = 0, s_th = 0, s_tw = 0;
-    // Per-row source offset / validity of the CURRENT tap are cached and only recomputed when the K walk enters a new
-    // tap (uniform mode: C % 16 == 0); inside a tap a step just advances by 16 floats.  The weight rows advance by 16
-    // floats per step unconditionally.
-    int64_t a_cur[A_LD], b_cur[B_LD];
-    bool a_valid[A_LD];
+    // Per-row source offset of the CURRENT tap is cached and only recomputed when the K walk enters a new tap (uniform
+    // mode: C % 16 == 0); inside a tap a step just advances the scalar offset by 64 bytes.
+    unsigned a_cur[A_LD];
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) { a_cur[j] = 0; a_valid[j] = false; }
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) b_cur[j] = b_off[j] + chunk * 4;
+    for (int j = 0; j < A_LD; ++j) a_cur[j] = OOB;
+    auto ldq = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+    };
     auto load_step = [&](int ks, f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
-        bool kvalid = true;
         if (uniform) {
             if (s_cc == 0) {
                 const int dh = s_th * g.dstep_h, dw = s_tw * g.dstep_w;
 #pragma unroll
                 for (int j = 0; j < A_LD; ++j) {
                     const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
-                    a_valid[j] = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                    a_cur[j] = a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + chunk * 4;
+                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    a_cur[j] = ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch) * 4u : OOB;
                 }
             }
 #pragma unroll
-            for (int j = 0; j < A_LD; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a_valid[j]) v = *reinterpret_cast<const f32x4*>(p.a + a_cur[j] + s_cc * 4);
-                ra[j] = v;
-            }
+            for (int j = 0; j < A_LD; ++j) ra[j] = ldq(a_rsrc, a_cur[j], s_cc * 16);
             s_cc += 4;
             if (s_cc == p.cpt) {
                 s_cc = 0;
                 if (++s_tw == g.TW) { s_tw = 0; ++s_th; }
             }
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) rb[j] = ldq(b_rsrc, b_off[j], ks * 64);
         } else {
             const int q = ks * 4 + chunk;
-            kvalid = q < p.nchunks;
+            const bool kvalid = q < p.nchunks;
             const int tap = q / p.cpt;
             const int cc = q - tap * p.cpt;
             const int th = tap / g.TW;
@@ -611,17 +613,11 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
             for (int j = 0; j < A_LD; ++j) {
                 const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
                 const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
-                ra[j] = v;
+                // a_nbase carries this lane's chunk within a 16-k step; here the chunk within the tap is cc instead
+                ra[j] = ldq(a_rsrc, ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch + (cc - chunk) * 4) * 4u : OOB, 0);
             }
-        }
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kvalid && b_ok[j]) v = *reinterpret_cast<const f32x4*>(p.wt + b_cur[j]);
-            rb[j] = v;
-            b_cur[j] += 16;
+            for (int j = 0; j < B_LD; ++j) rb[j] = ldq(b_rsrc, kvalid ? b_off[j] : OOB, ks * 64);
         }
     };
     // x = h + m + l with h, m, l the three successive 8-bit significand slices (truncation; every step exact)
@@ -709,30 +705,35 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     //   global loads of step ks+2 are issued into (na, nb); step ks+1 -- loaded one iteration ago into (ra0, rb0) -- is
     //   split and written to the other LDS buffer next to the MFMAs of step ks; the register sets are rotated after
     //   the barrier (by then the loads have had a whole MFMA phase to land).
-    f32x4 na[A_LD], nb[B_LD];
+    f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
     load_step(0, ra0, rb0);
     store_step(ra0, rb0, 0);
     if (nk > 1) load_step(1, ra0, rb0);
     __syncthreads();
     int ks = 0;
-    for (; ks + 2 < nk; ++ks) {          // steady state: no branches between the MFMAs and the split/stores
-        load_step(ks + 2, na, nb);
+    // steady state, two steps per trip so that the two register sets swap roles without copies (ks stays even: the
+    // LDS buffer indices are compile-time constants); no branches between the MFMAs and the split/stores
+    for (; ks + 3 < nk; ks += 2) {
+        load_step(ks + 2, ra1, rb1);
+        mma_step(0);
+        store_step(ra0, rb0, 1);
+        __syncthreads();
+        load_step(ks + 3, ra0, rb0);
+        mma_step(1);
+        store_step(ra1, rb1, 0);
+        __syncthreads();
+    }
+    for (; ks < nk; ++ks) {              // the last 1-3 steps
+        const bool more = ks + 1 < nk;
+        if (ks + 2 < nk) load_step(ks + 2, ra1, rb1);
         mma_step(ks & 1);
-        store_step(ra0, rb0, (ks + 1) & 1);
+        if (more) store_step(ra0, rb0, (ks + 1) & 1);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) ra0[j] = na[j];
+        for (int j = 0; j < A_LD; ++j) ra0[j] = ra1[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) rb0[j] = nb[j];
+        for (int j = 0; j < B_LD; ++j) rb0[j] = rb1[j];
     }
-    if (ks + 1 < nk) {                   // second to last step: nothing left to load
-        mma_step(ks & 1);
-        store_step(ra0, rb0, (ks + 1) & 1);
-        __syncthreads();
-        ++ks;
-    }
-    mma_step(ks & 1);                    // last step
-    __syncthreads();
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, acc, nullptr, NORM ? rowss : nullptr, m0, n0, tile_n);
 }
 
@@ -866,6 +867,32 @@ extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_
     p.tiles_n = p.n_big = p.n_small = p.rows_big = 0;
     p.uniform_tap = (g.C % BK == 0) ? 1 : 0;
     p.x3 = g_contraction_mode == 1 ? 1 : 0;
+    {   // the split-bf16 path addresses its operands through 32-bit buffer offsets: keep each launch below 2 GiB of A
+        // by splitting the batch (every tensor of the call is per-image separable); fall back to fp32 MFMA otherwise
+        const int64_t img_bytes = (int64_t)g.H * g.W * p.g.a_pitch * 4;
+        const int64_t a_bytes = img_bytes * g.N, wt_bytes = (int64_t)g.Cout * p.Ktot * 4;
+        const int64_t lim = (int64_t)1 << 31;
+        if (p.x3 && a_bytes >= lim && g.N > 1 && img_bytes < lim && wt_bytes < lim) {
+            const int per = (int)((lim - 1) / img_bytes);
+            for (int n0 = 0; n0 < g.N; n0 += per) {
+                bcos_tapconv_geom g2 = p.g;
+                bcos_epilogue e2 = *epi;
+                g2.N = g.N - n0 < per ? g.N - n0 : per;
+                const int64_t opix = (int64_t)n0 * g.OH * g.OW;
+                const float** cin[] = {&e2.addend, &e2.mul, &e2.mul2, &e2.gate2, &e2.relu_gate};
+                for (const float** q : cin) if (*q) *q += opix * p.g.out_pitch;
+                float** cout[] = {&e2.out, &e2.out2, &e2.scale_out};
+                for (float** q : cout) if (*q) *q += opix * p.g.out_pitch;
+                if (e2.norm_out) e2.norm_out += opix * p.g.norm_pitch;
+                const int rc = bcos_tapconv(a + (int64_t)n0 * g.H * g.W * p.g.a_pitch, wt, &g2, &e2, stream);
+                if (rc != BCOS_OK) return rc;
+            }
+            return BCOS_OK;
+        }
+        if (a_bytes >= lim || wt_bytes >= lim) p.x3 = 0;
+        p.a_bytes = (unsigned)(a_bytes < lim ? a_bytes : 0);
+        p.wt_bytes = (unsigned)(wt_bytes < lim ? wt_bytes : 0);
+    }
     {
         uintptr_t bits = 0;
         const void* ptrs[] = {epi->addend, epi->mul, epi->mul2, epi->gate2, epi->relu_gate, epi->out, epi->out2, epi->scale_out};
