@@ -33,6 +33,7 @@ import torch.distributed as dist  # noqa: E402
 GFLOP_FWD_PER_IMAGE = 8.611        # 2*MAC of the 54 B-cos convs of ResNet-50 @224
 GFLOP_PER_IMAGE = 2 * GFLOP_FWD_PER_IMAGE   # + one input-gradient contraction per layer
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the pipe the 6-product bf16x3 split runs on)
 
 
 def parse():
@@ -167,6 +168,12 @@ def main():
                     avg_launch_us=round(1e3 * kernel_ms / max(launches, 1), 2),
                     kernel_ms_per_step=round(kernel_ms / max(args.steps, 1), 3),
                     algorithmic_gflop_per_step=round(gflop_step, 1))
+    if contraction == "bf16x3":
+        # the same launches priced against the pipe they execute on: 6 bf16 products per algorithmic fp32 product
+        roofline["frac_of_bf16_pipe"] = round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4)
+        roofline["note"] = ("peak/frac: dense fp32 MFMA peak (fp32 is the arithmetic contract of the path); the default "
+                            "contraction evaluates each fp32 product as 6 exact bf16 MFMA products, frac_of_bf16_pipe "
+                            "prices those against the dense bf16 peak")
 
     result = {
         "metric": "images/sec (fwd+explanation) B-cos ResNet-50 @224, batch 256, 1/2/4/8 MI355X",
