@@ -40,7 +40,9 @@ class BcosAttentionPool2d(DetachableModule):
         n, c, h, w = x.shape
         tokens = x.flatten(start_dim=2).permute(0, 2, 1)                      # [N, HW, C]
         if self.attn_unpool:
-            y = self.c_proj(self.v_proj(tokens.permute(1, 0, 2)))             # (HW) N D'  (c_proj: B-cos if converted)
+            t = tokens.permute(1, 0, 2).contiguous()                          # (HW) N C
+            v = _hipfn.plain_linear(t, self.v_proj.weight, self.v_proj.bias, self._caches["v"], self.v_proj.weight)
+            y = self.c_proj(v)                                                # (HW) N D'  (c_proj: B-cos if converted)
             norm = y.norm(dim=-1, keepdim=True)
             return y / (norm.detach() if self.detach else norm)
         tokens = torch.cat([tokens.mean(dim=1, keepdim=True), tokens], dim=1).contiguous()   # mean token first

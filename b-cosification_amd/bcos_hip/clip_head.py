@@ -12,12 +12,23 @@ import torch
 from . import ops
 
 
-def zeroshot_logits(features: torch.Tensor, text_weights: torch.Tensor, scale: float = 100.0) -> torch.Tensor:
-    """features [N, D] (un-normalised image embeddings), text_weights [D, K] -> logits [N, K]."""
-    n, d = features.shape
-    gain = torch.full((n,), float(scale), device=features.device, dtype=torch.float32)
-    f = ops.weight_rownorm_scale(features.contiguous(), gain)           # scale * f / ||f||
-    return ops.matmul_nt(f, text_weights.t().contiguous())
+def zeroshot_logits(features: torch.Tensor, text_weights: torch.Tensor, scale: float = 100.0,
+                    attn_unpool: bool = False, cos_power: float = 1) -> torch.Tensor:
+    """features [N, D] (un-normalised image embeddings), text_weights [D, K] -> logits [N, K].
+
+    `attn_unpool` head (trainer.py:119-123, bcosattnpool.py:23-32): features are [(HW), N, D]; every location is
+    scored, logits * |logits|^(cos_power - 1), and the locations are summed."""
+    lead = features.shape[:-1]
+    d = features.shape[-1]
+    rows = features.reshape(-1, d).contiguous()
+    gain = torch.full((rows.shape[0],), float(scale), device=features.device, dtype=torch.float32)
+    f = ops.weight_rownorm_scale(rows, gain)                            # scale * f / ||f||
+    logits = ops.matmul_nt(f, text_weights.t().contiguous()).reshape(*lead, -1)
+    if attn_unpool:
+        if cos_power != 1:
+            logits = logits * logits.abs() ** (cos_power - 1)
+        logits = logits.sum(0)
+    return logits
 
 
 def topk_accuracy(logits: torch.Tensor, target: torch.Tensor, topk=(1, 5)):

@@ -30,8 +30,16 @@ for p in (os.path.join(REPO, "b-cosification_amd"), REPO):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-GFLOP_FWD_PER_IMAGE = 8.611        # 2*MAC of the 54 B-cos convs of ResNet-50 @224
-GFLOP_PER_IMAGE = 2 * GFLOP_FWD_PER_IMAGE   # + one input-gradient contraction per layer
+# forward GFLOP per image = 2*MAC of the B-cos convs / linears only; the
+# explanation adds one input-gradient contraction per layer = the same again.  The default (resnet50, batch 256) is the
+# configuration BASELINE.json's metric is quoted on; the other architectures are the remaining BASELINE configs and
+# are diagnostics (same JSON shape, `config.workload` names them).
+ARCHS = {
+    "resnet50": dict(gflop_fwd=8.611, family="resnet", explain=True),
+    "resnet18": dict(gflop_fwd=3.913, family="resnet", explain=True),
+    "vit_ti": dict(gflop_fwd=1.752, family="vit", explain=True),
+    "clip_rn50": dict(gflop_fwd=10.756, family="clip", explain=False),   # fused plan: forward (zero-shot) only
+}
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the pipe the 6-product bf16x3 split runs on)
 
@@ -42,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
-    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--arch", default="resnet50", choices=sorted(ARCHS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time the forward pass only")
@@ -65,7 +73,10 @@ def cpu_baseline(net, arch, n_images):
     torch.set_num_threads(cores)                                       # oversubscribes badly) far below 256 threads
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     x = synth.synthetic_images(n_images, seed=321)
-    fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
+    if ARCHS[arch]["family"] == "vit":
+        fwd = lambda xx, detach: O.simple_vit_logits(sd, xx, detach=detach)  # noqa: E731
+    else:
+        fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
     t0 = time.perf_counter()
     O.explain_batch(fwd, x[:2])                     # warm-up (oneDNN primitive creation) + cost probe
     probe = time.perf_counter() - t0
@@ -100,11 +111,20 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # -- model + data, resident in HBM --------------------------------------------------------------------------
-    net = synth.build_bcosified_resnet(args.arch, seed=0).to(dev)
+    spec = ARCHS[args.arch]
+    if not spec["explain"]:
+        args.forward_only = True
+    if spec["family"] == "vit":
+        from bcos_hip import vit_engine
+        net = synth.build_bcosified_vit(seed=0).to(dev)
+    elif spec["family"] == "clip":
+        net = synth.build_bcosified_clip_rn50(seed=0).to(dev)
+    else:
+        net = synth.build_bcosified_resnet(args.arch, seed=0).to(dev)
     calib = synth.synthetic_images(8, seed=123).to(dev)
     with torch.no_grad():
         synth.calibrate(net, calib)            # identical on every rank (same seeds, deterministic kernels)
-    eng = engine.attach(net)
+    eng = vit_engine.attach(net) if spec["family"] == "vit" else engine.attach(net)
     x = synth.synthetic_images(args.batch, seed=1000 + rank).to(dev)
     torch.cuda.synchronize()
 
@@ -112,7 +132,7 @@ def main():
 
     def step():
         if args.forward_only:
-            out = dict(logits=eng.forward(x))
+            out = dict(logits=eng.forward(x))      # clip_rn50: the image embeddings
             keys = ("logits",)
         else:
             out = eng.explain(x, want_weights=True)
@@ -153,7 +173,7 @@ def main():
 
     kernel_ms = sum(s.elapsed_time(e) for s, e in events)            # all tapconv launches of this rank
     launches = len(events)
-    gflop_step = (GFLOP_FWD_PER_IMAGE if args.forward_only else GFLOP_PER_IMAGE) * args.batch
+    gflop_step = spec["gflop_fwd"] * (1 if args.forward_only else 2) * args.batch
     achieved = gflop_step * args.steps / kernel_ms if kernel_ms > 0 else 0.0     # GFLOP/ms == TFLOP/s
     traffic = None
     tfile = os.path.join(REPO, "profiles", "traffic_latest.json")
@@ -176,7 +196,10 @@ def main():
                             "prices those against the dense bf16 peak")
 
     result = {
-        "metric": "images/sec (fwd+explanation) B-cos ResNet-50 @224, batch 256, 1/2/4/8 MI355X",
+        "metric": ("images/sec (fwd+explanation) B-cos ResNet-50 @224, batch 256, 1/2/4/8 MI355X"
+                   if args.arch == "resnet50" and not args.forward_only and args.batch == 256 else
+                   f"images/sec ({'fwd' if args.forward_only else 'fwd+explanation'}) B-cos {args.arch} @224, batch "
+                   f"{args.batch} -- diagnostic, not the BASELINE.json metric"),
         "value": round(value, 2),
         "unit": "images/s",
         "n_gpus": world,
@@ -194,7 +217,7 @@ def main():
                    "collective": "all_gather(logits, contribution maps)" if world > 1 else "none"},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and spec["family"] != "clip" and not args.forward_only:
         result["cpu_baseline"] = cpu_baseline(net, args.arch, args.cpu_sample)
     elif rank == 0:
         result["cpu_baseline"] = None

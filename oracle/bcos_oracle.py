@@ -396,7 +396,23 @@ def clip_rn50_embed(sd, x6, b=2, detach=False, mean=CLIP_MEAN_ADDINVERSE, std=CL
     return bcos_attention_pool(sd, prefix + "attnpool.", x, num_heads, detach)
 
 
-def zeroshot_logits(features, text_weights):
-    """clip_evaluate (bcos/training/trainer.py:112-118): L2-normalise the image features, 100 * f @ W_text."""
+def bcos_attention_unpool(sd, p, x, b=2, detach=False):
+    """BcosAttentionPool2d.forward, `attn_unpool` branch (bcosattnpool.py:23-32): no pooling -- every location is
+    projected by v_proj (plain nn.Linear WITH its bias) and c_proj (B-cosified by the converter, bcosify.py), then
+    L2-normalised over the feature dim (norm detached in explanation mode).  Returns (HW) x N x D'."""
+    t = x.flatten(start_dim=2).permute(2, 0, 1)                       # (HW) N C
+    t = F.linear(t, sd[p + "v_proj.weight"], sd.get(p + "v_proj.bias"))
+    t = bcos_linear(t, sd[p + "c_proj.linear.weight"], sd.get(p + "c_proj.linear.bias"), b=b, detach=detach)
+    norm = t.norm(dim=-1, keepdim=True)
+    return t / (norm.detach() if detach else norm)
+
+
+def zeroshot_logits(features, text_weights, attn_unpool=False, cos_power=1):
+    """clip_evaluate (bcos/training/trainer.py:112-123): L2-normalise the image features, 100 * f @ W_text; for the
+    `attn_unpool` head features are (HW) x N x D: logits * |logits|^(cos_power-1), summed over the locations."""
     f = features / features.norm(dim=-1, keepdim=True)
-    return 100.0 * f @ text_weights
+    logits = 100.0 * f @ text_weights
+    if attn_unpool:
+        logits = logits * (logits.abs().detach() ** (cos_power - 1))
+        logits = logits.sum(0)
+    return logits

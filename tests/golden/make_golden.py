@@ -376,8 +376,45 @@ def clip_rn50_embeddings():
                        torch_version=torch.__version__), f_, indent=1)
 
 
+# --------------------------------------------------------------------------------------------------------
+# a13/a20 `attn_unpool` variant: per-location v_proj -> B-cos c_proj -> L2 normalise; head with cos_power
+# --------------------------------------------------------------------------------------------------------
+def attn_unpool_head():
+    import importlib
+    ref_pool = importlib.import_module("bcos.modules.bcosattnpool")
+    g = torch.Generator().manual_seed(4242)
+    torch.manual_seed(4242)
+    cfg = dict(synth.clip_model_config(), attn_unpool=True)
+    m = ref_pool.BcosAttentionPool2d(3, 64, 2, 48, attn_unpool=True)
+    m.c_proj = R.bcosifylinear.BcosifyLinear.from_standard_module(m.c_proj, cfg)     # what bcosify.py does to it
+    m.eval()
+    x = torch.randn(2, 64, 3, 3, generator=g)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        y = m(x)                                                     # (HW) x N x D'
+    REPORT["unpool/oracle_y"] = rel(O.bcos_attention_unpool(sd, "", x), y)
+    wt = torch.randn(48, 10, generator=g)
+    # clip_evaluate, attn_unpool branch (bcos/training/trainer.py:112-123) with cos_power = 2
+    f = y / y.norm(dim=-1, keepdim=True)
+    logits = 100.0 * f @ wt
+    logits = (logits * (logits.abs().detach() ** (2 - 1))).sum(0)
+    REPORT["unpool/oracle_zeroshot"] = rel(O.zeroshot_logits(y, wt, attn_unpool=True, cos_power=2), logits)
+    # explanation mode: norm and the B-cos scale of c_proj detached
+    xr = x.clone().requires_grad_(True)
+    m.set_explanation_mode(True) if hasattr(m, "set_explanation_mode") else None
+    for sub in m.modules():
+        if hasattr(sub, "detach") and isinstance(getattr(sub, "detach"), bool):
+            sub.detach = True
+    (gr,) = torch.autograd.grad(m(xr)[:, :, 5].sum(), xr)
+    xo = x.clone().requires_grad_(True)
+    (go,) = torch.autograd.grad(O.bcos_attention_unpool(sd, "", xo, detach=True)[:, :, 5].sum(), xo)
+    REPORT["unpool/oracle_grad"] = rel(go, gr)
+    np.savez_compressed(os.path.join(HERE, "attn_unpool.npz"), x=x.numpy(), y=y.numpy(), text=wt.numpy(),
+                        zeroshot_cos2=logits.numpy(), grad_d5=gr.numpy(), **{"sd/" + k: v.numpy() for k, v in sd.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit", "clip"]
+    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit", "clip", "unpool"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -393,6 +430,8 @@ if __name__ == "__main__":
         vit_ti_end_to_end()
     if "clip" in which:
         clip_rn50_embeddings()
+    if "unpool" in which:
+        attn_unpool_head()
     with open(rep_path, "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     for k in sorted(REPORT):

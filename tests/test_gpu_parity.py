@@ -523,6 +523,28 @@ def test_clip_rn50_batch256_forward(lib):
     assert torch.equal(logits[40:42].argmax(1).cpu(), O.zeroshot_logits(ref, wt).argmax(1))
 
 
+def test_attn_unpool_head_against_reference_golden(lib, golden_dir):
+    """a13 / a20 `attn_unpool` variant on the HIP path: v_proj (plain linear with bias) and the B-cos c_proj run on the
+    contraction kernel, head = row-normalise + GEMM kernels; fixture recorded from the reference module."""
+    from test_host_cpu import _unpool_module
+    from bcos_hip import clip_head
+    m, sd, data = _unpool_module(golden_dir)
+    m = m.to(DEV)
+    x = torch.from_numpy(data["x"]).to(DEV)
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (9, 2, 48) and rel(y, data["y"]) <= 1e-5
+    wt = torch.from_numpy(data["text"]).to(DEV)
+    logits = clip_head.zeroshot_logits(y, wt, attn_unpool=True, cos_power=2)
+    assert rel(logits, data["zeroshot_cos2"]) <= 1e-5
+    xr = x.clone().requires_grad_(True)
+    for sub in m.modules():                         # what BcosUtilMixin.explanation_mode() does (bcos/common.py:347-384)
+        if hasattr(sub, "set_explanation_mode"):
+            sub.set_explanation_mode(True)
+    (g,) = torch.autograd.grad(m(xr)[:, :, 5].sum(), xr)
+    assert rel(g, data["grad_d5"]) <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------ both contraction modes
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 def test_contraction_modes_parity(lib, golden_dir, mode):

@@ -376,6 +376,41 @@ def test_clip_rn50_conversion_and_engine(monkeypatch):
     assert rel(clip_head.zeroshot_logits(emb, wt), O.zeroshot_logits(ref, wt)) <= 1e-5
 
 
+def _unpool_module(golden_dir):
+    from bcos.modules import BcosAttentionPool2d
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    from bcos_hip import synth
+    data = np.load(os.path.join(golden_dir, "attn_unpool.npz"))
+    m = BcosAttentionPool2d(3, 64, 2, 48, attn_unpool=True)
+    m.c_proj = BcosifyLinear.from_standard_module(m.c_proj, dict(synth.clip_model_config(), attn_unpool=True))
+    sd = {k[3:]: torch.from_numpy(data[k]) for k in data.files if k.startswith("sd/")}
+    assert set(sd) == set(m.state_dict())          # same keys as the reference module (incl. v_proj.bias)
+    m.load_state_dict(sd)
+    return m.eval(), sd, data
+
+
+def test_attn_unpool_head_against_reference_golden(monkeypatch, golden_dir):
+    """a13 / a20 `attn_unpool` variant (bcosattnpool.py:23-32, trainer.py:119-123): per-location v_proj -> B-cos c_proj
+    -> L2 normalise, head logits * |logits|^(cos_power-1) summed over locations; fixture recorded from the reference."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import clip_head
+    m, sd, data = _unpool_module(golden_dir)
+    x = torch.from_numpy(data["x"])
+    assert rel(O.bcos_attention_unpool(sd, "", x), data["y"]) <= 1e-6           # oracle pinned by the reference output
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (9, 2, 48) and rel(y, data["y"]) <= 1e-5
+    wt = torch.from_numpy(data["text"])
+    assert rel(O.zeroshot_logits(torch.from_numpy(data["y"]), wt, attn_unpool=True, cos_power=2), data["zeroshot_cos2"]) <= 1e-6
+    assert rel(clip_head.zeroshot_logits(y, wt, attn_unpool=True, cos_power=2), data["zeroshot_cos2"]) <= 1e-5
+    xr = x.clone().requires_grad_(True)
+    for sub in m.modules():                         # what BcosUtilMixin.explanation_mode() does (bcos/common.py:347-384)
+        if hasattr(sub, "set_explanation_mode"):
+            sub.set_explanation_mode(True)
+    (g,) = torch.autograd.grad(m(xr)[:, :, 5].sum(), xr)
+    assert rel(g, data["grad_d5"]) <= 1e-5
+
+
 def test_explainer_registry_and_ixg_semantics(monkeypatch):
     """get_explainer / Ours / IxG (captum InputXGradient semantics) and BcosUtilMixin.attribute(_selection)."""
     cpu_emulation.install(monkeypatch)
