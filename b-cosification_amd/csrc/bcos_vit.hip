@@ -2,9 +2,9 @@
 // DetachableLayerNorm (bcos/modules/norms/centered_norms.py:187-245), MyGELU (bcosify_vit.py:27-32), the softmax
 // attention of bcos/models/vit.py:143-158 / bcos/modules/bcosattnpool.py:22-59 with q,k detached in explanation
 // mode, the token positional-embedding add and the un-patchify end of the ViT explanation pass.
-// All of these are small next to the B-cos linears (ViT-Ti: 30 MFLOP of attention vs 1.75 GFLOP of B-cos GEMMs per
-// image), so they are written as streaming / VALU kernels: one wavefront per LayerNorm row, one workgroup per
-// (image, head) for attention with K, V (forward) or Q, dOut (backward) resident in LDS.
+// LayerNorm / GELU / embedding add are streaming kernels (one wavefront per LayerNorm row); the attention runs on fp32
+// MFMA, one workgroup per (image, head), with the walked operand and the transposed value operand resident in LDS and
+// the probabilities kept in registers between the two products.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -108,116 +108,154 @@ __global__ __launch_bounds__(TPB) void add_rows_bcast_kernel(float* __restrict__
     }
 }
 
-// ---- softmax attention, one workgroup per (batch, head), head dim 64 ----------------------------------------
+// ---- softmax attention on fp32 MFMA, one workgroup per (batch, head), head dim 64 -----------------------------
 // qkv: [B, T, 3*H*64] laid out "(three h d)" like vit.py:145-146; out: [B, T, H*64]
 // stats: [B, H, T, 2] = (row max, 1 / row sum) kept for the explanation backward instead of the T x T matrix.
+//
+// One kernel serves both directions.  Call the operand that is walked in 32-row chunks X, the one that owns the
+// output rows Y, and the value operand Z:
+//   forward   out[q]  = sum_k softmax_k(scale q.k) v[k]          X = K, Y = Q, Z = V,    softmax statistics online
+//   backward  gv[k]   = sum_q P[q][k] gout[q]   (q, k detached: vit.py:148-151, bcosattnpool.py:37-39)
+//                                                                X = Q, Y = K, Z = gout, P from the stored stats
+// A wavefront owns a 32-row tile of Y (held in registers as MFMA B fragments) and walks X (LDS, [Tpad][68]):
+//   S^T tile = X_chunk . Y_tile^T on v_mfma_f32_32x32x2_f32: D layout puts the Y row on the lane (column) and 16 X
+//   rows in registers, so per-Y-row softmax reductions are 16 in-register ops + one exchange with lane^32, and the
+//   probabilities are ALREADY in the B-operand layout of the second product  O^T[d][y] += Z^T[d][x] . P^T[x][y]
+//   (register r of lane half hf is X row 8(r>>2) + 4hf + (r&3); the A operand Z^T is read from LDS, [64][Tpad+4],
+//   with the same row permutation) -- the T x T matrix never leaves the register file.
+// Both LDS layouts are padded so that every ds_read_b128 of a 16-lane group hits 16 distinct bank quads.
 constexpr int DH = 64;
+constexpr int AT_XLD = DH + 4;      // floats per X row in LDS
 
-__global__ __launch_bounds__(TPB) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            float* __restrict__ stats, int B, int T, int H,
-                                                            float scale) {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool BWD>
+__global__ __launch_bounds__(TPB) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ zsrc,
+                                                             float* __restrict__ out, float* __restrict__ stats_out,
+                                                             const float* __restrict__ stats_in, int B, int T, int H,
+                                                             float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sK = smem;                 // [T][64]
-    float* sV = smem + (size_t)T * DH;
+    const int Tpad = (T + 31) & ~31;
+    const int zld = Tpad + 4;
+    float* sX = smem;                                  // [Tpad][68]
+    float* sZT = smem + (size_t)Tpad * AT_XLD;         // [64][Tpad + 4]
+    float* sS = sZT + (size_t)DH * zld;                // [Tpad][2]   (backward only)
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int inner = H * DH;
-    const float* base = qkv + (int64_t)b * T * 3 * inner;
-    for (int i = threadIdx.x; i < T * (DH / 4); i += TPB) {
-        const int t = i / (DH / 4), c4 = i % (DH / 4);
-        const float* row = base + (int64_t)t * 3 * inner + h * DH + c4 * 4;
-        *reinterpret_cast<f32x4*>(sK + t * DH + c4 * 4) = *reinterpret_cast<const f32x4*>(row + inner);
-        *reinterpret_cast<f32x4*>(sV + t * DH + c4 * 4) = *reinterpret_cast<const f32x4*>(row + 2 * inner);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < T; i += TPB) {      // query row i
-        float q[DH];
-        const float* qrow = base + (int64_t)i * 3 * inner + h * DH;
-#pragma unroll
-        for (int d = 0; d < DH; d += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(qrow + d);
-            q[d] = v[0]; q[d + 1] = v[1]; q[d + 2] = v[2]; q[d + 3] = v[3];
-        }
-        float mx = -INFINITY;
-        for (int j = 0; j < T; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) s = fmaf(q[d], sK[j * DH + d], s);
-            mx = fmaxf(mx, s * scale);
-        }
-        float l = 0.f;
-        for (int j = 0; j < T; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) s = fmaf(q[d], sK[j * DH + d], s);
-            l += expf(s * scale - mx);
-        }
-        const float rl = 1.0f / l;
-        float acc[DH];
-#pragma unroll
-        for (int d = 0; d < DH; ++d) acc[d] = 0.f;
-        for (int j = 0; j < T; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) s = fmaf(q[d], sK[j * DH + d], s);
-            const float pj = expf(s * scale - mx) * rl;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) acc[d] = fmaf(pj, sV[j * DH + d], acc[d]);
-        }
-        float* orow = out + ((int64_t)b * T + i) * inner + h * DH;
-#pragma unroll
-        for (int d = 0; d < DH; d += 4) *reinterpret_cast<f32x4*>(orow + d) = f32x4{acc[d], acc[d + 1], acc[d + 2], acc[d + 3]};
-        if (stats) {
-            float* st = stats + (((int64_t)b * H + h) * T + i) * 2;
-            st[0] = mx;
-            st[1] = rl;
-        }
-    }
-}
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* base = qkv + (int64_t)b * T * 3 * inner + h * DH;
+    const float* xsrc = base + (BWD ? 0 : inner);      // K (forward) / Q (backward), row stride 3*inner
+    const float* ysrc = base + (BWD ? inner : 0);      // Q (forward) / K (backward)
+    const float* zrow0 = BWD ? zsrc + (int64_t)b * T * inner + h * DH : base + 2 * inner;
+    const int zstride = BWD ? inner : 3 * inner;
 
-// explanation mode: q and k are detached (vit.py:148-151), so attn is a constant and only v receives gradient:
-//   gv[j, :] = sum_i attn[i, j] * gout[i, :],  attn[i, j] = exp(q_i . k_j * scale - max_i) / sum_i  (recomputed)
-__global__ __launch_bounds__(TPB) void attention_bwd_v_kernel(const float* __restrict__ qkv,
-                                                              const float* __restrict__ stats,
-                                                              const float* __restrict__ gout, float* __restrict__ gv,
-                                                              int B, int T, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sQ = smem;                         // [T][64]
-    float* sG = smem + (size_t)T * DH;        // [T][64]
-    float* sS = sG + (size_t)T * DH;          // [T][2]
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int inner = H * DH;
-    const float* base = qkv + (int64_t)b * T * 3 * inner;
-    for (int i = threadIdx.x; i < T * (DH / 4); i += TPB) {
+    for (int i = tid; i < Tpad * (DH / 4); i += TPB) {
         const int t = i / (DH / 4), c4 = i % (DH / 4);
-        *reinterpret_cast<f32x4*>(sQ + t * DH + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(base + (int64_t)t * 3 * inner + h * DH + c4 * 4);
-        *reinterpret_cast<f32x4*>(sG + t * DH + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(gout + ((int64_t)b * T + t) * inner + h * DH + c4 * 4);
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            xv = *reinterpret_cast<const f32x4*>(xsrc + (int64_t)t * 3 * inner + c4 * 4);
+            zv = *reinterpret_cast<const f32x4*>(zrow0 + (int64_t)t * zstride + c4 * 4);
+        }
+        *reinterpret_cast<f32x4*>(sX + t * AT_XLD + c4 * 4) = xv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sZT[(c4 * 4 + q) * zld + t] = zv[q];
     }
-    for (int i = threadIdx.x; i < 2 * T; i += TPB) sS[i] = stats[((int64_t)b * H + h) * T * 2 + i];
+    if (BWD) {
+        const float* st = stats_in + ((int64_t)b * H + h) * T * 2;
+        for (int i = tid; i < Tpad; i += TPB) {
+            sS[2 * i] = i < T ? st[2 * i] : INFINITY;          // padded query rows: exp(s - inf) * 0 = 0
+            sS[2 * i + 1] = i < T ? st[2 * i + 1] : 0.f;
+        }
+    }
     __syncthreads();
-    for (int j = threadIdx.x; j < T; j += TPB) {      // key / value row j
-        float k[DH];
-        const float* krow = base + (int64_t)j * 3 * inner + inner + h * DH;
+
+    const int col = lane & 31, hf = lane >> 5;
+    const int ntiles = Tpad / 32;
+    for (int tile = wave; tile < ntiles; tile += TPB / 64) {
+        const int y = tile * 32 + col;                 // the Y row (query fwd / key bwd) of this lane
+        f32x4 yf[8];
 #pragma unroll
-        for (int d = 0; d < DH; d += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(krow + d);
-            k[d] = v[0]; k[d + 1] = v[1]; k[d + 2] = v[2]; k[d + 3] = v[3];
+        for (int g = 0; g < 8; ++g) {
+            yf[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (y < T) yf[g] = *reinterpret_cast<const f32x4*>(ysrc + (int64_t)y * 3 * inner + 8 * g + 4 * hf);
         }
-        float acc[DH];
+        f32x16 o0, o1;
 #pragma unroll
-        for (int d = 0; d < DH; ++d) acc[d] = 0.f;
-        for (int i = 0; i < T; ++i) {
-            float s = 0.f;
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int chunk = 0; chunk < ntiles; ++chunk) {
+            f32x16 sacc;
 #pragma unroll
-            for (int d = 0; d < DH; ++d) s = fmaf(sQ[i * DH + d], k[d], s);
-            const float pij = expf(s * scale - sS[2 * i]) * sS[2 * i + 1];
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const float* xr = sX + (chunk * 32 + col) * AT_XLD + 4 * hf;
 #pragma unroll
-            for (int d = 0; d < DH; ++d) acc[d] = fmaf(pij, sG[i * DH + d], acc[d]);
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[c], yf[g][c], sacc, 0, 0, 0);
+            }
+            // register r <-> X row  chunk*32 + 8(r>>2) + 4hf + (r&3)
+            float pr[16];
+            if (!BWD) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int x = chunk * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                    pr[r] = x < T ? sacc[r] * scale : -INFINITY;
+                    mx = fmaxf(mx, pr[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run, mx);          // finite: every chunk holds at least one valid key
+                const float alpha = expf(m_run - m_new);
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pr[r] = expf(pr[r] - m_new); sum += pr[r]; }
+                sum += __shfl_xor(sum, 32);
+                l_run = l_run * alpha + sum;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* st = sS + 2 * (chunk * 32 + 8 * g + 4 * hf);
+                    const f32x4 s01 = *reinterpret_cast<const f32x4*>(st), s23 = *reinterpret_cast<const f32x4*>(st + 4);
+                    pr[4 * g + 0] = expf(sacc[4 * g + 0] * scale - s01[0]) * s01[1];
+                    pr[4 * g + 1] = expf(sacc[4 * g + 1] * scale - s01[2]) * s01[3];
+                    pr[4 * g + 2] = expf(sacc[4 * g + 2] * scale - s23[0]) * s23[1];
+                    pr[4 * g + 3] = expf(sacc[4 * g + 3] * scale - s23[2]) * s23[3];
+                }
+            }
+            const float* z0 = sZT + col * zld + chunk * 32 + 4 * hf;
+            const float* z1 = z0 + 32 * zld;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 za = *reinterpret_cast<const f32x4*>(z0 + 8 * g);
+                const f32x4 zb = *reinterpret_cast<const f32x4*>(z1 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[c], pr[4 * g + c], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(zb[c], pr[4 * g + c], o1, 0, 0, 0);
+                }
+            }
         }
-        float* grow = gv + ((int64_t)b * T + j) * inner + h * DH;
+        if (y < T) {
+            const float rl = BWD ? 1.0f : 1.0f / l_run;
+            float* orow = out + ((int64_t)b * T + y) * inner + h * DH + 4 * hf;    // d = 32 dt + 8 g + 4 hf + c
 #pragma unroll
-        for (int d = 0; d < DH; d += 4) *reinterpret_cast<f32x4*>(grow + d) = f32x4{acc[d], acc[d + 1], acc[d + 2], acc[d + 3]};
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(orow + 8 * g) =
+                    f32x4{o0[4 * g] * rl, o0[4 * g + 1] * rl, o0[4 * g + 2] * rl, o0[4 * g + 3] * rl};
+                *reinterpret_cast<f32x4*>(orow + 32 + 8 * g) =
+                    f32x4{o1[4 * g] * rl, o1[4 * g + 1] * rl, o1[4 * g + 2] * rl, o1[4 * g + 3] * rl};
+            }
+            if (!BWD && stats_out && hf == 0) {
+                float* st = stats_out + (((int64_t)b * H + h) * T + y) * 2;
+                st[0] = m_run;
+                st[1] = rl;
+            }
+        }
     }
 }
 
@@ -305,25 +343,29 @@ extern "C" int bcos_add_rows_bcast(float* x, const float* pe, int64_t total, int
     return check_launch("add_rows_bcast_kernel");
 }
 
-static int attn_lds_ok(int T, size_t floats, const void* fn, const char* what) {
-    const size_t bytes = floats * sizeof(float);
-    (void)T;
+static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, float* stats_out, const float* stats_in,
+                       int B, int T, int H, float scale, void* stream) {
+    const int Tpad = (T + 31) & ~31;
+    const size_t bytes = ((size_t)Tpad * AT_XLD + (size_t)DH * (Tpad + 4) + 2 * (size_t)Tpad) * sizeof(float);
     if (bytes > 160 * 1024) return bcos_set_error(BCOS_E_NOSUP, "attention: sequence too long for the LDS-resident kernel");
+    const void* fn = bwd ? reinterpret_cast<const void*>(attention_mfma_kernel<true>)
+                         : reinterpret_cast<const void*>(attention_mfma_kernel<false>);
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (err != hipSuccess) return bcos_set_hip_error(what, err);
-    return BCOS_OK;
+    if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute(attention)", err);
+    if (bwd)
+        hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((unsigned)(B * H)), dim3(TPB), bytes, STREAM(stream), qkv, z, out,
+                           stats_out, stats_in, B, T, H, scale);
+    else
+        hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((unsigned)(B * H)), dim3(TPB), bytes, STREAM(stream), qkv, z, out,
+                           stats_out, stats_in, B, T, H, scale);
+    return check_launch(bwd ? "attention_mfma_kernel<bwd>" : "attention_mfma_kernel<fwd>");
 }
 
 extern "C" int bcos_attention_fwd(const float* qkv, float* out, float* stats, int B, int T, int H, int Dh, float scale,
                                   void* stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_attention_fwd: bad argument");
     if (Dh != DH) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_fwd: head dimension must be 64");
-    const size_t floats = (size_t)2 * T * DH;
-    int rc = attn_lds_ok(T, floats, reinterpret_cast<const void*>(attention_fwd_kernel), "hipFuncSetAttribute(attention_fwd)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)(B * H)), dim3(TPB), floats * sizeof(float), STREAM(stream), qkv,
-                       out, stats, B, T, H, scale);
-    return check_launch("attention_fwd_kernel");
+    return attn_launch(false, qkv, nullptr, out, stats, nullptr, B, T, H, scale, stream);
 }
 
 extern "C" int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout, float* gv, int B, int T,
@@ -331,12 +373,7 @@ extern "C" int bcos_attention_bwd_v(const float* qkv, const float* stats, const 
     if (!qkv || !stats || !gout || !gv || B <= 0 || T <= 0 || H <= 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_attention_bwd_v: bad argument");
     if (Dh != DH) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_bwd_v: head dimension must be 64");
-    const size_t floats = (size_t)2 * T * DH + 2 * T;
-    int rc = attn_lds_ok(T, floats, reinterpret_cast<const void*>(attention_bwd_v_kernel), "hipFuncSetAttribute(attention_bwd)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(attention_bwd_v_kernel, dim3((unsigned)(B * H)), dim3(TPB), floats * sizeof(float), STREAM(stream),
-                       qkv, stats, gout, gv, B, T, H, scale);
-    return check_launch("attention_bwd_v_kernel");
+    return attn_launch(true, qkv, gout, gv, nullptr, stats, B, T, H, scale, stream);
 }
 
 extern "C" int bcos_finalize_explanation_patches(const float* gp, const float* x, const float* std6, float* weights_out,
