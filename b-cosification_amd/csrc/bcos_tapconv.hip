@@ -781,14 +781,16 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     p.tiles_n = (p.g.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int64_t total = (int64_t)tiles_m * p.tiles_n;
-    // how many BM-row tiles to keep at full height: whole "rounds" of SLOTS (of 256 when there is less than one round)
+    // how many BM-row tiles to keep at full height: whole "rounds" of SLOTS
     constexpr bool can_split = (BM / 2 >= 32) && (BN / (4 / ((BM / 64 >= WAVES_M) ? WAVES_M : BM / 64)) >= 32);
     int m_big = tiles_m;
-    if (can_split && total < 8 * SLOTS && !getenv("BCOS_NO_TAIL_SPLIT")) {
-        const int64_t unit = total >= SLOTS ? SLOTS : SLOTS / 2;
-        const int64_t full = (total / unit) * unit;
+    // Measured policy (ResNet-50 layer shapes, split-bf16 kernel): the split pays from two full rounds on (e.g. 1568
+    // tiles: -5 %); below that a CU left with a single resident workgroup runs it ~1.5x faster, which already hides
+    // most of the tail, and the half-height tiles' lower efficiency dominates (392 tiles: +25 % when split).
+    if (can_split && total >= 2 * SLOTS && total < 8 * SLOTS && !getenv("BCOS_NO_TAIL_SPLIT")) {
+        const int64_t full = (total / SLOTS) * SLOTS;
         const int64_t rem = total - full;
-        if (rem > 0 && rem < (unit * 9) / 10) m_big = (int)(full / p.tiles_n);
+        if (rem > 0 && rem < (SLOTS * 9) / 10) m_big = (int)(full / p.tiles_n);
     }
     p.rows_big = m_big * BM;
     if (p.rows_big > p.M) p.rows_big = p.M;
