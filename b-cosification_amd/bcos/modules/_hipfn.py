@@ -71,7 +71,7 @@ class WeightCache:
         self._sync(src)
         if self._fwd is None:
             w4 = w_eff if w_eff.dim() == 4 else w_eff[:, :, None, None]
-            self._fwd = _pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous()
+            self._fwd = ops.mark_static(_pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous())
         return self._fwd
 
     def dgrad(self, w_eff, src, stride, padding, dilation, groups):

@@ -57,7 +57,7 @@ class _Conv:
         wk = w.permute(0, 2, 3, 1)
         if cin_pad:
             wk = torch.nn.functional.pad(wk, (0, cin_pad))
-        self.w_fwd = wk.contiguous()
+        self.w_fwd = ops.mark_static(wk.contiguous())     # rebuilt by refresh() when parameters change
         self.bias = bias.detach().contiguous() if bias is not None else None
         self.dgrad = ops.DgradPlan(w, self.stride, self.padding, self.dilation)
         if bn is not None:

@@ -6,6 +6,8 @@ All activation tensors here are *physically* NHWC float32 HIP tensors of shape [
 import ctypes as C
 from typing import Optional
 
+import os
+
 import torch
 
 from . import lib as _l
@@ -49,6 +51,40 @@ def conv_out_size(size, k, s, p, d=1):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+_NO_PRESPLIT = bool(os.environ.get("BCOS_NO_PRESPLIT"))     # development switch: always split inside the kernel
+
+
+def mark_static(w: torch.Tensor) -> torch.Tensor:
+    """Declare `w` an inference-time constant (a layer's effective weight): tapconv() then keeps its pre-split bf16x3
+    image (bcos_split_weights) next to it and uses bcos_tapconv_presplit.  In-place updates are noticed through the
+    tensor version counter; the image is dropped with the tensor."""
+    w._bcos_static = True
+    return w
+
+
+def split_weights(w: torch.Tensor) -> torch.Tensor:
+    """Exact 3-way bf16 split of w [rows, ...] in MFMA fragment order (include/bcos_hip.h: bcos_split_weights)."""
+    lib = _l.load()
+    rows = w.shape[0]
+    ktot = w.numel() // rows
+    nbytes = C.c_int64(0)
+    _l.check(lib.bcos_split_weights_bytes(rows, ktot, C.byref(nbytes)), "bcos_split_weights_bytes")
+    out = torch.empty(nbytes.value, device=w.device, dtype=torch.uint8)
+    _l.check(lib.bcos_split_weights(_dev(w, "split_weights.w"), C.c_void_p(out.data_ptr()), rows, ktot, _stream()),
+             "bcos_split_weights")
+    return out
+
+
+def _presplit_of(wt: torch.Tensor):
+    if not getattr(wt, "_bcos_static", False) or _NO_PRESPLIT or _l.get_contraction_mode() != "bf16x3":
+        return None
+    cached = getattr(wt, "_bcos_wt3", None)
+    if cached is None or cached[0] != wt._version:
+        cached = (wt._version, split_weights(wt))
+        wt._bcos_wt3 = cached
+    return cached[1]
+
+
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
             gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0):
@@ -72,8 +108,14 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     timing = KERNEL_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    wt3 = _presplit_of(wt)          # before the timing events: a first-use split is not part of the launch
+    if timing is not None:
         ev0.record()
-    code = lib.bcos_tapconv(_dev(a, "tapconv.a", contiguous=False), _dev(wt, "tapconv.wt"), C.byref(g), C.byref(e), _stream())
+    if wt3 is not None:
+        code = lib.bcos_tapconv_presplit(_dev(a, "tapconv.a", contiguous=False), _dev(wt, "tapconv.wt"),
+                                         C.c_void_p(wt3.data_ptr()), C.byref(g), C.byref(e), _stream())
+    else:
+        code = lib.bcos_tapconv(_dev(a, "tapconv.a", contiguous=False), _dev(wt, "tapconv.wt"), C.byref(g), C.byref(e), _stream())
     if timing is not None:
         ev1.record()
         timing.append((ev0, ev1))
@@ -163,6 +205,7 @@ class DgradPlan:
                     continue
                 sub = w_oihw[:, :, rs_h][:, :, :, rs_w]                    # [Cout,Cin,TH,TW]
                 wt = sub.permute(1, 2, 3, 0).contiguous()                   # [Cin,TH,TW,Cout]
+                mark_static(wt)     # a DgradPlan is built once per weight version (engine plan / WeightCache)
                 self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
         self.has_empty = any(c[8] is None for c in self.classes)
 

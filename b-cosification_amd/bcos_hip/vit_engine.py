@@ -37,8 +37,8 @@ class _Lin:
         w, bias = self.module._effective_weight_and_bias()
         w = w.detach()
         self.b = self.module._b_value()
-        self.w = w.contiguous()                        # [Cout, Cin]
-        self.wt = w.t().contiguous()                   # [Cin, Cout] for the input gradient
+        self.w = ops.mark_static(w.contiguous())       # [Cout, Cin]
+        self.wt = ops.mark_static(w.t().contiguous())  # [Cin, Cout] for the input gradient
         self.bias = bias.detach().contiguous() if bias is not None else None
         self.cin, self.cout = w.shape[1], w.shape[0]
 

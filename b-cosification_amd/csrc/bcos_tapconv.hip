@@ -64,6 +64,8 @@ struct KArgs {
     int tiles_n;            // column tiles
     int n_big, n_small;     // tiles of BM rows, then tiles of BM/2 rows (tail of the launch)
     int rows_big;           // rows covered by the BM-row tiles
+    const void* wt3;              // optional pre-split weights in MFMA fragment order (bcos_split_weights), else NULL
+    unsigned wt3_bytes;
     unsigned a_bytes, wt_bytes;   // operand sizes for the buffer descriptors of the split-bf16 path (< 2 GiB there)
     int x3;          // contraction on split-bf16 MFMA (see tile_body_x3) instead of fp32 MFMA
     int uniform_tap; // C % 32 == 0: every K-step lies inside one tap
@@ -516,7 +518,7 @@ constexpr int X3_ROW = 32;     // bytes per LDS row of one split: 16 bf16, unpad
                                // when bit 3 of the row index is set, which makes both the 8-byte staging stores (4 rows x 32 B
                                // per 16-lane group) and the 16-byte fragment reads (16 rows per group) bank-conflict free
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool PRE>
 __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -599,8 +601,10 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
                 s_cc = 0;
                 if (++s_tw == g.TW) { s_tw = 0; ++s_th; }
             }
+            if (!PRE) {
 #pragma unroll
-            for (int j = 0; j < B_LD; ++j) rb[j] = ldq(b_rsrc, b_off[j], ks * 64);
+                for (int j = 0; j < B_LD; ++j) rb[j] = ldq(b_rsrc, b_off[j], ks * 64);
+            }
         } else {
             const int q = ks * 4 + chunk;
             const bool kvalid = q < p.nchunks;
@@ -616,8 +620,10 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
                 // a_nbase carries this lane's chunk within a 16-k step; here the chunk within the tap is cc instead
                 ra[j] = ldq(a_rsrc, ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch + (cc - chunk) * 4) * 4u : OOB, 0);
             }
+            if (!PRE) {
 #pragma unroll
-            for (int j = 0; j < B_LD; ++j) rb[j] = ldq(b_rsrc, kvalid ? b_off[j] : OOB, ks * 64);
+                for (int j = 0; j < B_LD; ++j) rb[j] = ldq(b_rsrc, kvalid ? b_off[j] : OOB, ks * 64);
+            }
         }
     };
     // x = h + m + l with h, m, l the three successive 8-bit significand slices (truncation; every step exact)
@@ -655,6 +661,7 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
             }
             split_store(ra[j], base + (r0 + 64 * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4)), A_SPLIT);
         }
+        if (!PRE)
 #pragma unroll
         for (int j = 0; j < B_LD; ++j)
             if (!B_HALF || r0 < BN)
@@ -674,7 +681,23 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     const int a_frag = (wave_m * WM + frag_row) * X3_ROW + frag_off;
     const int b_frag = B_BASE + (wave_n * WN + frag_row) * X3_ROW + frag_off;
 
-    auto mma_step = [&](int buf) {
+    // Pre-split weights (bcos_split_weights): [32-column tile][16-k step][plane][lane][8 bf16] = exactly the B fragment a
+    // wavefront feeds to v_mfma_f32_32x32x16_bf16, 1 KB per (tile, step, plane).  A step's B operand is then six
+    // perfectly coalesced 16-byte loads per lane straight into registers: no conversion, no LDS store, no LDS read,
+    // and the weights never take part in the workgroup barrier.  Offsets are scalar (voffset = lane * 16).
+    struct BFrag { bf16x8 b[3][TN]; };
+    const __amdgpu_buffer_rsrc_t b3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt3), 0, p.wt3_bytes, 0x00020000);
+    const int b3_tile0 = __builtin_amdgcn_readfirstlane((n0 + wave_n * WN) >> 5);
+    auto load_bfrag = [&](int ks, BFrag& f) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const int soff = (((b3_tile0 + j) * nk + ks) * 3 + sp) * 1024;
+                f.b[sp][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b3_rsrc, lane * 16, soff, 0));
+            }
+    };
+    auto mma_step = [&](int buf, const BFrag& pf) {
         const char* base = lds + buf * BUF;
         bf16x8 af[3][TM], bf[3][TN];
 #pragma unroll
@@ -683,8 +706,10 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
             for (int i = 0; i < TM; ++i)
                 af[sp][i] = *reinterpret_cast<const bf16x8*>(base + a_frag + sp * A_SPLIT + i * 32 * X3_ROW);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[sp][j] = *reinterpret_cast<const bf16x8*>(base + b_frag + sp * B_SPLIT + j * 32 * X3_ROW);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (PRE) bf[sp][j] = pf.b[sp][j];
+                else bf[sp][j] = *reinterpret_cast<const bf16x8*>(base + b_frag + sp * B_SPLIT + j * 32 * X3_ROW);
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -700,40 +725,43 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
             }
     };
 
-    // buf[ks & 1] holds step ks.  Three-stage software pipeline over one MFMA site per iteration (two sites make the
-    // compiler keep the accumulators in VGPRs and shuttle 64 registers to the AGPRs and back around every step):
-    //   global loads of step ks+2 are issued into (na, nb); step ks+1 -- loaded one iteration ago into (ra0, rb0) -- is
-    //   split and written to the other LDS buffer next to the MFMAs of step ks; the register sets are rotated after
-    //   the barrier (by then the loads have had a whole MFMA phase to land).
+    // buf[ks & 1] holds step ks.  Three-stage software pipeline: global loads of step ks+2 are issued into the free
+    // register set; step ks+1 -- loaded one step ago -- is split and written to the other LDS buffer next to the MFMAs
+    // of step ks.  Two steps per loop trip so that the register sets (and, with pre-split weights, the two B fragment
+    // sets: the fragments of step ks+1 are loaded during step ks) swap roles without copies; the accumulators stay in
+    // AGPRs; no branches between the MFMAs and the split/stores.
     f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
+    BFrag bf0, bf1;
     load_step(0, ra0, rb0);
+    if (PRE) load_bfrag(0, bf0);
     store_step(ra0, rb0, 0);
     if (nk > 1) load_step(1, ra0, rb0);
     __syncthreads();
     int ks = 0;
-    // steady state, two steps per trip so that the two register sets swap roles without copies (ks stays even: the
-    // LDS buffer indices are compile-time constants); no branches between the MFMAs and the split/stores
     for (; ks + 3 < nk; ks += 2) {
         load_step(ks + 2, ra1, rb1);
-        mma_step(0);
+        if (PRE) load_bfrag(ks + 1, bf1);
+        mma_step(0, bf0);
         store_step(ra0, rb0, 1);
         __syncthreads();
         load_step(ks + 3, ra0, rb0);
-        mma_step(1);
+        if (PRE) load_bfrag(ks + 2, bf0);
+        mma_step(1, bf1);
         store_step(ra1, rb1, 0);
         __syncthreads();
     }
-    for (; ks < nk; ++ks) {              // the last 1-3 steps
-        const bool more = ks + 1 < nk;
-        if (ks + 2 < nk) load_step(ks + 2, ra1, rb1);
-        mma_step(ks & 1);
-        if (more) store_step(ra0, rb0, (ks + 1) & 1);
+    // the last 1-3 steps (ks is even here)
+    auto tail_step = [&](int k, f32x4 (&la)[A_LD], f32x4 (&lb)[B_LD], const f32x4 (&sa)[A_LD], const f32x4 (&sb)[B_LD],
+                         const BFrag& fc, BFrag& fn) {
+        if (k + 2 < nk) load_step(k + 2, la, lb);
+        if (PRE && k + 1 < nk) load_bfrag(k + 1, fn);
+        mma_step(k & 1, fc);
+        if (k + 1 < nk) store_step(sa, sb, (k + 1) & 1);
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) ra0[j] = ra1[j];
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) rb0[j] = rb1[j];
-    }
+    };
+    if (ks < nk) tail_step(ks, ra1, rb1, ra0, rb0, bf0, bf1);
+    if (ks + 1 < nk) tail_step(ks + 1, ra0, rb0, ra1, rb1, bf1, bf0);
+    if (ks + 2 < nk) tail_step(ks + 2, ra1, rb1, ra0, rb0, bf0, bf1);
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, acc, nullptr, NORM ? rowss : nullptr, m0, n0, tile_n);
 }
 
@@ -749,7 +777,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 // dispatched in blockIdx order, so the half-height tiles fill the tail of the launch: with a few hundred equal
 // tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
 // = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool X3>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights
 __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
@@ -757,7 +785,8 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
         const int tile = xcd_remap(bid, p.n_big);
         const int tile_m = tile / p.tiles_n;
         const int tile_n = tile - tile_m * p.tiles_n;
-        if constexpr (X3) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        if constexpr (X3 == 2) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        else if constexpr (X3 == 1) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, tile_m * BM, tile_n * BN, tile_n);
         else tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
     } else {
         constexpr int BMS = BM / 2;
@@ -767,7 +796,8 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
             const int tile = xcd_remap(bid - p.n_big, p.n_small);
             const int tile_m = tile / p.tiles_n;
             const int tile_n = tile - tile_m * p.tiles_n;
-            if constexpr (X3) tile_body_x3<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            if constexpr (X3 == 2) tile_body_x3<BMS, BN, WMS, WNS, NORM, true>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            else if constexpr (X3 == 1) tile_body_x3<BMS, BN, WMS, WNS, NORM, false>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
             else tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
         }
     }
@@ -811,10 +841,12 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
         hipLaunchKernelGGL(k, grid, block, lds, stream, p);
         return hipSuccess;
     };
-    if (p.x3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, true>)
-                         : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, true>);
-    else err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, false>)
-                    : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, false>);
+    if (p.x3 && p.wt3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 2>)
+                                  : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 2>);
+    else if (p.x3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 1>)
+                              : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 1>);
+    else err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 0>)
+                    : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 0>);
     if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
     err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);
@@ -831,8 +863,71 @@ extern "C" int bcos_set_contraction_mode(int mode) {
 
 extern "C" int bcos_get_contraction_mode(void) { return g_contraction_mode; }
 
+namespace {
+
+// wt [rows][Ktot] fp32 -> wt3 [32-row tile][16-k step][plane h|m|l][lane][8 bf16]: lane = (row % 32) + 32 * ((k % 16) / 8),
+// i.e. the B operand of v_mfma_f32_32x32x16_bf16 for that (tile, step); rows are padded to a multiple of 128 and k to a
+// multiple of 16 with zeros.  Same truncating split as tile_body_x3::split_store (bit-identical products).
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ wt, uint4* __restrict__ wt3, int rows,
+                                                            int Ktot, int nk, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (tile, ks, lane)
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int64_t ts = i >> 6;
+    const int ks = (int)(ts % nk);
+    const int tile = (int)(ts / nk);
+    const int row = tile * 32 + (lane & 31);
+    const int k0 = ks * 16 + 8 * (lane >> 5);
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (row < rows && k0 + e < Ktot) ? wt[(int64_t)row * Ktot + k0 + e] : 0.f;
+        h[e] = __float_as_uint(x) & 0xffff0000u;
+        const float r1 = x - __uint_as_float(h[e]);
+        m[e] = __float_as_uint(r1) & 0xffff0000u;
+        l[e] = __float_as_uint(r1 - __uint_as_float(m[e])) & 0xffff0000u;
+    }
+    auto pack = [](const unsigned (&v)[8]) {
+        return uint4{(v[0] >> 16) | v[1], (v[2] >> 16) | v[3], (v[4] >> 16) | v[5], (v[6] >> 16) | v[7]};
+    };
+    uint4* dst = wt3 + (ts * 3) * 64 + lane;
+    dst[0] = pack(h);
+    dst[64] = pack(m);
+    dst[128] = pack(l);
+}
+
+inline int64_t split_bytes(int rows, int Ktot) {
+    const int64_t tiles = (((int64_t)rows + 127) / 128) * 4, nk = ((int64_t)Ktot + 15) / 16;
+    return tiles * nk * 3 * 1024;
+}
+
+}  // namespace
+
+extern "C" int bcos_split_weights_bytes(int rows, int Ktot, int64_t* bytes) {
+    if (rows <= 0 || Ktot <= 0 || !bytes) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights_bytes: bad argument");
+    *bytes = split_bytes(rows, Ktot);
+    return BCOS_OK;
+}
+
+extern "C" int bcos_split_weights(const float* wt, void* wt3, int rows, int Ktot, void* stream) {
+    if (!wt || !wt3 || rows <= 0 || Ktot <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights: bad argument");
+    if (reinterpret_cast<uintptr_t>(wt3) & 15) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights: wt3 must be 16-byte aligned");
+    const int nk = (Ktot + 15) / 16;
+    const int64_t total = split_bytes(rows, Ktot) / (3 * 16);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), wt, reinterpret_cast<uint4*>(wt3), rows, Ktot, nk, total);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("split_weights launch", err);
+    return BCOS_OK;
+}
+
 extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                             const bcos_epilogue* epi, void* stream) {
+    return bcos_tapconv_presplit(a, wt, nullptr, geom, epi, stream);
+}
+
+extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void* wt3, const bcos_tapconv_geom* geom,
+                                     const bcos_epilogue* epi, void* stream) {
     if (!a || !wt || !geom || !epi) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: NULL argument");
     const bcos_tapconv_geom& g = *geom;
     if (g.N <= 0 || g.H <= 0 || g.W <= 0 || g.C <= 0 || g.P <= 0 || g.Q <= 0 || g.TH <= 0 || g.TW <= 0 ||
@@ -886,7 +981,7 @@ extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_
                 float** cout[] = {&e2.out, &e2.out2, &e2.scale_out};
                 for (float** q : cout) if (*q) *q += opix * p.g.out_pitch;
                 if (e2.norm_out) e2.norm_out += opix * p.g.norm_pitch;
-                const int rc = bcos_tapconv(a + (int64_t)n0 * g.H * g.W * p.g.a_pitch, wt, &g2, &e2, stream);
+                const int rc = bcos_tapconv_presplit(a + (int64_t)n0 * g.H * g.W * p.g.a_pitch, wt, wt3, &g2, &e2, stream);
                 if (rc != BCOS_OK) return rc;
             }
             return BCOS_OK;
@@ -894,6 +989,9 @@ extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_
         if (a_bytes >= lim || wt_bytes >= lim) p.x3 = 0;
         p.a_bytes = (unsigned)(a_bytes < lim ? a_bytes : 0);
         p.wt_bytes = (unsigned)(wt_bytes < lim ? wt_bytes : 0);
+        const int64_t w3b = split_bytes(g.Cout, p.Ktot);
+        p.wt3 = (p.x3 && wt3 && w3b < lim && !(reinterpret_cast<uintptr_t>(wt3) & 15)) ? wt3 : nullptr;
+        p.wt3_bytes = (unsigned)(w3b < lim ? w3b : 0);
     }
     {
         uintptr_t bits = 0;

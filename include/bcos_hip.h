@@ -149,6 +149,18 @@ int bcos_get_contraction_mode(void);
 int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                  const bcos_epilogue* epi, void* stream);
 
+/* Pre-split weights for the bf16x3 contraction.  Weights are constant at inference (NormedConv2d / BcosifyConv2d
+ * weights only change in training, bcosconv2d.py:26-35), so their exact 3-way bf16 split is done once:
+ *   wt [rows][Ktot] fp32 -> wt3, laid out [32-row tile][16-k step][plane h|m|l][lane][8 bf16], which is exactly the B
+ *   fragment a wavefront feeds to v_mfma_f32_32x32x16_bf16 (rows padded to a multiple of 128, k to a multiple of 16).
+ * bcos_tapconv_presplit then loads B straight into registers (six coalesced 16-byte loads per lane and 16-k step): no
+ * conversion, no LDS traffic and no barrier participation for the weights.  Results are bit-identical to bcos_tapconv.
+ * wt3 == NULL, contraction mode 0 or a narrow-output launch fall back to wt (which must always be passed). */
+int bcos_split_weights_bytes(int rows, int Ktot, int64_t* bytes);
+int bcos_split_weights(const float* wt, void* wt3, int rows, int Ktot, void* stream);
+int bcos_tapconv_presplit(const float* a, const float* wt, const void* wt3, const bcos_tapconv_geom* geom,
+                          const bcos_epilogue* epi, void* stream);
+
 /*
  * Replaces BcosConv2d.forward_impl (bcos/modules/bcosconv2d.py:153-194) and
  * BcosifyConv2d.forward_impl (bcos/modules/bcosifyconv2d.py:50-102) for groups == 1,

@@ -545,6 +545,26 @@ def test_attn_unpool_head_against_reference_golden(lib, golden_dir):
     assert rel(g, data["grad_d5"]) <= 1e-5
 
 
+def test_presplit_weights_bit_identical(lib):
+    """bcos_tapconv_presplit (weights split once into MFMA fragment order, B operand loaded straight into registers)
+    must reproduce bcos_tapconv (weights split inside the kernel) bit for bit: same split, same products, same order."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(11)
+    for (N, H, Cin, Cout, k, s_, p_) in [(2, 14, 64, 200, 3, 1, 1), (3, 9, 24, 40, 1, 1, 0), (2, 16, 8, 64, 7, 2, 3),
+                                         (1, 7, 128, 1000, 1, 1, 0)]:
+        x = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+        w = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV)
+        y0, s0, _ = ops.conv2d_fwd(x, w, stride=(s_, s_), padding=(p_, p_), want_scale=True)
+        ws = ops.mark_static(w.clone())
+        y1, s1, _ = ops.conv2d_fwd(x, ws, stride=(s_, s_), padding=(p_, p_), want_scale=True)
+        assert getattr(ws, "_bcos_wt3", None) is not None
+        assert torch.equal(y0, y1) and torch.equal(s0, s1)
+        ws.mul_(2.0)                                   # in-place update: the cached image must be rebuilt
+        y2, _, _ = ops.conv2d_fwd(x, ws, stride=(s_, s_), padding=(p_, p_))
+        y3, _, _ = ops.conv2d_fwd(x, w * 2.0, stride=(s_, s_), padding=(p_, p_))
+        assert torch.equal(y2, y3)
+
+
 # ------------------------------------------------------------------------------------------ both contraction modes
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 def test_contraction_modes_parity(lib, golden_dir, mode):
