@@ -17,13 +17,16 @@ the derivative of the layer's (post-BN, post-ReLU) output w.r.t. its pre-scale c
 dynamic scale s = |lin| / ||patch|| held constant -- exactly what `.detach()` does in the reference.
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn
 
 from . import ops
-from .lib import BCOS_CONV_EPS, BCOS_NONE, BcosHipError
+from .lib import BCOS_CONV_EPS, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_SCALE_GATE_LSB, BCOS_NONE, BcosHipError
+
+_GATE_TENSOR = bool(os.environ.get("BCOS_GATE_TENSOR"))   # development switch: ReLU gates as tensors, not as the bit in t
 
 
 def _pair(v):
@@ -71,12 +74,12 @@ class _Conv:
         return (ops.conv_out_size(H, self.k[0], self.stride[0], self.padding[0], self.dilation[0]),
                 ops.conv_out_size(W, self.k[1], self.stride[1], self.padding[1], self.dilation[1]))
 
-    def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None):
+    def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None, flags=0):
         gate = gates.pop(0) if (relu and gates is not None) else None
         y, t, _ = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
                                  bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
                                  ch_shift=self.ch_shift, addend=addend, relu=relu, relu_gate=gate,
-                                 want_scale=want_scale)
+                                 want_scale=want_scale, flags=flags)
         self.last_gate = gate       # the replayed gate tensor, if any (else the output itself encodes the gate)
         return y, t
 
@@ -236,12 +239,17 @@ class ResNetEngine:
             else:
                 idn, td = inp, None
             hws.append((h.shape[1], h.shape[2]))
-            out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates)
+            # the block's ReLU decision travels in the low mantissa bit of the stored multiplier (include/bcos_hip.h:
+            # BCOS_EPI_SCALE_GATE_LSB): the explanation pass reads no separate gate tensor
+            out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates,
+                                       flags=BCOS_EPI_SCALE_GATE_LSB if (keep and blk.relu and not _GATE_TENSOR) else 0)
             ts.append(t)
             if keep:
-                pinned = blk.convs[-1].last_gate
-                rec.update(ts=ts, td=td, out=(pinned if pinned is not None else out) if blk.relu else None, hws=hws,
-                           pre_pool_hw=pre_pool_hw)
+                gate_t = None
+                if _GATE_TENSOR and blk.relu:       # development switch: separate gate tensor instead of the bit
+                    pinned = blk.convs[-1].last_gate
+                    gate_t = pinned if pinned is not None else out
+                rec.update(ts=ts, td=td, gated=bool(blk.relu), gate_t=gate_t, hws=hws, pre_pool_hw=pre_pool_hw)
                 st["blocks"].append(rec)
             cur = out
         if self.head_kind == "attnpool":
@@ -302,8 +310,8 @@ class ResNetEngine:
             H, W = st["blocks"][bi + 1]["in_hw"] if bi + 1 < nb else st["feat_hw"]
             # v = d logit / d out_b;  G_main = v * t_last (bn scale, ReLU gate and s of the block's last conv),
             # G_sc = v * gate(out_b) [* t_d]  for the shortcut
-            G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gate=rec["out"])
-            rec["ts"][-1] = rec["td"] = rec["out"] = None
+            G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gated=rec["gated"], gate_t=rec["gate_t"])
+            rec["ts"][-1] = rec["td"] = rec["gate_t"] = None
             gl = G_main
             convs = blk.convs
             for ci in range(len(convs) - 1, 0, -1):
@@ -320,7 +328,7 @@ class ResNetEngine:
             consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc, blk.shortcut_pool)
         # block 0 reads the stem pool output: raw gradient, pool backward (* t of the last stem conv), then the stem
         H0, W0 = st["blocks"][0]["in_hw"]
-        g_pool, _ = consumer.run(H0, W0, t_main=None, td=None, gate=None)
+        g_pool, _ = consumer.run(H0, W0, t_main=None, td=None, gated=False)
         k, s, p = self.pool
         a_h, a_w = st["a0_hw"]
         ts = st["stem_ts"]
@@ -347,13 +355,15 @@ class _Consumer:
     def __init__(self, conv, g_main, shortcut_conv, g_sc, sc_pool):
         self.conv, self.g_main, self.shortcut_conv, self.g_sc, self.sc_pool = conv, g_main, shortcut_conv, g_sc, sc_pool
 
-    def run(self, H, W, t_main, td, gate):
-        """-> (v * t_main, v * gate [* td]) with v = d logit / d X; both v when t_main is None."""
+    def run(self, H, W, t_main, td, gated, gate_t=None):
+        """-> (v * t_main, v * gate [* td]) with v = d logit / d X; both v when t_main is None.  `gated`: the block that
+        produced X ends in a ReLU, whose decision is the low mantissa bit of t_main."""
         g = self.g_main
         kw, out2 = {}, None
         if t_main is not None:
             out2 = torch.empty((g.shape[0], H, W, self.conv.cin), device=g.device, dtype=torch.float32)
-            kw = dict(mul=t_main, out2=out2, mul2=td, gate2=gate)
+            kw = dict(mul=t_main, out2=out2, mul2=td, gate2=gate_t,
+                      flags=BCOS_EPI_GATE2_FROM_MUL if (gated and gate_t is None) else 0)
         if self.shortcut_conv is not None:
             if self.sc_pool:
                 pooled = self.shortcut_conv.dgrad.run(self.g_sc, H // self.sc_pool, W // self.sc_pool)

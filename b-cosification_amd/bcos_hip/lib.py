@@ -23,6 +23,8 @@ SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_
 BCOS_NONE, BCOS_CONV_EPS, BCOS_LINEAR_EPS = 0, 1, 2
 BCOS_EPI_NORM_ONLY = 1
 BCOS_EPI_FORCE_POW = 2
+BCOS_EPI_SCALE_GATE_LSB = 4
+BCOS_EPI_GATE2_FROM_MUL = 8
 ABI_VERSION = 1
 
 

@@ -130,7 +130,7 @@ def fwd_geom(N, H, W, Cin, Cout, kh, kw, sh, sw, ph, pw, dh=1, dw=1):
 
 def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=None, b=2.0, mode=BCOS_CONV_EPS,
                ch_scale=None, ch_shift=None, addend=None, relu=False, relu_gate=None, want_scale=False,
-               want_norm=False, out=None, scale_out=None):
+               want_norm=False, out=None, scale_out=None, flags=0):
     """Fused B-cos convolution.  x [N,H,W,Cin], w [Cout,kh,kw,Cin] -> y [N,Ho,Wo,Cout] (+ scale, norm)."""
     N, H, W, Cin = x.shape
     Cout, kh, kw, Cin_w = w.shape
@@ -145,7 +145,7 @@ def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=Non
     if float(b) == 1.0:
         mode = BCOS_NONE
     tapconv(x, w, g, out=out, scale_out=scale_out, norm_out=norm, bias=bias, ch_scale=ch_scale,
-            ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu, relu_gate=relu_gate)
+            ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu, relu_gate=relu_gate, flags=flags)
     return out, scale_out, norm
 
 

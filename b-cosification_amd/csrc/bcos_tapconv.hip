@@ -154,6 +154,8 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
 
     const bool b_is_2 = e.b == 2.0f && !(e.flags & BCOS_EPI_FORCE_POW);
     const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
+    const bool gate_lsb = (e.flags & BCOS_EPI_SCALE_GATE_LSB) != 0;
+    const bool gate_mul = (e.flags & BCOS_EPI_GATE2_FROM_MUL) != 0 && e.mul != nullptr;
     const float bm1 = e.b - 1.0f;
     const int Cout = g.Cout;
     constexpr int CPR = BN / 4;              // 16-byte chunks per tile row
@@ -214,7 +216,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
-                        s[q] = open_gate ? s[q] : 0.f;
+                        s[q] = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s[q]) | 1u) : s[q]) : 0.f;
                         val[q] = open_gate ? val[q] : 0.f;
                     }
                 } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
@@ -230,7 +232,10 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                     if (e.out2) {
                         f32x4 o2 = val;
                         if (e.mul2) o2 *= m2[u];
-                        if (e.gate2) {
+                        if (gate_mul) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o2[q] = (__float_as_uint(m1[u][q]) & 1u) ? o2[q] : 0.f;
+                        } else if (e.gate2) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
                         }
@@ -259,7 +264,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                 if (e.addend) v += e.addend[idx];
                 if (e.relu == 1) {
                     const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
-                    s = open_gate ? s : 0.f;
+                    s = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s) | 1u) : s) : 0.f;
                     v = open_gate ? v : 0.f;
                 } else if (e.relu == 2) {
                     const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
@@ -270,7 +275,8 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                 if (e.out2) {
                     float o2 = v;
                     if (e.mul2) o2 *= e.mul2[idx];
-                    if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
+                    if (gate_mul) o2 = (__float_as_uint(e.mul[idx]) & 1u) ? o2 : 0.f;
+                    else if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
                     e.out2[idx] = o2;
                 }
                 if (e.scale_out) e.scale_out[idx] = s;

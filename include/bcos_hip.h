@@ -123,6 +123,13 @@ typedef struct bcos_epilogue {
 /* use the general (|lin/norm| + 1e-6)^(b-1) form even when b == 2: the reference takes that branch for
  * its learnable-B variants (bcosifyconv2d.py:91-98 with b_loss). */
 #define BCOS_EPI_FORCE_POW 2
+/* ReLU launches with scale_out: store the gate decision in the least significant mantissa bit of the stored
+ * multiplier t = s * ch_scale * gate (1 = open; a closed gate stores exactly 0).  The one-ulp change of t (6e-8
+ * relative) is far below the fp32 rounding of the products it enters, and the explanation pass then needs no
+ * separate gate tensor: */
+#define BCOS_EPI_SCALE_GATE_LSB 4
+/* out2 = v [* mul2] gated by that bit of `mul` (instead of gate2 > 0): saves one output-sized read per launch. */
+#define BCOS_EPI_GATE2_FROM_MUL 8
 
 /* -- library -------------------------------------------------------------------------- */
 

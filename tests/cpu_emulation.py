@@ -8,7 +8,8 @@ include/bcos_hip.h documents for each entry point.  Nothing here is reachable fr
 import torch
 import torch.nn.functional as F
 
-from bcos_hip.lib import BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_NORM_ONLY, BCOS_LINEAR_EPS, BCOS_NONE
+from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_NORM_ONLY,
+                          BCOS_EPI_SCALE_GATE_LSB, BCOS_LINEAR_EPS, BCOS_NONE)
 
 
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
@@ -74,13 +75,19 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
         open_gate = (rd(relu_gate) > 0) if relu_gate is not None else (v > 0)
         s = torch.where(open_gate, s, torch.zeros_like(s))
         v = torch.where(open_gate, v, torch.zeros_like(v))
+        if flags & BCOS_EPI_SCALE_GATE_LSB:       # gate decision in the low mantissa bit of the stored fp32 multiplier
+            bits = s.float().contiguous().view(torch.int32)
+            s = torch.where(open_gate, (bits | 1).view(torch.float32).double(), torch.zeros_like(s))
     if out is not None:
         wr(out, v * rd(mul) if mul is not None else v)
     if out2 is not None:
         o2 = v
         if mul2 is not None:
             o2 = o2 * rd(mul2)
-        if gate2 is not None:
+        if (flags & BCOS_EPI_GATE2_FROM_MUL) and mul is not None:
+            mbits = v4(mul)[:, oh][:, :, ow][..., :Cout].float().contiguous().view(torch.int32)
+            o2 = torch.where((mbits & 1).bool(), o2, torch.zeros_like(o2))
+        elif gate2 is not None:
             o2 = torch.where(rd(gate2) > 0, o2, torch.zeros_like(o2))
         wr(out2, o2)
     if scale_out is not None:
