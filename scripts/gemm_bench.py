@@ -7,6 +7,7 @@ from bcos_hip import ops
 dev = "cuda"
 def bench(M, K, N, bcos=False, iters=10):
     a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
+    if os.environ.get("STATIC"): ops.mark_static(w)
     out = torch.empty(M, N, device=dev)
     f = (lambda: ops.linear_fwd(a, w, out=out)) if bcos else (lambda: ops.matmul_nt(a, w, out=out))
     for _ in range(3): f()
