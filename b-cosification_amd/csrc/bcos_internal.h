@@ -15,4 +15,18 @@ struct bcos_epilogue;
 int bcos_try_skinny(const float* a, const float* wt, const bcos_tapconv_geom& g, const bcos_epilogue& e, int M,
                     hipStream_t stream);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per kernel: raise it only when a launch needs more than any
+// earlier one did (one runtime call per kernel and size class instead of one per launch; none while a launch sequence
+// is being captured into a hipGraph after a warm-up pass).  `high_water` is a per-kernel static of the caller.
+#include <atomic>
+inline hipError_t bcos_ensure_dynamic_lds(const void* fn, size_t bytes, std::atomic<size_t>& high_water) {
+    if (bytes <= high_water.load(std::memory_order_acquire)) return hipSuccess;
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err == hipSuccess) {
+        size_t cur = high_water.load(std::memory_order_relaxed);
+        while (cur < bytes && !high_water.compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    }
+    return err;
+}
+
 #endif

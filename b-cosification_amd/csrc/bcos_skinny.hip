@@ -222,8 +222,8 @@ int bcos_try_skinny(const float* a, const float* wt, const bcos_tapconv_geom& g,
     p.ldp = p.CH + 4;
     const int64_t blocks = (int64_t)g.N * p.tiles_i * p.tiles_j;
     if (blocks >= ((int64_t)1 << 31)) return 0;
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<size_t> lds_hw{0};
+    hipError_t err = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(skinny_kernel), lds, lds_hw);
     if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute(skinny)", err);
     hipLaunchKernelGGL(skinny_kernel, dim3((unsigned)blocks), dim3(SK_THREADS), lds, stream, p);
     err = hipGetLastError();

@@ -841,18 +841,19 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     const size_t lds_x3 = 2 * 3 * (size_t)(BM + BN) * X3_ROW;
     if (p.x3 && lds_x3 > lds_epi) lds = lds_x3;
     else if (p.x3) lds = lds_epi;
-    auto launch = [&](auto k) -> hipError_t {
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<size_t> lds_hw[6];           // per kernel instantiation of this tile configuration
+    auto launch = [&](auto k, int which) -> hipError_t {
+        hipError_t e2 = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_hw[which]);
         if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(k, grid, block, lds, stream, p);
         return hipSuccess;
     };
-    if (p.x3 && p.wt3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 2>)
-                                  : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 2>);
-    else if (p.x3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 1>)
-                              : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 1>);
-    else err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 0>)
-                    : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 0>);
+    if (p.x3 && p.wt3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 2>, 0)
+                                  : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 2>, 1);
+    else if (p.x3) err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 1>, 2)
+                              : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 1>, 3);
+    else err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 0>, 4)
+                    : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 0>, 5);
     if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
     err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);

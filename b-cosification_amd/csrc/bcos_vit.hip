@@ -350,7 +350,8 @@ static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, f
     if (bytes > 160 * 1024) return bcos_set_error(BCOS_E_NOSUP, "attention: sequence too long for the LDS-resident kernel");
     const void* fn = bwd ? reinterpret_cast<const void*>(attention_mfma_kernel<true>)
                          : reinterpret_cast<const void*>(attention_mfma_kernel<false>);
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    static std::atomic<size_t> lds_hw[2];
+    hipError_t err = bcos_ensure_dynamic_lds(fn, bytes, lds_hw[bwd ? 1 : 0]);
     if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute(attention)", err);
     if (bwd)
         hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((unsigned)(B * H)), dim3(TPB), bytes, STREAM(stream), qkv, z, out,

@@ -12,7 +12,8 @@ weights are resident in HBM before the timed region.  Weak scaling: every rank p
 Besides the contract fields the JSON line carries
   roofline      fp32-MFMA roofline of the dominant kernel family (tapconv_kernel): algorithmic FLOP of the B-cos
                 contractions of one step (17.22 GFLOP/image) / the time spent in those launches,
-                measured live with HIP events on the launch stream inside the timed region;
+                measured live with HIP events on the launch stream inside the timed region (around every contraction
+                launch of every 5th timed step: on every step the 240 events cost 0.9 ms = 2 % of the step);
   cpu_baseline  the CPU oracle (the PyTorch-CPU restatement of the reference's path) timed on this host's cores on
                 a bounded sample (rank 0, N = 1 only).
 """
@@ -54,6 +55,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time the forward pass only")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured hipGraph (engine.CapturedPass) instead of launching eagerly; "
+                         "measured 1 %% SLOWER than eager launches on ROCm 7.2 (6 667 vs 6 745 images/s), hence off")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: do not bracket the contraction launches with HIP events (roofline fields become null)")
     ap.add_argument("--contraction", choices=("bf16x3", "f32"), default=None,
                     help="arithmetic of the contraction kernel (include/bcos_hip.h: bcos_set_contraction_mode); default: "
                          "the library default (bf16x3 = exact 3-way bf16 split, 6 products, fp32 accumulation)")
@@ -130,8 +136,21 @@ def main():
 
     gathered = {}
 
-    def step():
-        if args.forward_only:
+    # --graph: the step is recorded once into a hipGraph (engine.CapturedPass) and replayed; the steps that carry the
+    # per-launch HIP events for the roofline run the very same launches eagerly (events cannot be read back from a graph).
+    captured = None
+    if args.graph and spec["family"] == "resnet":
+        try:
+            captured = engine.CapturedPass(eng, x, explain=not args.forward_only, want_weights=True)
+        except Exception as exc:        # capture is an optimisation: fall back to eager launches, say so
+            print(f"bench.py: hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            captured = None
+
+    def step(eager=False):
+        if captured is not None and not eager:
+            out = captured()
+            keys = ("logits",) if args.forward_only else ("logits", "contribution_map")
+        elif args.forward_only:
             out = dict(logits=eng.forward(x))      # clip_rn50: the image embeddings
             keys = ("logits",)
         else:
@@ -152,16 +171,25 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.KERNEL_TIMING = []          # (start, end) HIP events on the launch stream around every tapconv launch
+    # HIP events on the launch stream around every contraction launch of a SAMPLE of the timed steps (every 5th: the
+    # two events per launch cost ~7 us of stream time each, 0.9 ms per step if taken on every step)
+    EVENT_STRIDE = 5
+    event_steps = [] if args.no_kernel_events else [i for i in range(args.steps) if i % EVENT_STRIDE == 0]
+    events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        if i in event_steps:
+            ops.KERNEL_TIMING = []
+            step(eager=True)
+            events += ops.KERNEL_TIMING
+            ops.KERNEL_TIMING = None
+        else:
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    events, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -171,10 +199,11 @@ def main():
     images = args.batch * world * args.steps
     value = images / elapsed
 
-    kernel_ms = sum(s.elapsed_time(e) for s, e in events)            # all tapconv launches of this rank
+    kernel_ms = sum(s.elapsed_time(e) for s, e in events)            # all contraction launches of the sampled steps
     launches = len(events)
+    n_ev = max(len(event_steps), 1)
     gflop_step = spec["gflop_fwd"] * (1 if args.forward_only else 2) * args.batch
-    achieved = gflop_step * args.steps / kernel_ms if kernel_ms > 0 else 0.0     # GFLOP/ms == TFLOP/s
+    achieved = gflop_step * n_ev / kernel_ms if kernel_ms > 0 else 0.0     # GFLOP/ms == TFLOP/s
     traffic = None
     tfile = os.path.join(REPO, "profiles", "traffic_latest.json")
     if os.path.exists(tfile):
@@ -184,9 +213,9 @@ def main():
             traffic = None
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                    kernel="tapconv_kernel (all instantiations)", launches_per_step=launches // max(args.steps, 1),
+                    kernel="tapconv_kernel (all instantiations) + skinny_kernel", launches_per_step=launches // n_ev,
                     avg_launch_us=round(1e3 * kernel_ms / max(launches, 1), 2),
-                    kernel_ms_per_step=round(kernel_ms / max(args.steps, 1), 3),
+                    kernel_ms_per_step=round(kernel_ms / n_ev, 3), steps_with_events=len(event_steps),
                     algorithmic_gflop_per_step=round(gflop_step, 1))
     if contraction == "bf16x3":
         # the same launches priced against the pipe they execute on: 6 bf16 products per algorithmic fp32 product
@@ -214,6 +243,7 @@ def main():
         "config": {"workload": f"B-cosified {args.arch} {'forward' if args.forward_only else 'forward+explanation'}, "
                                f"batch {args.batch} per GPU, 224x224x6 (AddInverse), calibrated random-init weights",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "contraction": contraction,
+                   "launch": "hipGraph replay (event-carrying steps eager)" if captured is not None else "eager",
                    "collective": "all_gather(logits, contribution maps)" if world > 1 else "none"},
         "roofline": roofline,
     }

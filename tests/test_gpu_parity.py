@@ -545,6 +545,27 @@ def test_attn_unpool_head_against_reference_golden(lib, golden_dir):
     assert rel(g, data["grad_d5"]) <= 1e-5
 
 
+def test_captured_pass_matches_eager(lib):
+    """engine.CapturedPass: the whole forward+explanation step recorded into a hipGraph and replayed on new inputs must
+    reproduce the eager launches bit for bit."""
+    from bcos_hip import engine, synth
+    net = synth.build_bcosified_resnet("resnet18").to(DEV)
+    x1 = synth.synthetic_images(4, seed=5, size=96).to(DEV)
+    x2 = synth.synthetic_images(4, seed=6, size=96).to(DEV)
+    with torch.no_grad():
+        synth.calibrate(net, x1)
+    eng = engine.attach(net)
+    ref1 = {k: v.clone() for k, v in eng.explain(x1).items()}
+    ref2 = {k: v.clone() for k, v in eng.explain(x2).items()}
+    cap = engine.CapturedPass(eng, x1)
+    for x, ref in ((x1, ref1), (x2, ref2), (x1, ref1)):
+        out = cap(x)
+        for k in ("logits", "prediction", "dynamic_linear_weights", "contribution_map"):
+            assert torch.equal(out[k], ref[k]), k
+    fwd = engine.CapturedPass(eng, x2, explain=False)
+    assert torch.equal(fwd(x1)["logits"], ref1["logits"])
+
+
 def test_presplit_weights_bit_identical(lib):
     """bcos_tapconv_presplit (weights split once into MFMA fragment order, B operand loaded straight into registers)
     must reproduce bcos_tapconv (weights split inside the kernel) bit for bit: same split, same products, same order."""
