@@ -380,8 +380,8 @@ class CapturedPass:
     """One forward (+ explanation) pass of an engine for a FIXED input shape, recorded once into a hipGraph and replayed:
     the ~130 launches of a ResNet-50 step are then submitted as one graph instead of one by one.  Eager launches leave
     ~10 us of idle time between dependent kernels (1.3 ms per step); on ROCm 7.2 the graph replay does not close that
-    gap -- measured 38.4 ms vs 37.9 ms per step eager at batch 256 -- so bench.py keeps it opt-in (--graph).  It does
-    remove the host-side launch work (useful when the host is the bottleneck, e.g. small batches).
+    gap -- measured 38.4 ms vs 37.9 ms per step eager at ResNet-50 batch 256, 4.00 vs 4.04 ms at ResNet-18 batch 8 --
+    so bench.py keeps it opt-in (--graph).  It does remove the host-side launch work.
     Outputs live in static buffers that every replay overwrites; call the object with a new input batch of the same
     shape.  Weights must not be re-laid out between capture and replay (refresh() -> capture again)."""
 
