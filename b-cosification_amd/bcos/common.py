@@ -91,13 +91,25 @@ class BcosUtilMixin:
         return result
 
     # -- batched explanation (MI355X addition) -----------------------------------------------------------
-    def explain_batch(self, images: Tensor, targets: Optional[Tensor] = None) -> "Dict[str, Tensor]":
+    def explain_batch(self, images: Tensor, targets: Optional[Tensor] = None, render: bool = False,
+                      smooth: int = 15, alpha_percentile: float = 99.5) -> "Dict[str, Tensor]":
         """Forward + explanation for a whole batch.
 
         Returns logits [N,K], prediction [N], explained_class_idx [N], dynamic_linear_weights [N,C,H,W]
         and contribution_map [N,H,W]; row n equals `explain(images[n:n+1], idx=targets[n])`.
         Uses the fused engine when one is attached (`bcos_hip.engine.attach`), else autograd over the modules.
+        `render=True` adds "explanation" [N,H,W,4]: the RGBA images of `gradient_to_image` for the whole batch, rendered
+        on the device (bcos_render_explanations).
         """
+        out = self._explain_batch(images, targets)
+        if render:
+            from bcos_hip import ops
+            out["explanation"] = ops.render_explanations(images.detach().contiguous(),
+                                                         out["dynamic_linear_weights"].contiguous(), smooth=smooth,
+                                                         alpha_percentile=alpha_percentile)
+        return out
+
+    def _explain_batch(self, images: Tensor, targets: Optional[Tensor] = None) -> "Dict[str, Tensor]":
         engine = getattr(self, "_bcos_engine", None)
         if engine is not None and getattr(engine, "supports_explain", True):
             return engine.explain(images, targets)
@@ -141,8 +153,18 @@ def gradient_to_image(image, linear_mapping, smooth=15, alpha_percentile=99.5, r
     per-pixel weight direction over the (r,g,b,1-r,1-g,1-b) channels, alpha = its L2 norm, zeroed where the
     contribution is negative, box-smoothed and clipped at the `alpha_percentile` quantile.
 
-    Host-side rendering with torch ops on whatever device the tensors live on (SURVEY.md section 8(f) N1 moves it
-    into a batched HIP kernel)."""
+    Tensors on a HIP device are rendered by the batched device kernel (bcos_hip.ops.render_explanations: per-pixel
+    colour/alpha, LDS box filter, exact quantile by radix select -- SURVEY.md section 8(f) N1); CPU tensors take the
+    reference's torch formulation below."""
+    if image.is_cuda and linear_mapping.is_cuda and image.dim() == 3 and image.shape[0] == 6 and (not smooth or smooth % 2):
+        from bcos_hip import ops
+        rgba_t = ops.render_explanations(image.detach()[None].float().contiguous(),
+                                         linear_mapping.detach()[None].float().contiguous(), smooth=smooth,
+                                         alpha_percentile=alpha_percentile)[0]
+        rgba = rgba_t.cpu().numpy()
+        if return_contribs:
+            return rgba, (image * linear_mapping).sum(0, keepdim=True).detach().cpu().numpy()
+        return rgba
     contribs = (image * linear_mapping).sum(0, keepdim=True)
     direction = linear_mapping / (linear_mapping.abs().max(0, keepdim=True).values + 1e-12)
     direction = direction.clamp(min=0)

@@ -18,7 +18,7 @@ REPO_ROOT = PKG_ROOT.parent
 LIB_PATH = Path(os.environ["BCOS_HIP_LIB"]) if os.environ.get("BCOS_HIP_LIB") else PKG_ROOT / "lib" / "libbcos_hip.so"
 CSRC = PKG_ROOT / "csrc"
 INCLUDE = REPO_ROOT / "include"
-SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_vit.hip", "bcos_abi.hip"]
+SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_vit.hip", "bcos_render.hip", "bcos_abi.hip"]
 
 BCOS_NONE, BCOS_CONV_EPS, BCOS_LINEAR_EPS = 0, 1, 2
 BCOS_EPI_NORM_ONLY = 1
@@ -80,6 +80,7 @@ SIGNATURES = {
     "bcos_attention_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_attention_bwd_v": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_finalize_explanation_patches": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "bcos_render_explanations": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
 }
 
 _lib = None

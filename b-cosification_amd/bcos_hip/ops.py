@@ -457,3 +457,21 @@ def finalize_explanation_patches(gp, x_nchw, std6, patch, add_inverse=False, wan
                                                    _dev(cout, "c"), N, Cx, H, W, patch, cpad, int(add_inverse), _stream()),
              "bcos_finalize_explanation_patches")
     return wout, cout
+
+
+def render_explanations(x: torch.Tensor, weights: torch.Tensor, smooth: int = 15, alpha_percentile: float = 99.5,
+                        want_quantiles: bool = False):
+    """Batched gradient_to_image on the device (include/bcos_hip.h: bcos_render_explanations).
+    x [N,3|6,H,W], weights [N,6,H,W] -> rgba [N,H,W,4] (and the per-image alpha divisors [N])."""
+    lib = _l.load()
+    N, Cx, H, W = x.shape
+    if tuple(weights.shape) != (N, 6, H, W):
+        raise BcosHipError(f"render_explanations: weights {tuple(weights.shape)} do not match input {tuple(x.shape)}")
+    rgba = torch.empty((N, H, W, 4), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((2, N, H, W), device=x.device, dtype=torch.float32)
+    qv = torch.empty((N,), device=x.device, dtype=torch.float32) if want_quantiles else None
+    code = lib.bcos_render_explanations(_dev(x, "render.x"), _dev(weights, "render.weights"), _dev(rgba, "render.rgba"),
+                                        _dev(scratch, "render.scratch"), _dev(qv, "render.q"), N, Cx, H, W, int(smooth or 0),
+                                        float(alpha_percentile) / 100.0, 1 if Cx == 3 else 0, _stream())
+    _l.check(code, "bcos_render_explanations")
+    return (rgba, qv) if want_quantiles else rgba

@@ -313,6 +313,16 @@ int bcos_finalize_explanation_patches(const float* gp, const float* x, const flo
                                       float* contrib_out, int N, int Cx, int H, int W, int patch, int Cpad,
                                       int add_inverse, void* stream);
 
+/* Batched RGBA rendering of explanations on the device: gradient_to_image (bcos/common.py:387-436; duplicate in
+ * interpretability/analyses/text_localisation.py:106-119) for N images at once.
+ *   x [N,Cx,H,W] network input (Cx = 3 with add_inverse, else 6), weights [N,6,H,W] = W(x)  ->  rgba [N,H,W,4]:
+ *   rgb = pair-normalised positive weight direction, alpha = ||W||_2 (1e-12 where the contribution is negative),
+ *   box-smoothed (smooth x smooth, zero padded, count_include_pad; smooth odd, 0/1 = off) and divided by its
+ *   q-quantile per image (torch.quantile linear interpolation: exact order statistics by radix select), clipped to [0,1].
+ * scratch: 2*N*H*W floats; quantiles: NULL or [N] (the per-image divisor). */
+int bcos_render_explanations(const float* x, const float* weights, float* rgba, float* scratch, float* quantiles,
+                             int N, int Cx, int H, int W, int smooth, float q, int add_inverse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

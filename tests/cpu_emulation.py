@@ -182,13 +182,30 @@ def contrib_map(x, gx):
     return (x * gx).sum(1)
 
 
+def render_explanations(x, weights, smooth=15, alpha_percentile=99.5, want_quantiles=False):
+    import torch.nn.functional as F
+    x6 = torch.cat([x, 1 - x], 1) if x.shape[1] == 3 else x
+    contribs = (x6 * weights).sum(1, keepdim=True)
+    d = (weights / (weights.abs().amax(1, keepdim=True) + 1e-12)).clamp(min=0)
+    rgb = d[:, :3] / (d[:, :3] + d[:, 3:] + 1e-12)
+    alpha = weights.norm(p=2, dim=1, keepdim=True)
+    alpha = torch.where(contribs < 0, torch.full_like(alpha, 1e-12), alpha)
+    if smooth and smooth > 1:
+        alpha = F.avg_pool2d(alpha, smooth, stride=1, padding=(smooth - 1) // 2)
+    qv = torch.stack([torch.quantile(a, q=alpha_percentile / 100) for a in alpha])
+    alpha = (alpha / qv.view(-1, 1, 1, 1)).clip(0, 1)
+    rgba = torch.cat([rgb, alpha], 1).permute(0, 2, 3, 1).contiguous()
+    return (rgba, qv) if want_quantiles else rgba
+
+
 def install(monkeypatch):
     """Patch bcos_hip.ops with the emulators (pytest monkeypatch fixture) and lift the HIP-device checks."""
     from bcos_hip import ops
     for name in ("tapconv", "prep_input", "finalize_explanation", "avgpool2d_fwd", "avgpool2d_bwd",
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
                  "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
-                 "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches"):
+                 "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
+                 "render_explanations"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

@@ -545,6 +545,36 @@ def test_attn_unpool_head_against_reference_golden(lib, golden_dir):
     assert rel(g, data["grad_d5"]) <= 1e-5
 
 
+def test_render_explanations_against_reference_and_oracle(lib, golden_dir):
+    """batched gradient_to_image on the device (colour, alpha, 15x15 box filter, exact 99.5 %
+    quantile by radix select) against the reference's recorded RGBA image and the oracle on edge cases."""
+    from bcos_hip import ops, synth
+    data = np.load(os.path.join(golden_dir, "resnet18_e2e.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "resnet18_e2e.json")))
+    x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"])[:2]
+    w = torch.from_numpy(data["weights_01"])
+    rgba, qv = ops.render_explanations(x.to(DEV), w.to(DEV), want_quantiles=True)
+    assert rgba.shape == (2, 224, 224, 4)
+    assert float(np.abs(rgba[0].cpu().numpy() - data["rgba_0"]).max()) <= 1e-5          # reference-recorded image
+    for n in range(2):
+        assert float(np.abs(rgba[n].cpu().numpy() - O.gradient_to_image(x[n], w[n])).max()) <= 1e-5
+    # bcos.common.gradient_to_image on device tensors routes to the same kernel (single image, numpy out)
+    from bcos.common import gradient_to_image
+    assert np.array_equal(gradient_to_image(x[0].to(DEV), w[0].to(DEV)), rgba[0].cpu().numpy())
+    # edge cases: ragged sizes, no / small smoothing, low percentiles inside a plateau of equal alphas (negative
+    # contributions all carry alpha = 1e-12), 3-channel input (AddInverse applied by the kernel)
+    g = torch.Generator().manual_seed(3)
+    for (N, H, W_, smooth, pct, three) in [(3, 37, 53, 15, 99.5, False), (2, 16, 16, 0, 50.0, False), (2, 40, 24, 3, 10.0, True),
+                                           (1, 9, 7, 5, 100.0, False), (2, 33, 65, 1, 0.0, True)]:
+        x3 = torch.rand(N, 3, H, W_, generator=g)
+        x6 = torch.cat([x3, 1 - x3], 1)
+        wt = torch.randn(N, 6, H, W_, generator=g) * torch.rand(N, 1, H, W_, generator=g)
+        out = ops.render_explanations((x3 if three else x6).to(DEV), wt.to(DEV), smooth=smooth, alpha_percentile=pct).cpu().numpy()
+        for n in range(N):
+            ref = O.gradient_to_image(x6[n], wt[n], smooth=smooth, alpha_percentile=pct)
+            assert float(np.abs(out[n] - ref).max()) <= 1e-5, (N, H, W_, smooth, pct, n)
+
+
 def test_captured_pass_matches_eager(lib):
     """engine.CapturedPass: the whole forward+explanation step recorded into a hipGraph and replayed on new inputs must
     reproduce the eager launches bit for bit."""

@@ -411,6 +411,20 @@ def test_attn_unpool_head_against_reference_golden(monkeypatch, golden_dir):
     assert rel(g, data["grad_d5"]) <= 1e-5
 
 
+def test_explain_batch_render(monkeypatch):
+    """explain_batch(render=True): the batched RGBA rendering equals gradient_to_image of every row (host logic on
+    emulated kernels; the device kernel itself is checked in the gpu suite)."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import synth
+    net = synth.build_bcosified_resnet("resnet18")
+    x = synth.synthetic_images(2, size=64)
+    out = net.explain_batch(x, render=True)
+    assert out["explanation"].shape == (2, 64, 64, 4)
+    for n in range(2):
+        ref = O.gradient_to_image(x[n], out["dynamic_linear_weights"][n])
+        assert float(np.abs(out["explanation"][n].numpy() - ref).max()) <= 1e-6
+
+
 def test_explainer_registry_and_ixg_semantics(monkeypatch):
     """get_explainer / Ours / IxG (captum InputXGradient semantics) and BcosUtilMixin.attribute(_selection)."""
     cpu_emulation.install(monkeypatch)
