@@ -298,9 +298,43 @@ class ResNetEngine:
         logits, st = self._run_forward(x, keep=True, gates=gates)
         pred, _ = ops.argmax_rows(logits)
         cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
+        wts, contrib = self._backward(x, st, cls, want_weights, consume=True)
+        return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
+                    contribution_map=contrib)
+
+    @torch.no_grad()
+    def explain_targets(self, x: torch.Tensor, targets: torch.Tensor, want_weights: bool = False) -> Dict[str, torch.Tensor]:
+        """ONE forward in explanation mode, then one input-gradient pass per target column: `targets` [N, T] (or [T],
+        shared by all images).  The reference's `attribute_selection` (interpretability/explanation_methods/utils.py:84-99,
+        bcos/common.py:319-344) re-runs the forward for every target; the dynamic weights of the forward do not depend on
+        the explained logit, so they are kept and only the backward is repeated.
+        Returns logits [N,K], contribution_maps [N,T,H,W] and, if requested, dynamic_linear_weights [N,T,6,H,W]."""
+        if not self.supports_explain:
+            raise NotImplementedError("engine.explain_targets: attention-pool (CLIP) heads are forward-only in the fused engine")
+        logits, st = self._run_forward(x, keep=True)
+        tg = targets.to(device=logits.device, dtype=torch.int64)
+        if tg.dim() == 1:
+            tg = tg.view(1, -1).expand(x.shape[0], -1)
+        T = tg.shape[1]
+        maps = torch.empty((x.shape[0], T, st["H"], st["W"]), device=x.device, dtype=torch.float32)
+        wall = torch.empty((x.shape[0], T, 6, st["H"], st["W"]), device=x.device, dtype=torch.float32) if want_weights else None
+        for k in range(T):
+            wts, contrib = self._backward(x, st, tg[:, k].contiguous(), want_weights, consume=(k == T - 1))
+            maps[:, k] = contrib
+            if want_weights:
+                wall[:, k] = wts
+        out = dict(logits=logits, contribution_maps=maps)
+        if want_weights:
+            out["dynamic_linear_weights"] = wall
+        return out
+
+    def _backward(self, x, st, cls, want_weights: bool, consume: bool):
+        """Input-gradient pass of logit[cls[n]] for every image n over the state `st` of a kept forward; `consume` frees
+        each saved multiplier as soon as it has been used (last / only pass over this state)."""
         # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale
         g_head = ops.head_onehot_grad(cls, st["tf"], self.logit_temperature)
-        st["tf"] = None
+        if consume:
+            st["tf"] = None
         # A "consumer" owns the g_lin tensors of the layers that read some activation X and can therefore
         # finish d logit / d X; its epilogue applies the multipliers of the block that PRODUCED X.
         consumer = _Consumer(self.head, g_head, None, None, 0)
@@ -311,7 +345,8 @@ class ResNetEngine:
             # v = d logit / d out_b;  G_main = v * t_last (bn scale, ReLU gate and s of the block's last conv),
             # G_sc = v * gate(out_b) [* t_d]  for the shortcut
             G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gated=rec["gated"], gate_t=rec["gate_t"])
-            rec["ts"][-1] = rec["td"] = rec["gate_t"] = None
+            if consume:
+                rec["ts"][-1] = rec["td"] = rec["gate_t"] = None
             gl = G_main
             convs = blk.convs
             for ci in range(len(convs) - 1, 0, -1):
@@ -324,7 +359,8 @@ class ResNetEngine:
                     gl = ops.avgpool2d_bwd(gp, ph, pw, blk.pool, blk.pool, 0, mul=rec["ts"][ci - 1])
                 else:
                     gl = convs[ci].dgrad.run(gl, h, w, mul=rec["ts"][ci - 1])
-                rec["ts"][ci - 1] = None
+                if consume:
+                    rec["ts"][ci - 1] = None
             consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc, blk.shortcut_pool)
         # block 0 reads the stem pool output: raw gradient, pool backward (* t of the last stem conv), then the stem
         H0, W0 = st["blocks"][0]["in_hw"]
@@ -333,18 +369,19 @@ class ResNetEngine:
         a_h, a_w = st["a0_hw"]
         ts = st["stem_ts"]
         gl = ops.avgpool2d_bwd(g_pool, a_h, a_w, k, s, p, mul=ts[-1])
-        ts[-1] = None
+        if consume:
+            ts[-1] = None
         for si in range(len(self.stem) - 1, 0, -1):
             h, w = st["stem_hws"][si]
             gl = self.stem[si][0].dgrad.run(gl, h, w, mul=ts[si - 1])
-            ts[si - 1] = None
+            if consume:
+                ts[si - 1] = None
         gxn = torch.empty((x.shape[0], st["H"], st["W"], 8), device=x.device, dtype=torch.float32)
         self.stem[0][0].dgrad.run(gl, st["H"], st["W"], out=gxn)     # channels 0..5 of the padded buffer
         _, std = self._consts(x.device)
         wts, contrib = ops.finalize_explanation(gxn, st["x"], std, add_inverse=st["add_inverse"],
                                                 want_weights=want_weights, want_contrib=True)
-        return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
-                    contribution_map=contrib)
+        return wts, contrib
 
 
 class _Consumer:

@@ -81,6 +81,8 @@ SIGNATURES = {
     "bcos_attention_bwd_v": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_finalize_explanation_patches": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "bcos_render_explanations": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "bcos_box_filter": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "bcos_localisation_fractions": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -475,3 +475,25 @@ def render_explanations(x: torch.Tensor, weights: torch.Tensor, smooth: int = 15
                                         float(alpha_percentile) / 100.0, 1 if Cx == 3 else 0, _stream())
     _l.check(code, "bcos_render_explanations")
     return (rgba, qv) if want_quantiles else rgba
+
+
+def box_filter(maps: torch.Tensor, k: int) -> torch.Tensor:
+    """avg_pool2d(maps, k, stride=1, padding=(k-1)//2) of [N,H,W] maps (include/bcos_hip.h: bcos_box_filter)."""
+    lib = _l.load()
+    N, H, W = maps.shape
+    out = torch.empty_like(maps)
+    _l.check(lib.bcos_box_filter(_dev(maps, "box_filter.in"), _dev(out, "box_filter.out"), N, H, W, int(k), _stream()),
+             "bcos_box_filter")
+    return out
+
+
+def localisation_fractions(attr: torch.Tensor, cell_h: int, cell_w: int, neg: bool = False) -> torch.Tensor:
+    """attr [T,H,W] -> [T, cells] share of positive attribution per grid cell (bcos_localisation_fractions)."""
+    lib = _l.load()
+    T, H, W = attr.shape
+    cells = (H // cell_h) * (W // cell_w)
+    out = torch.empty((T, cells), device=attr.device, dtype=torch.float32)
+    _l.check(lib.bcos_localisation_fractions(_dev(attr, "localisation.attr"), _dev(out, "localisation.frac"), T, H, W,
+                                             int(cell_h), int(cell_w), 1 if neg else 0, _stream()),
+             "bcos_localisation_fractions")
+    return out

@@ -139,7 +139,74 @@ __global__ __launch_bounds__(TPB) void quantile_normalise_kernel(const float* __
     for (int i = threadIdx.x; i < HW; i += TPB) o[(int64_t)i * 4 + 3] = fminf(fmaxf(a[i] / qv, 0.f), 1.f);
 }
 
+// Grid pointing game (interpretability/analyses/localisation.py:319-321,387-401): one workgroup per attribution map.
+// a = clamp(+-attr, 0); mean of a over every cell_h x cell_w cell (avg_pool2d, floor mode); frac = mean / sum of means
+// where (sum * mean) > 0, else 0; written in the reference's order (permute(0,1,3,2).reshape): index = col * rows + row.
+__global__ __launch_bounds__(TPB) void localisation_kernel(const float* __restrict__ attr, float* __restrict__ frac, int H,
+                                                           int W, int cell_h, int cell_w, int neg) {
+    __shared__ float s_part[TPB / 64];
+    __shared__ float s_mean[64];
+    const int t = blockIdx.x;
+    const int rows = H / cell_h, cols = W / cell_w;
+    const float* a = attr + (int64_t)t * H * W;
+    const int cell_px = cell_h * cell_w;
+    for (int c = 0; c < rows * cols; ++c) {
+        const int r = c / cols, q = c - r * cols;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < cell_px; i += TPB) {        // fixed order: deterministic sums
+            const int y = i / cell_w, x = i - y * cell_w;
+            float v = a[(int64_t)(r * cell_h + y) * W + q * cell_w + x];
+            v = neg ? -v : v;
+            acc += fmaxf(v, 0.f);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int wv = 0; wv < TPB / 64; ++wv) tot += s_part[wv];
+            s_mean[c] = tot / (float)cell_px;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int c = 0; c < rows * cols; ++c) total += s_mean[c];
+        for (int c = 0; c < rows * cols; ++c) {
+            const int r = c / cols, q = c - r * cols;
+            const float m = s_mean[c];
+            frac[(int64_t)t * rows * cols + q * rows + r] = (total * m > 0.f) ? m / total : 0.f;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int bcos_box_filter(const float* in, float* out, int N, int H, int W, int k, void* stream) {
+    if (!in || !out || in == out || N <= 0 || H <= 0 || W <= 0 || k < 1 || k % 2 == 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_box_filter: bad argument (odd window, distinct buffers)");
+    if (N > 65535) return bcos_set_error(BCOS_E_NOSUP, "bcos_box_filter: more than 65535 maps per call");
+    const size_t lds = ((size_t)(BY + k - 1) * (BX + k - 1) + (size_t)(BY + k - 1) * BX) * sizeof(float);
+    if (lds > 64 * 1024) return bcos_set_error(BCOS_E_NOSUP, "bcos_box_filter: window too large");
+    hipLaunchKernelGGL(box_filter_kernel, dim3((W + BX - 1) / BX, (H + BY - 1) / BY, N), dim3(TPB), lds,
+                       reinterpret_cast<hipStream_t>(stream), in, out, H, W, k);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("box_filter launch", err);
+    return BCOS_OK;
+}
+
+extern "C" int bcos_localisation_fractions(const float* attr, float* frac, int T, int H, int W, int cell_h, int cell_w,
+                                           int neg, void* stream) {
+    if (!attr || !frac || T <= 0 || H <= 0 || W <= 0 || cell_h <= 0 || cell_w <= 0 || cell_h > H || cell_w > W)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_localisation_fractions: bad argument");
+    if ((H / cell_h) * (W / cell_w) > 64) return bcos_set_error(BCOS_E_NOSUP, "bcos_localisation_fractions: more than 64 cells");
+    hipLaunchKernelGGL(localisation_kernel, dim3(T), dim3(TPB), 0, reinterpret_cast<hipStream_t>(stream), attr, frac, H, W,
+                       cell_h, cell_w, neg);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("localisation launch", err);
+    return BCOS_OK;
+}
 
 extern "C" int bcos_render_explanations(const float* x, const float* weights, float* rgba, float* scratch, float* quantiles,
                                         int N, int Cx, int H, int W, int smooth, float q, int add_inverse, void* stream) {

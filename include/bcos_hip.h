@@ -323,6 +323,17 @@ int bcos_finalize_explanation_patches(const float* gp, const float* x, const flo
 int bcos_render_explanations(const float* x, const float* weights, float* rgba, float* scratch, float* quantiles,
                              int N, int Cx, int H, int W, int smooth, float q, int add_inverse, void* stream);
 
+/* -- localisation (grid pointing game) harness, SURVEY.md section 8(f) N2 ----------------------------------------- */
+/* out = avg_pool2d(in, k, stride 1, padding (k-1)/2) of N maps [N,H,W] (zero padded, divisor k*k; k odd): the
+ * attribution smoothing of interpretability/analyses/localisation.py:313-317.  in != out. */
+int bcos_box_filter(const float* in, float* out, int N, int H, int W, int k, void* stream);
+
+/* Per-cell share of the positive attribution (localisation.py:319-321,387-401): attr [T,H,W] -> frac [T, cells]:
+ * a = clamp(neg ? -attr : attr, 0); cell means over the (H/cell_h) x (W/cell_w) grid; mean / sum of means where that is
+ * positive, else 0; cell order as the reference's permute(0,1,3,2).reshape: index = col * rows + row. */
+int bcos_localisation_fractions(const float* attr, float* frac, int T, int H, int W, int cell_h, int cell_w, int neg,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -416,3 +416,41 @@ def zeroshot_logits(features, text_weights, attn_unpool=False, cos_power=1):
         logits = logits * (logits.abs().detach() ** (cos_power - 1))
         logits = logits.sum(0)
     return logits
+
+
+# ----------------------------------------------------------------------------------------------
+# Grid pointing game: interpretability/analyses/localisation.py
+# ----------------------------------------------------------------------------------------------
+def make_multi_image(imgs):
+    """LocalisationAnalyser.make_multi_image, tensor part (localisation.py:434-446): [g*g, C, h, w] -> [1, C, g*h, g*w];
+    image i = a*g + b lands in grid row b, column a."""
+    g = int(round(imgs.shape[0] ** 0.5))
+    return imgs.view(-1, g, g, *imgs.shape[-3:]).permute(0, 3, 2, 4, 1, 5).reshape(-1, imgs.shape[1], imgs.shape[2] * g,
+                                                                                   imgs.shape[3] * g)
+
+
+def attribute_selection_maps(forward_fn, img, targets):
+    """explainer.attribute_selection(img, tgts).sum(1, keepdim=True) for IxG / Ours (explanation_methods/utils.py:82-99,
+    explainers/captum.py:29-32, bcos/common.py:319-344): one full forward + backward per target.  -> [T, 1, H, W]."""
+    maps = []
+    for t in targets:
+        x = img.detach().clone().requires_grad_(True)
+        logits = forward_fn(x, True)
+        (g,) = torch.autograd.grad(logits[:, int(t)].sum(), x)
+        maps.append((x.detach() * g).sum(1, keepdim=True))
+    return torch.cat(maps, 0)
+
+
+def localisation_fractions(attributions, single_shape, smooth=0, neg=False):
+    """localisation.py:313-321 and 387-401: smooth, (negate), keep positive attributions, per-cell means, shares.
+    attributions [T,1,H,W] -> contribs [T, cells] (reference cell order), metric [T] = contribs[i, i]."""
+    if smooth:
+        attributions = F.avg_pool2d(attributions, smooth, stride=1, padding=(smooth - 1) // 2)
+    if neg:
+        attributions = -attributions
+    attributions = attributions.clamp(min=0)
+    contribs = F.avg_pool2d(attributions, single_shape, stride=single_shape).permute(0, 1, 3, 2).reshape(attributions.shape[0], -1)
+    total = contribs.sum(1, keepdim=True)
+    contribs = torch.where(total * contribs > 0, contribs / total, torch.zeros_like(contribs))
+    metric = torch.stack([contribs[i, i] for i in range(contribs.shape[0])])
+    return contribs, metric

@@ -198,6 +198,19 @@ def render_explanations(x, weights, smooth=15, alpha_percentile=99.5, want_quant
     return (rgba, qv) if want_quantiles else rgba
 
 
+def box_filter(maps, k):
+    import torch.nn.functional as F
+    return F.avg_pool2d(maps[:, None], k, stride=1, padding=(k - 1) // 2)[:, 0]
+
+
+def localisation_fractions(attr, cell_h, cell_w, neg=False):
+    import torch.nn.functional as F
+    a = (-attr if neg else attr).clamp(min=0)[:, None]
+    contribs = F.avg_pool2d(a, (cell_h, cell_w), stride=(cell_h, cell_w)).permute(0, 1, 3, 2).reshape(a.shape[0], -1)
+    total = contribs.sum(1, keepdim=True)
+    return torch.where(total * contribs > 0, contribs / total, torch.zeros_like(contribs))
+
+
 def install(monkeypatch):
     """Patch bcos_hip.ops with the emulators (pytest monkeypatch fixture) and lift the HIP-device checks."""
     from bcos_hip import ops
@@ -205,7 +218,7 @@ def install(monkeypatch):
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
                  "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
-                 "render_explanations"):
+                 "render_explanations", "box_filter", "localisation_fractions"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

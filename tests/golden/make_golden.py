@@ -413,8 +413,80 @@ def attn_unpool_head():
                         zeroshot_cos2=logits.numpy(), grad_d5=gr.numpy(), **{"sd/" + k: v.numpy() for k, v in sd.items()})
 
 
+# --------------------------------------------------------------------------------------------------------
+# N2: grid pointing game.  The reference's analyser cannot be imported (Experiment / datamodule / matplotlib at import
+# time), so its own statements are lifted from the source file with `ast` AT GENERATION TIME and executed here:
+# make_multi_image (tensor part) and the smoothing / clamping / per-cell shares of LocalisationAnalyser.analysis.
+# --------------------------------------------------------------------------------------------------------
+def _reference_localisation_code():
+    import ast
+    path = os.path.join(refimport.REFERENCE_ROOT, "interpretability", "analyses", "localisation.py")
+    tree = ast.parse(open(path).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LocalisationAnalyser")
+    fns = {n.name: n for n in cls.body if isinstance(n, ast.FunctionDef)}
+    # make_multi_image: the statements after the sampling loop (img = torch.cat(imgs) ... reshape), as a function of imgs
+    mm = fns["make_multi_image"]
+    tail = [st for st in mm.body if isinstance(st, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "img" for t in st.targets)]
+    mm_src = "\n".join(ast.unparse(st) for st in tail)
+    # analysis: inside the sample loop, the statements from `if smooth:` to the `contribs = torch.where(...)` assignment
+    loop = next(st for st in fns["analysis"].body if isinstance(st, ast.For))
+    keep, on = [], False
+    for st in loop.body:
+        src = ast.unparse(st)
+        if src.startswith("if smooth:"):
+            on = True
+        if on and (src.startswith("if smooth:") or src.startswith("if self.config['neg']") or
+                   src.startswith("attributions = attributions.clamp") or src.startswith("with torch.no_grad()") or
+                   src.startswith("contribs = torch.where")):
+            keep.append(src)
+        if src.startswith("contribs = torch.where"):
+            break
+    return mm_src, "\n".join(keep)
+
+
+def localisation_grid():
+    import types
+    mm_src, metric_src = _reference_localisation_code()
+    arch = "resnet18"
+    net = reference_resnet(arch)
+    gold = np.load(os.path.join(HERE, "resnet18_e2e.npz"))
+    meta = json.load(open(os.path.join(HERE, "resnet18_e2e.json")))
+    synth.apply_calibration(net, {k: torch.from_numpy(gold["calib/" + k]) for k in meta["calib_order"]})
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    singles = synth.synthetic_images(4, seed=777, size=112)
+    ns = dict(torch=torch, np=np, imgs=[s_[None] for s_ in singles], n_imgs=4)
+    exec(mm_src, ns)                                      # reference statements: img = torch.cat(imgs) ... reshape
+    multi = ns["img"]
+    REPORT["loc/oracle_multi_image"] = rel(O.make_multi_image(singles), multi)
+    with torch.no_grad():
+        tgts = [int(net(s_[None]).argmax()) for s_ in singles]
+    if len(set(tgts)) < 4:                               # the harness needs distinct classes: spread them
+        tgts = [tgts[0], (tgts[0] + 111) % 1000, (tgts[0] + 333) % 1000, (tgts[0] + 777) % 1000]
+    atts = []
+    for t in tgts:                                       # reference attribution: explain(idx=t) -> x * dL/dx summed over c
+        xi = multi.clone().requires_grad_(True)
+        atts.append(net.explain(xi, idx=t)["contribution_map"].detach()[:, None])
+    attributions = torch.cat(atts, 0)                    # [T,1,H,W] == attribute_selection(...).sum(1, keepdim=True)
+    fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
+    REPORT["loc/oracle_attributions"] = rel(O.attribute_selection_maps(fwd, multi, tgts), attributions)
+    out = {}
+    for smooth, neg in ((0, False), (15, False), (15, True)):
+        ns2 = dict(torch=torch, F=torch.nn.functional, attributions=attributions.clone(), smooth=smooth, single_shape=112,
+                   self=types.SimpleNamespace(config={"neg": neg}))
+        exec(metric_src, ns2)                            # reference statements
+        contribs_ref = torch.from_numpy(np.asarray(ns2["contribs"]))     # the reference ends with .cpu().numpy()
+        oc, om = O.localisation_fractions(attributions.clone(), 112, smooth=smooth, neg=neg)
+        REPORT[f"loc/oracle_fractions_s{smooth}_neg{int(neg)}"] = rel(oc, contribs_ref)
+        out[f"fractions_s{smooth}_neg{int(neg)}"] = contribs_ref.numpy()
+    np.savez_compressed(os.path.join(HERE, "localisation.npz"), attributions=attributions.numpy(), targets=np.array(tgts), **out)
+    with open(os.path.join(HERE, "localisation.json"), "w") as f:
+        json.dump(dict(arch=arch, image_seed=777, single_shape=112, n_imgs=4, net_fixture="resnet18_e2e",
+                       reference_statements_sha256=__import__("hashlib").sha256((mm_src + metric_src).encode()).hexdigest()),
+                  f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit", "clip", "unpool"]
+    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -432,6 +504,8 @@ if __name__ == "__main__":
         clip_rn50_embeddings()
     if "unpool" in which:
         attn_unpool_head()
+    if "loc" in which:
+        localisation_grid()
     with open(rep_path, "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     for k in sorted(REPORT):

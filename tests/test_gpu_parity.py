@@ -575,6 +575,40 @@ def test_render_explanations_against_reference_and_oracle(lib, golden_dir):
             assert float(np.abs(out[n] - ref).max()) <= 1e-5, (N, H, W_, smooth, pct, n)
 
 
+def test_grid_pointing_game_on_device(lib, golden_dir):
+    """N2: multi-image built from 4 singles, one forward + 4 backward passes on the fused engine, smoothing and per-cell
+    shares on the device -- against the reference-recorded attributions / shares of the same network and images."""
+    from bcos_hip import engine, localisation, ops, synth
+    net, meta, _ = _golden_net(golden_dir, "resnet18_e2e")
+    loc = json.load(open(os.path.join(golden_dir, "localisation.json")))
+    data = np.load(os.path.join(golden_dir, "localisation.npz"))
+    singles = synth.synthetic_images(loc["n_imgs"], seed=loc["image_seed"], size=loc["single_shape"]).to(DEV)
+    multi = localisation.make_multi_image(singles)
+    tgts = torch.from_numpy(data["targets"]).view(1, -1)
+    eng = engine.attach(net)
+    res = localisation.grid_pointing_game(eng, multi, tgts, loc["single_shape"], smooth=15)
+    gold_att = torch.from_numpy(data["attributions"])[:, 0]
+    assert rel(res["attributions"][0], gold_att) <= 2e-3                 # free ReLU gates: the ResNet-18 map floor (see above)
+    assert float((res["fractions"][0].cpu() - torch.from_numpy(data["fractions_s15_neg0"])).abs().max()) <= 2e-3
+    # kernels alone, on the recorded attributions: exact arithmetic of the reference statements
+    att = gold_att[None].to(DEV)
+    for smooth, neg in ((0, False), (15, False), (15, True)):
+        out = localisation.grid_pointing_game(None, multi, tgts, loc["single_shape"], smooth=smooth, neg=neg, attributions=att)
+        assert rel(out["fractions"][0], data[f"fractions_s{smooth}_neg{int(neg)}"]) <= 1e-5
+    # one forward + T backward == T x (forward + backward), bit for bit
+    again = eng.explain(multi, targets=tgts[:, 1].to(DEV))
+    assert torch.equal(res["attributions"][0, 1], again["contribution_map"][0])
+    # batched form: two multi-images, 3x3 grids of 32-pixel cells
+    s9 = synth.synthetic_images(18, seed=4, size=32).to(DEV)
+    m9 = localisation.make_multi_images(s9, 3)
+    t9 = torch.randint(0, 1000, (2, 9), generator=torch.Generator().manual_seed(1))
+    r9 = localisation.grid_pointing_game(eng, m9, t9, 32, smooth=5)
+    assert r9["fractions"].shape == (2, 9, 9) and torch.allclose(r9["fractions"].sum(-1).cpu(), torch.ones(2, 9), atol=1e-5)
+    ref_c, ref_m = O.localisation_fractions(r9["attributions"][1].cpu()[:, None], 32, smooth=5)
+    assert rel(r9["fractions"][1], ref_c) <= 1e-5 and rel(r9["metric"][1], ref_m) <= 1e-5
+    assert rel(ops.box_filter(r9["attributions"][0], 7), F.avg_pool2d(r9["attributions"][0].cpu()[:, None], 7, 1, 3)[:, 0]) <= 1e-6
+
+
 def test_captured_pass_matches_eager(lib):
     """engine.CapturedPass: the whole forward+explanation step recorded into a hipGraph and replayed on new inputs must
     reproduce the eager launches bit for bit."""

@@ -425,6 +425,39 @@ def test_explain_batch_render(monkeypatch):
         assert float(np.abs(out["explanation"][n].numpy() - ref).max()) <= 1e-6
 
 
+def test_grid_pointing_game_harness(monkeypatch, golden_dir):
+    """N2 on emulated kernels: one forward + T backward passes (engine.explain_targets) give the same attributions as
+    the reference's forward-per-target loop (oracle), and the harness reproduces the reference-recorded cell shares."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import engine, localisation, synth
+    net = synth.build_bcosified_resnet("resnet18")
+    singles = synth.synthetic_images(4, size=32, seed=9)
+    multi = localisation.make_multi_image(singles)
+    assert torch.equal(multi, O.make_multi_image(singles)) and multi.shape == (1, 6, 64, 64)
+    assert torch.equal(localisation.make_multi_images(torch.cat([singles, singles.flip(0)]), 2)[1], O.make_multi_image(singles.flip(0))[0])
+    eng = engine.ResNetEngine(net)
+    tgts = torch.tensor([[3, 500, 77, 999]])
+    res = localisation.grid_pointing_game(eng, multi, tgts, single_shape=32, smooth=5)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref_att = O.attribute_selection_maps(lambda xx, detach: O.resnet_logits(sd, xx, "resnet18", detach=detach), multi, tgts[0].tolist())
+    assert rel(res["attributions"][0], ref_att[:, 0]) <= 1e-4
+    # explain_targets leaves the per-target result equal to a fresh explain() of that target
+    single = eng.explain(multi, targets=tgts[:, 2])
+    assert rel(res["attributions"][0, 2], single["contribution_map"][0]) <= 1e-6
+    contribs, metric = O.localisation_fractions(ref_att, 32, smooth=5)
+    assert rel(res["fractions"][0], contribs) <= 1e-4 and rel(res["metric"][0], metric) <= 1e-4
+    # recorded reference attributions -> recorded reference shares, through the harness' kernels
+    data = np.load(os.path.join(golden_dir, "localisation.npz"))
+    att = torch.from_numpy(data["attributions"])[:, 0][None]              # [1, T, H, W]
+    for smooth, neg in ((0, False), (15, False), (15, True)):
+        out = localisation.grid_pointing_game(None, torch.zeros(1, 6, 224, 224), torch.from_numpy(data["targets"])[None], 112,
+                                              smooth=smooth, neg=neg, attributions=att)
+        gold = torch.from_numpy(data[f"fractions_s{smooth}_neg{int(neg)}"])
+        assert rel(out["fractions"][0], gold) <= 1e-6
+        diag = torch.diagonal(gold)
+        assert rel(out["metric"][0], 1 - diag if neg else diag) <= 1e-6
+
+
 def test_explainer_registry_and_ixg_semantics(monkeypatch):
     """get_explainer / Ours / IxG (captum InputXGradient semantics) and BcosUtilMixin.attribute(_selection)."""
     cpu_emulation.install(monkeypatch)

@@ -81,6 +81,23 @@ def test_invariants(golden_dir):
     assert torch.equal(wa, torch.cat([wb, -wb], 1) / 2)
 
 
+def test_localisation_oracle_against_reference_fixture(golden_dir):
+    """N2: the oracle's grid-pointing-game arithmetic against the shares produced by the reference's own statements
+    (lifted from interpretability/analyses/localisation.py and executed by make_golden.py)."""
+    data = np.load(os.path.join(golden_dir, "localisation.npz"))
+    rep = json.load(open(os.path.join(golden_dir, "oracle_vs_reference.json")))
+    assert rep["loc/oracle_multi_image"][0] == 0.0 and rep["loc/oracle_attributions"][0] <= 1e-6
+    att = torch.from_numpy(data["attributions"])
+    for smooth, neg in ((0, False), (15, False), (15, True)):
+        contribs, metric = O.localisation_fractions(att.clone(), 112, smooth=smooth, neg=neg)
+        gold = data[f"fractions_s{smooth}_neg{int(neg)}"]
+        assert rel(contribs, gold) <= 1e-6
+        assert torch.equal(metric, torch.diagonal(contribs))
+    # tensor layout of make_multi_image: image i = a*g + b -> grid row b, column a
+    imgs = torch.arange(4.0).view(4, 1, 1, 1).expand(4, 1, 2, 2).contiguous()
+    assert O.make_multi_image(imgs)[0, 0].tolist() == [[0, 0, 2, 2], [0, 0, 2, 2], [1, 1, 3, 3], [1, 1, 3, 3]]
+
+
 def test_oracle_properties():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 8, 7, 7, generator=g)
