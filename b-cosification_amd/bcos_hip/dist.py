@@ -23,7 +23,7 @@ def init(backend: Optional[str] = None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("BCOS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -76,3 +76,73 @@ def explain_sharded(engine, images: torch.Tensor, targets: Optional[torch.Tensor
             res[k] = all_gather_rows(out[k], counts)
     res["shard"] = (lo, hi)
     return res
+
+
+class OverlappedGather:
+    """The path's one collective, taken off the critical path: every step's per-rank results (e.g. logits and
+    contribution maps) are packed into ONE flat buffer, all-gathered with a single asynchronous
+    `all_gather_into_tensor` (RCCL runs it on its own stream over xGMI) and only waited for when the slot is needed
+    again -- so the exchange of step i overlaps the compute of step i+1.  `depth` slots are cycled (2 = double buffer).
+
+        pipe = OverlappedGather(depth=2)
+        for batch in batches:
+            out = engine.explain(batch)
+            done = pipe.submit({"logits": out["logits"], "contribution_map": out["contribution_map"]})
+            ...                      # `done` = gathered tensors of the step submitted `depth` steps ago (or None)
+        rest = pipe.flush()          # list of the gathered dicts still in flight, oldest first
+
+    Every rank must submit tensors of identical shapes (equal shards).  With world size 1 it is a pass-through."""
+
+    def __init__(self, depth: int = 2):
+        self.depth = max(1, int(depth))
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._slots = [None] * self.depth          # (send, recv, work, layout)
+        self._next = 0
+
+    def _finish(self, slot):
+        send, recv, work, layout = slot
+        if work is not None:
+            work.wait()                            # NCCL: makes the current stream wait; no host block
+        out, off = {}, 0
+        for name, shape, numel in layout:
+            out[name] = recv[:, off:off + numel].reshape((self.world * shape[0],) + tuple(shape[1:]))
+            off += numel
+        return out
+
+    def submit(self, tensors: Dict[str, torch.Tensor], copy_out: bool = True) -> Optional[Dict[str, torch.Tensor]]:
+        """Queue this step's tensors; returns the gathered result of the step that used this slot `depth` submissions
+        ago (None while the pipeline fills).  `copy_out=False` returns views into the slot's receive buffer, which the
+        exchange started by THIS call overwrites -- only for callers that drop the return value."""
+        if self.world == 1:
+            return dict(tensors)
+        i = self._next
+        self._next = (i + 1) % self.depth
+        prev = self._slots[i]
+        done = self._finish(prev) if prev is not None else None
+        if done is not None and copy_out:          # the slot's buffers are reused below: hand out copies on request
+            done = {k: v.clone() for k, v in done.items()}
+        layout = [(k, tuple(v.shape), v.numel()) for k, v in tensors.items()]
+        total = sum(n for _, _, n in layout)
+        first = next(iter(tensors.values()))
+        if prev is not None and prev[0].numel() == total and prev[0].device == first.device:
+            send, recv = prev[0], prev[1]
+        else:
+            send = torch.empty((total,), device=first.device, dtype=torch.float32)
+            recv = torch.empty((self.world, total), device=first.device, dtype=torch.float32)
+        off = 0
+        for (_, _, n), v in zip(layout, tensors.values()):
+            send[off:off + n].copy_(v.reshape(-1))
+            off += n
+        work = dist.all_gather_into_tensor(recv.view(-1), send, async_op=True)
+        self._slots[i] = (send, recv, work, layout)
+        return done
+
+    def flush(self):
+        """Wait for everything in flight; returns the gathered dicts oldest first and empties the pipeline."""
+        outs = []
+        for k in range(self.depth):
+            i = (self._next + k) % self.depth
+            if self._slots[i] is not None:
+                outs.append(self._finish(self._slots[i]))
+                self._slots[i] = None
+        return outs

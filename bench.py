@@ -113,6 +113,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("BCOS_SINGLE_DEVICE"):     # functional check of the N > 1 control flow on a 1-GPU box (with
+        local_rank = 0                           # BCOS_DIST_BACKEND=gloo); never set by the driver
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -134,7 +136,7 @@ def main():
     x = synth.synthetic_images(args.batch, seed=1000 + rank).to(dev)
     torch.cuda.synchronize()
 
-    gathered = {}
+    pipe = bdist.OverlappedGather(depth=2) if world > 1 else None
 
     # --graph: the step is recorded once into a hipGraph (engine.CapturedPass) and replayed; the steps that carry the
     # per-launch HIP events for the roofline run the very same launches eagerly (events cannot be read back from a graph).
@@ -156,17 +158,14 @@ def main():
         else:
             out = eng.explain(x, want_weights=True)
             keys = ("logits", "contribution_map")
-        if world > 1:       # the single collective of the path: all-gather of per-rank results over RCCL/xGMI
-            for k in keys:
-                buf = gathered.get(k)
-                if buf is None:
-                    buf = gathered[k] = torch.empty((world * out[k].shape[0],) + tuple(out[k].shape[1:]),
-                                                    device=dev, dtype=out[k].dtype)
-                dist.all_gather_into_tensor(buf, out[k].contiguous())
+        if world > 1:       # the single collective of the path: ONE packed all-gather per step over RCCL/xGMI, asynchronous
+            pipe.submit({k: out[k] for k in keys}, copy_out=False)      # (overlaps the next step's compute; drained inside the timed region)
         return out
 
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -185,6 +184,8 @@ def main():
             ops.KERNEL_TIMING = None
         else:
             step()
+    if pipe is not None:
+        gathered = pipe.flush()             # the last exchanges complete inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -244,7 +245,7 @@ def main():
                                f"batch {args.batch} per GPU, 224x224x6 (AddInverse), calibrated random-init weights",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "contraction": contraction,
                    "launch": "hipGraph replay (event-carrying steps eager)" if captured is not None else "eager",
-                   "collective": "all_gather(logits, contribution maps)" if world > 1 else "none"},
+                   "collective": "one packed async all_gather(logits, contribution maps) per step, double buffered" if world > 1 else "none"},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and spec["family"] != "clip" and not args.forward_only:

@@ -67,3 +67,46 @@ def test_sharded_explanation_world2_gloo(n_images):
     results.sort()
     assert all(ok for _, ok, _, _ in results), results
     assert results[0][2] == 0 and results[0][3] == results[1][2] and results[1][3] == n_images
+
+
+def _overlap_worker(rank, world, port, q):
+    repo = os.path.dirname(HERE)
+    for p in (os.path.join(repo, "b-cosification_amd"), repo, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from bcos_hip import dist as bdist
+    bdist.init(backend="gloo")
+    pipe = bdist.OverlappedGather(depth=2)
+    steps, got = 5, []
+    for i in range(steps):            # rank r, step i contributes logits filled with 100 i + r and maps with -(100 i + r)
+        out = {"logits": torch.full((3, 7), float(100 * i + rank)), "contribution_map": torch.full((3, 4, 5), -float(100 * i + rank))}
+        done = pipe.submit(out)
+        if done is not None:
+            got.append(done)
+    got += pipe.flush()
+    ok = len(got) == steps
+    for i, d in enumerate(got):
+        exp_l = torch.cat([torch.full((3, 7), float(100 * i + r)) for r in range(world)])
+        exp_m = torch.cat([torch.full((3, 4, 5), -float(100 * i + r)) for r in range(world)])
+        ok = ok and torch.equal(d["logits"], exp_l) and torch.equal(d["contribution_map"], exp_m)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_world2_gloo():
+    """bench.py's N > 1 collective: one packed asynchronous all-gather per step, double buffered, results in order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results
