@@ -194,23 +194,22 @@ __global__ __launch_bounds__(TPB) void avgpool_fwd_kernel(const float* __restric
     }
 }
 
+// One workgroup per input row (n, h): 32-bit index arithmetic only (the flat 64-bit div/mod version was ALU-bound at
+// 3.2 TB/s on the stem's 822 MB gradient).
 __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mul,
                                                           float* __restrict__ gx, int N, int H, int W, int C4,
                                                           int k, int s, int p, int OH, int OW) {
-    const int64_t total = (int64_t)N * H * W * C4;
-    const int64_t stride = (int64_t)gridDim.x * TPB;
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
-        const int c4 = (int)(i % C4);
-        int64_t t = i / C4;
-        const int w = (int)(t % W); t /= W;
-        const int h = (int)(t % H);
-        const int64_t n = t / H;
-        // windows oh with oh*s - p <= h < oh*s - p + k
-        int oh_lo = (h + p - k + s) / s;  // ceil((h+p-k+1)/s) for non-negative numerator
-        if (h + p - k + 1 <= 0) oh_lo = 0;
+    const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+    // windows oh with oh*s - p <= h < oh*s - p + k
+    int oh_lo = (h + p - k + s) / s;      // ceil((h+p-k+1)/s) for non-negative numerator
+    if (h + p - k + 1 <= 0) oh_lo = 0;
+    const int oh_hi = min((h + p) / s, OH - 1);
+    const int64_t row = ((int64_t)n * H + h) * W * C4;
+    const f32x4* gy4 = reinterpret_cast<const f32x4*>(gy) + (int64_t)n * OH * OW * C4;
+    for (int i = threadIdx.x; i < W * C4; i += TPB) {
+        const int w = i / C4, c4 = i - w * C4;
         int ow_lo = (w + p - k + s) / s;
         if (w + p - k + 1 <= 0) ow_lo = 0;
-        const int oh_hi = min((h + p) / s, OH - 1);
         const int ow_hi = min((w + p) / s, OW - 1);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int oh = oh_lo; oh <= oh_hi; ++oh) {
@@ -220,11 +219,11 @@ __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restric
                 const int ws = ow * s - p;
                 const int we = min(ws + k, W + p);
                 const float pool = (float)((he - hs) * (we - ws));
-                acc += reinterpret_cast<const f32x4*>(gy)[((n * OH + oh) * OW + ow) * C4 + c4] / pool;
+                acc += gy4[(oh * OW + ow) * C4 + c4] / pool;
             }
         }
-        if (mul) acc *= reinterpret_cast<const f32x4*>(mul)[i];
-        reinterpret_cast<f32x4*>(gx)[i] = acc;
+        if (mul) acc *= reinterpret_cast<const f32x4*>(mul)[row + i];
+        reinterpret_cast<f32x4*>(gx)[row + i] = acc;
     }
 }
 
@@ -376,7 +375,9 @@ extern "C" int bcos_avgpool2d_fwd(const float* x, float* y, int N, int H, int W,
 extern "C" int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, int N, int H, int W, int C, int k,
                                   int s, int p, int OH, int OW, void* stream) {
     if (!gy || !gx || !pool_args_ok(N, H, W, C, k, s, p, OH, OW)) return bcos_set_error(BCOS_E_INVAL, "bcos_avgpool2d_bwd: bad argument");
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(TPB), 0, STREAM(stream), gy,
+    if ((int64_t)N * H >= ((int64_t)1 << 31) || (int64_t)OH * OW * (C / 4) >= ((int64_t)1 << 31))
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_avgpool2d_bwd: tensor too large");
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)(N * H)), dim3(TPB), 0, STREAM(stream), gy,
                        mul, gx, N, H, W, C / 4, k, s, p, OH, OW);
     return check_launch("avgpool_bwd_kernel");
 }
