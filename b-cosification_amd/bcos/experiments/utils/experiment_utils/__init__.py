@@ -1,0 +1,2 @@
+from .experiment_utils import *  # noqa: F401,F403
+from .loading_utils import *  # noqa: F401,F403

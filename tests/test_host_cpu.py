@@ -458,6 +458,58 @@ def test_grid_pointing_game_harness(monkeypatch, golden_dir):
         assert rel(out["metric"][0], 1 - diag if neg else diag) <= 1e-6
 
 
+def test_experiment_checkpoint_loading(monkeypatch, tmp_path):
+    """N3: Experiment lookup (dataset / base_network / experiment_name -> config + save dir) and the checkpoint
+    containers of the reference: Lightning dict with "model." / "ema.module." prefixes, simple dict, stripped flat
+    state dict, last.ckpt / epoch=<N>-*.ckpt file convention -- B-cosified state dicts load with zero key edits."""
+    cpu_emulation.install(monkeypatch)
+    from bcos.experiments.utils import Experiment
+    from bcos.experiments.utils.experiment_utils import loading_utils as LU
+    from bcos_hip import synth
+    src = synth.build_bcosified_resnet("resnet18", seed=3)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    ema = {k: (v * 0.5 if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    save_dir = tmp_path / "experiments" / "ImageNet" / "bcosification" / "resnet_18"
+    save_dir.mkdir(parents=True)
+    pl = {"state_dict": {**{"model." + k: v for k, v in sd.items()}, **{"ema.module." + k: v for k, v in ema.items()},
+                         "criterion.weight": torch.zeros(1)}, "epoch": 89, "pytorch-lightning_version": "2.2.0"}
+    torch.save(pl, save_dir / "last.ckpt")
+    torch.save({**pl, "epoch": 41}, save_dir / "epoch=41-step=1000.ckpt")
+    exp = Experiment("ImageNet", "bcosification", "resnet_18", base_directory=tmp_path / "experiments")
+    assert exp.config["model"]["name"] == "resnet18" and exp.config["model"]["bcosify_args"]["norm_layer"] == "BnUncV2"
+    assert Experiment(save_dir).save_dir == save_dir                                # path form
+    net = exp.load_trained_model()
+    assert not net.training and all(torch.equal(v, sd[k]) for k, v in net.state_dict().items())
+    net_ema, ckpt = exp.load_trained_model(ema=True, return_training_ckpt_if_possible=True)
+    assert ckpt["epoch"] == 89 and torch.equal(net_ema.state_dict()["model.conv1.linear.weight"], ema["model.conv1.linear.weight"])
+    assert torch.equal(exp.load_trained_model(reload="epoch_41").state_dict()["model.fc.linear.weight"], sd["model.fc.linear.weight"])
+    x = synth.synthetic_images(1, size=32)
+    assert torch.equal(net(x), src(x))                                              # same network, same logits
+    # other containers
+    assert LU.load_model_state_dict_from_training_ckpt({"model_state_dict": sd}) is sd
+    assert LU.load_model_state_dict_from_training_ckpt(sd) is sd                    # stripped checkpoint
+    with pytest.raises(LU.EMANotFound):
+        LU.load_model_state_dict_from_training_ckpt({"state_dict": {"model.a": torch.zeros(1)}, "epoch": 0,
+                                                     "pytorch-lightning_version": "2"}, ema=True)
+    with pytest.raises(NotImplementedError):
+        LU.load_model_state_dict_from_training_ckpt({"foo": 1})
+    with pytest.raises(FileNotFoundError):
+        exp.load_trained_model(reload="epoch_7")
+    with pytest.raises(NotImplementedError):
+        exp.load_trained_model(reload="best")
+    with pytest.raises(KeyError):
+        Experiment("ImageNet", "bcosification", "resnet_101", base_directory=tmp_path)
+    # the other two families: names of the reference tables resolve to model sections their factories accept
+    vit = Experiment("ImageNet", "vit_bcosification", "bcosifyv2_bcos_simple_vit_ti_patch16_224_0.001_lrWarmup_gapReorder-seed=5",
+                     base_directory=tmp_path)
+    assert vit.config["seed"] == 5 and vit.config["model"]["args"]["gap_reorder"] and vit.config["model"]["act_layer"]
+    vnet = vit.get_model()
+    assert "model.linear_head.linear.linear.weight" in vnet.state_dict() and vnet.model.gap_reorder
+    clip = Experiment("ImageNet", "clip_bcosification", "resnet_50_clip_b2_noBias_randomResizedCrop_cyclicLR_sigLip_ImageNet_bcosification",
+                      base_directory=tmp_path)
+    assert clip.config["model"]["name"] == "resnet50clip" and clip.config["model"]["bcosify_args"]["clip_kd"]
+
+
 def test_explainer_registry_and_ixg_semantics(monkeypatch):
     """get_explainer / Ours / IxG (captum InputXGradient semantics) and BcosUtilMixin.attribute(_selection)."""
     cpu_emulation.install(monkeypatch)
