@@ -31,15 +31,6 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef OPT_PREFETCH
-#define OPT_PREFETCH 0
-#endif
-#ifndef OPT_BRANCHFREE
-#define OPT_BRANCHFREE 0
-#endif
-#ifndef OPT_LOADFIRST
-#define OPT_LOADFIRST 0
-#endif
 
 namespace {
 
@@ -369,29 +360,16 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
         for (int j = 0; j < A_LD; ++j) {
             const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
             const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-#if OPT_BRANCHFREE
-            const int64_t off = ok ? a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4 : 0;
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.a + off);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[j] = ok ? v : z;
-#else
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
             ra[j] = v;
-#endif
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             const bool ok = kvalid && b_ok[j];
-#if OPT_BRANCHFREE
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.wt + (ok ? b_off[j] + (int64_t)q * 4 : 0));
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            rb[j] = ok ? v : z;
-#else
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[j] + (int64_t)q * 4);
             rb[j] = v;
-#endif
         }
     };
     auto store_step = [&](int buf) {
@@ -431,45 +409,6 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
         const int cur = ks & 1;
         const bool more = ks + 1 < p.nk;
         const float* sbuf = smem + cur * BUF;
-#if OPT_PREFETCH
-        f32x4 af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(sbuf + a_frag + i * 32 * LDS_LD);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(sbuf + b_frag + j * 32 * LDS_LD);
-        if (more) load_step(ks + 1);
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            const int cs = kk & 1, ns = cs ^ 1;
-            if (kk + 1 < BK / 8) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[ns][i] = *reinterpret_cast<const f32x4*>(sbuf + a_frag + i * 32 * LDS_LD + (kk + 1) * 8);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bf[ns][j] = *reinterpret_cast<const f32x4*>(sbuf + b_frag + j * 32 * LDS_LD + (kk + 1) * 8);
-            }
-            if (NORM) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ss[i] = fmaf(af[cs][i][0], af[cs][i][0], ss[i]);
-                    ss[i] = fmaf(af[cs][i][1], af[cs][i][1], ss[i]);
-                    ss[i] = fmaf(af[cs][i][2], af[cs][i][2], ss[i]);
-                    ss[i] = fmaf(af[cs][i][3], af[cs][i][3], ss[i]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cs][i][c], bf[cs][j][c], acc[i][j], 0, 0, 0);
-        }
-#else
-#if OPT_LOADFIRST
-        if (more) load_step(ks + 1);
-#endif
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 af[TM], bf[TN];
@@ -479,9 +418,7 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[j] = *reinterpret_cast<const f32x4*>(sbuf + b_frag + j * 32 * LDS_LD + kk * 8);
-#if !OPT_LOADFIRST
             if (kk == 0 && more) load_step(ks + 1);
-#endif
             if (NORM) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -499,7 +436,6 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
-#endif
         if (more) store_step(cur ^ 1);
         __syncthreads();
     }
