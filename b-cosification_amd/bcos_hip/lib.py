@@ -57,6 +57,7 @@ SIGNATURES = {
     "bcos_split_weights_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_tapconv_presplit": (C.c_int, [_P, _P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
+    "bcos_tapconv_group": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(TapconvGeom), C.POINTER(Epilogue), _I, _P]),
     "bcos_conv2d_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P] + [_I] * 13 + [_F, _P]),
     "bcos_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "bcos_conv2d_dgrad_s1": (C.c_int, [_P, _P, _P] + [_I] * 9 + [_P]),

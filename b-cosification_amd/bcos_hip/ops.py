@@ -52,6 +52,7 @@ def conv_out_size(size, k, s, p, d=1):
 
 
 _NO_PRESPLIT = bool(os.environ.get("BCOS_NO_PRESPLIT"))     # development switch: always split inside the kernel
+_NO_GROUP = bool(os.environ.get("BCOS_NO_GROUP"))           # development switch: one launch per parity class
 
 
 def mark_static(w: torch.Tensor) -> torch.Tensor:
@@ -120,6 +121,35 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         ev1.record()
         timing.append((ev0, ev1))
     _l.check(code, "bcos_tapconv")
+
+
+def tapconv_group(a: torch.Tensor, wts, geoms, *, out, addend=None, mul=None):
+    """Several tap sets over the same input in one call (include/bcos_hip.h: bcos_tapconv_group): the parity classes of
+    a strided input gradient.  Same result as tapconv() per entry; narrow outputs run as one fused launch."""
+    lib = _l.load()
+    n = len(wts)
+    garr = (TapconvGeom * n)()
+    earr = (Epilogue * n)()
+    warr = (C.c_void_p * n)()
+    for i, (w, geom) in enumerate(zip(wts, geoms)):
+        for k in ("a_pitch", "out_pitch", "norm_pitch"):
+            setattr(garr[i], k, 0)
+        for k, v in geom.items():
+            setattr(garr[i], k, int(v))
+        for k, t in dict(out=out, addend=addend, mul=mul).items():
+            ptr = _dev(t, f"tapconv_group.{k}", contiguous=False)
+            setattr(earr[i], k, ptr.value if ptr is not None else None)
+        earr[i].bcos_mode, earr[i].relu, earr[i].b, earr[i].flags = BCOS_NONE, 0, 2.0, 0
+        warr[i] = _dev(w, "tapconv_group.wt").value
+    timing = KERNEL_TIMING
+    if timing is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    code = lib.bcos_tapconv_group(_dev(a, "tapconv_group.a", contiguous=False), warr, garr, earr, n, _stream())
+    if timing is not None:
+        ev1.record()
+        timing.append((ev0, ev1))
+    _l.check(code, "bcos_tapconv_group")
 
 
 def fwd_geom(N, H, W, Cin, Cout, kh, kw, sh, sw, ph, pw, dh=1, dw=1):
@@ -236,6 +266,21 @@ class DgradPlan:
                 out = torch.empty((N, H, W, self.Cin), device=glin.device, dtype=torch.float32)
         pitch = out.shape[-1]
         sh, sw = self.stride
+        if (self.Cin <= 8 and len(self.classes) > 1 and not self.has_empty and set(epi) <= {"addend", "mul"}
+                and not _NO_GROUP):
+            # narrow output (the stem gradient): all parity classes in one launch, the input patch staged once
+            geoms, wts = [], []
+            for (rh, rw, TH, TW, dh0, dw0, step_h, step_w, wt) in self.classes:
+                P = (H - rh + sh - 1) // sh
+                Q = (W - rw + sw - 1) // sw
+                if P <= 0 or Q <= 0:
+                    continue
+                geoms.append(dict(N=N, H=Ho, W=Wo, C=Cout, P=P, Q=Q, in_sh=1, in_sw=1, dh0=dh0, dw0=dw0, dstep_h=step_h,
+                                  dstep_w=step_w, TH=TH, TW=TW, OH=H, OW=W, out_sh=sh, out_sw=sw, out_h0=rh, out_w0=rw,
+                                  Cout=self.Cin, out_pitch=pitch))
+                wts.append(wt)
+            tapconv_group(glin, wts, geoms, out=out, **epi)
+            return out
         for (rh, rw, TH, TW, dh0, dw0, step_h, step_w, wt) in self.classes:
             P = (H - rh + sh - 1) // sh
             Q = (W - rw + sw - 1) // sw

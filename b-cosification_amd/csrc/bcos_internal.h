@@ -15,6 +15,10 @@ struct bcos_epilogue;
 int bcos_try_skinny(const float* a, const float* wt, const bcos_tapconv_geom& g, const bcos_epilogue& e, int M,
                     hipStream_t stream);
 
+// several tap sets over one input (parity classes of a strided gradient) fused into one launch, bcos_skinny.hip
+int bcos_try_skinny_group(const float* a, const float* const* wts, const bcos_tapconv_geom* gs, const bcos_epilogue* es,
+                          int count, hipStream_t stream);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per kernel: raise it only when a launch needs more than any
 // earlier one did (one runtime call per kernel and size class instead of one per launch; none while a launch sequence
 // is being captured into a hipGraph after a warm-up pass).  `high_water` is a per-kernel static of the caller.

@@ -952,3 +952,17 @@ extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void
     if (g.Cout > 32) return launch_cfg<128, 64, 2, 2>(p, norm, s);
     return launch_cfg<128, 32, 4, 1>(p, norm, s);
 }
+
+
+extern "C" int bcos_tapconv_group(const float* a, const float* const* wts, const bcos_tapconv_geom* geoms,
+                                  const bcos_epilogue* epis, int count, void* stream) {
+    if (!a || !wts || !geoms || !epis || count <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv_group: bad argument");
+    const int fused = bcos_try_skinny_group(a, wts, geoms, epis, count, reinterpret_cast<hipStream_t>(stream));
+    if (fused < 0) return fused;
+    if (fused == 1) return BCOS_OK;
+    for (int i = 0; i < count; ++i) {
+        const int rc = bcos_tapconv(a, wts[i], &geoms[i], &epis[i], stream);
+        if (rc != BCOS_OK) return rc;
+    }
+    return BCOS_OK;
+}

@@ -168,6 +168,13 @@ int bcos_split_weights(const float* wt, void* wt3, int rows, int Ktot, void* str
 int bcos_tapconv_presplit(const float* a, const float* wt, const void* wt3, const bcos_tapconv_geom* geom,
                           const bcos_epilogue* epi, void* stream);
 
+/* `count` tapconv launches over the SAME input `a` (e.g. the parity classes of a strided input gradient, one tap set,
+ * weight tensor and output offset each): same result as calling bcos_tapconv once per entry.  Narrow outputs
+ * (Cout <= 8, count <= 4, identical shapes, plain / addend / mul epilogue on one output tensor) run as ONE launch in
+ * which every workgroup stages its input patch once for all tap sets (the ResNet stem gradient: 4 launches -> 1). */
+int bcos_tapconv_group(const float* a, const float* const* wts, const bcos_tapconv_geom* geoms,
+                       const bcos_epilogue* epis, int count, void* stream);
+
 /*
  * Replaces BcosConv2d.forward_impl (bcos/modules/bcosconv2d.py:153-194) and
  * BcosifyConv2d.forward_impl (bcos/modules/bcosifyconv2d.py:50-102) for groups == 1,

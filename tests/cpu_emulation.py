@@ -211,6 +211,11 @@ def localisation_fractions(attr, cell_h, cell_w, neg=False):
     return torch.where(total * contribs > 0, contribs / total, torch.zeros_like(contribs))
 
 
+def tapconv_group(a, wts, geoms, *, out, addend=None, mul=None):
+    for w, g in zip(wts, geoms):
+        tapconv(a, w, g, out=out, addend=addend, mul=mul)
+
+
 def install(monkeypatch):
     """Patch bcos_hip.ops with the emulators (pytest monkeypatch fixture) and lift the HIP-device checks."""
     from bcos_hip import ops
@@ -218,7 +223,7 @@ def install(monkeypatch):
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
                  "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
-                 "render_explanations", "box_filter", "localisation_fractions"):
+                 "render_explanations", "box_filter", "localisation_fractions", "tapconv_group"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

@@ -609,6 +609,31 @@ def test_grid_pointing_game_on_device(lib, golden_dir):
     assert rel(ops.box_filter(r9["attributions"][0], 7), F.avg_pool2d(r9["attributions"][0].cpu()[:, None], 7, 1, 3)[:, 0]) <= 1e-6
 
 
+def test_tapconv_group_matches_separate_launches(lib):
+    """bcos_tapconv_group: the parity classes of a strided input gradient in ONE launch (narrow outputs: the input patch
+    is staged once for all classes) must equal one launch per class; wide outputs take the per-entry fallback."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(21)
+    for (N, Ho, Cout, Cin, k, s_, p_) in [(3, 20, 64, 8, 7, 2, 3), (2, 9, 32, 4, 3, 2, 1), (2, 12, 16, 24, 3, 2, 1)]:
+        w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cout) ** 0.5).to(DEV)
+        plan = ops.DgradPlan(w, (s_, s_), (p_, p_), (1, 1))
+        H = (Ho - 1) * s_ + k - 2 * p_ + (1 if Cin == 8 else 0)
+        H -= H % 2                                                   # even sizes: all classes have the same P x Q
+        Ho2 = (H + 2 * p_ - k) // s_ + 1
+        gl = torch.randn(N, Ho2, Ho2, Cout, generator=g).to(DEV)
+        add = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+        ops._NO_GROUP = False
+        a = plan.run(gl, H, H, addend=add)
+        ops._NO_GROUP = True
+        try:
+            b = plan.run(gl, H, H, addend=add)
+        finally:
+            ops._NO_GROUP = False
+        assert rel(a, b) <= 1e-6, (Cin, k)        # same products; the channel-slice grouping of the sums may differ
+        ref = torch.nn.grad.conv2d_input((N, Cin, H, H), w.cpu(), gl.permute(0, 3, 1, 2).cpu(), stride=s_, padding=p_)
+        assert rel(a.permute(0, 3, 1, 2), ref + add.permute(0, 3, 1, 2).cpu()) <= 1e-5
+
+
 def test_captured_pass_matches_eager(lib):
     """engine.CapturedPass: the whole forward+explanation step recorded into a hipGraph and replayed on new inputs must
     reproduce the eager launches bit for bit."""
