@@ -22,16 +22,26 @@ def hooked(a, wt, geom, **kw):
     M = g["N"] * g["P"] * g["Q"]; K = g["TH"] * g["TW"] * g["C"]; Nn = g["Cout"]
     nbytes = 4 * (M * Nn * sum(1 for k in ("out", "out2", "scale_out", "addend", "mul", "mul2", "gate2") if kw.get(k) is not None))
     nbytes += 4 * g["N"] * g["H"] * g["W"] * g["C"] + 4 * K * Nn
-    records.append((e0, e1, M, K, Nn, g["TH"], g["in_sh"], g["out_sh"], nbytes, "fwd" if kw.get("bcos_mode", 0) else "bwd"))
+    records.append((e0, e1, M, K, Nn, g["TH"], g["in_sh"], g["out_sh"], nbytes, "fwd" if kw.get("bcos_mode", 0) else "bwd", 2.0 * M * K * Nn))
 ops.tapconv = hooked
+orig_group = ops.tapconv_group
+def hooked_group(a, wts, geoms, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); orig_group(a, wts, geoms, **kw); e1.record()
+    g = geoms[0]
+    M = sum(q["N"] * q["P"] * q["Q"] for q in geoms); K = max(q["TH"] * q["TW"] * q["C"] for q in geoms); Nn = g["Cout"]
+    fl = sum(2.0 * q["N"] * q["P"] * q["Q"] * q["TH"] * q["TW"] * q["C"] * q["Cout"] for q in geoms)
+    nbytes = 4 * (g["N"] * g["H"] * g["W"] * g["C"] + M * Nn)
+    records.append((e0, e1, M, K, Nn, 0, 1, g["out_sh"], nbytes, "bwd", fl))
+ops.tapconv_group = hooked_group
 for _ in range(2):
     records.clear()
     eng.explain(x)
 torch.cuda.synchronize()
 tot = 0; totf = 0
 agg = {}
-for (e0, e1, M, K, Nn, TH, ins, outs, nbytes, kind) in records:
-    ms = e0.elapsed_time(e1); fl = 2.0 * M * K * Nn
+for (e0, e1, M, K, Nn, TH, ins, outs, nbytes, kind, fl) in records:
+    ms = e0.elapsed_time(e1)
     key = (kind, M, K, Nn, TH, ins, outs)
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl; a[3] += nbytes
     tot += ms; totf += fl
