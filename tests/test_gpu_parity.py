@@ -634,6 +634,25 @@ def test_tapconv_group_matches_separate_launches(lib):
         assert rel(a.permute(0, 3, 1, 2), ref + add.permute(0, 3, 1, 2).cpu()) <= 1e-5
 
 
+def test_operand_larger_than_2gib_is_split_by_images(lib):
+    """The split-bf16 path addresses its operands through 32-bit buffer offsets; a call whose input exceeds 2 GiB is
+    split by images inside bcos_tapconv.  2 x 1024 x 1024 x 272 fp32 = 2.28 GB in, 1x1 conv to 16 channels."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(2)
+    N, H, C, Cout = 2, 1024, 272, 16
+    x = torch.randn(N, H, H, C, generator=g).to(DEV)
+    assert x.numel() * 4 >= 2 ** 31
+    w = (torch.randn(Cout, 1, 1, C, generator=g) / C ** 0.5).to(DEV)
+    add = torch.randn(N, H, H, Cout, generator=g).to(DEV)
+    y, s_, _ = ops.conv2d_fwd(x, w, addend=add, want_scale=True)
+    for n in range(N):                                   # per image: below the limit, no split
+        yn, sn, _ = ops.conv2d_fwd(x[n:n + 1], w, addend=add[n:n + 1], want_scale=True)
+        assert torch.equal(y[n:n + 1], yn) and torch.equal(s_[n:n + 1], sn)
+    ref = O.bcos_conv2d(x[:, :64, :64].permute(0, 3, 1, 2).cpu(), w.permute(0, 3, 1, 2).cpu(), None, 1, 0, 1, 1, 2, 1,
+                        detach=True, normalize_weight=False)
+    assert rel(y[:, :64, :64].permute(0, 3, 1, 2) - add[:, :64, :64].permute(0, 3, 1, 2), ref) <= 1e-5
+
+
 def test_captured_pass_matches_eager(lib):
     """engine.CapturedPass: the whole forward+explanation step recorded into a hipGraph and replayed on new inputs must
     reproduce the eager launches bit for bit."""
