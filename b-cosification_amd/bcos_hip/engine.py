@@ -169,7 +169,7 @@ class ResNetEngine:
         ll = net.logit_layer
         self.logit_bias = ll.logit_bias if ll is not None else None
         self.logit_temperature = ll.logit_temperature if ll is not None else None
-        self.supports_explain = self.head_kind == "gap_fc"
+        self.supports_explain = True
         if self.head_kind == "attnpool":
             self._refresh_attnpool()
 
@@ -178,6 +178,11 @@ class ResNetEngine:
         w = lambda lin: lin.weight.detach().contiguous()   # noqa: E731  (c_proj may be a BcosifyLinear: .weight property)
         self.ap_w = dict(q=w(ap.q_proj), k=w(ap.k_proj), v=w(ap.v_proj), c=w(ap.c_proj))
         self.ap_heads = ap.num_heads
+        # explanation mode detaches q and k (bcosattnpool.py:37-39): the gradient reaches the feature map through v only,
+        # i.e. through v_proj seen as a 1x1 convolution over the HW positions (+ the mean token, folded in _backward)
+        C = self.ap_w["v"].shape[1]
+        self.ap_cT = ops.mark_static(self.ap_w["c"].t().contiguous())          # [C, D]: g_pooled = g_emb @ W_c
+        self.ap_vconv = _HeadConv(ops.DgradPlan(self.ap_w["v"].view(C, C, 1, 1), (1, 1), (0, 0), (1, 1)), C)
 
     def refresh(self):
         """Re-read parameters after they changed (load_state_dict, calibration, ...)."""
@@ -253,14 +258,17 @@ class ResNetEngine:
                 st["blocks"].append(rec)
             cur = out
         if self.head_kind == "attnpool":
-            return self._attnpool_forward(cur), st
+            emb = self._attnpool_forward(cur, st)
+            if keep:
+                st["feat_hw"] = (cur.shape[1], cur.shape[2])
+            return emb, st
         f, tf = self.head.fwd(cur, relu=False, want_scale=keep)
         logits = ops.global_avgpool_logits(f, self.logit_temperature, self.logit_bias)
         if keep:
             st.update(tf=tf, feat_hw=(cur.shape[1], cur.shape[2]))
         return logits, st
 
-    def _attnpool_forward(self, feat):
+    def _attnpool_forward(self, feat, st=None):
         """BcosAttentionPool2d.forward, pooled mode (bcosattnpool.py:33-59): tokens = [mean; HW positions], plain q/k/v
         projections (no bias, no positional embedding), 32-head softmax attention of the mean token, plain c_proj."""
         N, H, W, C = feat.shape
@@ -272,7 +280,9 @@ class ResNetEngine:
         qkv = torch.empty((N, T, 3 * C), device=feat.device, dtype=torch.float32)
         for i, key in enumerate("qkv"):
             ops.tapconv(flat, self.ap_w[key], _linear_geom(N * T, C, C, out_pitch=3 * C), out=qkv.view(N * T, 3 * C)[:, i * C:])
-        out, _ = ops.attention_fwd(qkv, self.ap_heads, (C // self.ap_heads) ** -0.5)
+        out, stats = ops.attention_fwd(qkv, self.ap_heads, (C // self.ap_heads) ** -0.5, want_stats=st is not None)
+        if st is not None:
+            st["ap_qkv"], st["ap_stats"] = qkv, stats
         pooled = out[:, 0, :].contiguous()
         emb = ops.matmul_nt(pooled, self.ap_w["c"])
         if self.logit_temperature is not None:
@@ -280,6 +290,26 @@ class ResNetEngine:
         if self.logit_bias is not None:
             emb = emb + self.logit_bias
         return emb
+
+    def _attnpool_backward(self, st, cls, consume):
+        """d emb[n, cls[n]] / d v_lin at the HW positions, with q and k detached (bcosattnpool.py:37-39): back through the
+        plain c_proj, through the attention of the mean token (gradient w.r.t. v only), and the mean token's own v row
+        spread over the positions it averages (tokens[0] = mean of the HW positions, :35).  The remaining step, through
+        v_proj, is the 1x1-convolution input gradient the consumer runs."""
+        qkv, stats = st["ap_qkv"], st["ap_stats"]
+        if consume:
+            st["ap_qkv"] = st["ap_stats"] = None
+        N, T, C3 = qkv.shape
+        C = C3 // 3
+        H, W = st["feat_hw"]
+        D = self.ap_cT.shape[1]
+        g_emb = torch.zeros((N, D), device=qkv.device, dtype=torch.float32)
+        g_emb.scatter_(1, cls.view(-1, 1), 1.0 if self.logit_temperature is None else 1.0 / float(self.logit_temperature))
+        g_out = torch.zeros((N, T, C), device=qkv.device, dtype=torch.float32)
+        g_out[:, 0] = ops.matmul_nt(g_emb, self.ap_cT)                    # g_emb @ W_c
+        g_v = ops.attention_bwd_v(qkv, stats, g_out, self.ap_heads, (C // self.ap_heads) ** -0.5)
+        g_lin = g_v[:, 1:] + g_v[:, :1] / float(H * W)                   # positions + their share of the mean token
+        return g_lin.reshape(N, H, W, C).contiguous()
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -292,9 +322,6 @@ class ResNetEngine:
         (batched bcos/common.py:163-181).  `targets` [N] int64 selects the logits (default: arg-max).
         `gates`: optional list of NHWC 0/1 tensors, one per ReLU in execution order, that REPLACE the v > 0
         decisions (replay of gates recorded elsewhere; used by the gate-pinned parity test)."""
-        if not self.supports_explain:
-            raise NotImplementedError("engine.explain: attention-pool (CLIP) heads are forward-only in the fused engine; "
-                                      "use the module path (net.explain_batch without an attached engine)")
         logits, st = self._run_forward(x, keep=True, gates=gates)
         pred, _ = ops.argmax_rows(logits)
         cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
@@ -309,8 +336,6 @@ class ResNetEngine:
         bcos/common.py:319-344) re-runs the forward for every target; the dynamic weights of the forward do not depend on
         the explained logit, so they are kept and only the backward is repeated.
         Returns logits [N,K], contribution_maps [N,T,H,W] and, if requested, dynamic_linear_weights [N,T,6,H,W]."""
-        if not self.supports_explain:
-            raise NotImplementedError("engine.explain_targets: attention-pool (CLIP) heads are forward-only in the fused engine")
         logits, st = self._run_forward(x, keep=True)
         tg = targets.to(device=logits.device, dtype=torch.int64)
         if tg.dim() == 1:
@@ -331,13 +356,16 @@ class ResNetEngine:
     def _backward(self, x, st, cls, want_weights: bool, consume: bool):
         """Input-gradient pass of logit[cls[n]] for every image n over the state `st` of a kept forward; `consume` frees
         each saved multiplier as soon as it has been used (last / only pass over this state)."""
-        # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale
-        g_head = ops.head_onehot_grad(cls, st["tf"], self.logit_temperature)
-        if consume:
-            st["tf"] = None
         # A "consumer" owns the g_lin tensors of the layers that read some activation X and can therefore
         # finish d logit / d X; its epilogue applies the multipliers of the block that PRODUCED X.
-        consumer = _Consumer(self.head, g_head, None, None, 0)
+        if self.head_kind == "attnpool":
+            consumer = _Consumer(self.ap_vconv, self._attnpool_backward(st, cls, consume), None, None, 0)
+        else:
+            # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale
+            g_head = ops.head_onehot_grad(cls, st["tf"], self.logit_temperature)
+            if consume:
+                st["tf"] = None
+            consumer = _Consumer(self.head, g_head, None, None, 0)
         nb = len(self.blocks)
         for bi in range(nb - 1, -1, -1):
             blk, rec = self.blocks[bi], st["blocks"][bi]
@@ -382,6 +410,13 @@ class ResNetEngine:
         wts, contrib = ops.finalize_explanation(gxn, st["x"], std, add_inverse=st["add_inverse"],
                                                 want_weights=want_weights, want_contrib=True)
         return wts, contrib
+
+
+class _HeadConv:
+    """What a _Consumer needs from the layer that reads the last feature map: its input-gradient plan and width."""
+
+    def __init__(self, dgrad, cin):
+        self.dgrad, self.cin = dgrad, cin
 
 
 class _Consumer:

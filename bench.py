@@ -39,7 +39,7 @@ ARCHS = {
     "resnet50": dict(gflop_fwd=8.611, family="resnet", explain=True),
     "resnet18": dict(gflop_fwd=3.913, family="resnet", explain=True),
     "vit_ti": dict(gflop_fwd=1.752, family="vit", explain=True),
-    "clip_rn50": dict(gflop_fwd=10.756, family="clip", explain=False),   # fused plan: forward (zero-shot) only
+    "clip_rn50": dict(gflop_fwd=10.756, family="clip", explain=True),    # explains the arg-max embedding coordinate
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the pipe the 6-product bf16x3 split runs on)

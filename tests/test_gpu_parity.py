@@ -496,6 +496,10 @@ def test_clip_rn50_against_reference_golden(lib, golden_dir):
     with torch.no_grad():
         emb = net(x)                                    # fused plan
     assert rel(emb, data["embeddings"]) <= 1e-4
+    # fused explanation through the attention-pool head against the reference-recorded gradient of embedding coordinate 7
+    fused = eng.explain(x[:1], targets=torch.tensor([7]))
+    assert rel(fused["dynamic_linear_weights"], data["grad_e7_image0"]) <= 2e-3      # ReLU-gate floor, as above
+    assert rel(fused["dynamic_linear_weights"], g) <= 2e-3                           # and the module path
     wt = torch.randn(1024, 16, generator=torch.Generator().manual_seed(meta["text_seed"])).to(DEV)
     logits = clip_head.zeroshot_logits(emb, wt)
     assert rel(logits, data["zeroshot_logits"]) <= 1e-4

@@ -358,9 +358,16 @@ def test_clip_rn50_conversion_and_engine(monkeypatch):
     x = synth.synthetic_images(2, size=64)
     ref = O.clip_rn50_embed(sd, x)
     eng = engine.ResNetEngine(net)
-    assert not eng.supports_explain
     emb = eng.forward(x)
     assert rel(emb, ref) <= 1e-5
+    # fused explanation through the attention-pool head (q, k detached: gradient through v only, mean token folded in)
+    xo_ = x.clone().requires_grad_(True)
+    eo_ = O.clip_rn50_embed(sd, xo_, detach=True)
+    (go_,) = torch.autograd.grad(eo_[:, 7].sum(), xo_)
+    fused = eng.explain(x, targets=torch.tensor([7, 7]))
+    assert eng.supports_explain and rel(fused["logits"], ref) <= 1e-5
+    assert rel(fused["dynamic_linear_weights"], go_) <= 1e-4
+    assert rel(fused["contribution_map"], (x * go_).sum(1)) <= 1e-4
     # nn.Module path incl. explanation-mode gradient of an embedding coordinate (q, k detached)
     xr = x.clone().requires_grad_(True)
     with net.explanation_mode():
