@@ -129,8 +129,12 @@ constexpr int AT_XLD = DH + 4;      // floats per X row in LDS
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 8 wavefronts per workgroup: the 7 column tiles of a 196-token sequence run in one round (with 4 they took two, the
+// second one quarter full); the workgroup owns the CU either way (119 KB of LDS)
+constexpr int ATPB = 512;
+
 template <bool BWD>
-__global__ __launch_bounds__(TPB) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ zsrc,
+__global__ __launch_bounds__(ATPB) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ zsrc,
                                                              float* __restrict__ out, float* __restrict__ stats_out,
                                                              const float* __restrict__ stats_in, int B, int T, int H,
                                                              float scale) {
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(TPB) void attention_mfma_kernel(const float* __rest
     const float* zrow0 = BWD ? zsrc + (int64_t)b * T * inner + h * DH : base + 2 * inner;
     const int zstride = BWD ? inner : 3 * inner;
 
-    for (int i = tid; i < Tpad * (DH / 4); i += TPB) {
+    for (int i = tid; i < Tpad * (DH / 4); i += ATPB) {
         const int t = i / (DH / 4), c4 = i % (DH / 4);
         f32x4 xv = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(TPB) void attention_mfma_kernel(const float* __rest
     }
     if (BWD) {
         const float* st = stats_in + ((int64_t)b * H + h) * T * 2;
-        for (int i = tid; i < Tpad; i += TPB) {
+        for (int i = tid; i < Tpad; i += ATPB) {
             sS[2 * i] = i < T ? st[2 * i] : INFINITY;          // padded query rows: exp(s - inf) * 0 = 0
             sS[2 * i + 1] = i < T ? st[2 * i + 1] : 0.f;
         }
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(TPB) void attention_mfma_kernel(const float* __rest
 
     const int col = lane & 31, hf = lane >> 5;
     const int ntiles = Tpad / 32;
-    for (int tile = wave; tile < ntiles; tile += TPB / 64) {
+    for (int tile = wave; tile < ntiles; tile += ATPB / 64) {
         const int y = tile * 32 + col;                 // the Y row (query fwd / key bwd) of this lane
         f32x4 yf[8];
 #pragma unroll
@@ -354,10 +358,10 @@ static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, f
     hipError_t err = bcos_ensure_dynamic_lds(fn, bytes, lds_hw[bwd ? 1 : 0]);
     if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute(attention)", err);
     if (bwd)
-        hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((unsigned)(B * H)), dim3(TPB), bytes, STREAM(stream), qkv, z, out,
+        hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((unsigned)(B * H)), dim3(ATPB), bytes, STREAM(stream), qkv, z, out,
                            stats_out, stats_in, B, T, H, scale);
     else
-        hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((unsigned)(B * H)), dim3(TPB), bytes, STREAM(stream), qkv, z, out,
+        hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((unsigned)(B * H)), dim3(ATPB), bytes, STREAM(stream), qkv, z, out,
                            stats_out, stats_in, B, T, H, scale);
     return check_launch(bwd ? "attention_mfma_kernel<bwd>" : "attention_mfma_kernel<fwd>");
 }
