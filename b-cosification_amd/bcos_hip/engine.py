@@ -74,12 +74,22 @@ class _Conv:
         return (ops.conv_out_size(H, self.k[0], self.stride[0], self.padding[0], self.dilation[0]),
                 ops.conv_out_size(W, self.k[1], self.stride[1], self.padding[1], self.dilation[1]))
 
-    def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None, flags=0):
+    @property
+    def k_fwd(self):
+        """K of the forward contraction (its A operand is the layer input)."""
+        return self.cin * self.k[0] * self.k[1]
+
+    @property
+    def k_dgrad(self):
+        """largest K of the input-gradient launches (their A operand is the gradient w.r.t. this layer's `lin`)."""
+        return self.cout * self.k[0] * self.k[1]
+
+    def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None, flags=0, track=None):
         gate = gates.pop(0) if (relu and gates is not None) else None
         y, t, _ = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
                                  bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
                                  ch_shift=self.ch_shift, addend=addend, relu=relu, relu_gate=gate,
-                                 want_scale=want_scale, flags=flags)
+                                 want_scale=want_scale, flags=flags, track_absmax=track)
         self.last_gate = gate       # the replayed gate tensor, if any (else the output itself encodes the gate)
         return y, t
 
@@ -170,6 +180,7 @@ class ResNetEngine:
         self.logit_bias = ll.logit_bias if ll is not None else None
         self.logit_temperature = ll.logit_temperature if ll is not None else None
         self.supports_explain = True
+        self._absmax_arena = ops.AbsmaxArena()      # per-pixel operand maxima of one pass (f16x2 contraction)
         if self.head_kind == "attnpool":
             self._refresh_attnpool()
 
@@ -211,42 +222,58 @@ class ResNetEngine:
         x = x if x.is_contiguous() else x.contiguous()
         mean, std = self._consts(x.device)
         add_inverse = x.shape[1] == 3
-        xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse)
+        self._absmax_arena.reset(x.device)
+        ops.set_absmax_arena(self._absmax_arena)
+        xn = ops.ensure_absmax(ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse))
         gates = list(gates) if gates is not None else None
         st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3], stem_ts=[], stem_hws=[], blocks=[]) if keep else None
         a = xn
-        for conv, relu in self.stem:
+        need = lambda k: k >= ops.F16X2_MIN_K      # noqa: E731  will the reader of a tensor use its per-pixel maxima?
+        for si, (conv, relu) in enumerate(self.stem):
             if keep:
                 st["stem_hws"].append((a.shape[1], a.shape[2]))
-            a, t = conv.fwd(a, relu=relu, want_scale=keep, gates=gates)
+            nxt = self.stem[si + 1][0].k_fwd if si + 1 < len(self.stem) else 0       # the last stem conv feeds a pool
+            a, t = conv.fwd(a, relu=relu, want_scale=keep, gates=gates, track=need(nxt))
             if keep:
                 st["stem_ts"].append(t)
         k, s, p = self.pool
         cur = ops.avgpool2d_fwd(a, k, s, p)
+        if need(self.blocks[0].convs[0].k_fwd):
+            ops.ensure_absmax(cur)
         if keep:
             st["a0_hw"] = (a.shape[1], a.shape[2])
         del a
-        for blk in self.blocks:
+        for bi, blk in enumerate(self.blocks):
             inp = cur
             rec = dict(in_hw=(inp.shape[1], inp.shape[2])) if keep else None
             h = inp
             ts, hws = [], []
-            for c in blk.convs[:-1]:
+            for ci, c in enumerate(blk.convs[:-1]):
                 hws.append((h.shape[1], h.shape[2]))
-                h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates)
+                pooled_next = blk.pool and ci == len(blk.convs) - 2              # a pool sits between this conv and the next
+                h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates,
+                             track=need(blk.convs[ci + 1].k_fwd) and not pooled_next)
                 ts.append(t)
             pre_pool_hw = (h.shape[1], h.shape[2])
             if blk.pool:
                 h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0)
+                if need(blk.convs[-1].k_fwd):
+                    ops.ensure_absmax(h)
             if blk.shortcut is not None:
                 sc_in = ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0) if blk.shortcut_pool else inp
-                idn, td = blk.shortcut.fwd(sc_in, relu=False, want_scale=keep)
+                if blk.shortcut_pool and need(blk.shortcut.k_fwd):
+                    ops.ensure_absmax(sc_in)
+                idn, td = blk.shortcut.fwd(sc_in, relu=False, want_scale=keep, track=False)      # only ever an addend
             else:
                 idn, td = inp, None
             hws.append((h.shape[1], h.shape[2]))
             # the block's ReLU decision travels in the low mantissa bit of the stored multiplier (include/bcos_hip.h:
             # BCOS_EPI_SCALE_GATE_LSB): the explanation pass reads no separate gate tensor
-            out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates,
+            if bi + 1 < len(self.blocks):
+                k_next = self.blocks[bi + 1].convs[0].k_fwd
+            else:
+                k_next = self.head.k_fwd if self.head is not None else ops.F16X2_MIN_K
+            out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates, track=need(k_next),
                                        flags=BCOS_EPI_SCALE_GATE_LSB if (keep and blk.relu and not _GATE_TENSOR) else 0)
             ts.append(t)
             if keep:
@@ -262,7 +289,7 @@ class ResNetEngine:
             if keep:
                 st["feat_hw"] = (cur.shape[1], cur.shape[2])
             return emb, st
-        f, tf = self.head.fwd(cur, relu=False, want_scale=keep)
+        f, tf = self.head.fwd(cur, relu=False, want_scale=keep, track=False)
         logits = ops.global_avgpool_logits(f, self.logit_temperature, self.logit_bias)
         if keep:
             st.update(tf=tf, feat_hw=(cur.shape[1], cur.shape[2]))
@@ -276,7 +303,7 @@ class ResNetEngine:
         tokens = torch.empty((N, T, C), device=feat.device, dtype=torch.float32)
         tokens[:, 1:] = feat.view(N, H * W, C)
         tokens[:, 0] = ops.global_avgpool_logits(feat, None, None)
-        flat = tokens.view(N * T, C)
+        flat = ops.ensure_absmax(tokens.view(N * T, C))
         qkv = torch.empty((N, T, 3 * C), device=feat.device, dtype=torch.float32)
         for i, key in enumerate("qkv"):
             ops.tapconv(flat, self.ap_w[key], _linear_geom(N * T, C, C, out_pitch=3 * C), out=qkv.view(N * T, 3 * C)[:, i * C:])
@@ -309,7 +336,7 @@ class ResNetEngine:
         g_out[:, 0] = ops.matmul_nt(g_emb, self.ap_cT)                    # g_emb @ W_c
         g_v = ops.attention_bwd_v(qkv, stats, g_out, self.ap_heads, (C // self.ap_heads) ** -0.5)
         g_lin = g_v[:, 1:] + g_v[:, :1] / float(H * W)                   # positions + their share of the mean token
-        return g_lin.reshape(N, H, W, C).contiguous()
+        return ops.ensure_absmax(g_lin.reshape(N, H, W, C).contiguous())
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -362,7 +389,7 @@ class ResNetEngine:
             consumer = _Consumer(self.ap_vconv, self._attnpool_backward(st, cls, consume), None, None, 0)
         else:
             # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale
-            g_head = ops.head_onehot_grad(cls, st["tf"], self.logit_temperature)
+            g_head = ops.ensure_absmax(ops.head_onehot_grad(cls, st["tf"], self.logit_temperature))
             if consume:
                 st["tf"] = None
             consumer = _Consumer(self.head, g_head, None, None, 0)
@@ -372,7 +399,9 @@ class ResNetEngine:
             H, W = st["blocks"][bi + 1]["in_hw"] if bi + 1 < nb else st["feat_hw"]
             # v = d logit / d out_b;  G_main = v * t_last (bn scale, ReLU gate and s of the block's last conv),
             # G_sc = v * gate(out_b) [* t_d]  for the shortcut
-            G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gated=rec["gated"], gate_t=rec["gate_t"])
+            G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gated=rec["gated"], gate_t=rec["gate_t"],
+                                        track=blk.convs[-1].k_dgrad >= ops.F16X2_MIN_K,
+                                        track2=blk.shortcut is not None and blk.shortcut.k_dgrad >= ops.F16X2_MIN_K)
             if consume:
                 rec["ts"][-1] = rec["td"] = rec["gate_t"] = None
             gl = G_main
@@ -382,26 +411,32 @@ class ResNetEngine:
                 if blk.pool and ci == len(convs) - 1:
                     # anti-aliasing pool between conv(ci-1) and conv(ci): gradient w.r.t. the pooled tensor, then
                     # the pool's input gradient times the scale of conv(ci-1)
-                    gp = convs[ci].dgrad.run(gl, h, w)
+                    gp = convs[ci].dgrad.run(gl, h, w, track_absmax=False)
                     ph, pw = rec["pre_pool_hw"]
                     gl = ops.avgpool2d_bwd(gp, ph, pw, blk.pool, blk.pool, 0, mul=rec["ts"][ci - 1])
+                    if convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K:
+                        ops.ensure_absmax(gl)
                 else:
-                    gl = convs[ci].dgrad.run(gl, h, w, mul=rec["ts"][ci - 1])
+                    gl = convs[ci].dgrad.run(gl, h, w, mul=rec["ts"][ci - 1],
+                                             track_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K)
                 if consume:
                     rec["ts"][ci - 1] = None
             consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc, blk.shortcut_pool)
         # block 0 reads the stem pool output: raw gradient, pool backward (* t of the last stem conv), then the stem
         H0, W0 = st["blocks"][0]["in_hw"]
-        g_pool, _ = consumer.run(H0, W0, t_main=None, td=None, gated=False)
+        g_pool, _ = consumer.run(H0, W0, t_main=None, td=None, gated=False, track=False)
         k, s, p = self.pool
         a_h, a_w = st["a0_hw"]
         ts = st["stem_ts"]
         gl = ops.avgpool2d_bwd(g_pool, a_h, a_w, k, s, p, mul=ts[-1])
+        if self.stem[-1][0].k_dgrad >= ops.F16X2_MIN_K:
+            ops.ensure_absmax(gl)
         if consume:
             ts[-1] = None
         for si in range(len(self.stem) - 1, 0, -1):
             h, w = st["stem_hws"][si]
-            gl = self.stem[si][0].dgrad.run(gl, h, w, mul=ts[si - 1])
+            gl = self.stem[si][0].dgrad.run(gl, h, w, mul=ts[si - 1],
+                                            track_absmax=self.stem[si - 1][0].k_dgrad >= ops.F16X2_MIN_K)
             if consume:
                 ts[si - 1] = None
         gxn = torch.empty((x.shape[0], st["H"], st["W"], 8), device=x.device, dtype=torch.float32)
@@ -427,7 +462,7 @@ class _Consumer:
     def __init__(self, conv, g_main, shortcut_conv, g_sc, sc_pool):
         self.conv, self.g_main, self.shortcut_conv, self.g_sc, self.sc_pool = conv, g_main, shortcut_conv, g_sc, sc_pool
 
-    def run(self, H, W, t_main, td, gated, gate_t=None):
+    def run(self, H, W, t_main, td, gated, gate_t=None, track=None, track2=None):
         """-> (v * t_main, v * gate [* td]) with v = d logit / d X; both v when t_main is None.  `gated`: the block that
         produced X ends in a ReLU, whose decision is the low mantissa bit of t_main."""
         g = self.g_main
@@ -438,13 +473,13 @@ class _Consumer:
                       flags=BCOS_EPI_GATE2_FROM_MUL if (gated and gate_t is None) else 0)
         if self.shortcut_conv is not None:
             if self.sc_pool:
-                pooled = self.shortcut_conv.dgrad.run(self.g_sc, H // self.sc_pool, W // self.sc_pool)
+                pooled = self.shortcut_conv.dgrad.run(self.g_sc, H // self.sc_pool, W // self.sc_pool, track_absmax=False)
                 addend = ops.avgpool2d_bwd(pooled, H, W, self.sc_pool, self.sc_pool, 0)
             else:
-                addend = self.shortcut_conv.dgrad.run(self.g_sc, H, W)
+                addend = self.shortcut_conv.dgrad.run(self.g_sc, H, W, track_absmax=False)
         else:
             addend = self.g_sc
-        out = self.conv.dgrad.run(g, H, W, addend=addend, **kw)
+        out = self.conv.dgrad.run(g, H, W, addend=addend, track_absmax=track, track_absmax2=track2, **kw)
         return out, (out2 if out2 is not None else out)
 
 

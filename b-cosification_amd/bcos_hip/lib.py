@@ -25,7 +25,7 @@ BCOS_EPI_NORM_ONLY = 1
 BCOS_EPI_FORCE_POW = 2
 BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class BcosHipError(RuntimeError):
@@ -42,9 +42,16 @@ class TapconvGeom(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2", "relu_gate",
-        "out", "out2", "scale_out", "norm_out")] + [
+        "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax")] + [
         ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32)]
 
+
+class Operands(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("a_absmax", C.c_void_p), ("wt", C.c_void_p), ("wt_bf16x3", C.c_void_p),
+                ("wt_f16x2", C.c_void_p), ("contraction", C.c_int32)]
+
+
+CONTRACT_DEFAULT, CONTRACT_F32, CONTRACT_BF16X3, CONTRACT_F16X2 = 0, 1, 2, 3
 
 # name -> (restype, argtypes); mirrors include/bcos_hip.h one to one
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -54,6 +61,10 @@ SIGNATURES = {
     "bcos_set_contraction_mode": (C.c_int, [_I]),
     "bcos_get_contraction_mode": (C.c_int, []),
     "bcos_tapconv": (C.c_int, [_P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
+    "bcos_tapconv_ops": (C.c_int, [C.POINTER(Operands), C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
+    "bcos_split_weights_f16x2_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
+    "bcos_split_weights_f16x2": (C.c_int, [_P, _P, _I, _I, _P]),
+    "bcos_rows_absmax": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "bcos_split_weights_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_tapconv_presplit": (C.c_int, [_P, _P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
@@ -125,21 +136,24 @@ def load():
         raise BcosHipError(f"libbcos_hip.so ABI version {v}, bindings expect {ABI_VERSION}")
     _lib = lib
     mode = os.environ.get("BCOS_CONTRACTION", "").lower()
-    if mode in ("f32", "fp32", "0"):
-        lib.bcos_set_contraction_mode(0)
-    elif mode in ("bf16x3", "1"):
-        lib.bcos_set_contraction_mode(1)
+    if mode in _MODE_CODES:
+        lib.bcos_set_contraction_mode(_MODE_CODES[mode])
     return lib
 
 
+_MODE_NAMES = {0: "f32", 1: "bf16x3", 2: "f16x2"}
+_MODE_CODES = {"f32": 0, "fp32": 0, "0": 0, "bf16x3": 1, "1": 1, "f16x2": 2, "2": 2}
+
+
 def get_contraction_mode() -> str:
-    return {0: "f32", 1: "bf16x3"}[load().bcos_get_contraction_mode()]
+    """The process-wide DEFAULT arithmetic of the contraction (include/bcos_hip.h); a call may override it."""
+    return _MODE_NAMES[load().bcos_get_contraction_mode()]
 
 
 def set_contraction_mode(mode: str):
-    """'f32' (v_mfma_f32_32x32x2_f32) or 'bf16x3' (exact 3-way bf16 split, 6 products; include/bcos_hip.h)."""
-    code = {"f32": 0, "bf16x3": 1}[mode]
-    check(load().bcos_set_contraction_mode(code), "bcos_set_contraction_mode")
+    """'f32' (v_mfma_f32_32x32x2_f32), 'bf16x3' (exact 3-way bf16 split, 6 products) or 'f16x2' (scaled 2-way fp16 split,
+    3 products; falls back to bf16x3 for launches without operand maxima) -- include/bcos_hip.h."""
+    check(load().bcos_set_contraction_mode(_MODE_CODES[mode]), "bcos_set_contraction_mode")
 
 
 def check(code: int, what: str):

@@ -56,9 +56,9 @@ _NO_GROUP = bool(os.environ.get("BCOS_NO_GROUP"))           # development switch
 
 
 def mark_static(w: torch.Tensor) -> torch.Tensor:
-    """Declare `w` an inference-time constant (a layer's effective weight): tapconv() then keeps its pre-split bf16x3
-    image (bcos_split_weights) next to it and uses bcos_tapconv_presplit.  In-place updates are noticed through the
-    tensor version counter; the image is dropped with the tensor."""
+    """Declare `w` an inference-time constant (a layer's effective weight): tapconv() then keeps its pre-split images
+    (bcos_split_weights / bcos_split_weights_f16x2) next to it.  In-place updates are noticed through the tensor version
+    counter; the images are dropped with the tensor."""
     w._bcos_static = True
     return w
 
@@ -76,20 +76,121 @@ def split_weights(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _presplit_of(wt: torch.Tensor):
-    if not getattr(wt, "_bcos_static", False) or _NO_PRESPLIT or _l.get_contraction_mode() != "bf16x3":
-        return None
-    cached = getattr(wt, "_bcos_wt3", None)
+def split_weights_f16x2(w: torch.Tensor) -> torch.Tensor:
+    """Row-scaled 2-way fp16 split of w [rows, ...] in MFMA fragment order + inverse row scales
+    (include/bcos_hip.h: bcos_split_weights_f16x2)."""
+    lib = _l.load()
+    rows = w.shape[0]
+    ktot = w.numel() // rows
+    nbytes = C.c_int64(0)
+    _l.check(lib.bcos_split_weights_f16x2_bytes(rows, ktot, C.byref(nbytes)), "bcos_split_weights_f16x2_bytes")
+    out = torch.empty(nbytes.value, device=w.device, dtype=torch.uint8)
+    _l.check(lib.bcos_split_weights_f16x2(_dev(w, "split_weights_f16x2.w"), C.c_void_p(out.data_ptr()), rows, ktot, _stream()),
+             "bcos_split_weights_f16x2")
+    return out
+
+
+def _image_of(wt: torch.Tensor, attr: str, make):
+    cached = getattr(wt, attr, None)
     if cached is None or cached[0] != wt._version:
-        cached = (wt._version, split_weights(wt))
-        wt._bcos_wt3 = cached
+        cached = (wt._version, make(wt))
+        setattr(wt, attr, cached)
     return cached[1]
+
+
+# ---- per-pixel max |x| side tensors (the operand scales of the f16x2 contraction) -------------------------------------
+class AbsmaxArena:
+    """One zero-filled int32 buffer per pass instead of one memset launch per tensor: `reset()` zeroes what the previous
+    pass handed out, `take(n)` returns the next n words (torch.zeros once the arena is exhausted; it then grows)."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+        self.want = 0
+
+    def reset(self, device):
+        need = max(self.want, self.used)
+        if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < need:
+            self.buf = torch.zeros(max(need, 1 << 20), device=device, dtype=torch.int32)
+        elif self.used:
+            self.buf[:self.used].zero_()
+        self.used = self.want = 0
+
+    def take(self, n: int, device):
+        n_al = (n + 3) & ~3
+        self.want += n_al
+        if self.buf is None or self.buf.device != torch.device(device) or self.used + n_al > self.buf.numel():
+            return torch.zeros(n, device=device, dtype=torch.int32)
+        out = self.buf[self.used:self.used + n]
+        self.used += n_al
+        return out
+
+
+_ARENA: Optional[AbsmaxArena] = None
+F16X2_MIN_K = 512     # csrc/bcos_tapconv.hip: below this K a launch is HBM-bound and keeps the bf16x3 loop (no operand maxima needed)
+
+
+def set_absmax_arena(arena: Optional[AbsmaxArena]):
+    global _ARENA
+    _ARENA = arena
+
+
+def _new_absmax(n: int, device) -> torch.Tensor:
+    return _ARENA.take(n, device) if _ARENA is not None else torch.zeros(n, device=device, dtype=torch.int32)
+
+
+def _attach_absmax(t: torch.Tensor, am: torch.Tensor):
+    t._bcos_absmax = (am, t._version)
+
+
+def absmax_of(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """The valid per-pixel max |t| side tensor of `t`, or None (never produced, or `t` was modified in place since)."""
+    rec = getattr(t, "_bcos_absmax", None)
+    if rec is None or rec[1] != t._version:
+        return None
+    return rec[0]
+
+
+def drop_absmax(t: torch.Tensor):
+    if hasattr(t, "_bcos_absmax"):
+        del t._bcos_absmax
+
+
+def ensure_absmax(t: torch.Tensor) -> torch.Tensor:
+    """Attach the per-pixel max |t| of an NHWC / [rows, C] tensor made by something other than a tapconv epilogue
+    (include/bcos_hip.h: bcos_rows_absmax; one extra read of t).  No-op unless the f16x2 contraction is selected."""
+    if _l.get_contraction_mode() != "f16x2" or absmax_of(t) is not None:
+        return t
+    Cc = t.shape[-1]
+    if Cc % 4 != 0 or not t.is_contiguous():
+        return t
+    rows = t.numel() // Cc
+    am = torch.empty(rows, device=t.device, dtype=torch.int32)
+    _l.check(_l.load().bcos_rows_absmax(_dev(t, "rows_absmax.x"), C.c_void_p(am.data_ptr()), rows, Cc, Cc, _stream()),
+             "bcos_rows_absmax")
+    _attach_absmax(t, am)
+    return t
+
+
+def _out_absmax(t: Optional[torch.Tensor], pixels: int):
+    """absmax buffer of an output tensor: reused when several launches fill disjoint pixels of the same tensor object."""
+    if t is None:
+        return None
+    am = absmax_of(t)
+    if am is None or am.numel() != pixels:
+        am = _new_absmax(pixels, t.device)
+        _attach_absmax(t, am)
+    return am
 
 
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
-            gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0):
-    """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv)."""
+            gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0, contraction=None,
+            track_absmax=None, track_absmax2=None):
+    """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv_ops).
+    `contraction`: None = the library default, or 'f32' / 'bf16x3' / 'f16x2' for this call.
+    `track_absmax` / `track_absmax2`: emit the per-pixel maxima of out / out2 (default: whenever the f16x2 contraction is
+    selected; a caller that knows the reader of a tensor will not use them -- K < F16X2_MIN_K -- passes False)."""
     lib = _l.load()
     g = TapconvGeom()
     for k in ("a_pitch", "out_pitch", "norm_pitch"):
@@ -106,17 +207,36 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     e.relu = int(relu)          # 0 none, 1 ReLU, 2 GELU with constant gate
     e.b = float(b)
     e.flags = int(flags)
+    mode = contraction if contraction is not None else _l.get_contraction_mode()
+    o = _l.Operands()
+    o.a = _dev(a, "tapconv.a", contiguous=False).value
+    o.wt = _dev(wt, "tapconv.wt").value
+    o.contraction = {"f32": _l.CONTRACT_F32, "bf16x3": _l.CONTRACT_BF16X3, "f16x2": _l.CONTRACT_F16X2}[mode]
+    static = getattr(wt, "_bcos_static", False) and not _NO_PRESPLIT
+    keep = []
+    if mode == "f16x2":
+        # outputs carry their per-pixel maxima for the launch that will read them as its A operand
+        pixels = int(g.N) * int(g.OH) * int(g.OW)
+        for name, t, want in (("out_absmax", out, track_absmax), ("out2_absmax", out2, track_absmax2)):
+            am = _out_absmax(t, pixels) if (want is None or want) else None
+            if am is not None:
+                setattr(e, name, am.data_ptr())
+                keep.append(am)
+        am_a = absmax_of(a)
+        ktot = int(g.TH) * int(g.TW) * int(g.C)
+        if (am_a is not None and static and am_a.numel() == int(g.N) * int(g.H) * int(g.W)
+                and (ktot >= F16X2_MIN_K or (int(g.C) <= 16 and ktot >= 128) or contraction == "f16x2")):
+            o.a_absmax = am_a.data_ptr()
+            o.wt_f16x2 = _image_of(wt, "_bcos_wt2", split_weights_f16x2).data_ptr()
+        elif static:
+            o.wt_bf16x3 = _image_of(wt, "_bcos_wt3", split_weights).data_ptr()
+    elif mode == "bf16x3" and static:
+        o.wt_bf16x3 = _image_of(wt, "_bcos_wt3", split_weights).data_ptr()
     timing = KERNEL_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    wt3 = _presplit_of(wt)          # before the timing events: a first-use split is not part of the launch
-    if timing is not None:
         ev0.record()
-    if wt3 is not None:
-        code = lib.bcos_tapconv_presplit(_dev(a, "tapconv.a", contiguous=False), _dev(wt, "tapconv.wt"),
-                                         C.c_void_p(wt3.data_ptr()), C.byref(g), C.byref(e), _stream())
-    else:
-        code = lib.bcos_tapconv(_dev(a, "tapconv.a", contiguous=False), _dev(wt, "tapconv.wt"), C.byref(g), C.byref(e), _stream())
+    code = lib.bcos_tapconv_ops(C.byref(o), C.byref(g), C.byref(e), _stream())
     if timing is not None:
         ev1.record()
         timing.append((ev0, ev1))
@@ -160,7 +280,7 @@ def fwd_geom(N, H, W, Cin, Cout, kh, kw, sh, sw, ph, pw, dh=1, dw=1):
 
 def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=None, b=2.0, mode=BCOS_CONV_EPS,
                ch_scale=None, ch_shift=None, addend=None, relu=False, relu_gate=None, want_scale=False,
-               want_norm=False, out=None, scale_out=None, flags=0):
+               want_norm=False, out=None, scale_out=None, flags=0, track_absmax=None):
     """Fused B-cos convolution.  x [N,H,W,Cin], w [Cout,kh,kw,Cin] -> y [N,Ho,Wo,Cout] (+ scale, norm)."""
     N, H, W, Cin = x.shape
     Cout, kh, kw, Cin_w = w.shape
@@ -175,7 +295,8 @@ def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=Non
     if float(b) == 1.0:
         mode = BCOS_NONE
     tapconv(x, w, g, out=out, scale_out=scale_out, norm_out=norm, bias=bias, ch_scale=ch_scale,
-            ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu, relu_gate=relu_gate, flags=flags)
+            ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu, relu_gate=relu_gate, flags=flags,
+            track_absmax=track_absmax)
     return out, scale_out, norm
 
 
@@ -256,6 +377,7 @@ class DgradPlan:
         """glin [N,Ho,Wo,Cout] -> gx [N,H,W,Cin]; **epi are tapconv epilogue tensors indexed like gx.
         `out` may be wider than Cin (padded channel pitch); only the first Cin channels are written."""
         N, Ho, Wo, Cout = glin.shape
+        track = {k: epi.pop(k) for k in ("track_absmax", "track_absmax2") if k in epi}
         epi = {k: v for k, v in epi.items() if v is not None}
         zero_filled = False
         if out is None:
@@ -294,12 +416,13 @@ class DgradPlan:
             g = dict(N=N, H=Ho, W=Wo, C=Cout, P=P, Q=Q, in_sh=1, in_sw=1, dh0=dh0, dw0=dw0, dstep_h=step_h,
                      dstep_w=step_w, TH=TH, TW=TW, OH=H, OW=W, out_sh=sh, out_sw=sw, out_h0=rh, out_w0=rw,
                      Cout=self.Cin, out_pitch=pitch)
-            tapconv(glin, wt, g, out=out, **epi)
+            tapconv(glin, wt, g, out=out, **epi, **track)
         return out
 
     def _empty_class(self, out, N, H, W, rh, rw, P, Q, epi):
         sh, sw = self.stride
         view = out[:, rh::sh, rw::sw, :self.Cin]
+        drop_absmax(out)          # these pixels are filled outside the kernels: no per-pixel maxima for `out`
         addend, mul = epi.get("addend"), epi.get("mul")
         if addend is None:
             view.zero_()
@@ -466,6 +589,7 @@ def gelu_gate(x, want_gate=False, out=None):
 def add_rows_bcast(x, pe):
     lib = _l.load()
     _l.check(lib.bcos_add_rows_bcast(_dev(x, "x"), _dev(pe, "pe"), x.numel(), pe.numel(), _stream()), "bcos_add_rows_bcast")
+    drop_absmax(x)              # modified in place by a kernel: the recorded per-pixel maxima no longer bound it
     return x
 
 

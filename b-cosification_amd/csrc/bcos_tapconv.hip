@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
+#include <type_traits>
 #include "bcos_hip.h"
 #include "bcos_internal.h"
 
@@ -34,12 +36,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-int g_contraction_mode = 1;   // process-wide: 0 = v_mfma_f32_32x32x2_f32, 1 (default) = 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way splits
+// process-wide DEFAULT for calls that do not choose (bcos_operands.contraction == 0): 0 = v_mfma_f32_32x32x2_f32,
+// 1 = 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way splits, 2 (default) = 3 x v_mfma_f32_32x32x16_f16 on scaled 2-way splits
+// where the call provides what that needs (a_absmax + wt_f16x2), else 1
+std::atomic<int> g_contraction_mode{2};
 
 constexpr int BK = 32;            // K floats per step
 constexpr int LDS_LD = BK + 4;    // padded LDS row (floats): 144 B, 16 rows hit 16 distinct 16-B slots
 constexpr int NTHREADS = 256;
 constexpr int NXCD = 8;
+constexpr int EPI_ROWS = 128;     // rows of a tile drained per epilogue part (LDS transpose buffer = EPI_ROWS x 132 floats)
 
 struct KArgs {
     const float* a;
@@ -58,19 +64,53 @@ struct KArgs {
     const void* wt3;              // optional pre-split weights in MFMA fragment order (bcos_split_weights), else NULL
     unsigned wt3_bytes;
     unsigned a_bytes, wt_bytes;   // operand sizes for the buffer descriptors of the split-bf16 path (< 2 GiB there)
+    const unsigned* a_absmax;     // split-f16 path: per-pixel max |A| bit patterns (the operand scale source)
+    unsigned absmax_bytes;
+    const void* wt2;              // split-f16 path: pre-split, pre-scaled weights in MFMA fragment order (bcos_split_weights_f16x2)
+    unsigned wt2_bytes;
+    const float* wt2_cinv;        // ... their inverse column scales [padded Cout]
+    int h2;          // contraction on split-f16 MFMA (see tile_body_h2)
     int x3;          // contraction on split-bf16 MFMA (see tile_body_x3) instead of fp32 MFMA
     int uniform_tap; // C % 32 == 0: every K-step lies inside one tap
     int vec_ok;     // every per-element epilogue tensor is 16-byte addressable (pitch % 4 == 0, aligned bases)
 };
 
-// Fused epilogue of one tile (include/bcos_hip.h: bcos_epilogue), shared by the fp32 and the split-bf16 main loops.
+// max over groups of G consecutive lanes (G = 8, 16, 32; groups aligned to G) on the vector ALU (DPP), no LDS traffic.
+// After the call the lanes with (lane % G) == group_max_lane<G>() hold the group's max.
+template <int G>
+__device__ __forceinline__ unsigned group_max_u32(unsigned v) {
+    static_assert(G == 8 || G == 16 || G == 32, "group size");
+    auto dpp = [](unsigned x, auto ctrl) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, decltype(ctrl)::value, 0xF, 0xF, false); };
+    v = max(v, dpp(v, std::integral_constant<int, 0xB1>{}));       // quad_perm [1,0,3,2]
+    v = max(v, dpp(v, std::integral_constant<int, 0x4E>{}));       // quad_perm [2,3,0,1]
+    v = max(v, dpp(v, std::integral_constant<int, 0x141>{}));      // row_half_mirror: 8 lanes agree
+    if (G >= 16) v = max(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror: 16 lanes agree
+    if (G == 32)                                                    // row_bcast15 into rows 1 and 3: lanes 16..31 of each half
+        v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));
+    return v;
+}
+template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
+
+// Fused epilogue of one tile (include/bcos_hip.h: bcos_epilogue), shared by the fp32, split-bf16 and split-f16 main loops.
 // `ss` = per-lane partial row sums in MFMA fragment layout, or `ROWSS` = partial row sums in staging layout.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+// SCALED (split-f16 loop): accumulators carry the power-of-two operand scales; `AINV` (staging layout) holds the inverse
+// row scales, p.wt2_cinv the inverse column scales.
+// Tiles larger than 128 x 128 are drained in 128 x 128 parts (one part = the accumulators of two of the four waves) so
+// that the LDS transpose buffer stays at 66 KB and two workgroups fit a CU.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED>
 __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
-                                              const float* ss, const float* ROWSS, const int m0, const int n0,
+                                              const float* ss, const float* ROWSS, const float* AINV, const int m0, const int n0,
                                               const int tile_n) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
+    // part (pm, pn) = accumulator tiles i in [pm*TM/PM, ...), j in [pn*TN/PN, ...) of EVERY wave, so each wave retires half
+    // of its accumulator registers per part; local row l of a part is tile row (l / HM) * WM + pm * HM + l % HM
+    constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
+    constexpr int PN = BN > 128 ? BN / 128 : 1;                                   // parts
+    constexpr int SBM = BM / PM, SBN = BN / PN;                                   // part size
+    constexpr int HM = WM / PM, HN = WN / PN;                                     // rows / columns of one wave per part
+    constexpr int TMP = TM / PM, TNP = TN / PN;
+    static_assert(TM % PM == 0 && TN % PN == 0 && HN % 4 == 0, "parts split the wave tile evenly");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -78,28 +118,19 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
     const bcos_tapconv_geom& g = p.g;
     // ---- epilogue ---------------------------------------------------------------------------------
     // (all waves are past the last barrier: the staging buffers are free)
-    // 1. accumulators -> LDS tile sC[BM][BN+4] (MFMA layout: lane = column, 16 rows per lane);
+    // 1. accumulators -> LDS tile sC[SBM][SBN+4] (MFMA layout: lane = column, 16 rows per lane);
     // 2. every thread then owns 16-byte column chunks of whole rows: wave-wide accesses are 2..8 full rows of
-    //    BN*4 contiguous bytes, all epilogue tensors move as dwordx4, and the loads of a group of EPI_G chunks are
+    //    SBN*4 contiguous bytes, all epilogue tensors move as dwordx4, and the loads of a group of EPI_G chunks are
     //    issued together before any of them is consumed (the streaming layers 64<->256 @56^2 are HBM-bound here).
-    constexpr int LDC = BN + 4;
+    constexpr int LDC = SBN + 4;
     float* sC = smem;
-    int64_t* sPix = reinterpret_cast<int64_t*>(smem + BM * LDC);   // [BM] output pixel index or -1
+    int64_t* sPix = reinterpret_cast<int64_t*>(smem + SBM * LDC);  // [BM] output pixel index or -1
     float* sNorm = reinterpret_cast<float*>(sPix + BM);            // [BM] patch norm
     float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
+    float* sAinv = sRinv + BM;                                     // [BM] inverse operand scale of the row (SCALED)
     const bcos_epilogue& e = p.e;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int colt = wave_n * WN + j * 32 + (lane & 31);
-                sC[row * LDC + colt] = acc[i][j][r];
-            }
-    if (tid < BM) {
-        const int m = m0 + tid;
+    for (int r = tid; r < BM; r += NTHREADS) {
+        const int m = m0 + r;
         int64_t pix = -1;
         if (m < p.M) {
             const int n = m / p.PQ;
@@ -108,7 +139,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
             const int jj = rem - i * g.Q;
             pix = ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
         }
-        sPix[tid] = pix;
+        sPix[r] = pix;
     }
     if (NORM && ROWSS == nullptr) {
         // row sums of squares in MFMA fragment layout (fp32 kernel): lane (row, k-half), two halves per row
@@ -123,7 +154,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
             }
         }
     } else if (NORM) {
-        // row sums of squares in staging layout (split kernel): thread (r0 + 64 j, chunk), 4 chunk-lanes per row
+        // row sums of squares in staging layout (split kernels): thread (r0 + 64 j, chunk), 4 chunk-lanes per row
 #pragma unroll
         for (int j = 0; j < BM / 64; ++j) {
             float t = ROWSS[j];
@@ -137,140 +168,200 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
             }
         }
     }
-    __syncthreads();
-    if (NORM && e.norm_out != nullptr && tile_n == 0 && tid < BM) {
-        const int64_t pix = sPix[tid];
-        if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[tid];
+    if (SCALED) {
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j)
+            if ((tid & 3) == 0) sAinv[(tid >> 2) + 64 * j] = AINV[j];
     }
 
     const bool b_is_2 = e.b == 2.0f && !(e.flags & BCOS_EPI_FORCE_POW);
     const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
     const bool gate_lsb = (e.flags & BCOS_EPI_SCALE_GATE_LSB) != 0;
     const bool gate_mul = (e.flags & BCOS_EPI_GATE2_FROM_MUL) != 0 && e.mul != nullptr;
+    const bool want_max = e.out_absmax != nullptr || e.out2_absmax != nullptr;
     const float bm1 = e.b - 1.0f;
     const int Cout = g.Cout;
-    constexpr int CPR = BN / 4;              // 16-byte chunks per tile row
+    constexpr int CPR = SBN / 4;             // 16-byte chunks per part row
     constexpr int RPP = NTHREADS / CPR;      // rows per pass
-    constexpr int PASSES = BM / RPP;
+    constexpr int PASSES = SBM / RPP;
     constexpr int EPI_G = 4;                 // chunks whose loads are in flight together
     static_assert(PASSES % EPI_G == 0, "epilogue grouping");
     const int cq = tid % CPR;
     const int rbase = tid / CPR;
-    const int col = n0 + cq * 4;
-    const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = col + q < Cout ? col + q : 0;
-        if (e.bias) bias4[q] = e.bias[c];
-        if (e.ch_scale) csc4[q] = e.ch_scale[c];
-        if (e.ch_shift) csh4[q] = e.ch_shift[c];
-    }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    if (vec) {
-#pragma unroll 1
-        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
-            f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
-            int64_t idx[EPI_G];
-            bool ok[EPI_G];
-            float rinv[EPI_G], nrm[EPI_G];
 #pragma unroll
-            for (int u = 0; u < EPI_G; ++u) {
-                const int row = rbase + (p0 + u) * RPP;
-                const int64_t pix = sPix[row];
-                ok[u] = pix >= 0;
-                idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
-                v[u] = *reinterpret_cast<const f32x4*>(sC + row * LDC + cq * 4);
-                rinv[u] = NORM ? sRinv[row] : 1.f;
-                nrm[u] = NORM ? sNorm[row] : 1.f;
-                ad[u] = e.addend ? *reinterpret_cast<const f32x4*>(e.addend + idx[u]) : zero4;
-                rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
-                m1[u] = e.mul ? *reinterpret_cast<const f32x4*>(e.mul + idx[u]) : zero4;
-                m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
-                g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
-            }
+    for (int part = 0; part < PM * PN; ++part) {
+        const int pm = part / PN, pn = part - pm * PN;
+        if (part > 0) __syncthreads();           // the previous part's sC has been consumed
 #pragma unroll
-            for (int u = 0; u < EPI_G; ++u) {
-                f32x4 val = v[u] + bias4;
-                f32x4 s = {1.f, 1.f, 1.f, 1.f};
-                if (NORM && !norm_only) {
+        for (int ii = 0; ii < TMP; ++ii)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        s[q] = b_is_2 ? fabsf(val[q]) * rinv[u] : powf(fabsf(val[q] / nrm[u]) + 1e-6f, bm1);
-                    val *= s;
+            for (int jj = 0; jj < TNP; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave_m * HM + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int colt = wave_n * HN + jj * 32 + (lane & 31);
+                    sC[row * LDC + colt] = acc[pm * TMP + ii][pn * TNP + jj][r];
                 }
-                val = val * csc4 + csh4;
-                s *= csc4;
-                if (e.addend) val += ad[u];
-                if (e.relu == 1) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
-                        s[q] = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s[q]) | 1u) : s[q]) : 0.f;
-                        val[q] = open_gate ? val[q] : 0.f;
-                    }
-                } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
-                        s[q] *= gate;
-                        val[q] *= gate;
-                    }
-                }
-                if (ok[u]) {
-                    if (e.out) *reinterpret_cast<f32x4*>(e.out + idx[u]) = e.mul ? val * m1[u] : val;
-                    if (e.out2) {
-                        f32x4 o2 = val;
-                        if (e.mul2) o2 *= m2[u];
-                        if (gate_mul) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) o2[q] = (__float_as_uint(m1[u][q]) & 1u) ? o2[q] : 0.f;
-                        } else if (e.gate2) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
-                        }
-                        *reinterpret_cast<f32x4*>(e.out2 + idx[u]) = o2;
-                    }
-                    if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + idx[u]) = s;
-                }
+        __syncthreads();                         // (part 0: also publishes the row metadata written above)
+        if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
+            for (int r = tid; r < BM; r += NTHREADS) {
+                const int64_t pix = sPix[r];
+                if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[r];
             }
         }
-    } else if (col < Cout) {
-        // ragged right edge (Cout % 4 != 0) or unaligned tensors: same math, element by element
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int row = rbase + ps * RPP;
-            const int64_t pix = sPix[row];
-            if (pix < 0) continue;
-            for (int q = 0; q < 4 && col + q < Cout; ++q) {
-                const int64_t idx = pix * g.out_pitch + col + q;
-                float v = sC[row * LDC + cq * 4 + q] + bias4[q];
-                float s = 1.f;
-                if (NORM && !norm_only) {
-                    s = b_is_2 ? fabsf(v) * sRinv[row] : powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
-                    v *= s;
+        const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
+        const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = col + q < Cout ? col + q : 0;
+            if (e.bias) bias4[q] = e.bias[c];
+            if (e.ch_scale) csc4[q] = e.ch_scale[c];
+            if (e.ch_shift) csh4[q] = e.ch_shift[c];
+            if (SCALED) cinv4[q] = p.wt2_cinv[c];
+        }
+#pragma unroll 1
+        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
+            unsigned mx1[EPI_G], mx2[EPI_G];
+            int64_t pixs[EPI_G];
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                const int lrow = rbase + (p0 + u) * RPP;
+                mx1[u] = 0u; mx2[u] = 0u;
+                pixs[u] = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
+            }
+            if (vec) {
+                f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
+                int64_t idx[EPI_G];
+                bool ok[EPI_G];
+                float rinv[EPI_G], nrm[EPI_G];
+#pragma unroll
+                for (int u = 0; u < EPI_G; ++u) {
+                    const int lrow = rbase + (p0 + u) * RPP;
+                    const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
+                    const int64_t pix = pixs[u];
+                    ok[u] = pix >= 0;
+                    idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
+                    v[u] = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
+                    if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
+                    rinv[u] = NORM ? sRinv[row] : 1.f;
+                    nrm[u] = NORM ? sNorm[row] : 1.f;
+                    ad[u] = e.addend ? *reinterpret_cast<const f32x4*>(e.addend + idx[u]) : zero4;
+                    rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
+                    m1[u] = e.mul ? *reinterpret_cast<const f32x4*>(e.mul + idx[u]) : zero4;
+                    m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
+                    g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
                 }
-                v = v * csc4[q] + csh4[q];
-                s *= csc4[q];
-                if (e.addend) v += e.addend[idx];
-                if (e.relu == 1) {
-                    const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
-                    s = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s) | 1u) : s) : 0.f;
-                    v = open_gate ? v : 0.f;
-                } else if (e.relu == 2) {
-                    const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
-                    s *= gate;
-                    v *= gate;
+#pragma unroll
+                for (int u = 0; u < EPI_G; ++u) {
+                    f32x4 val = v[u] + bias4;
+                    f32x4 s = {1.f, 1.f, 1.f, 1.f};
+                    if (NORM && !norm_only) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            s[q] = b_is_2 ? fabsf(val[q]) * rinv[u] : powf(fabsf(val[q] / nrm[u]) + 1e-6f, bm1);
+                        val *= s;
+                    }
+                    val = val * csc4 + csh4;
+                    s *= csc4;
+                    if (e.addend) val += ad[u];
+                    if (e.relu == 1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
+                            s[q] = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s[q]) | 1u) : s[q]) : 0.f;
+                            val[q] = open_gate ? val[q] : 0.f;
+                        }
+                    } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
+                            s[q] *= gate;
+                            val[q] *= gate;
+                        }
+                    }
+                    if (ok[u]) {
+                        const f32x4 o1 = e.mul ? val * m1[u] : val;
+                        if (e.out) *reinterpret_cast<f32x4*>(e.out + idx[u]) = o1;
+                        if (want_max)
+                            mx1[u] = max(max(__float_as_uint(o1[0]) & 0x7fffffffu, __float_as_uint(o1[1]) & 0x7fffffffu),
+                                         max(__float_as_uint(o1[2]) & 0x7fffffffu, __float_as_uint(o1[3]) & 0x7fffffffu));
+                        if (e.out2) {
+                            f32x4 o2 = val;
+                            if (e.mul2) o2 *= m2[u];
+                            if (gate_mul) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) o2[q] = (__float_as_uint(m1[u][q]) & 1u) ? o2[q] : 0.f;
+                            } else if (e.gate2) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
+                            }
+                            *reinterpret_cast<f32x4*>(e.out2 + idx[u]) = o2;
+                            if (want_max)
+                                mx2[u] = max(max(__float_as_uint(o2[0]) & 0x7fffffffu, __float_as_uint(o2[1]) & 0x7fffffffu),
+                                             max(__float_as_uint(o2[2]) & 0x7fffffffu, __float_as_uint(o2[3]) & 0x7fffffffu));
+                        }
+                        if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + idx[u]) = s;
+                    }
                 }
-                if (e.out) e.out[idx] = e.mul ? v * e.mul[idx] : v;
-                if (e.out2) {
-                    float o2 = v;
-                    if (e.mul2) o2 *= e.mul2[idx];
-                    if (gate_mul) o2 = (__float_as_uint(e.mul[idx]) & 1u) ? o2 : 0.f;
-                    else if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
-                    e.out2[idx] = o2;
+            } else if (col < Cout) {
+                // ragged right edge (Cout % 4 != 0) or unaligned tensors: same math, element by element
+                for (int u = 0; u < EPI_G; ++u) {
+                    const int lrow = rbase + (p0 + u) * RPP;
+                    const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
+                    const int64_t pix = pixs[u];
+                    if (pix < 0) continue;
+                    for (int q = 0; q < 4 && col + q < Cout; ++q) {
+                        const int64_t idx = pix * g.out_pitch + col + q;
+                        float v = sC[lrow * LDC + cq * 4 + q];
+                        if (SCALED) v = v * sAinv[row] * cinv4[q];
+                        v += bias4[q];
+                        float s = 1.f;
+                        if (NORM && !norm_only) {
+                            s = b_is_2 ? fabsf(v) * sRinv[row] : powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
+                            v *= s;
+                        }
+                        v = v * csc4[q] + csh4[q];
+                        s *= csc4[q];
+                        if (e.addend) v += e.addend[idx];
+                        if (e.relu == 1) {
+                            const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
+                            s = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s) | 1u) : s) : 0.f;
+                            v = open_gate ? v : 0.f;
+                        } else if (e.relu == 2) {
+                            const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
+                            s *= gate;
+                            v *= gate;
+                        }
+                        const float o1 = e.mul ? v * e.mul[idx] : v;
+                        if (e.out) e.out[idx] = o1;
+                        mx1[u] = max(mx1[u], __float_as_uint(o1) & 0x7fffffffu);
+                        if (e.out2) {
+                            float o2 = v;
+                            if (e.mul2) o2 *= e.mul2[idx];
+                            if (gate_mul) o2 = (__float_as_uint(e.mul[idx]) & 1u) ? o2 : 0.f;
+                            else if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
+                            e.out2[idx] = o2;
+                            mx2[u] = max(mx2[u], __float_as_uint(o2) & 0x7fffffffu);
+                        }
+                        if (e.scale_out) e.scale_out[idx] = s;
+                    }
                 }
-                if (e.scale_out) e.scale_out[idx] = s;
+            }
+            if (want_max) {
+                // per-pixel max |value| of what this tile wrote (bit pattern: monotonic for non-negative floats), for the
+                // operand scaling of the split-f16 contraction in the layer that reads the tensor; all lanes are active here
+#pragma unroll
+                for (int u = 0; u < EPI_G; ++u) {
+                    unsigned a1 = e.out_absmax ? group_max_u32<CPR>(mx1[u]) : 0u;
+                    unsigned a2 = e.out2_absmax ? group_max_u32<CPR>(mx2[u]) : 0u;
+                    if (cq == group_max_lane<CPR>() && pixs[u] >= 0) {
+                        if (e.out_absmax && a1) atomicMax(e.out_absmax + pixs[u], a1);
+                        if (e.out2_absmax && a2) atomicMax(e.out2_absmax + pixs[u], a2);
+                    }
+                }
             }
         }
     }
@@ -440,7 +531,7 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
         __syncthreads();
     }
 
-    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, acc, ss, nullptr, m0, n0, tile_n);
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, acc, ss, nullptr, nullptr, m0, n0, tile_n);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -704,7 +795,318 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     if (ks < nk) tail_step(ks, ra1, rb1, ra0, rb0, bf0, bf1);
     if (ks + 1 < nk) tail_step(ks + 1, ra0, rb0, ra1, rb1, bf1, bf0);
     if (ks + 2 < nk) tail_step(ks + 2, ra1, rb1, ra0, rb0, bf0, bf1);
-    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, acc, nullptr, NORM ? rowss : nullptr, m0, n0, tile_n);
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, acc, nullptr, NORM ? rowss : nullptr, nullptr, m0, n0, tile_n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-f16 main loop ("f16x2"): every fp32 operand x is written as x * 2^e = h + l with h, l fp16 (round to nearest:
+// |x 2^e - h - l| <= 2^-22 |x|, fp32-rounding class) and a*b is evaluated as  l_a h_b + h_a l_b + h_a h_b  on
+// v_mfma_f32_32x32x16_f16: 3 matrix instructions per 16 k instead of 6 (bf16x3) or 8 x 64 cycles (fp32); products of fp16
+// numbers are exact in fp32, accumulation is fp32, the dropped l_a l_b term is <= 2^-22 |a b|.
+// fp16 has a 5-bit exponent, so the operands are brought into range by POWER-OF-TWO scales that are exact to apply and
+// to undo: one per GEMM row (from the per-pixel max |A| side tensor `a_absmax` that the producer of A emitted: the row's
+// max over its taps has its leading bit moved to 2^14) and one per weight row (static, stored with the pre-split image).
+// Elements within 2^-17 of their row's max keep full precision; below that the absolute error stays <= 2^-40 of the max.
+// Structure: BM x BN x 16 steps through two LDS buffers as in tile_body_x3, but
+//   * the weights arrive pre-split in MFMA fragment order ([32-col tile][16-k step][plane][lane][8 f16], 1 KB blocks) and
+//     are copied verbatim into LDS by whole wavefronts (coalesced 16-byte loads, conflict-free 16-byte stores and fragment
+//     reads): the four waves share one copy instead of each fetching its own fragments through the texture path;
+//   * the activation split costs ~4 VALU per element (scale, 2 converts, 1 mixed FMA) instead of ~9;
+//   * tiles of 256 x 128 / 128 x 256 (8 accumulator tiles per wave) halve the bytes staged per MFMA.
+#ifndef H2_PIPE_SMALL
+#define H2_PIPE_SMALL 2           // pipeline of the <= 4-accumulator tiles: 2 = one 16-k step per barrier, 3 = two
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int PIPE = ((BM / WAVES_M) * (BN / WAVES_N) <= 64 * 64 ? H2_PIPE_SMALL : 1)>
+__device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM / 64;                   // float4 loads per thread per 16-k step
+    constexpr int NBLK = (BN / 32) * 2;             // 1-KB fragment blocks of B per step: (32-column tile, plane)
+    constexpr int B_LD = (NBLK + 3) / 4;            // blocks per wave
+    char* lds = reinterpret_cast<char*>(smem);
+    constexpr int A_SPLIT = BM * X3_ROW, B_BASE = 2 * A_SPLIT;
+    constexpr int BUF = B_BASE + NBLK * 1024;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int chunk = tid & 3;       // 16-byte chunk (4 k) within the 16-k step
+    const int r0 = tid >> 2;         // staging row 0..63 (+64 per pass)
+    const bcos_tapconv_geom& g = p.g;
+    const int H = g.H, W = g.W;
+    const int a_pitch = g.a_pitch;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt2), 0, p.wt2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.a_absmax), 0, p.absmax_bytes, 0x00020000);
+    unsigned a_nbase[A_LD];          // byte offset of the row's image (+ this lane's 16-byte chunk)
+    int a_ih0[A_LD], a_iw0[A_LD];
+    float a_scale[A_LD], a_inv[A_LD];
+    {
+        // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 chunk-lanes of a row share the taps
+        unsigned rmax[A_LD];
+        int pix0[A_LD];
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int m = m0 + r0 + 64 * j;
+            rmax[j] = 0u;
+            if (m < p.M) {
+                const int n = m / p.PQ;
+                const int rem = m - n * p.PQ;
+                const int i = rem / g.Q;
+                const int jj = rem - i * g.Q;
+                a_nbase[j] = ((unsigned)n * H * W * a_pitch + chunk * 4) * 4u;
+                pix0[j] = n * H * W;
+                a_ih0[j] = i * g.in_sh + g.dh0;
+                a_iw0[j] = jj * g.in_sw + g.dw0;
+            } else {
+                a_nbase[j] = 0;
+                pix0[j] = 0;
+                a_ih0[j] = -(1 << 28);
+                a_iw0[j] = -(1 << 28);
+            }
+        }
+        const int ntaps = g.TH * g.TW;
+        for (int t = chunk; t < ntaps; t += 4) {
+            const int th = t / g.TW, tw = t - th * g.TW;
+            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)(pix0[j] + ih * W + iw) * 4u : OOB, 0, 0);
+                rmax[j] = max(rmax[j], v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            unsigned v = rmax[j];
+            v = max(v, (unsigned)__shfl_xor((int)v, 1));
+            v = max(v, (unsigned)__shfl_xor((int)v, 2));
+            unsigned E = v >> 23;                  // biased exponent of the row max (the bit patterns carry no sign)
+            E = E < 15u ? 15u : E;
+            a_scale[j] = __uint_as_float((268u - E) << 23);     // max * scale in [2^14, 2^15)
+            a_inv[j] = __uint_as_float((E - 14u) << 23);
+        }
+    }
+
+    const int nk = (p.nchunks + 3) / 4;
+    const bool uniform = (g.C % X3_BK) == 0;
+    // C = 4 or 8 (the 6 -> 8 channel network input): a 16-k step spans 16 / C taps and every lane walks its own tap
+    // coordinates incrementally instead of dividing its chunk index by runtime values each step
+    const bool small_c = g.C == 4 || g.C == 8;
+    const int tps = small_c ? 16 / g.C : 1;                                // taps per step
+    const int l_cc = small_c ? (g.C == 8 ? (chunk & 1) : 0) : 0;            // this lane's chunk inside its tap
+    int l_th = 0, l_tw = 0;                                                 // this lane's tap (small_c)
+    if (small_c) {
+        const int sub = g.C == 8 ? (chunk >> 1) : chunk;
+        l_th = sub / g.TW;
+        l_tw = sub - l_th * g.TW;
+    }
+    int s_cc = 0, s_th = 0, s_tw = 0;
+    unsigned a_cur[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) a_cur[j] = OOB;
+    auto ldq = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+    };
+    // B: wave w copies blocks w, w + 4, ... of the step (block = (32-column tile c, plane sp) = 1 KB, lane-linear)
+    const int b_tile0 = n0 >> 5;
+    auto load_step = [&](int ks, f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
+        if (uniform) {
+            if (s_cc == 0) {
+                const int dh = s_th * g.dstep_h, dw = s_tw * g.dstep_w;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) {
+                    const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    a_cur[j] = ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch) * 4u : OOB;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) ra[j] = ldq(a_rsrc, a_cur[j], s_cc * 16);
+            s_cc += 4;
+            if (s_cc == p.cpt) {
+                s_cc = 0;
+                if (++s_tw == g.TW) { s_tw = 0; ++s_th; }
+            }
+        } else if (small_c) {
+            const bool kvalid = l_th < g.TH;
+            const int dh = l_th * g.dstep_h, dw = l_tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                ra[j] = ldq(a_rsrc, ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch + (l_cc - chunk) * 4) * 4u : OOB, 0);
+            }
+            l_tw += tps;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (l_tw >= g.TW) { l_tw -= g.TW; ++l_th; }
+        } else {
+            const int q = ks * 4 + chunk;
+            const bool kvalid = q < p.nchunks;
+            const int tap = q / p.cpt;
+            const int cc = q - tap * p.cpt;
+            const int th = tap / g.TW;
+            const int tw = tap - th * g.TW;
+            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                ra[j] = ldq(a_rsrc, ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch + (cc - chunk) * 4) * 4u : OOB, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int blk = wave + 4 * j;
+            if (NBLK % 4 == 0 || blk < NBLK) {
+                const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
+                rb[j] = ldq(b_rsrc, lane * 16, soff);
+            }
+        }
+    };
+    float rowss[BM / 32];
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) rowss[j] = 0.f;
+    auto store_step = [&](const f32x4 (&ra)[A_LD], const f32x4 (&rb)[B_LD], int buf) {
+        char* base = lds + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            if (NORM) {
+                rowss[j] = fmaf(ra[j][0], ra[j][0], rowss[j]);
+                rowss[j] = fmaf(ra[j][1], ra[j][1], rowss[j]);
+                rowss[j] = fmaf(ra[j][2], ra[j][2], rowss[j]);
+                rowss[j] = fmaf(ra[j][3], ra[j][3], rowss[j]);
+            }
+            f16x4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xs = ra[j][q] * a_scale[j];
+                const _Float16 hh = (_Float16)xs;
+                h[q] = hh;
+                l[q] = (_Float16)(xs - (float)hh);
+            }
+            char* dst = base + (r0 + 64 * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4));
+            *reinterpret_cast<f16x4*>(dst) = h;
+            *reinterpret_cast<f16x4*>(dst + A_SPLIT) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int blk = wave + 4 * j;
+            if (NBLK % 4 == 0 || blk < NBLK) *reinterpret_cast<f32x4*>(base + B_BASE + blk * 1024 + lane * 16) = rb[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    const int frag_off = (frag_half * 16) ^ (((frag_row >> 3) & 1) << 4);
+    const int a_frag = (wave_m * WM + frag_row) * X3_ROW + frag_off;
+    const int b_frag = B_BASE + (wave_n * TN) * 2048 + lane * 16;
+
+    auto mma_step = [&](int buf) {
+        const char* base = lds + buf * BUF;
+        f16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[sp][i] = *reinterpret_cast<const f16x8*>(base + a_frag + sp * A_SPLIT + i * 32 * X3_ROW);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[sp][j] = *reinterpret_cast<const f16x8*>(base + b_frag + j * 2048 + sp * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    if constexpr (PIPE == 2) {
+        // same three-stage pipeline as tile_body_x3: loads of step ks+2 in flight, step ks+1 converted and written to the
+        // other LDS buffer next to the MFMAs of step ks; two steps per trip so the register sets swap roles without copies
+        f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
+        load_step(0, ra0, rb0);
+        store_step(ra0, rb0, 0);
+        if (nk > 1) load_step(1, ra0, rb0);
+        __syncthreads();
+        int ks = 0;
+        for (; ks + 3 < nk; ks += 2) {
+            load_step(ks + 2, ra1, rb1);
+            mma_step(0);
+            store_step(ra0, rb0, 1);
+            __syncthreads();
+            load_step(ks + 3, ra0, rb0);
+            mma_step(1);
+            store_step(ra1, rb1, 0);
+            __syncthreads();
+        }
+        auto tail_step = [&](int k, f32x4 (&la)[A_LD], f32x4 (&lb)[B_LD], const f32x4 (&sa)[A_LD], const f32x4 (&sb)[B_LD]) {
+            if (k + 2 < nk) load_step(k + 2, la, lb);
+            mma_step(k & 1);
+            if (k + 1 < nk) store_step(sa, sb, (k + 1) & 1);
+            __syncthreads();
+        };
+        if (ks < nk) tail_step(ks, ra1, rb1, ra0, rb0);
+        if (ks + 1 < nk) tail_step(ks + 1, ra0, rb0, ra1, rb1);
+        if (ks + 2 < nk) tail_step(ks + 2, ra1, rb1, ra0, rb0);
+    } else if constexpr (PIPE == 3) {
+        // two 16-k sub-steps per barrier (four LDS sub-buffers): the loads of macro-step m+1 are issued before the 24 MFMAs
+        // of macro-step m and written to the other buffer pair after them -- the same latency budget as the pipeline above
+        // with half the barriers
+        f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
+        const int nm = (nk + 1) / 2;
+        load_step(0, ra0, rb0);
+        if (nk > 1) load_step(1, ra1, rb1);
+        store_step(ra0, rb0, 0);
+        if (nk > 1) store_step(ra1, rb1, 1);
+        __syncthreads();
+        for (int m = 0; m < nm; ++m) {
+            const int cur = (m & 1) * 2, nxt = cur ^ 2;
+            const bool n0_ = 2 * m + 2 < nk, n1_ = 2 * m + 3 < nk;
+            if (n0_) load_step(2 * m + 2, ra0, rb0);
+            if (n1_) load_step(2 * m + 3, ra1, rb1);
+            mma_step(cur);
+            if (2 * m + 1 < nk) mma_step(cur + 1);
+            if (n0_) store_step(ra0, rb0, nxt);
+            if (n1_) store_step(ra1, rb1, nxt + 1);
+            __syncthreads();
+        }
+    } else {
+        // 8-accumulator tiles leave room for ONE staging register set: the loads of step ks+2 are issued right after the
+        // set has been written to LDS (end of step ks) and have one whole step -- the co-resident workgroup's MFMAs
+        // included -- to arrive
+        f32x4 ra[A_LD], rb[B_LD];
+        load_step(0, ra, rb);
+        store_step(ra, rb, 0);
+        if (nk > 1) load_step(1, ra, rb);
+        __syncthreads();
+        for (int ks = 0; ks < nk; ++ks) {
+            mma_step(ks & 1);
+            if (ks + 1 < nk) store_step(ra, rb, (ks + 1) & 1);
+            if (ks + 2 < nk) load_step(ks + 2, ra, rb);
+            __syncthreads();
+        }
+    }
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n);
 }
 
 // XCD-aware id remap: the 8 XCDs (private L2s) each get a contiguous range of `nt` work items (bijective for any nt)
@@ -719,15 +1121,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 // dispatched in blockIdx order, so the half-height tiles fill the tail of the launch: with a few hundred equal
 // tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
 // = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights
-__global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights, 3 split-f16
+__global__ __launch_bounds__(NTHREADS, 2) void tapconv_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     if (bid < p.n_big) {
         const int tile = xcd_remap(bid, p.n_big);
         const int tile_m = tile / p.tiles_n;
         const int tile_n = tile - tile_m * p.tiles_n;
-        if constexpr (X3 == 2) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        if constexpr (X3 == 3) tile_body_h2<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        else if constexpr (X3 == 2) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, tile_m * BM, tile_n * BN, tile_n);
         else if constexpr (X3 == 1) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, tile_m * BM, tile_n * BN, tile_n);
         else tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
     } else {
@@ -738,7 +1141,8 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
             const int tile = xcd_remap(bid - p.n_big, p.n_small);
             const int tile_m = tile / p.tiles_n;
             const int tile_n = tile - tile_m * p.tiles_n;
-            if constexpr (X3 == 2) tile_body_x3<BMS, BN, WMS, WNS, NORM, true>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            if constexpr (X3 == 3) tile_body_h2<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            else if constexpr (X3 == 2) tile_body_x3<BMS, BN, WMS, WNS, NORM, true>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
             else if constexpr (X3 == 1) tile_body_x3<BMS, BN, WMS, WNS, NORM, false>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
             else tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
         }
@@ -747,9 +1151,9 @@ __global__ __launch_bounds__(NTHREADS) void tapconv_kernel(const KArgs p) {
 
 constexpr int SLOTS = 512;   // 256 CUs x 2 resident workgroups (LDS- and VGPR-limited)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
-    KArgs p = base;
+// tile counts of a launch: n_big tiles of BM rows, then n_small half-height tiles (see tapconv_kernel)
+template <int BM, int BN, int WAVES_M>
+void plan_tiles(KArgs& p) {
     p.tiles_n = (p.g.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int64_t total = (int64_t)tiles_m * p.tiles_n;
@@ -769,8 +1173,21 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     p.n_big = m_big * p.tiles_n;
     const int rows_small = p.M - p.rows_big;
     p.n_small = rows_small > 0 ? ((rows_small + BM / 2 - 1) / (BM / 2)) * p.tiles_n : 0;
+}
+
+template <int BM, int BN, int WAVES_M>
+constexpr size_t epilogue_lds() {
+    constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
+    constexpr int SBM = BM / PM, SBN = BN > 128 ? 128 : BN;
+    return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
+    KArgs p = base;
+    plan_tiles<BM, BN, WAVES_M>(p);
     size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
-    const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float) + (size_t)BM * 16;
+    const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
     if (lds_epi > lds) lds = lds_epi;
     const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
     hipError_t err;
@@ -796,10 +1213,44 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     return BCOS_OK;
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+constexpr size_t h2_staging_lds() {
+    constexpr int nbuf = ((BM / WAVES_M) * (BN / WAVES_N) <= 64 * 64 && H2_PIPE_SMALL == 3) ? 4 : 2;
+    return nbuf * ((size_t)2 * BM * X3_ROW + (size_t)(BN / 32) * 2048);
+}
+
+// split-f16 launches (their own tile configurations: only this loop is instantiated for them)
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_h2(const KArgs& base, bool norm, hipStream_t stream) {
+    KArgs p = base;
+    plan_tiles<BM, BN, WAVES_M>(p);
+    // staging buffers of the full-height body and of the half-height tail body (its own wave layout and pipeline)
+    constexpr int BMS = BM / 2, WMS = (BMS / 32 >= WAVES_M) ? WAVES_M : BMS / 32, WNS = 4 / WMS;
+    size_t lds = h2_staging_lds<BM, BN, WAVES_M, WAVES_N>();
+    if (BMS >= 32 && BN / WNS >= 32 && h2_staging_lds<BMS, BN, WMS, WNS>() > lds) lds = h2_staging_lds<BMS, BN, WMS, WNS>();
+    const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
+    if (lds_epi > lds) lds = lds_epi;
+    const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
+    static std::atomic<size_t> lds_hw[2];
+    auto launch = [&](auto k, int which) -> hipError_t {
+        hipError_t e2 = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_hw[which]);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+        return hipSuccess;
+    };
+    hipError_t err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 3>, 0)
+                          : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 3>, 1);
+    if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
+    err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);
+    return BCOS_OK;
+}
+
 }  // namespace
 
 extern "C" int bcos_set_contraction_mode(int mode) {
-    if (mode != 0 && mode != 1) return bcos_set_error(BCOS_E_INVAL, "bcos_set_contraction_mode: 0 = fp32 MFMA, 1 = split-bf16 MFMA");
+    if (mode < 0 || mode > 2)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_set_contraction_mode: 0 = fp32 MFMA, 1 = split-bf16 MFMA, 2 = split-f16 MFMA");
     g_contraction_mode = mode;
     return BCOS_OK;
 }
@@ -864,14 +1315,141 @@ extern "C" int bcos_split_weights(const float* wt, void* wt3, int rows, int Ktot
     return BCOS_OK;
 }
 
+namespace {
+
+// f16x2 image of wt [rows][Ktot]: [32-row tile][16-k step][plane h|l][lane][8 f16] (B fragments of v_mfma_f32_32x32x16_f16,
+// rows padded to a multiple of 128, k to a multiple of 16) followed by the inverse row scales float[padded rows].
+// Row r is scaled by 2^e_r so that its max |w| lands in [2^14, 2^15) before the split (exact), cinv[r] = 2^-e_r.
+__global__ __launch_bounds__(256) void weight_rowscale_kernel(const float* __restrict__ wt, float* __restrict__ cinv, int rows,
+                                                              int rows_pad, int Ktot) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows_pad) return;
+    unsigned m = 0u;
+    if (row < rows)
+        for (int k = lane; k < Ktot; k += 64) m = max(m, __float_as_uint(wt[(int64_t)row * Ktot + k]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    unsigned E = m >> 23;
+    E = E < 15u ? 15u : E;
+    if (lane == 0) cinv[row] = __uint_as_float((E - 14u) << 23);
+}
+
+__global__ __launch_bounds__(256) void split_weights_h2_kernel(const float* __restrict__ wt, uint4* __restrict__ wt2,
+                                                               const float* __restrict__ cinv, int rows, int Ktot, int nk,
+                                                               int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (tile, ks, lane)
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int64_t ts = i >> 6;
+    const int ks = (int)(ts % nk);
+    const int tile = (int)(ts / nk);
+    const int row = tile * 32 + (lane & 31);
+    const int k0 = ks * 16 + 8 * (lane >> 5);
+    const float scale = 1.0f / cinv[row];                             // exact: a power of two
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (row < rows && k0 + e < Ktot) ? wt[(int64_t)row * Ktot + k0 + e] * scale : 0.f;
+        const _Float16 hh = (_Float16)x;
+        h[e] = hh;
+        l[e] = (_Float16)(x - (float)hh);
+    }
+    uint4* dst = wt2 + (ts * 2) * 64 + lane;
+    dst[0] = __builtin_bit_cast(uint4, h);
+    dst[64] = __builtin_bit_cast(uint4, l);
+}
+
+inline int64_t h2_tiles(int rows) { return (((int64_t)rows + 127) / 128) * 4; }
+inline int64_t h2_image_bytes(int rows, int Ktot) { return h2_tiles(rows) * (((int64_t)Ktot + 15) / 16) * 2 * 1024; }
+
+}  // namespace
+
+extern "C" int bcos_split_weights_f16x2_bytes(int rows, int Ktot, int64_t* bytes) {
+    if (rows <= 0 || Ktot <= 0 || !bytes) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights_f16x2_bytes: bad argument");
+    *bytes = h2_image_bytes(rows, Ktot) + h2_tiles(rows) * 32 * 4;
+    return BCOS_OK;
+}
+
+extern "C" int bcos_split_weights_f16x2(const float* wt, void* wt2, int rows, int Ktot, void* stream) {
+    if (!wt || !wt2 || rows <= 0 || Ktot <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights_f16x2: bad argument");
+    if (reinterpret_cast<uintptr_t>(wt2) & 15) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights_f16x2: image must be 16-byte aligned");
+    const int nk = (Ktot + 15) / 16;
+    const int rows_pad = (int)h2_tiles(rows) * 32;
+    float* cinv = reinterpret_cast<float*>(static_cast<char*>(wt2) + h2_image_bytes(rows, Ktot));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(weight_rowscale_kernel, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, wt, cinv, rows, rows_pad, Ktot);
+    const int64_t total = h2_tiles(rows) * nk * 64;
+    hipLaunchKernelGGL(split_weights_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wt,
+                       reinterpret_cast<uint4*>(wt2), cinv, rows, Ktot, nk, total);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("split_weights_f16x2 launch", err);
+    return BCOS_OK;
+}
+
+// per-pixel max |x| bit patterns of an NHWC tensor (for tensors whose producer is not a tapconv epilogue)
+namespace {
+__global__ __launch_bounds__(256) void rows_absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ out, int64_t rows,
+                                                          int C, int pitch) {
+    // LPR lanes per row (power of two <= 64), float4 loads
+    int lpr = 1;
+    while (lpr < 64 && lpr * 4 < C) lpr <<= 1;
+    const int rpw = 64 / lpr;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = wave * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    unsigned m = 0u;
+    if (row < rows) {
+        const float* src = x + row * pitch;
+        for (int c = sub * 4; c < C; c += lpr * 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = max(m, __float_as_uint(v[q]) & 0x7fffffffu);
+        }
+    }
+    for (int o = lpr >> 1; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (row < rows && sub == 0) out[row] = m;
+}
+}  // namespace
+
+extern "C" int bcos_rows_absmax(const float* x, uint32_t* out, int64_t rows, int C, int pitch, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || C % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_rows_absmax: bad argument");
+    if (pitch == 0) pitch = C;
+    if (pitch % 4 != 0 || pitch < C || (reinterpret_cast<uintptr_t>(x) & 15))
+        return bcos_set_error(BCOS_E_INVAL, "bcos_rows_absmax: rows must be 16-byte addressable");
+    int lpr = 1;
+    while (lpr < 64 && lpr * 4 < C) lpr <<= 1;
+    const int64_t rows_per_block = 4 * (64 / lpr);
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, out, rows, C, pitch);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("rows_absmax launch", err);
+    return BCOS_OK;
+}
+
 extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                             const bcos_epilogue* epi, void* stream) {
-    return bcos_tapconv_presplit(a, wt, nullptr, geom, epi, stream);
+    bcos_operands o = {a, nullptr, wt, nullptr, nullptr, BCOS_CONTRACT_DEFAULT};
+    return bcos_tapconv_ops(&o, geom, epi, stream);
 }
 
 extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void* wt3, const bcos_tapconv_geom* geom,
                                      const bcos_epilogue* epi, void* stream) {
-    if (!a || !wt || !geom || !epi) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: NULL argument");
+    bcos_operands o = {a, nullptr, wt, wt3, nullptr, BCOS_CONTRACT_DEFAULT};
+    return bcos_tapconv_ops(&o, geom, epi, stream);
+}
+
+extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geom* geom, const bcos_epilogue* epi, void* stream) {
+    if (!ops || !geom || !epi) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: NULL argument");
+    const float* a = ops->a;
+    const float* wt = ops->wt;
+    const void* wt3 = ops->wt_bf16x3;
+    if (!a || !wt) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: NULL operand");
+    if (ops->contraction < 0 || ops->contraction > BCOS_CONTRACT_F16X2)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad contraction selector");
+    const int mode = ops->contraction == BCOS_CONTRACT_DEFAULT ? g_contraction_mode.load(std::memory_order_relaxed)
+                                                               : ops->contraction - 1;
     const bcos_tapconv_geom& g = *geom;
     if (g.N <= 0 || g.H <= 0 || g.W <= 0 || g.C <= 0 || g.P <= 0 || g.Q <= 0 || g.TH <= 0 || g.TW <= 0 ||
         g.Cout <= 0 || g.OH <= 0 || g.OW <= 0)
@@ -906,7 +1484,13 @@ extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void
     p.nk = (p.nchunks + 7) / 8;
     p.tiles_n = p.n_big = p.n_small = p.rows_big = 0;
     p.uniform_tap = (g.C % BK == 0) ? 1 : 0;
-    p.x3 = g_contraction_mode == 1 ? 1 : 0;
+    p.x3 = mode >= 1 ? 1 : 0;
+    p.h2 = 0;
+    p.a_absmax = nullptr;
+    p.absmax_bytes = 0;
+    p.wt2 = nullptr;
+    p.wt2_bytes = 0;
+    p.wt2_cinv = nullptr;
     {   // the split-bf16 path addresses its operands through 32-bit buffer offsets: keep each launch below 2 GiB of A
         // by splitting the batch (every tensor of the call is per-image separable); fall back to fp32 MFMA otherwise
         const int64_t img_bytes = (int64_t)g.H * g.W * p.g.a_pitch * 4;
@@ -924,7 +1508,12 @@ extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void
                 float** cout[] = {&e2.out, &e2.out2, &e2.scale_out};
                 for (float** q : cout) if (*q) *q += opix * p.g.out_pitch;
                 if (e2.norm_out) e2.norm_out += opix * p.g.norm_pitch;
-                const int rc = bcos_tapconv_presplit(a + (int64_t)n0 * g.H * g.W * p.g.a_pitch, wt, wt3, &g2, &e2, stream);
+                if (e2.out_absmax) e2.out_absmax += opix;
+                if (e2.out2_absmax) e2.out2_absmax += opix;
+                bcos_operands o2 = *ops;
+                o2.a = a + (int64_t)n0 * g.H * g.W * p.g.a_pitch;
+                if (o2.a_absmax) o2.a_absmax += (int64_t)n0 * g.H * g.W;
+                const int rc = bcos_tapconv_ops(&o2, &g2, &e2, stream);
                 if (rc != BCOS_OK) return rc;
             }
             return BCOS_OK;
@@ -935,6 +1524,19 @@ extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void
         const int64_t w3b = split_bytes(g.Cout, p.Ktot);
         p.wt3 = (p.x3 && wt3 && w3b < lim && !(reinterpret_cast<uintptr_t>(wt3) & 15)) ? wt3 : nullptr;
         p.wt3_bytes = (unsigned)(w3b < lim ? w3b : 0);
+        const int64_t w2b = h2_image_bytes(g.Cout, p.Ktot), pixb = (int64_t)g.N * g.H * g.W * 4;
+        // below K = 512 a launch is HBM-bound: the leaner bf16x3 loop is as fast there, unless the caller insists on f16x2
+        // (the stem's K is all taps over 8 channels: compute-bound at any K)
+        const bool h2_pays = p.Ktot >= 512 || (g.C <= 16 && p.Ktot >= 128) || ops->contraction == BCOS_CONTRACT_F16X2;
+        if (mode == 2 && h2_pays && p.x3 && ops->a_absmax && ops->wt_f16x2 && w2b < lim && pixb < lim &&
+            !(reinterpret_cast<uintptr_t>(ops->wt_f16x2) & 15)) {
+            p.h2 = 1;
+            p.a_absmax = ops->a_absmax;
+            p.absmax_bytes = (unsigned)pixb;
+            p.wt2 = ops->wt_f16x2;
+            p.wt2_bytes = (unsigned)w2b;
+            p.wt2_cinv = reinterpret_cast<const float*>(static_cast<const char*>(ops->wt_f16x2) + w2b);
+        }
     }
     {
         uintptr_t bits = 0;
@@ -944,9 +1546,25 @@ extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void
     }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g.Cout <= 8) {
+    if (g.Cout <= 8 && !epi->out_absmax && !epi->out2_absmax) {
         const int handled = bcos_try_skinny(a, wt, p.g, p.e, p.M, s);
         if (handled != 0) return handled < 0 ? handled : BCOS_OK;
+    }
+    if (p.h2) {
+        if (g.Cout > 64) {
+            // 128 x 256 tiles stage half the A bytes per MFMA; they pay when they do not cost an extra round of tiles
+            // (measured on the ResNet-50 shapes: M = 50176, N = 256: -3 %; M = 12544, N = 512: +17 % -> stays 128 x 128)
+            const char* force = getenv("BCOS_H2_TILE");      // development switch: "128x128" | "128x256"
+            const int64_t tm = (M64 + 127) / 128;
+            const int64_t t1 = tm * ((g.Cout + 127) / 128), t2 = tm * ((g.Cout + 255) / 256);
+            const int64_t c1 = (t1 + SLOTS - 1) / SLOTS, c2 = 2 * ((t2 + SLOTS - 1) / SLOTS);
+            bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && p.Ktot >= 1024));
+            if (force) wide = g.Cout > 128 && force[4] == '2';
+            if (wide) return launch_h2<128, 256, 2, 2>(p, norm, s);
+            return launch_h2<128, 128, 2, 2>(p, norm, s);
+        }
+        if (g.Cout > 32) return launch_h2<128, 64, 2, 2>(p, norm, s);
+        return launch_h2<128, 32, 4, 1>(p, norm, s);
     }
     if (g.Cout > 64) return launch_cfg<128, 128, 2, 2>(p, norm, s);
     if (g.Cout > 32) return launch_cfg<128, 64, 2, 2>(p, norm, s);

@@ -12,8 +12,9 @@
  *   - every pointer is a DEVICE pointer to fp32 data unless the name says otherwise;
  *     the caller owns every buffer; the library never allocates or frees device memory.
  *   - all work is enqueued on the hipStream_t passed as `void* stream` (NULL = default
- *     stream); calls are asynchronous and re-entrant, no global mutable state except the
- *     thread-local last-error string.
+ *     stream); calls are asynchronous and re-entrant; the only global mutable state is the
+ *     thread-local last-error string and the process-wide DEFAULT contraction mode, which
+ *     a call overrides through bcos_operands.contraction.
  *   - return value: 0 = ok, negative = error (BCOS_E_*); never throws.
  *   - activations are NHWC ("channels-last": pixel-major, channels contiguous).  The
  *     logical NCHW shape of the reference is kept by the Python layer through
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 1
+#define BCOS_ABI_VERSION 2
 
 enum {
     BCOS_OK = 0,
@@ -58,7 +59,7 @@ enum { BCOS_NONE = 0, BCOS_CONV_EPS = 1, BCOS_LINEAR_EPS = 2 };
  * A forward convolution (stride s, padding p, dilation d) is
  *     in_s = s, dh0 = -p, dstep = d, TH x TW = kernel, P x Q = OH x OW, out_s = 1, out_0 = 0.
  * The input-gradient ("dgrad") of a strided convolution is one launch per output parity
- * class with the matching sub-kernel, in_s = 1 and out_s = stride (see bcos_hip/conv.py).
+ * class with the matching sub-kernel, in_s = 1 and out_s = stride (bcos_hip/ops.py: DgradPlan).
  */
 typedef struct bcos_tapconv_geom {
     int32_t N, H, W, C;          /* A operand: NHWC, C % 4 == 0                      */
@@ -97,6 +98,10 @@ typedef struct bcos_tapconv_geom {
  *     scale_out[idx] = s                             d out / d lin with the dynamic scale detached
  *                                                    (explanation mode: bcosconv2d.py:181-184)
  *     norm_out[pix] = norm[m]                        (only written by blocks of the first Cout tile)
+ *     out_absmax[pix]  = max(out_absmax[pix],  bits(max_c |out [idx]|))   atomically; the caller zeroes the buffer.
+ *     out2_absmax[pix] = ... of out2                  "bits" = the fp32 bit pattern (monotonic for non-negative values).
+ *                                                    These per-pixel maxima are the `a_absmax` of the launch that reads
+ *                                                    the tensor as its A operand (f16x2 contraction, see bcos_operands).
  */
 typedef struct bcos_epilogue {
     const float* bias;
@@ -111,6 +116,8 @@ typedef struct bcos_epilogue {
     float* out2;
     float* scale_out;
     float* norm_out;
+    uint32_t* out_absmax;   /* NULL or [N*OH*OW] */
+    uint32_t* out2_absmax;  /* NULL or [N*OH*OW] */
     int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
     int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */
@@ -139,22 +146,55 @@ int bcos_version(void);
 /* Human-readable description of the last error on this thread ("" if none). */
 const char* bcos_last_error_string(void);
 
-/* Arithmetic of the contraction inside bcos_tapconv (process-wide; inputs, outputs and accumulation are fp32 in
- * both modes):
- *   0  v_mfma_f32_32x32x2_f32: exact fp32 FMA chain
- *   1  "bf16x3" (default): every fp32 operand is split exactly into three bf16 slices (x = h + m + l, 3 x 8 significand
- *      bits, fp32 exponent range) and a*b is evaluated with the 6 leading products on v_mfma_f32_32x32x16_bf16
- *      (products of bf16 numbers are exact in fp32; dropped terms <= 2^-21 |a b|, i.e. fp32-rounding class -- the
- *      "error-compensated split scheme" of SURVEY.md fact 10 / H2); ~2.7x fewer matrix-pipe cycles.  Measured against an
- *      fp64 reference both modes give the same error (relL2 7.5e-7 vs 8.6e-7 at K = 2304). */
+/* Arithmetic of the contraction inside bcos_tapconv.  Inputs, outputs, accumulation and every stored tensor are fp32 in
+ * all modes; the mode only chooses how an fp32 product is evaluated on the matrix pipe:
+ *   f32     v_mfma_f32_32x32x2_f32: exact fp32 FMA chain (64 cycles per 32x32x2).
+ *   bf16x3  every fp32 operand is split exactly into three bf16 slices (x = h + m + l, 3 x 8 significand bits, fp32
+ *           exponent range) and a*b is evaluated with the 6 leading products on v_mfma_f32_32x32x16_bf16 (products of
+ *           bf16 numbers are exact in fp32; dropped terms <= 2^-21 |a b|).  Needs nothing from the caller.
+ *   f16x2   every operand is scaled by a power of two (exact) and split into two fp16 numbers, x 2^e = h + l
+ *           (|x 2^e - h - l| <= 2^-22 |x|), a*b = l_a h_b + h_a l_b + h_a h_b on v_mfma_f32_32x32x16_f16: 3 matrix
+ *           instructions per 16 k.  The scales are per GEMM row (taken from `a_absmax`, the per-pixel max |A| side tensor
+ *           that the producer of A emitted through bcos_epilogue.out_absmax or bcos_rows_absmax) and per weight row
+ *           (stored in the image made by bcos_split_weights_f16x2), and are undone exactly in the epilogue.  A call that
+ *           lacks either falls back to bf16x3.  All three agree with an fp64 reference to fp32-rounding level
+ *           (relL2 ~8e-7 at K = 2304); tests/test_gpu_parity.py runs every parity case in every mode.
+ * The mode is chosen PER CALL by bcos_operands.contraction; BCOS_CONTRACT_DEFAULT defers to a process-wide default
+ * (the only process-wide setting of the library; initial value f16x2) that bcos_set_contraction_mode changes:
+ * 0 = f32, 1 = bf16x3, 2 = f16x2. */
 int bcos_set_contraction_mode(int mode);
 int bcos_get_contraction_mode(void);
 
-/* -- contraction kernels (fp32 MFMA v_mfma_f32_32x32x2_f32, LDS-tiled implicit GEMM) ----- */
+enum { BCOS_CONTRACT_DEFAULT = 0, BCOS_CONTRACT_F32 = 1, BCOS_CONTRACT_BF16X3 = 2, BCOS_CONTRACT_F16X2 = 3 };
 
-/* The generic fused implicit GEMM every entry point below lowers to. */
+/* Operands of one bcos_tapconv launch. */
+typedef struct bcos_operands {
+    const float* a;             /* A: activations (forward) or gradients (dgrad), NHWC fp32                          */
+    const uint32_t* a_absmax;   /* NULL or [N*H*W]: fp32 bit pattern of max_c |a[pixel, c]| (any value >= the true max
+                                   and < 2^8 times it keeps full precision)                                        */
+    const float* wt;            /* [Cout][taps][C] fp32; always required (fallback paths read it)                  */
+    const void* wt_bf16x3;      /* NULL or the image made by bcos_split_weights                                    */
+    const void* wt_f16x2;       /* NULL or the image made by bcos_split_weights_f16x2                              */
+    int32_t contraction;        /* BCOS_CONTRACT_*                                                                  */
+} bcos_operands;
+
+/* -- contraction kernels (LDS-tiled implicit GEMM on the matrix cores) ---------------------------------------- */
+
+/* The generic fused implicit GEMM every entry point below lowers to (bcos_tapconv / bcos_tapconv_presplit are the
+ * same call with only `a`, `wt` [, `wt_bf16x3`] set). */
+int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geom* geom, const bcos_epilogue* epi, void* stream);
 int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                  const bcos_epilogue* epi, void* stream);
+
+/* Pre-split, pre-scaled weights for the f16x2 contraction: wt [rows][Ktot] fp32 -> image
+ * [32-row tile][16-k step][plane h|l][lane][8 f16] (B fragments of v_mfma_f32_32x32x16_f16; rows padded to a multiple of
+ * 128, k to a multiple of 16) followed by float[padded rows] inverse row scales.  Copied verbatim into LDS by the kernel. */
+int bcos_split_weights_f16x2_bytes(int rows, int Ktot, int64_t* bytes);
+int bcos_split_weights_f16x2(const float* wt, void* image, int rows, int Ktot, void* stream);
+
+/* out[r] = fp32 bit pattern of max_c |x[r*pitch + c]|, c < C (C % 4 == 0; pitch 0 = C): the `a_absmax` of a tensor whose
+ * producer is not a bcos_tapconv epilogue (network input, pooling, attention ...).  One pass over x. */
+int bcos_rows_absmax(const float* x, uint32_t* out, int64_t rows, int C, int pitch, void* stream);
 
 /* Pre-split weights for the bf16x3 contraction.  Weights are constant at inference (NormedConv2d / BcosifyConv2d
  * weights only change in training, bcosconv2d.py:26-35), so their exact 3-way bf16 split is done once:
@@ -205,7 +245,7 @@ int bcos_linear_fwd(const float* x, const float* w, const float* bias, float* y,
  * autograd convolution_backward + mul of bcos/common.py:177.
  *     gx = conv_transpose(gy * s, w)
  * gy, s: [N,Ho,Wo,Cout]; wT: [Cin,kh,kw,Cout] = w with the spatial taps flipped and
- * Cout/Cin swapped (stride 1) -- produced by bcos_hip.conv.prepare_dgrad_weights; for
+ * Cout/Cin swapped (stride 1) -- produced by bcos_hip/ops.py: DgradPlan; for
  * stride > 1 the Python layer issues one bcos_tapconv per parity class instead.
  * `gylin` is gy*s precomputed by the caller (bcos_mul) or fused into the producer.
  */

@@ -14,7 +14,9 @@ from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM
 
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
             ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
-            b=2.0, relu=False, flags=0):
+            b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None):
+    # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
+    # launch's operand scaling -- no effect on the documented result
     g = dict(a_pitch=0, out_pitch=0, norm_pitch=0)
     g.update(geom)
     N, H, W, C = g["N"], g["H"], g["W"], g["C"]
@@ -211,6 +213,10 @@ def localisation_fractions(attr, cell_h, cell_w, neg=False):
     return torch.where(total * contribs > 0, contribs / total, torch.zeros_like(contribs))
 
 
+def ensure_absmax(t):
+    return t
+
+
 def tapconv_group(a, wts, geoms, *, out, addend=None, mul=None):
     for w, g in zip(wts, geoms):
         tapconv(a, w, g, out=out, addend=addend, mul=mul)
@@ -223,7 +229,7 @@ def install(monkeypatch):
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
                  "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
-                 "render_explanations", "box_filter", "localisation_fractions", "tapconv_group"):
+                 "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn
