@@ -111,7 +111,7 @@ class BcosUtilMixin:
 
     def _explain_batch(self, images: Tensor, targets: Optional[Tensor] = None) -> "Dict[str, Tensor]":
         engine = getattr(self, "_bcos_engine", None)
-        if engine is not None and getattr(engine, "supports_explain", True):
+        if engine is not None and getattr(engine, "supports_explain", True) and not self.training:
             return engine.explain(images, targets)
         x = images.detach().clone().requires_grad_(True)
         with torch.enable_grad(), self.explanation_mode():

@@ -7,10 +7,10 @@ Inference-side restatement of bcos/experiments/utils/experiment_utils/experiment
 `model.get_model` and loads the checkpoint with zero key edits.  Training-side members (trainer, datamodule, metrics)
 are not provided.
 """
-import importlib
 from pathlib import Path
 from typing import Any, Dict, Optional, Union
 
+from ..config_utils import get_configs_and_model_factory, update_config
 from .loading_utils import get_state_dict_and_training_ckpt_from_save_dir
 
 __all__ = ["Experiment"]
@@ -30,19 +30,14 @@ class Experiment:
         self.base_directory = Path(base_directory)
         self.dataset, self.base_network, self.experiment_name = str(path_or_dataset), base_network, experiment_name
         self.save_dir = self.base_directory / self.dataset / self.base_network / self.experiment_name
-        self._pkg = f"bcos.experiments.{self.dataset}.{self.base_network}"
-        self.config = self._get_config()
-
-    def _get_config(self) -> Dict[str, Any]:
-        configs = importlib.import_module(self._pkg + ".experiment_parameters").CONFIGS
+        configs, self._model_factory = get_configs_and_model_factory(self.dataset, self.base_network)
         if self.experiment_name not in configs:
             raise KeyError(f"Unknown experiment '{self.experiment_name}' for {self.dataset}/{self.base_network}")
-        return configs[self.experiment_name]
+        self.config: Dict[str, Any] = configs[self.experiment_name]
 
     def get_model(self, **kwargs):
-        cfg = dict(self.config["model"])
-        cfg.update(kwargs)
-        return importlib.import_module(self._pkg + ".model").get_model(cfg)
+        """The network of this experiment; keyword arguments override entries of its `model` section (deep merge)."""
+        return self._model_factory(update_config(self.config["model"], kwargs))
 
     def load_trained_model(self, reload: str = "last", verbose: bool = False, ema: bool = False, return_training_ckpt_if_possible: bool = False):
         model = self.get_model()

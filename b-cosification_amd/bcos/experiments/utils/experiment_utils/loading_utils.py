@@ -6,7 +6,9 @@ Restates the inference-side behaviour of bcos/experiments/utils/experiment_utils
   * simple training checkpoints {"model_state_dict": ...} (:110-133);
   * stripped flat state dicts written by scripts/strip_checkpoints.py:52-84 (plain {key: tensor});
   * directory convention <save_dir>/last.ckpt and epoch=<N>-*.ckpt (:47-75, structure_constants.py:15).
-Selecting the *best* epoch needs the trainer's metrics files and is out of scope (raises).
+  * reload = "best" / "best_any" (:180-199, 273-321): the epoch with the highest validation accuracy in
+    <save_dir>/metrics/eval_acc1[.ema].gz (metric_utils.Metrics), "best_any" switching to the EMA weights when their best
+    accuracy is higher.
 """
 from pathlib import Path
 from typing import Any, Dict, Optional, Tuple, Union
@@ -89,17 +91,41 @@ def get_state_dict_and_training_ckpt_from_save_dir(save_dir: PathLike, reload: s
         raise ValueError(f"Unknown reload type: '{reload}'")
     if reload == ReloadTypes.LAST:
         ckpt = device_safe_load_state_dict_from_path(get_last_checkpoint_path_in_save_dir(save_dir))
-    elif reload.startswith(ReloadTypes.EPOCH):
-        epoch = int(reload.split("_")[1])
-        try:
-            path = next(save_dir.glob(f"epoch={epoch}-*.ckpt"))
-        except StopIteration:
-            raise FileNotFoundError(f"Tried loading checkpoint for epoch {epoch} but none was found in {save_dir}!")
-        ckpt = device_safe_load_state_dict_from_path(path)
     else:
-        raise NotImplementedError("reload='best' / 'best_any' needs the trainer's metrics files (out of scope: SURVEY.md "
-                                  "section 8(f) N3 covers last / epoch_<N>)")
+        if reload in (ReloadTypes.BEST, ReloadTypes.BEST_ANY):
+            epoch, ema = _determine_best_epoch_and_ema_status(save_dir, ema, reload)
+        else:
+            epoch = int(reload.split("_")[1])
+        ckpt = load_training_checkpoint_for_epoch_in(save_dir, epoch)
     sd = load_model_state_dict_from_training_ckpt(ckpt, ema=ema)
     if verbose and isinstance(ckpt, dict) and "epoch" in ckpt:
-        print(f"Loaded epoch: {ckpt['epoch'] + 1}" + (" (EMA)" if ema else ""))
+        print(f"Loaded epoch: {ckpt['epoch']}" + (" (EMA)" if ema else ""))
     return sd, ckpt
+
+
+def load_training_checkpoint_for_epoch_in(save_dir: PathLike, epoch: int) -> StateDictType:
+    """<save_dir>/epoch=<N>-*.ckpt, the per-epoch files of the trainer's checkpoint callback."""
+    try:
+        path = next(Path(save_dir).glob(f"epoch={epoch}-*.ckpt"))
+    except StopIteration:
+        raise FileNotFoundError(f"Tried loading checkpoint for epoch {epoch} but none was found in {save_dir}!")
+    return device_safe_load_state_dict_from_path(path)
+
+
+def _determine_best_epoch_and_ema_status(save_dir: PathLike, ema: bool, reload: str) -> Tuple[int, bool]:
+    """"best": the best epoch of the EMA weights if `ema` else of the plain weights; "best_any": whichever of the two
+    reached the higher validation accuracy (plain weights on a tie or when no EMA metrics exist)."""
+    from .metric_utils import Metrics, MetricsNotFoundError
+    try:
+        metrics = Metrics.from_experiment_dir(save_dir)
+    except MetricsNotFoundError:
+        raise MetricsNotFoundError("Unable to find metrics! These are required to find the best checkpoint!")
+    if reload == ReloadTypes.BEST:
+        epoch, _ = metrics.get_best_epoch_and_accuracy_ema() if ema else metrics.get_best_epoch_and_accuracy()
+        return epoch, ema
+    epoch, acc = metrics.get_best_epoch_and_accuracy()
+    try:
+        epoch_ema, acc_ema = metrics.get_best_epoch_and_accuracy_ema()
+    except EMANotFound:
+        epoch_ema, acc_ema = -1, -1.0
+    return (epoch_ema, True) if acc_ema > acc else (epoch, False)

@@ -61,21 +61,23 @@ class WeightCache:
         self._fwd = None
         self._dgrad = {}
 
-    def _sync(self, w):
-        key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
+    def _sync(self, w, w_eff):
+        # keyed on the parameter AND on the effective weight derived from it: NormedConv2d's unit-norm projection /
+        # set_scale / toggle_weight_norm change w_eff while the parameter stays the same (bcosconv2d.py:26-41)
+        key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device), w_eff.data_ptr(), w_eff._version)
         if key != self._key:
             self._key, self._fwd, self._dgrad = key, None, {}
 
     def fwd(self, w_eff, src):
         """w_eff: effective OIHW (or [O,I]) weight actually used (after unit-norm projection if any)."""
-        self._sync(src)
+        self._sync(src, w_eff)
         if self._fwd is None:
             w4 = w_eff if w_eff.dim() == 4 else w_eff[:, :, None, None]
             self._fwd = ops.mark_static(_pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous())
         return self._fwd
 
     def dgrad(self, w_eff, src, stride, padding, dilation, groups):
-        self._sync(src)
+        self._sync(src, w_eff)
         k = (stride, padding, dilation, groups)
         if k not in self._dgrad:
             w4 = w_eff.detach() if w_eff.dim() == 4 else w_eff.detach()[:, :, None, None]

@@ -29,23 +29,44 @@ class BcosifyLinear(BcosLinear):
     def weight(self) -> Tensor:
         return self.linear.weight
 
-    def _b_value(self) -> float:
+    def _b_host(self) -> float:
+        """self.b as a host float; a tensor / Parameter B (trainer.py:463) is read back once per in-place version instead
+        of forcing a device sync in every forward."""
         b = self.b
-        if self.clamping:
-            b = b.clamp(1 + 1e-6)
+        if not isinstance(b, torch.Tensor):
+            return float(b)
+        key = (b.data_ptr(), b._version)
+        cached = getattr(self, "_b_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, float(b.detach().item()))
+            object.__setattr__(self, "_b_cache", cached)
+        return cached[1]
+
+    def _scaling(self):
+        """(exponent B handed to the kernel, force the general pow form) following the reference's branches
+        (bcosifyconv2d.py:60-65,78-79,91-98 / bcosifylinear.py:52-57,70-71,83-90): `self.b == 1` without b_loss returns the
+        plain linear output even when clamping is on; `self.b == 2` without b_loss takes |lin| / norm; everything else is
+        (|cos| + 1e-6)^(B_eff - 1) with B_eff = b + 2 (b_loss), clamp(b, 1 + 1e-6) (clamping) or b."""
+        b = self._b_host()
+        if not self.b_loss:
+            if b == 1:
+                return 1.0, False
+            if b == 2:
+                return 2.0, False
         if self.b_loss:
-            b = self.b + 2
-        return float(b.detach().item()) if isinstance(b, torch.Tensor) else float(b)
+            return b + 2.0, True
+        if self.clamping:
+            return max(b, 1.0 + 1e-6), True
+        return b, False
+
+    def _b_value(self) -> float:
+        return self._scaling()[0]
 
     def forward(self, in_tensor: Tensor) -> Tensor:
-        b = self._b_value()
-        if not self.b_loss and not self.clamping:
-            plain_b = self.b.detach().item() if isinstance(self.b, torch.Tensor) else self.b
-            if plain_b == 1:
-                b = 1.0
+        b, force_pow = self._scaling()
         lin = self.linear
         cfg = dict(b=b, max_out=self.max_out, detach=self.detach, cache=self._wcache, w_src=lin.weight,
-                   force_pow=bool(self.b_loss))
+                   force_pow=force_pow)
         return _hipfn.BcosLinearFn.apply(in_tensor, lin.weight, lin.bias, cfg)
 
     @classmethod

@@ -24,7 +24,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .lib import BCOS_CONV_EPS, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_SCALE_GATE_LSB, BCOS_NONE, BcosHipError
+from .lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_SCALE_GATE_LSB, BCOS_NONE,
+                  BcosHipError)
 
 _GATE_TENSOR = bool(os.environ.get("BCOS_GATE_TENSOR"))   # development switch: ReLU gates as tensors, not as the bit in t
 
@@ -51,11 +52,26 @@ class _Conv:
         self.cin, self.cout = lin.in_channels, lin.out_channels
         self.refresh()
 
+    def fingerprint(self):
+        """(storage, in-place version) of every tensor refresh() reads: a changed fingerprint means the kernel-side copies
+        (weight layouts, pre-split images, dgrad plans, BN scale/shift, B) are stale.  Edits through `.data` of an existing
+        storage do not bump the version counter and stay invisible -- call refresh() after those."""
+        conv, bn = self.module, self.bn
+        lin = conv.linear
+        ts = [getattr(lin, "weight", None), getattr(lin, "bias", None), getattr(conv, "b", None), getattr(conv, "scale", None)]
+        if bn is not None:
+            ts += [bn.weight, bn.bias, bn.running_var, bn.running_mean]
+        return tuple((t.data_ptr(), t._version) if isinstance(t, torch.Tensor) else t for t in ts) + \
+            (getattr(conv, "use_weight_norm", None), bn.training if bn is not None else None)
+
     def refresh(self):
         conv, bn = self.module, self.bn
+        self._fp = self.fingerprint()
         w, bias = conv._effective_weight_and_bias()
         w = w.detach()
         self.b = conv._b_value()
+        # learnable-B variants take the general pow form even at B = 2 (bcosifyconv2d.py:91-98)
+        self.force_pow = bool(conv._scaling()[1]) if hasattr(conv, "_scaling") else False
         cin_pad = (-self.cin) % 4
         wk = w.permute(0, 2, 3, 1)
         if cin_pad:
@@ -89,7 +105,8 @@ class _Conv:
         y, t, _ = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
                                  bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
                                  ch_shift=self.ch_shift, addend=addend, relu=relu, relu_gate=gate,
-                                 want_scale=want_scale, flags=flags, track_absmax=track)
+                                 want_scale=want_scale, flags=flags | (BCOS_EPI_FORCE_POW if self.force_pow else 0),
+                                 track_absmax=track)
         self.last_gate = gate       # the replayed gate tensor, if any (else the output itself encodes the gate)
         return y, t
 
@@ -186,6 +203,7 @@ class ResNetEngine:
 
     def _refresh_attnpool(self):
         ap = self.attnpool
+        self._ap_fp = tuple((p.weight.data_ptr(), p.weight._version) for p in (ap.q_proj, ap.k_proj, ap.v_proj, ap.c_proj))
         w = lambda lin: lin.weight.detach().contiguous()   # noqa: E731  (c_proj may be a BcosifyLinear: .weight property)
         self.ap_w = dict(q=w(ap.q_proj), k=w(ap.k_proj), v=w(ap.v_proj), c=w(ap.c_proj))
         self.ap_heads = ap.num_heads
@@ -196,7 +214,8 @@ class ResNetEngine:
         self.ap_vconv = _HeadConv(ops.DgradPlan(self.ap_w["v"].view(C, C, 1, 1), (1, 1), (0, 0), (1, 1)), C)
 
     def refresh(self):
-        """Re-read parameters after they changed (load_state_dict, calibration, ...)."""
+        """Re-read parameters after they changed (load_state_dict, calibration, ...).  forward()/explain() call this
+        themselves when a parameter's storage or in-place version differs from what the plan was built from."""
         for c, _ in self.stem:
             c.refresh()
         if self.head is not None:
@@ -205,6 +224,27 @@ class ResNetEngine:
             self._refresh_attnpool()
         for b in self.blocks:
             b.refresh()
+
+    def _all_convs(self):
+        for c, _ in self.stem:
+            yield c
+        if self.head is not None:
+            yield self.head
+        for b in self.blocks:
+            yield from b.convs
+            if b.shortcut is not None:
+                yield b.shortcut
+
+    def _ensure_fresh(self):
+        """Cheap staleness check (a few hundred integer compares): refresh the layers whose parameters changed."""
+        for c in self._all_convs():
+            if c.fingerprint() != c._fp:
+                c.refresh()
+        if self.head_kind == "attnpool":
+            ap = self.attnpool
+            fp = tuple((p.weight.data_ptr(), p.weight._version) for p in (ap.q_proj, ap.k_proj, ap.v_proj, ap.c_proj))
+            if fp != getattr(self, "_ap_fp", None):
+                self._refresh_attnpool()
 
     def _consts(self, device):
         key = str(device)
@@ -218,6 +258,7 @@ class ResNetEngine:
         if x.dim() != 4 or x.shape[1] not in (3, 6):
             raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
         ops.require_device(x, "bcos_hip.engine")
+        self._ensure_fresh()
         x = x.detach()
         x = x if x.is_contiguous() else x.contiguous()
         mean, std = self._consts(x.device)

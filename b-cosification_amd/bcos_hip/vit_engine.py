@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .lib import BCOS_LINEAR_EPS, BcosHipError
+from .lib import BCOS_EPI_FORCE_POW, BCOS_LINEAR_EPS, BcosHipError
 
 
 class _Lin:
@@ -37,6 +37,7 @@ class _Lin:
         w, bias = self.module._effective_weight_and_bias()
         w = w.detach()
         self.b = self.module._b_value()
+        self.force_pow = bool(self.module._scaling()[1]) if hasattr(self.module, "_scaling") else False
         self.w = ops.mark_static(w.contiguous())       # [Cout, Cin]
         self.wt = ops.mark_static(w.t().contiguous())  # [Cin, Cout] for the input gradient
         self.bias = bias.detach().contiguous() if bias is not None else None
@@ -49,7 +50,8 @@ class _Lin:
         y = torch.empty((rows, self.cout), device=x2d.device, dtype=torch.float32)
         t = torch.empty_like(y) if want_scale else None
         ops.tapconv(x2d, self.w, g, out=y, scale_out=t, bias=self.bias, addend=addend,
-                    bcos_mode=BCOS_LINEAR_EPS if self.b != 1.0 else 0, b=self.b, relu=act)
+                    bcos_mode=BCOS_LINEAR_EPS if self.b != 1.0 else 0, b=self.b, relu=act,
+                    flags=BCOS_EPI_FORCE_POW if self.force_pow else 0)
         return y, t
 
     def dgrad(self, glin, *, mul=None):
@@ -116,8 +118,18 @@ class ViTEngine:
         self.logit_temperature = ll.logit_temperature if ll is not None else None
         self.refresh()
 
+    def _fingerprint(self):
+        """(storage, in-place version) of every parameter and buffer of the network the plan was compiled from."""
+        m = self.net
+        return tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
+
+    def _ensure_fresh(self):
+        if self._fingerprint() != self._fp:
+            self.refresh()
+
     def refresh(self):
         from bcos.modules.bcoslinear import BcosLinear
+        self._fp = self._fingerprint()
         e = self.embed_mod
         if not isinstance(e, BcosLinear) or e.max_out != 1:
             raise BcosHipError("vit engine: patch embedding must be a B-cos linear")
@@ -163,6 +175,7 @@ class ViTEngine:
         if x.dim() != 4 or x.shape[1] not in (3, 6):
             raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
         ops.require_device(x, "bcos_hip.vit_engine")
+        self._ensure_fresh()
         x = x.detach()
         x = x if x.is_contiguous() else x.contiguous()
         N, _, H, W = x.shape

@@ -81,8 +81,8 @@ class BcosifyNetwork(BcosUtilMixin, nn.Module):
 
     def forward(self, x):
         engine = getattr(self, "_bcos_engine", None)
-        if engine is not None and not torch.is_grad_enabled():
-            return engine.forward(x)
+        if engine is not None and not torch.is_grad_enabled() and not self.training:
+            return engine.forward(x)          # eval + no_grad: the fused plan (it re-reads parameters that changed)
         out = self.model(self.bcosifynormalize(x))
         return self.logit_layer(out) if self.logit_layer else out
 

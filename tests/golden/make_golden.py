@@ -139,6 +139,53 @@ def layer_cases():
 
 
 # --------------------------------------------------------------------------------------------------------
+# F1b: the learnable-B variants of the B-cosified layers (bcosifyconv2d.py:60-65,78-79,91-98): clamping / b_loss
+# --------------------------------------------------------------------------------------------------------
+VARIANT_CASES = [
+    # name,             layer,   b (clamping: a tensor, as trainer.py:463 makes it), clamping, b_loss
+    ("conv_clamp_b1",   "conv",   1.0,  True,  False),     # self.b == 1 -> plain linear output even with clamping
+    ("conv_clamp_b2",   "conv",   2.0,  True,  False),     # self.b == 2 -> |lin| / norm
+    ("conv_clamp_b1p5", "conv",   1.5,  True,  False),     # pow(|cos| + 1e-6, 0.5)
+    ("conv_clamp_b0p5", "conv",   0.5,  True,  False),     # clamped to 1 + 1e-6
+    ("conv_bloss_bm1",  "conv",  -1.0,  False, True),      # B_eff = b + 2 = 1 through the pow form
+    ("conv_bloss_b0",   "conv",   0.0,  False, True),      # B_eff = 2 through the pow form (with the 1e-6)
+    ("conv_bloss_b0p3", "conv",   0.3,  False, True),
+    ("conv_both_b0",    "conv",   0.0,  True,  True),      # b_loss overrides the clamp
+    ("lin_clamp_b1",    "linear", 1.0,  True,  False),
+    ("lin_clamp_b2",    "linear", 2.0,  True,  False),
+    ("lin_clamp_b1p5",  "linear", 1.5,  True,  False),
+    ("lin_bloss_b0",    "linear", 0.0,  False, True),
+    ("lin_bloss_b0p3",  "linear", 0.3,  False, True),
+]
+
+
+def variant_cases():
+    out = {}
+    g = torch.Generator().manual_seed(777)
+    for (name, layer, b, clamping, b_loss) in VARIANT_CASES:
+        if layer == "conv":
+            mod = R.bcosifyconv2d.BcosifyConv2d(12, 20, 3, 1, 1, b=2, clamping=clamping, b_loss=b_loss)
+            x = torch.randn(2, 12, 8, 8, generator=g)
+        else:
+            mod = R.bcosifylinear.BcosifyLinear(48, 40, b=2, clamping=clamping, b_loss=b_loss)
+            x = torch.randn(3, 7, 48, generator=g)
+        mod.b = torch.tensor(b) if clamping else b
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+        mod.eval()
+        mod.set_explanation_mode(True)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, xr, gy)
+        for kk, vv in dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=gx).items():
+            out[f"{name}/{kk}"] = vv
+    np.savez_compressed(os.path.join(HERE, "layer_variants.npz"), **t2n(out))
+    with open(os.path.join(HERE, "layer_variants.json"), "w") as f:
+        json.dump([dict(zip(("name", "layer", "b", "clamping", "b_loss"), c)) for c in VARIANT_CASES], f, indent=1)
+
+
+# --------------------------------------------------------------------------------------------------------
 # F2-F5: patch norms fast vs slow, BNU fold, add_channels, scale invariance
 # --------------------------------------------------------------------------------------------------------
 def small_invariants():
@@ -486,12 +533,14 @@ def localisation_grid():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
+    which = sys.argv[1:] or ["layers", "variants", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
     if "layers" in which:
         layer_cases()
+    if "variants" in which:
+        variant_cases()
     if "inv" in which:
         small_invariants()
     if "r18" in which:

@@ -69,6 +69,29 @@ def test_module_layers_against_golden(lib, golden_dir):
         assert rel(gx, data[f"{n}/gx"]) <= 1e-5, n
 
 
+def test_learnable_b_variants_against_golden(lib, golden_dir):
+    """clamping / b_loss variants of the B-cosified layers on the HIP path (BCOS_EPI_FORCE_POW, the B == 1 and B == 2
+    shortcuts) against the reference-recorded outputs and input gradients (bcosifyconv2d.py:60-65,78-79,91-98)."""
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    data = np.load(os.path.join(golden_dir, "layer_variants.npz"))
+    for c in json.load(open(os.path.join(golden_dir, "layer_variants.json"))):
+        n = c["name"]
+        if c["layer"] == "conv":
+            m = BcosifyConv2d(12, 20, 3, 1, 1, b=2, clamping=c["clamping"], b_loss=c["b_loss"])
+        else:
+            m = BcosifyLinear(48, 40, b=2, clamping=c["clamping"], b_loss=c["b_loss"])
+        with torch.no_grad():
+            m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+        m = m.to(DEV)
+        m.b = torch.tensor(c["b"], device=DEV) if c["clamping"] else c["b"]
+        m.set_explanation_mode(True)
+        x = torch.from_numpy(data[f"{n}/x"]).to(DEV).requires_grad_(True)
+        y = m(x)
+        (gx,) = torch.autograd.grad(y, x, torch.from_numpy(data[f"{n}/gy"]).to(DEV))
+        assert rel(y, data[f"{n}/y"]) <= 1e-5 and rel(gx, data[f"{n}/gx"]) <= 1e-5, n
+
+
 CONV_GEOMS = [  # N, Cin, H, W, Cout, k, s, p   (the distinct R18/R50 geometry classes at reduced size + ragged edges)
     (2, 64, 14, 14, 64, 1, 1, 0), (2, 64, 14, 14, 256, 1, 1, 0), (2, 256, 14, 14, 64, 1, 1, 0),
     (2, 64, 14, 14, 64, 3, 1, 1), (2, 128, 14, 14, 128, 3, 2, 1), (2, 256, 14, 14, 512, 1, 2, 0),
@@ -622,6 +645,105 @@ def test_grid_pointing_game_on_device(lib, golden_dir):
     ref_c, ref_m = O.localisation_fractions(r9["attributions"][1].cpu()[:, None], 32, smooth=5)
     assert rel(r9["fractions"][1], ref_c) <= 1e-5 and rel(r9["metric"][1], ref_m) <= 1e-5
     assert rel(ops.box_filter(r9["attributions"][0], 7), F.avg_pool2d(r9["attributions"][0].cpu()[:, None], 7, 1, 3)[:, 0]) <= 1e-6
+
+
+def test_explainer_api_on_hip_path(lib, golden_dir):
+    """a18 on the device: get_explainer(net, "IxG" | "Ours"), BcosUtilMixin.attribute / attribute_selection
+    (interpretability/explanation_methods/explainers/__init__.py:88-104, utils.py:70-99, captum.py:29-32,
+    bcos/common.py:280-344) -- over the per-layer HIP modules (autograd) and over the fused engine -- against the oracle's
+    attribute_selection_maps and the reference-recorded attributions of the localisation fixture."""
+    from bcos_hip import engine, localisation, synth
+    from interpretability.explanation_methods import get_explainer
+    net, meta, _ = _golden_net(golden_dir, "resnet18_e2e")
+    loc = json.load(open(os.path.join(golden_dir, "localisation.json")))
+    data = np.load(os.path.join(golden_dir, "localisation.npz"))
+    singles = synth.synthetic_images(loc["n_imgs"], seed=loc["image_seed"], size=loc["single_shape"]).to(DEV)
+    multi = localisation.make_multi_image(singles)                                  # [1, 6, 224, 224]
+    tgts = [int(t) for t in data["targets"]]
+    gold = torch.from_numpy(data["attributions"])                                   # [T, 1, H, W], recorded from the reference
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    fwd = lambda xx, detach: O.resnet_logits(sd, xx, meta["arch"], detach=detach)    # noqa: E731
+    small = synth.synthetic_images(2, seed=77, size=64).to(DEV)
+    small_t = [[3, 500, 999], [17, 3, 250]]
+    ref_small = torch.stack([O.attribute_selection_maps(fwd, small[i:i + 1].cpu(), small_t[i])[:, 0] for i in range(2)])
+
+    def check(tag):
+        # "Ours" is the model itself (ours.py:8-13); attribute / attribute_selection enter explanation mode themselves
+        ours = get_explainer(net, "Ours", "default")
+        assert ours is net
+        sel = ours.attribute_selection(multi, tgts)                                  # [T, 6, H, W]
+        assert sel.shape == (len(tgts), 6, 224, 224), tag
+        assert rel(sel.sum(1, keepdim=True), gold) <= 2e-3, tag                      # free ReLU gates: the R18 map floor
+        one = net.attribute(multi, tgts[1])
+        assert torch.equal(one[0], sel[1]), tag
+        # IxG = captum InputXGradient over the model as it is: in explanation mode it equals the model-inherent explanation
+        ixg = get_explainer(net, "IxG", "default")
+        with net.explanation_mode():
+            multi_sel = ixg.attribute_selection(small, small_t)                      # [N * T, 6, h, w], sample-major
+            single = ixg.attribute(small, [3, 17])
+        assert multi_sel.shape == (6, 6, 64, 64), tag
+        maps = multi_sel.sum(1).view(2, 3, 64, 64)
+        assert rel(maps, ref_small) <= 2e-3, tag
+        assert torch.equal(single[0], multi_sel[0]) and torch.equal(single[1], multi_sel[3]), tag
+        assert rel((small * _w(small, [3, 17])), single) <= 1e-6, tag               # attribution == x * W(x)
+        # outside explanation mode IxG differentiates through the dynamic scale: a different (larger) attribution
+        return sel, multi_sel
+
+    def _w(x, t):
+        with net.explanation_mode():
+            return net.explain_batch(x, targets=torch.tensor(t))["dynamic_linear_weights"]
+
+    sel_mod, small_mod = check("modules")                                            # autograd over the per-layer HIP kernels
+    eng = engine.attach(net)
+    sel_eng, small_eng = check("engine")                                             # the fused plan under the same API
+    assert rel(sel_eng, sel_mod) <= 2e-3 and rel(small_eng, small_mod) <= 2e-3
+    direct = eng.explain(multi.expand(len(tgts), -1, -1, -1).contiguous(), targets=torch.tensor(tgts))
+    assert torch.equal(sel_eng, multi * direct["dynamic_linear_weights"])            # the API adds nothing to the engine pass
+    with pytest.raises(KeyError, match="out of scope"):
+        get_explainer(net, "RISE", "default")
+
+
+def test_checkpoint_containers_load_into_hip_path(lib, golden_dir, tmp_path):
+    """N3 on the device: a Lightning-style container ("model." + "ema.module." prefixes, loading_utils.py:78-107) and a
+    stripped flat .pth are written, found through Experiment, loaded with zero key edits, and the HIP forward +
+    explanation of the loaded network is compared with the oracle run on the very same state dict."""
+    from bcos.experiments.utils import Experiment
+    from bcos_hip import engine, synth
+    src, meta, _ = _golden_net(golden_dir, "resnet18_e2e")
+    sd = {k: v.detach().cpu().clone() for k, v in src.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    ema = {k: (v * (1 + 0.05 * torch.randn(v.shape, generator=g)) if v.dtype.is_floating_point and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    save_dir = tmp_path / "experiments" / "ImageNet" / "bcosification" / "resnet_18"
+    save_dir.mkdir(parents=True)
+    pl = {"state_dict": {**{"model." + k: v for k, v in sd.items()}, **{"ema.module." + k: v for k, v in ema.items()}},
+          "epoch": 89, "pytorch-lightning_version": "2.2.0"}
+    torch.save(pl, save_dir / "last.ckpt")
+    exp = Experiment("ImageNet", "bcosification", "resnet_18", base_directory=tmp_path / "experiments")
+    x = synth.synthetic_images(3, seed=5, size=96).to(DEV)
+    for use_ema, want in ((False, sd), (True, ema)):
+        net = exp.load_trained_model(ema=use_ema).to(DEV)
+        assert all(torch.equal(v.cpu(), want[k]) for k, v in net.state_dict().items())
+        eng = engine.attach(net)
+        out = net.explain_batch(x)
+        ref = O.explain_batch(lambda xx, detach: O.resnet_logits(want, xx, "resnet18", detach=detach), x.cpu())
+        assert rel(out["logits"], ref["logits"]) <= 1e-4 and torch.equal(out["prediction"].cpu(), ref["prediction"])
+        pinned = eng.explain(x, gates=_oracle_gates(net, x, "resnet18"))
+        assert rel(pinned["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
+        assert rel(net(x), ref["logits"]) <= 1e-4                                    # plain forward under no_grad -> engine
+    # stripped checkpoint (scripts/strip_checkpoints.py:52-84): the flat state dict itself, as last.ckpt of another run
+    other = tmp_path / "experiments" / "ImageNet" / "bcosification" / "resnet_18-seed=5"
+    other.mkdir(parents=True)
+    torch.save(ema, other / "last.ckpt")
+    net2 = Experiment(other).load_trained_model().to(DEV)
+    engine.attach(net2)
+    ref2 = O.resnet_logits(ema, x.cpu(), "resnet18")
+    with torch.no_grad():
+        assert rel(net2(x), ref2) <= 1e-4
+    # the engine notices parameters that change after attach (load_state_dict into the attached network)
+    net2.load_state_dict(sd)
+    with torch.no_grad():
+        assert rel(net2(x), O.resnet_logits(sd, x.cpu(), "resnet18")) <= 1e-4
 
 
 def test_tapconv_group_matches_separate_launches(lib):

@@ -227,6 +227,36 @@ def test_module_path_matches_golden_layers(monkeypatch, golden_dir):
         assert rel(gx, data[f"{n}/gx"]) <= 2e-6, n
 
 
+def _variant_module(c, data):
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    n = c["name"]
+    if c["layer"] == "conv":
+        m = BcosifyConv2d(12, 20, 3, 1, 1, b=2, clamping=c["clamping"], b_loss=c["b_loss"])
+    else:
+        m = BcosifyLinear(48, 40, b=2, clamping=c["clamping"], b_loss=c["b_loss"])
+    m.b = torch.tensor(c["b"]) if c["clamping"] else c["b"]     # the trainer makes B a tensor when it is learnt (trainer.py:463)
+    with torch.no_grad():
+        m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+    return m
+
+
+def test_learnable_b_variants_match_reference_golden(monkeypatch, golden_dir):
+    """clamping / b_loss branches of BcosifyConv2d / BcosifyLinear (bcosifyconv2d.py:60-65,78-79,91-98) against outputs
+    and input gradients recorded from the reference: B == 1 stays linear even with clamping, B == 2 stays |lin| / norm,
+    b_loss always takes the pow form with B + 2."""
+    cpu_emulation.install(monkeypatch)
+    data = np.load(os.path.join(golden_dir, "layer_variants.npz"))
+    for c in json.load(open(os.path.join(golden_dir, "layer_variants.json"))):
+        n = c["name"]
+        m = _variant_module(c, data)
+        m.set_explanation_mode(True)
+        x = torch.from_numpy(data[f"{n}/x"]).requires_grad_(True)
+        y = m(x)
+        (gx,) = torch.autograd.grad(y, x, torch.from_numpy(data[f"{n}/gy"]))
+        assert rel(y, data[f"{n}/y"]) <= 2e-6 and rel(gx, data[f"{n}/gx"]) <= 2e-6, n
+
+
 def test_training_mode_backward_is_refused(monkeypatch):
     cpu_emulation.install(monkeypatch)
     from bcos.modules.bcosifyconv2d import BcosifyConv2d
@@ -502,8 +532,35 @@ def test_experiment_checkpoint_loading(monkeypatch, tmp_path):
         LU.load_model_state_dict_from_training_ckpt({"foo": 1})
     with pytest.raises(FileNotFoundError):
         exp.load_trained_model(reload="epoch_7")
-    with pytest.raises(NotImplementedError):
+    # reload="best" / "best_any": epoch chosen from <save_dir>/metrics/eval_acc1[_ema].gz (loading_utils.py:273-321)
+    from bcos.experiments.utils.experiment_utils.metric_utils import Metrics, MetricsNotFoundError
+    with pytest.raises(MetricsNotFoundError):
         exp.load_trained_model(reload="best")
+    (save_dir / "metrics").mkdir()
+    np.savetxt(save_dir / "metrics" / "eval_acc1.gz", np.array([[40, 0.61], [41, 0.74], [89, 0.70]]))
+    assert Metrics.from_experiment_dir(save_dir).get_best_epoch_and_accuracy() == (41, 0.74)
+    _, best_ckpt = exp.load_trained_model(reload="best", return_training_ckpt_if_possible=True)
+    assert best_ckpt["epoch"] == 41
+    with pytest.raises(LU.EMANotFound):
+        exp.load_trained_model(reload="best", ema=True)                              # no EMA metrics recorded
+    np.savetxt(save_dir / "metrics" / "eval_acc1_ema.gz", np.array([[41, 0.60], [89, 0.75]]))
+    torch.save(pl, save_dir / "epoch=89-step=2000.ckpt")
+    net_any, any_ckpt = exp.load_trained_model(reload="best_any", return_training_ckpt_if_possible=True)
+    assert any_ckpt["epoch"] == 89                                                   # the EMA weights of epoch 89 win
+    assert torch.equal(net_any.state_dict()["model.conv1.linear.weight"], ema["model.conv1.linear.weight"])
+    # config helpers of the experiment tables (config_utils.py:38-66, 140-177, 227-257)
+    from bcos.experiments.utils import create_configs_with_different_seeds, get_configs_and_model_factory, update_config
+    base = {"model": {"name": "resnet18", "bcos_args": {"b": 2, "max_out": 1}}, "lr": 1e-3}
+    upd = update_config(base, {"model": {"bcos_args": {"b": 1.5}}, "epochs": 90})
+    assert upd == {"model": {"name": "resnet18", "bcos_args": {"b": 1.5, "max_out": 1}}, "lr": 1e-3, "epochs": 90}
+    assert base["model"]["bcos_args"]["b"] == 2                                      # the old config is left alone
+    with pytest.raises(AssertionError):
+        update_config(base, {"model": 3})
+    seeded = create_configs_with_different_seeds({"a": {"seed": 0, "m": {}}}, [5, 7])
+    assert set(seeded) == {"a-seed=5", "a-seed=7"} and seeded["a-seed=7"]["seed"] == 7
+    cfgs, factory = get_configs_and_model_factory("ImageNet", "bcosification")
+    assert "resnet_18" in cfgs and callable(factory)
+    assert exp.get_model(bcos_args=dict(b=1.5)).model.conv1.b == 1.5                # overrides merge into the model section
     with pytest.raises(KeyError):
         Experiment("ImageNet", "bcosification", "resnet_101", base_directory=tmp_path)
     # the other two families: names of the reference tables resolve to model sections their factories accept
