@@ -62,14 +62,37 @@ def all_gather_rows(t: torch.Tensor, counts=None) -> torch.Tensor:
     return torch.cat([out[r * mx: r * mx + c] for r, c in enumerate(counts)], 0)
 
 
+def all_gather_batch(t: torch.Tensor, dim: int = 0, counts=None) -> torch.Tensor:
+    """all_gather_rows along an arbitrary batch dimension: the CLIP `attn_unpool` head returns [HW, N, D] -- batch is
+    dim 1 (bcosattnpool.py:23-32) -- so its shards are concatenated along that dimension, not along dim 0."""
+    if dim == 0:
+        return all_gather_rows(t, counts)
+    return all_gather_rows(t.movedim(dim, 0).contiguous(), counts).movedim(0, dim)
+
+
+_OUT_TAILS = {"logits": lambda x, k: (k,), "contribution_map": lambda x, k: tuple(x.shape[2:]),
+              "dynamic_linear_weights": lambda x, k: (6,) + tuple(x.shape[2:]), "prediction": lambda x, k: (),
+              "explained_class_idx": lambda x, k: ()}
+_OUT_DTYPES = {"prediction": torch.int64, "explained_class_idx": torch.int64}
+
+
 def explain_sharded(engine, images: torch.Tensor, targets: Optional[torch.Tensor] = None, gather=("logits", "contribution_map"),
-                    want_weights: bool = False) -> Dict[str, torch.Tensor]:
+                    want_weights: bool = False, num_outputs: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """Run `engine.explain` on this rank's shard of `images` (the full batch, identical on every rank) and
-    all-gather the requested outputs."""
+    all-gather the requested outputs.  A rank whose shard is empty (fewer images than ranks: the last ragged batch of an
+    evaluation) skips the kernels and contributes zero-row tensors, so every rank still reaches the collective;
+    `num_outputs` (the logit count) is only needed for that case when 'logits' is gathered."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-    lo, hi = shard_bounds(images.shape[0], rank, world)
-    out = engine.explain(images[lo:hi], None if targets is None else targets[lo:hi], want_weights=want_weights)
-    counts = [shard_bounds(images.shape[0], r, world)[1] - shard_bounds(images.shape[0], r, world)[0] for r in range(world)]
+    n = images.shape[0]
+    lo, hi = shard_bounds(n, rank, world)
+    counts = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
+    if hi > lo:
+        out = engine.explain(images[lo:hi], None if targets is None else targets[lo:hi], want_weights=want_weights)
+    else:
+        if "logits" in gather and num_outputs is None:
+            raise ValueError("explain_sharded: rank without images needs num_outputs to shape its empty logits")
+        out = {k: torch.empty((0,) + _OUT_TAILS[k](images, num_outputs), device=images.device, dtype=_OUT_DTYPES.get(k, torch.float32))
+               for k in gather}
     res = dict(out)
     for k in gather:
         if out.get(k) is not None:
@@ -121,6 +144,9 @@ class OverlappedGather:
         done = self._finish(prev) if prev is not None else None
         if done is not None and copy_out:          # the slot's buffers are reused below: hand out copies on request
             done = {k: v.clone() for k, v in done.items()}
+        for k, v in tensors.items():               # one packed fp32 buffer: an int64 tensor would be silently rounded
+            if v.dtype != torch.float32:
+                raise TypeError(f"OverlappedGather packs float32 tensors only ('{k}' is {v.dtype}); gather it separately")
         layout = [(k, tuple(v.shape), v.numel()) for k, v in tensors.items()]
         total = sum(n for _, _, n in layout)
         first = next(iter(tensors.values()))

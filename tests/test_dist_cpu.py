@@ -40,19 +40,23 @@ def _worker(rank, world, port, n_images, q):
                 m.linear.weight.mul_(3.0)
     eng = engine.ResNetEngine(net)
     x = synth.synthetic_images(n_images, size=32)
-    res = bdist.explain_sharded(eng, x, gather=("logits", "contribution_map", "prediction"))
+    res = bdist.explain_sharded(eng, x, gather=("logits", "contribution_map", "prediction"), num_outputs=1000)
     full = eng.explain(x)
     ok = (torch.allclose(res["logits"], full["logits"], rtol=1e-5, atol=1e-6)
           and torch.allclose(res["contribution_map"], full["contribution_map"], rtol=1e-4, atol=1e-7)
           and torch.equal(res["prediction"], full["prediction"])
           and res["logits"].shape[0] == n_images)
+    # batch along dim 1 (the CLIP attn_unpool head's [HW, N, D]): gathered along that dimension
     lo, hi = res["shard"]
+    t = torch.arange(5 * n_images * 3, dtype=torch.float32).view(5, n_images, 3)
+    counts = [bdist.shard_bounds(n_images, r, world)[1] - bdist.shard_bounds(n_images, r, world)[0] for r in range(world)]
+    ok = ok and torch.equal(bdist.all_gather_batch(t[:, lo:hi].contiguous(), dim=1, counts=counts), t)
     q.put((rank, bool(ok), lo, hi))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_images", [4, 3])
+@pytest.mark.parametrize("n_images", [4, 3, 1])          # equal shards, ragged shards, fewer images than ranks
 def test_sharded_explanation_world2_gloo(n_images):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
