@@ -2,10 +2,13 @@
 
 Forward = ONE fused launch per B-cos layer (contraction + patch norm + |cos|^(B-1) scaling;
 reference bcosconv2d.py:153-194 issues 9 ATen launches for the same thing).
-Backward is implemented for *explanation mode* (`detach=True`): the dynamic scale is a constant, so
-d out / d x = conv_transpose(g * s, W) -- the "dynamic linear weights" W(x) of bcos/common.py:177-181.
-The training-mode backward (extra d s terms, weight gradients) is SURVEY.md section 8(f) row N4 and is not
-built; asking for it raises instead of silently producing explanation-mode gradients.
+Backward:
+  * explanation mode (`detach=True`): the dynamic scale is a constant, so d out / d x = conv_transpose(g * s, W) -- the
+    "dynamic linear weights" W(x) of bcos/common.py:177-181 -- and d out / d W = wgrad(g * s, x);
+  * training mode (first slice: max_out == 1, groups == 1): the scale is differentiated too
+    (bcosconv2d.py:176-194 without .detach()):  gx = dgrad(g * dy/dlin, W) + x (.) PatchSum^T(dL/dnorm / norm),
+    gW = wgrad(g * dy/dlin, x), gbias = sum_pixels g * dy/dlin  (csrc/bcos_train.hip).
+MaxOut / grouped layers outside explanation mode still raise instead of silently producing explanation-mode gradients.
 """
 import torch
 import torch.nn.functional as F
@@ -50,6 +53,17 @@ def _pad_last(t: torch.Tensor, mult: int = 4) -> torch.Tensor:
     c = t.shape[-1]
     r = (-c) % mult
     return t if r == 0 else F.pad(t, (0, r))
+
+
+def refuse_unit_norm_training(module, w_eff, w_src):
+    """The unit-norm projection of NormedConv2d / NormedLinear runs as a HIP kernel outside autograd, so gradients cannot
+    reach the raw weight through it.  Explanation (eval, or explanation mode) never needs them; a training step does and
+    must not run silently without weight updates (SURVEY.md section 8(f) N4 covers the B-cosified, un-normalised layers)."""
+    if (w_eff is not w_src and module.training and not module.detach and torch.is_grad_enabled() and w_src.requires_grad):
+        raise NotImplementedError(
+            f"{type(module).__name__}: weight gradients through the unit-norm projection (native B-cos layers in training "
+            "mode) are not built for MI355X; train the B-cosified layers (BcosifyConv2d / BcosifyLinear), call .eval(), or "
+            "freeze the weight")
 
 
 class WeightCache:
@@ -116,11 +130,20 @@ class BcosConv2dFn(Function):
             xh = _pad_last(xh)
         elif cin_g % 4 != 0:
             raise BcosHipError(f"grouped B-cos conv needs in_channels/groups % 4 == 0 (got {cin_g})")
-        want_scale = bool(need_grad and b != 1.0)
+        need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        train = (need_grad or need_w or need_b) and not cfg["detach"] and b != 1.0     # the scale is differentiated
+        if (train or need_w or need_b) and (max_out != 1 or groups != 1):
+            raise NotImplementedError(
+                "BcosConv2d: weight gradients / training-mode gradients are built for max_out == 1, groups == 1 "
+                "(SURVEY.md section 8(f) N4); MaxOut and grouped layers support explanation-mode input gradients only")
+        want_scale = bool((need_grad or need_w or need_b) and b != 1.0)
         fused = max_out == 1
         y_cl, y = empty_cl(N, Cout_all, Ho, Wo, x.device)
         scale = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if (want_scale and fused) else None
-        norm = None if fused or b == 1.0 else torch.empty((N, Ho, Wo, groups), device=x.device, dtype=torch.float32)
+        if train:
+            norm = torch.empty((N, Ho, Wo), device=x.device, dtype=torch.float32)
+        else:
+            norm = None if fused or b == 1.0 else torch.empty((N, Ho, Wo, groups), device=x.device, dtype=torch.float32)
         mode = BCOS_NONE if b == 1.0 else BCOS_CONV_EPS
         cout_g = Cout_all // groups
         for g in range(groups):
@@ -149,26 +172,51 @@ class BcosConv2dFn(Function):
         ctx.cfg = cfg
         ctx.in_shape = (N, Cin, H, W)
         ctx.w_eff = w_eff
-        ctx.detached = bool(cfg["detach"]) or b == 1.0
-        ctx.save_for_backward(*(t for t in (scale, argmax) if t is not None))
-        ctx.has = (scale is not None, argmax is not None)
+        ctx.train = bool(train)
+        ctx.geom = (kh, kw, Ho, Wo)
+        keep_x = xh if (train or need_w) else None                  # the padded NHWC input: weight gradient / norm term
+        keep_y = y_cl if train else None
+        keep_n = norm if train else None
+        ctx.save_for_backward(*(t for t in (scale, argmax, keep_x, keep_y, keep_n) if t is not None))
+        ctx.has = (scale is not None, argmax is not None, keep_x is not None, keep_y is not None, keep_n is not None)
         return y_cl
 
     @staticmethod
     def backward(ctx, gy):
         cfg = ctx.cfg
-        if not ctx.detached:
-            raise NotImplementedError(
-                "BcosConv2d backward outside explanation mode (training-mode gradients through the dynamic "
-                "scale, weight gradients) is not implemented in the MI355X build: wrap the call in "
-                "model.explanation_mode() (SURVEY.md section 8(f) N4).")
         saved = list(ctx.saved_tensors)
         scale = saved.pop(0) if ctx.has[0] else None
         argmax = saved.pop(0) if ctx.has[1] else None
+        xh = saved.pop(0) if ctx.has[2] else None
+        y_cl = saved.pop(0) if ctx.has[3] else None
+        norm = saved.pop(0) if ctx.has[4] else None
         N, Cin, H, W = ctx.in_shape
+        kh, kw, Ho, Wo = ctx.geom
         groups, max_out = cfg["groups"], cfg["max_out"]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         g = to_nhwc(gy)
-        glin = ops.mul(g, scale) if scale is not None else g
+        addend = None
+        if ctx.train:
+            Cout = g.shape[3]
+            if Cout % 4:
+                raise NotImplementedError("training-mode backward needs out_channels % 4 == 0")
+            glin, rnorm = ops.train_scale_bwd(g.view(-1, Cout), to_nhwc(y_cl).view(-1, Cout), scale.view(-1, Cout),
+                                              norm.view(-1), BCOS_CONV_EPS, float(cfg["b"]), bool(cfg.get("force_pow")))
+            glin = glin.view(N, Ho, Wo, Cout)
+            if need_x:      # gradient through calc_patch_norms: x * PatchSum^T(dL/dnorm / norm), added by the dgrad epilogue
+                addend = ops.patch_norm_bwd(xh, rnorm.view(N, Ho, Wo), Cin, (kh, kw), cfg["stride"], cfg["padding"], cfg["dilation"])
+        else:
+            glin = ops.mul(g, scale) if scale is not None else g
+        gw = gb = None
+        if need_w or need_b:
+            gl4 = _pad_last(glin).contiguous()
+            if need_w:
+                gwk = ops.conv2d_wgrad(gl4, xh, Cin, glin.shape[3], (kh, kw), cfg["stride"], cfg["padding"], cfg["dilation"])
+                gw = gwk.permute(0, 3, 1, 2).contiguous()                     # [Cout,kh,kw,Cin] -> OIHW
+            if need_b:
+                gb = ops.colsum(gl4.view(-1, gl4.shape[3]))[:glin.shape[3]].contiguous()
+        if not need_x:
+            return None, gw, gb, None
         if argmax is not None:   # MaxOut: route the gradient to the winning filter of each unit
             full = torch.zeros(glin.shape[:3] + (glin.shape[3] * max_out,), device=glin.device, dtype=torch.float32)
             idx = (torch.arange(glin.shape[3], device=glin.device) * max_out) + argmax.view(glin.shape).long()
@@ -182,10 +230,10 @@ class BcosConv2dFn(Function):
             gl = glin[..., gi * cout_g:(gi + 1) * cout_g]
             gl = _pad_last(gl).contiguous() if (groups > 1 or cout_g % 4) else gl
             if groups == 1:
-                plan.run(gl, H, W, out=gx)
+                plan.run(gl, H, W, out=gx, addend=addend)
             else:
                 gx[..., gi * cin_g:(gi + 1) * cin_g] = plan.run(gl, H, W)
-        return gx_cl, None, None, None
+        return gx_cl, gw, gb, None
 
 
 class BcosLinearFn(Function):
@@ -200,12 +248,19 @@ class BcosLinearFn(Function):
         x2 = x.reshape(-1, Cin)
         x2 = _pad_last(x2 if x2.is_contiguous() else x2.contiguous())
         wk = cfg["cache"].fwd(w_eff, cfg["w_src"]).view(w_eff.shape[0], -1)
-        want_scale = bool(need_grad and b != 1.0)
+        need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        train = (need_grad or need_w or need_b) and not cfg["detach"] and b != 1.0
+        if (train or need_w or need_b) and max_out != 1:
+            raise NotImplementedError(
+                "BcosLinear: weight gradients / training-mode gradients are built for max_out == 1 (SURVEY.md section 8(f) "
+                "N4); MaxOut layers support explanation-mode input gradients only")
+        want_scale = bool((need_grad or need_w or need_b) and b != 1.0)
         Cout_all = w_eff.shape[0]
         argmax = None
+        norm = None
         if max_out == 1:
-            y, scale, _ = ops.linear_fwd(x2, wk, bias=bias, b=b, want_scale=want_scale,
-                                         flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0)
+            y, scale, norm = ops.linear_fwd(x2, wk, bias=bias, b=b, want_scale=want_scale, want_norm=train,
+                                            flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0)
         else:
             rows = x2.shape[0]
             lin = torch.empty((rows, Cout_all), device=x.device, dtype=torch.float32)
@@ -219,25 +274,49 @@ class BcosLinearFn(Function):
         ctx.cfg = cfg
         ctx.w_eff = w_eff
         ctx.in_shape = tuple(x.shape)
-        ctx.detached = bool(cfg["detach"]) or b == 1.0
-        ctx.save_for_backward(*(t for t in (scale, argmax) if t is not None))
-        ctx.has = (scale is not None, argmax is not None)
+        ctx.train = bool(train)
+        keep_x = x2 if (train or need_w) else None
+        keep_y = y if train else None
+        keep_n = norm if train else None
+        ctx.save_for_backward(*(t for t in (scale, argmax, keep_x, keep_y, keep_n) if t is not None))
+        ctx.has = (scale is not None, argmax is not None, keep_x is not None, keep_y is not None, keep_n is not None)
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
     def backward(ctx, gy):
         cfg = ctx.cfg
-        if not ctx.detached:
-            raise NotImplementedError(
-                "BcosLinear backward outside explanation mode is not implemented in the MI355X build: wrap the "
-                "call in model.explanation_mode() (SURVEY.md section 8(f) N4).")
         saved = list(ctx.saved_tensors)
         scale = saved.pop(0) if ctx.has[0] else None
         argmax = saved.pop(0) if ctx.has[1] else None
+        x2 = saved.pop(0) if ctx.has[2] else None
+        y = saved.pop(0) if ctx.has[3] else None
+        norm = saved.pop(0) if ctx.has[4] else None
         max_out = cfg["max_out"]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        Cin = ctx.in_shape[-1]
         g2 = gy.reshape(-1, gy.shape[-1])
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
-        glin = ops.mul(g2, scale) if scale is not None else g2
+        addend = None
+        if ctx.train:
+            if g2.shape[1] % 4:
+                raise NotImplementedError("training-mode backward needs out_features % 4 == 0")
+            glin, rnorm = ops.train_scale_bwd(g2, y, scale, norm, BCOS_LINEAR_EPS, float(cfg["b"]), bool(cfg.get("force_pow")))
+            if need_x:      # gradient through ||x||: x * dL/dnorm / ||x||, added by the dgrad epilogue
+                rows = x2.shape[0]
+                addend = ops.patch_norm_bwd(x2.view(1, 1, rows, x2.shape[1]), rnorm.view(1, 1, rows), Cin, (1, 1), (1, 1), (0, 0), (1, 1))
+        else:
+            glin = ops.mul(g2, scale) if scale is not None else g2
+        gw = gb = None
+        if need_w or need_b:
+            gl4 = _pad_last(glin).contiguous()
+            if need_w:
+                rows = x2.shape[0]
+                gw = ops.conv2d_wgrad(gl4.view(1, 1, rows, gl4.shape[1]), x2.view(1, 1, rows, x2.shape[1]), Cin, glin.shape[1],
+                                      (1, 1), (1, 1), (0, 0), (1, 1)).view(glin.shape[1], Cin)
+            if need_b:
+                gb = ops.colsum(gl4)[:glin.shape[1]].contiguous()
+        if not need_x:
+            return None, gw, gb, None
         if argmax is not None:
             full = torch.zeros((glin.shape[0], glin.shape[1] * max_out), device=glin.device, dtype=torch.float32)
             idx = (torch.arange(glin.shape[1], device=glin.device) * max_out) + argmax.long()
@@ -246,8 +325,8 @@ class BcosLinearFn(Function):
         plan = cfg["cache"].dgrad(ctx.w_eff, cfg["w_src"], (1, 1), (0, 0), (1, 1), 1)[0]
         rows = glin.shape[0]
         glin = _pad_last(glin).contiguous()
-        gx = plan.run(glin.view(1, 1, rows, glin.shape[1]), 1, rows)      # [1,1,rows,Cin]
-        return gx.view(ctx.in_shape), None, None, None
+        gx = plan.run(glin.view(1, 1, rows, glin.shape[1]), 1, rows, addend=addend)      # [1,1,rows,Cin]
+        return gx.view(ctx.in_shape), gw, gb, None
 
 
 def plain_conv2d(x, w_eff, bias, stride, padding, dilation, groups, cache, w_src):

@@ -141,6 +141,7 @@ class BcosConv2d(DetachableModule):
         if lin.padding_mode != "zeros":
             raise NotImplementedError("only zero padding is implemented by the HIP kernels")
         w, bias = self._effective_weight_and_bias()
+        _hipfn.refuse_unit_norm_training(self, w, lin.weight)
         cfg = dict(stride=tuple(lin.stride), padding=tuple(lin.padding), dilation=tuple(lin.dilation),
                    groups=lin.groups, b=self._b_value(), max_out=self.max_out, detach=self.detach,
                    cache=self._wcache, w_src=lin.weight)

@@ -81,6 +81,7 @@ class BcosLinear(DetachableModule):
 
     def forward(self, in_tensor: Tensor) -> Tensor:
         w, bias = self._effective_weight_and_bias()
+        _hipfn.refuse_unit_norm_training(self, w, self.linear.weight)
         cfg = dict(b=self._b_value(), max_out=self.max_out, detach=self.detach, cache=self._wcache,
                    w_src=self.linear.weight)
         return _hipfn.BcosLinearFn.apply(in_tensor, w, bias, cfg)

@@ -1,12 +1,16 @@
-"""BatchNormUncentered2d (eval path) on MI355X.
+"""BatchNormUncentered2d on MI355X.
 
 Reference: bcos/modules/norms/uncentered_norms/batchnorm_uncentered.py -- functional :21-60, class :63-115,
 `from_standard_module` :117-141.  In eval mode the layer is a per-channel affine map
     y = x / sqrt(running_var + eps) * weight (+ bias)
 which is linear in x, so it needs no special handling in explanation mode.  Standalone it runs as one
 streaming HIP kernel (bcos_channel_affine); inside the fused engine (bcos_hip/engine.py) it disappears
-into the epilogue of the preceding B-cos convolution.  Training-mode batch statistics are SURVEY.md
-section 8(f) N4 (not built).
+into the epilogue of the preceding B-cos convolution.
+Training mode (reference :36-44): var = x.var((0,2,3), unbiased=False) of the batch -- the
+centred variance, although the normalisation itself does not subtract the mean --, running_var <- (1-m) running_var + m var,
+y = x / sqrt(var + eps) * weight + bias.  Statistics are two column-reduction launches (mean, then centred squares), the
+backward  gx = gy w/std - (x - mean) w (sum gy x) / (M (var+eps)^1.5)  one more reduction and one streaming kernel
+(csrc/bcos_train.hip); with `detach` (explanation mode) the variance is a constant and the second term vanishes.
 """
 import torch
 import torch.nn as nn
@@ -41,13 +45,64 @@ class _ChannelAffineFn(Function):
         return g_cl, None, None
 
 
+class _BatchStatsFn(Function):
+    """y = x / sqrt(var_batch(x) + eps) * weight + bias with gradients to x, weight and bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, detach, stats_out):
+        _hipfn.require_hip(x, "BatchNormUncentered2d")
+        xh = _hipfn.to_nhwc(x)
+        c = xh.shape[-1]
+        if c % 4 != 0:
+            raise _hipfn.BcosHipError(f"BatchNormUncentered2d HIP kernels need C % 4 == 0 (got {c})")
+        x2 = xh.view(-1, c)
+        m = x2.shape[0]
+        mean = ops.colsum(x2) / m
+        var = ops.colsum(x2, x2, mean, mean) / m                 # centred second moment: x.var(unbiased=False)
+        stats_out.append(var)
+        rstd = torch.rsqrt(var + eps)
+        g = rstd if weight is None else weight.detach() * rstd
+        y_cl, y = _hipfn.empty_cl(x.shape[0], c, x.shape[2], x.shape[3], x.device)
+        ops.channel_affine(xh, g.contiguous(), bias.detach().contiguous() if bias is not None else None, out=y)
+        ctx.save_for_backward(xh, mean, rstd, g, weight if weight is not None else rstd)
+        ctx.flags = (bool(detach), weight is not None, bias is not None, float(eps))
+        return y_cl
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, mean, rstd, g, weight = ctx.saved_tensors
+        detach, has_w, has_b, eps = ctx.flags
+        c = xh.shape[-1]
+        gh = _hipfn.to_nhwc(gy)
+        g2, x2 = gh.view(-1, c), xh.view(-1, c)
+        m = x2.shape[0]
+        gx_cl = gw = gb = None
+        sgx = ops.colsum(g2, x2) if (has_w and ctx.needs_input_grad[1]) or (ctx.needs_input_grad[0] and not detach) else None
+        if ctx.needs_input_grad[0]:
+            gx_cl, gx = _hipfn.empty_cl(gy.shape[0], c, gy.shape[2], gy.shape[3], gy.device)
+            if detach:                                                # variance held constant: a per-channel scale
+                ops.channel_affine(gh, g.contiguous(), None, out=gx)
+            else:                                                     # + dL/dvar * 2 (x - mean) / M
+                coef = -(g * sgx) * rstd * rstd / m
+                ops.channel_axpby(gh, g.contiguous(), xh, mean.contiguous(), coef.contiguous(), out=gx)
+        if has_w and ctx.needs_input_grad[1]:
+            gw = sgx * rstd                                           # sum gy * x / std
+        if has_b and ctx.needs_input_grad[2]:
+            gb = ops.colsum(g2)
+        return gx_cl, gw, gb, None, None, None
+
+
 def batch_norm_uncentered_2d(input, running_var, weight=None, bias=None, training=False, momentum=0.1,
                              eps=1e-5, detach=False):
-    """Functional form (reference :21-60); eval only."""
+    """Functional form (reference :21-60)."""
     assert input.dim() == 4, "input should be a 4d tensor!"
     if training:
-        raise NotImplementedError("BatchNormUncentered2d with batch statistics (training mode) is not built "
-                                  "for MI355X yet: call model.eval() (SURVEY.md section 8(f) N4)")
+        stats = []
+        out = _BatchStatsFn.apply(input, weight, bias, eps, detach, stats)
+        if running_var is not None:
+            with torch.no_grad():
+                running_var.copy_((1 - momentum) * running_var + momentum * stats[0])
+        return out
     assert running_var is not None, "running_var must be defined in eval mode"
     scale = 1.0 / (running_var.detach() + eps).sqrt()
     if weight is not None:
@@ -63,10 +118,15 @@ class BatchNormUncentered2d(nn.BatchNorm2d, DetachableModule):
         super().__init__(*args, **kwargs)
 
     def forward(self, input):
+        momentum = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:                                  # cumulative moving average (reference :84-88)
+                momentum = 1.0 / float(self.num_batches_tracked)
         use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
-        return batch_norm_uncentered_2d(input, self.running_var, self.weight, self.bias, training=use_batch_stats,
-                                        momentum=0.0 if self.momentum is None else self.momentum, eps=self.eps,
-                                        detach=self.detach)
+        running_var = self.running_var if (not self.training or self.track_running_stats) else None
+        return batch_norm_uncentered_2d(input, running_var, self.weight, self.bias, training=use_batch_stats,
+                                        momentum=momentum, eps=self.eps, detach=self.detach)
 
     def channel_scale_shift(self):
         """(scale[C], shift[C] or None) of the eval-mode affine map, for fusion into a conv epilogue."""

@@ -172,3 +172,39 @@ class OverlappedGather:
                 outs.append(self._finish(self._slots[i]))
                 self._slots[i] = None
         return outs
+
+
+def allreduce_gradients(parameters, bucket_bytes: int = 64 << 20, average: bool = True):
+    """Data-parallel training: sum (or average) the `.grad` of every parameter over the ranks.
+    What the reference gets from Lightning's DDP strategy (bcos/training/trainer.py:916-918) is done here explicitly:
+    gradients are packed into flat fp32 buckets of ~`bucket_bytes` (few large collectives: the xGMI links are point to
+    point, a ring all-reduce is bound per link), every bucket is all-reduced asynchronously on RCCL's stream (backend
+    "nccl" on ROCm; "gloo" in the CPU tests) while the next one is being packed, and unpacked in order afterwards.
+    Parameters without a gradient are skipped on every rank alike (the same model runs everywhere).  No-op for world 1."""
+    params = [p for p in parameters if p.grad is not None]
+    if not dist.is_initialized() or dist.get_world_size() == 1 or not params:
+        return
+    world = dist.get_world_size()
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nbytes = p.grad.numel() * 4
+        if cur and cur_bytes + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    inflight = []
+    for bucket in buckets:
+        flat = torch.cat([p.grad.detach().reshape(-1).float() for p in bucket])
+        inflight.append((bucket, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)))
+    for bucket, flat, work in inflight:
+        work.wait()
+        if average:
+            flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n

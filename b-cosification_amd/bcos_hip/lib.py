@@ -18,7 +18,8 @@ REPO_ROOT = PKG_ROOT.parent
 LIB_PATH = Path(os.environ["BCOS_HIP_LIB"]) if os.environ.get("BCOS_HIP_LIB") else PKG_ROOT / "lib" / "libbcos_hip.so"
 CSRC = PKG_ROOT / "csrc"
 INCLUDE = REPO_ROOT / "include"
-SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_vit.hip", "bcos_render.hip", "bcos_abi.hip"]
+SOURCES = ["bcos_tapconv.hip", "bcos_skinny.hip", "bcos_elementwise.hip", "bcos_vit.hip", "bcos_render.hip", "bcos_train.hip",
+           "bcos_abi.hip"]
 
 BCOS_NONE, BCOS_CONV_EPS, BCOS_LINEAR_EPS = 0, 1, 2
 BCOS_EPI_NORM_ONLY = 1
@@ -73,6 +74,11 @@ SIGNATURES = {
     "bcos_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "bcos_conv2d_dgrad_s1": (C.c_int, [_P, _P, _P] + [_I] * 9 + [_P]),
     "bcos_linear_dgrad": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
+    "bcos_train_scale_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "bcos_patch_norm_bwd": (C.c_int, [_P, _P, _P] + [_I] * 15 + [_P]),
+    "bcos_conv2d_wgrad": (C.c_int, [_P, _P, _P] + [_I] * 18 + [_P]),
+    "bcos_colsum": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
+    "bcos_channel_axpby": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_maxout_scale": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),

@@ -556,6 +556,67 @@ def channel_affine(x, scale, shift=None, relu=False, out=None):
     return out
 
 
+# ---- training-mode backward (csrc/bcos_train.hip) --------------------------------------------
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False):
+    """(gy * dy/dlin [rows,C], dL/dnorm / norm-denominator [rows]) of y = s(lin, norm) * lin with s not detached
+    (include/bcos_hip.h: bcos_train_scale_bwd)."""
+    lib = _l.load()
+    rows, Cc = gy2d.shape
+    glin = torch.empty_like(gy2d)
+    rnorm = torch.empty((rows,), device=gy2d.device, dtype=torch.float32)
+    _l.check(lib.bcos_train_scale_bwd(_dev(gy2d, "gy"), _dev(y2d, "y"), _dev(s2d, "s"), _dev(norm, "norm"), _dev(glin, "glin"),
+                                      _dev(rnorm, "rnorm"), rows, Cc, int(mode), float(b), int(bool(force_pow)), _stream()),
+             "bcos_train_scale_bwd")
+    return glin, rnorm
+
+
+def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation):
+    """x [N,H,W,pitch] (first C_used channels), rnorm [N,P,Q] -> x * PatchSum^T(rnorm) [N,H,W,C_used]
+    (include/bcos_hip.h: bcos_patch_norm_bwd)."""
+    lib = _l.load()
+    N, H, W, pitch = x.shape
+    _, P, Q = rnorm.shape
+    out = torch.empty((N, H, W, C_used), device=x.device, dtype=torch.float32)
+    _l.check(lib.bcos_patch_norm_bwd(_dev(x, "x"), _dev(rnorm, "rnorm"), _dev(out, "out"), N, H, W, C_used, pitch, P, Q,
+                                     kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                     _stream()), "bcos_patch_norm_bwd")
+    return out
+
+
+def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation):
+    """glin [N,P,Q,g_pitch] (first Cout channels), x [N,H,W,x_pitch] (first C_used) -> gw [Cout,kh,kw,C_used]
+    (include/bcos_hip.h: bcos_conv2d_wgrad; fp32 MFMA, pixel chunks combined with atomics)."""
+    lib = _l.load()
+    N, H, W, x_pitch = x.shape
+    _, P, Q, g_pitch = glin.shape
+    gw = torch.zeros((Cout, kernel[0], kernel[1], C_used), device=x.device, dtype=torch.float32)
+    _l.check(lib.bcos_conv2d_wgrad(_dev(glin, "glin"), _dev(x, "x"), _dev(gw, "gw"), N, H, W, C_used, x_pitch, P, Q, Cout, g_pitch,
+                                   kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                   C_used, _stream()), "bcos_conv2d_wgrad")
+    return gw
+
+
+def colsum(a2d, b2d=None, shift_a=None, shift_b=None):
+    """out[c] = sum_r (a[r,c] - shift_a[c]) * (b[r,c] - shift_b[c])   (b None: plain column sums); C % 4 == 0."""
+    lib = _l.load()
+    rows, Cc = a2d.shape
+    out = torch.zeros((Cc,), device=a2d.device, dtype=torch.float32)
+    _l.check(lib.bcos_colsum(_dev(a2d, "a"), _dev(b2d, "b"), _dev(shift_a, "shift_a"), _dev(shift_b, "shift_b"), _dev(out, "out"),
+                             rows, Cc, _stream()), "bcos_colsum")
+    return out
+
+
+def channel_axpby(a, sa, b=None, mb=None, sb=None, out=None):
+    """out = a * sa[c] + (b - mb[c]) * sb[c] over the last (channel) dimension."""
+    lib = _l.load()
+    Cc = a.shape[-1]
+    if out is None:
+        out = torch.empty_like(a)
+    _l.check(lib.bcos_channel_axpby(_dev(a, "a"), _dev(sa, "sa"), _dev(b, "b"), _dev(mb, "mb"), _dev(sb, "sb"), _dev(out, "out"),
+                                    a.numel() // Cc, Cc, _stream()), "bcos_channel_axpby")
+    return out
+
+
 # ---- transformer pieces (csrc/bcos_vit.hip) ----------------------------------------------------------------
 def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None):
     lib = _l.load()

@@ -1,0 +1,380 @@
+// bcos_train.hip -- training-mode backward of the B-cos layers on gfx950.
+//
+// Outside explanation mode the dynamic scale s = |lin| / norm is NOT detached (bcos/modules/bcosconv2d.py:176-194,
+// bcosifyconv2d.py:85-101), so for y = s(lin, norm) * lin with lin = conv(x, W) (+ bias), norm = ||patch(x)||:
+//     dL/dlin  = gy * dy/dlin                      B == 2:  dy/dlin  = 2 s
+//     dL/dnorm = sum_c gy_c * dy_c/dnorm           B == 2:  dy/dnorm = -y / norm
+//     gx = dgrad(dL/dlin, W)  +  x (.) PatchSum^T(dL/dnorm / norm)        (d norm / d x_j = x_j / norm)
+//     gW = wgrad(dL/dlin, x),  gbias = sum_pixels dL/dlin
+// The input gradient reuses the tapconv kernel (bcos_tapconv.hip) with the norm term as its epilogue addend; this
+// file holds what is new: the per-pixel scale derivative, the transposed patch sum, the weight-gradient contraction
+// on v_mfma_f32_32x32x2_f32 (its operand layout -- 32 consecutive channels of one pixel per half-wavefront -- is exactly
+// how NHWC tensors lie in memory, so the pixel-contraction needs no transposes), and per-channel reductions for bias
+// gradients and the batch statistics of BatchNormUncentered2d (batchnorm_uncentered.py:36-44).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bcos_hip.h"
+#include "bcos_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+inline int check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error(what, err);
+    return BCOS_OK;
+}
+
+// ---- dy/dlin and dL/dnorm of one output pixel: one wavefront per row ---------------------------------------------------
+__global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                        const float* __restrict__ s, const float* __restrict__ norm,
+                                                        float* __restrict__ glin, float* __restrict__ rnorm, int64_t rows, int C,
+                                                        int linear_eps, float b, int pow_form) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float nrm = norm[row];
+    const float bm1 = b - 1.0f;
+    const float inv_e = bm1 != 0.f ? 1.0f / bm1 : 0.f;
+    float acc = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const int64_t i = row * C + c;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gy + i);
+        const f32x4 y4 = *reinterpret_cast<const f32x4*>(y + i);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(s + i);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!pow_form) {                       // s = |lin| / norm:  dy/dlin = 2 s,  dy/dnorm = -y / norm
+                o[q] = g4[q] * 2.0f * s4[q];
+                acc = fmaf(g4[q], -y4[q] / nrm, acc);
+            } else {                               // s = (|lin| / norm + 1e-6)^(b-1) = c^(b-1), q = c - 1e-6
+                const float cc = powf(s4[q], inv_e);
+                const float qq = fmaxf(cc - 1e-6f, 0.f);
+                const float ratio = qq / cc;       // (|lin| / norm) / c
+                o[q] = g4[q] * s4[q] * (1.0f + bm1 * ratio);
+                acc = fmaf(g4[q], -bm1 * y4[q] * ratio / nrm, acc);
+            }
+        }
+        *reinterpret_cast<f32x4*>(glin + i) = o;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        // d norm / d x_j = x_j / ||.||: sqrt(S + 1e-6) differentiates to x / norm, ||x|| + 1e-12 to x / (norm - 1e-12)
+        const float div = linear_eps ? fmaxf(nrm - 1e-12f, 1e-30f) : nrm;
+        rnorm[row] = acc / div;
+    }
+}
+
+// ---- transposed patch sum times x: out[n,h,w,:] = x[n,h,w,:] * sum_{(i,j): patch(i,j) contains (h,w)} r[n,i,j] -----------
+__global__ __launch_bounds__(256) void patch_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                             float* __restrict__ out, int N, int H, int W, int C, int x_pitch,
+                                                             int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                                                             int dw, int vec) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t total = (int64_t)N * H * W;
+    if (pix >= total) return;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const int n = (int)(pix / ((int64_t)W * H));
+    float t = 0.f;
+    for (int tap = lane; tap < kh * kw; tap += 64) {
+        const int th = tap / kw, tw = tap - th * kw;
+        const int hn = h + ph - th * dh, wn = w + pw - tw * dw;
+        if (hn >= 0 && wn >= 0 && hn % sh == 0 && wn % sw == 0) {
+            const int i = hn / sh, j = wn / sw;
+            if (i < P && j < Q) t += r[((int64_t)n * P + i) * Q + j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    const float* src = x + pix * x_pitch;
+    float* dst = out + pix * C;
+    if (vec) {
+        for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c) * t;
+    } else {                                       // C % 4 != 0 (e.g. the 6-channel network input): element by element
+        for (int c = lane; c < C; c += 64) dst[c] = src[c] * t;
+    }
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------------
+// gw[co][th][tw][ci] += sum_m glin[m, co] * x[pix(m, th, tw), ci]: per (128 co x 128 ci tile, tap, pixel chunk) one workgroup;
+// operands staged pixel-major through LDS ([32 pixels][128 channels], the memory order), fragments of v_mfma_f32_32x32x2_f32
+// are 32 consecutive channels of two pixels = two conflict-free ds_read_b32 rows; partial tiles of the pixel chunks are
+// combined with fp32 atomics (the caller zeroes gw).
+struct WgradArgs {
+    const float* glin;
+    const float* x;
+    float* gw;
+    int N, H, W, C, x_pitch;       // x: [N,H,W,x_pitch], C channels used
+    int P, Q, Cout, g_pitch;       // glin: [N,P,Q,g_pitch]
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int gw_cin;                    // channels per tap in gw (its innermost pitch)
+    int tiles_ci;
+    int64_t M;                     // N*P*Q
+    int64_t chunk;                 // pixels per workgroup (multiple of 32)
+};
+
+constexpr int WG_T = 128;          // tile edge (channels)
+constexpr int WG_K = 32;           // pixels per stage
+constexpr int WG_LD = WG_T + 4;    // LDS row pitch (floats): rows of different pixels start in different banks
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* sA = wsm;                               // [2][WG_K][WG_LD] glin
+    float* sB = wsm + 2 * WG_K * WG_LD;            // [2][WG_K][WG_LD] x
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int tile = blockIdx.x;
+    const int tile_co = tile / p.tiles_ci, tile_ci = tile - tile_co * p.tiles_ci;
+    const int co0 = tile_co * WG_T, ci0 = tile_ci * WG_T;
+    const int tap = blockIdx.y;
+    const int th = tap / p.kw, tw = tap - th * p.kw;
+    const int64_t m_lo = (int64_t)blockIdx.z * p.chunk;
+    const int64_t m_hi = m_lo + p.chunk < p.M ? m_lo + p.chunk : p.M;
+    const int PQ = p.P * p.Q;
+
+    // staging: thread -> (pixel row lr + 8 j, 16-byte channel chunk cq) of both operands
+    const int cq = tid & 31, lr = tid >> 5;
+    f32x4 ra[4], rb[4];
+    auto load = [&](int64_t m0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + lr + 8 * j;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_hi) {
+                const int n = (int)(m / PQ);
+                const int rem = (int)(m - (int64_t)n * PQ);
+                const int i = rem / p.Q, jj = rem - i * p.Q;
+                const int co = co0 + cq * 4;
+                if (co + 3 < p.Cout) a = *reinterpret_cast<const f32x4*>(p.glin + m * p.g_pitch + co);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (co + q < p.Cout) a[q] = p.glin[m * p.g_pitch + co + q];
+                }
+                const int ih = i * p.sh - p.ph + th * p.dh, iw = jj * p.sw - p.pw + tw * p.dw;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+                    const float* src = p.x + (((int64_t)n * p.H + ih) * p.W + iw) * p.x_pitch;
+                    const int ci = ci0 + cq * 4;
+                    if (ci + 3 < p.C) b = *reinterpret_cast<const f32x4*>(src + ci);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (ci + q < p.C) b[q] = src[ci + q];
+                    }
+                }
+            }
+            ra[j] = a;
+            rb[j] = b;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x4*>(sA + (buf * WG_K + lr + 8 * j) * WG_LD + cq * 4) = ra[j];
+            *reinterpret_cast<f32x4*>(sB + (buf * WG_K + lr + 8 * j) * WG_LD + cq * 4) = rb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fk = lane >> 5;
+    const int nst = (int)((m_hi - m_lo + WG_K - 1) / WG_K);
+    if (nst > 0) {
+        load(m_lo);
+        store(0);
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < nst) load(m_lo + (int64_t)(st + 1) * WG_K);
+            const float* a = sA + cur * WG_K * WG_LD + wave_m * 64 + fr;
+            const float* b = sB + cur * WG_K * WG_LD + wave_n * 64 + fr;
+#pragma unroll
+            for (int kk = 0; kk < WG_K; kk += 2) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = a[(kk + fk) * WG_LD + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = b[(kk + fk) * WG_LD + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (st + 1 < nst) store(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // accumulator (row = co, column = ci): lane = column, 16 rows per lane
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wave_n * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < p.Cout && ci < p.C)
+                    atomicAdd(p.gw + ((int64_t)co * p.kh * p.kw + tap) * p.gw_cin + ci, acc[i][j][r]);
+            }
+        }
+}
+
+// ---- per-channel sums over rows: out[c] += sum_r (a[r,c] - sa[c]) * (b ? b[r,c] - sb[c] : 1) -----------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ sa, const float* __restrict__ sb,
+                                                     float* __restrict__ out, int64_t rows, int C, int64_t rows_per_block) {
+    __shared__ float red[256 * 4];
+    const int c4 = C / 4;                                  // float4 columns
+    const int tpc = c4 < 256 ? c4 : 256;                   // threads along the channel dimension
+    const int rstride = 256 / tpc;                         // rows handled concurrently
+    const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+    const int64_t r_lo = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_hi = r_lo + rows_per_block < rows ? r_lo + rows_per_block : rows;
+    for (int base = 0; base < c4; base += tpc) {            // uniform trip count: the loop body holds barriers
+        const int cg = base + tc;
+        const bool live = cg < c4 && tr < rstride;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sa4 = {0.f, 0.f, 0.f, 0.f}, sb4 = {0.f, 0.f, 0.f, 0.f};
+        if (live && sa) sa4 = *reinterpret_cast<const f32x4*>(sa + cg * 4);
+        if (live && sb) sb4 = *reinterpret_cast<const f32x4*>(sb + cg * 4);
+        if (live)
+            for (int64_t r = r_lo + tr; r < r_hi; r += rstride) {
+                f32x4 va = *reinterpret_cast<const f32x4*>(a + r * C + cg * 4) - sa4;
+                if (b) va *= *reinterpret_cast<const f32x4*>(b + r * C + cg * 4) - sb4;
+                acc += va;
+            }
+        // combine the rstride partial sums of this channel group through LDS
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[threadIdx.x * 4 + q] = acc[q];
+        __syncthreads();
+        if (tr == 0 && cg < c4) {
+            for (int k = 1; k < rstride; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += red[(k * tpc + tc) * 4 + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(out + cg * 4 + q, acc[q]);
+        }
+    }
+}
+
+// out[r,c] = a[r,c] * sa[c] + (b[r,c] - mb[c]) * sb[c]        (b, mb, sb optional as a group)
+__global__ __launch_bounds__(256) void channel_axpby_kernel(const float* __restrict__ a, const float* __restrict__ sa,
+                                                            const float* __restrict__ b, const float* __restrict__ mb,
+                                                            const float* __restrict__ sb, float* __restrict__ out,
+                                                            int64_t n4, int c4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int cg = (int)(i % c4);
+        f32x4 v = reinterpret_cast<const f32x4*>(a)[i] * reinterpret_cast<const f32x4*>(sa)[cg];
+        if (b) {
+            f32x4 w = reinterpret_cast<const f32x4*>(b)[i];
+            if (mb) w -= reinterpret_cast<const f32x4*>(mb)[cg];
+            v += w * reinterpret_cast<const f32x4*>(sb)[cg];
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin,
+                                    float* rnorm, int64_t rows, int C, int bcos_mode, float b, int force_pow, void* stream) {
+    if (!gy || !y || !s || !norm || !glin || !rnorm || rows <= 0 || C <= 0 || C % 4 != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: bad argument (C must be a multiple of 4)");
+    if (bcos_mode != BCOS_CONV_EPS && bcos_mode != BCOS_LINEAR_EPS)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: bcos_mode must be BCOS_CONV_EPS or BCOS_LINEAR_EPS");
+    if (b == 1.0f) return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: B == 1 has no dynamic scale");
+    const int pow_form = (b != 2.0f || force_pow) ? 1 : 0;
+    hipLaunchKernelGGL(scale_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       gy, y, s, norm, glin, rnorm, rows, C, bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b, pow_form);
+    return check_launch("train_scale_bwd launch");
+}
+
+extern "C" int bcos_patch_norm_bwd(const float* x, const float* rnorm, float* out, int N, int H, int W, int C, int x_pitch,
+                                   int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream) {
+    if (!x || !rnorm || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || kh <= 0 || kw <= 0 ||
+        sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_patch_norm_bwd: bad argument");
+    if (x_pitch == 0) x_pitch = C;
+    if (x_pitch < C) return bcos_set_error(BCOS_E_INVAL, "bcos_patch_norm_bwd: bad x_pitch");
+    const int vec = (C % 4 == 0 && x_pitch % 4 == 0 && !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15)) ? 1 : 0;
+    const int64_t total = (int64_t)N * H * W;
+    hipLaunchKernelGGL(patch_norm_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, rnorm, out, N, H, W, C, x_pitch, P, Q, kh, kw, sh, sw, ph, pw, dh, dw, vec);
+    return check_launch("patch_norm_bwd launch");
+}
+
+extern "C" int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, int N, int H, int W, int C, int x_pitch, int P,
+                                 int Q, int Cout, int g_pitch, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                 int gw_cin, void* stream) {
+    if (!glin || !x || !gw || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
+        sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad: bad argument");
+    if (x_pitch == 0) x_pitch = C;
+    if (g_pitch == 0) g_pitch = Cout;
+    if (gw_cin == 0) gw_cin = C;
+    if (x_pitch % 4 != 0 || g_pitch % 4 != 0 || x_pitch < C || g_pitch < Cout || gw_cin < C ||
+        ((reinterpret_cast<uintptr_t>(glin) | reinterpret_cast<uintptr_t>(x)) & 15))
+        return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad: operands must be 16-byte addressable per pixel");
+    WgradArgs p;
+    p.glin = glin; p.x = x; p.gw = gw;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.x_pitch = x_pitch;
+    p.P = P; p.Q = Q; p.Cout = Cout; p.g_pitch = g_pitch;
+    p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
+    p.gw_cin = gw_cin;
+    p.M = (int64_t)N * P * Q;
+    const int tiles_co = (Cout + WG_T - 1) / WG_T;
+    p.tiles_ci = (C + WG_T - 1) / WG_T;
+    const int64_t tiles = (int64_t)tiles_co * p.tiles_ci * kh * kw;
+    // split the pixels so that ~4 workgroups per CU are in flight, chunks of at least 256 pixels
+    int64_t split = (1024 + tiles - 1) / tiles;
+    const int64_t max_split = (p.M + 255) / 256;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    p.chunk = (((p.M + split - 1) / split) + WG_K - 1) / WG_K * WG_K;
+    split = (p.M + p.chunk - 1) / p.chunk;
+    const size_t lds = (size_t)4 * WG_K * WG_LD * sizeof(float);
+    static std::atomic<size_t> lds_hw{0};
+    hipError_t e = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_kernel), lds, lds_hw);
+    if (e != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", e);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(tiles_co * p.tiles_ci), (unsigned)(kh * kw), (unsigned)split), dim3(256), lds,
+                       reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("wgrad launch");
+}
+
+extern "C" int bcos_colsum(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out,
+                           int64_t rows, int C, void* stream) {
+    if (!a || !out || rows <= 0 || C <= 0 || C % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_colsum: bad argument");
+    int64_t blocks = (rows + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const int64_t rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, shift_a,
+                       shift_b, out, rows, C, rpb);
+    return check_launch("colsum launch");
+}
+
+extern "C" int bcos_channel_axpby(const float* a, const float* sa, const float* b, const float* mb, const float* sb, float* out,
+                                  int64_t rows, int C, void* stream) {
+    if (!a || !sa || !out || rows <= 0 || C <= 0 || C % 4 != 0 || (b && !sb))
+        return bcos_set_error(BCOS_E_INVAL, "bcos_channel_axpby: bad argument");
+    const int64_t n4 = rows * (C / 4);
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(channel_axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, sa, b,
+                       mb, sb, out, n4, C / 4);
+    return check_launch("channel_axpby launch");
+}

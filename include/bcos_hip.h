@@ -325,6 +325,45 @@ int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N, int C, voi
 int bcos_channel_affine(const float* x, const float* scale, const float* shift, float* y,
                         int64_t pixels, int C, int relu, void* stream);
 
+/* -- training-mode backward (bcos_train.hip) ------------------------------------------ */
+/* Outside explanation mode the dynamic scale is not detached (bcosconv2d.py:176-194), so with lin = conv(x, W) (+ bias),
+ * y = s(lin, norm) * lin:   gx = dgrad(gy * dy/dlin, W) + x (.) PatchSum^T(dL/dnorm / norm),   gW = wgrad(gy * dy/dlin, x).
+ *
+ * bcos_train_scale_bwd: per output pixel m (rows) and channel c, from the forward's y, s (scale_out) and norm (norm_out):
+ *     glin[m,c] = gy[m,c] * dy/dlin            B == 2: 2 s                  else: s (1 + (B-1) q / (q + 1e-6)), q = |lin| / norm
+ *     rnorm[m]  = sum_c gy[m,c] * dy/dnorm / (d norm / d x denominator)
+ *                                              B == 2: dy/dnorm = -y / norm   else: -(B-1) y q / ((q + 1e-6) norm)
+ *   with the denominator norm (BCOS_CONV_EPS: sqrt(S + 1e-6)) or norm - 1e-12 (BCOS_LINEAR_EPS: ||x|| + 1e-12).
+ *   force_pow selects the general form at B == 2 (the b_loss variants, bcosifyconv2d.py:91-98). */
+int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin, float* rnorm,
+                         int64_t rows, int C, int bcos_mode, float b, int force_pow, void* stream);
+
+/* out[n,h,w,c] = x[n,h,w,c] * sum of rnorm[n,i,j] over the output pixels (i,j) whose patch (kernel kh x kw, stride,
+ * padding, dilation) contains (h,w): the input gradient through calc_patch_norms (bcosconv2d.py:196-231).  x [N,H,W,x_pitch]
+ * (C channels used, x_pitch 0 = C), rnorm [N,P,Q], out [N,H,W,C]; handed to the dgrad launch as its epilogue addend. */
+int bcos_patch_norm_bwd(const float* x, const float* rnorm, float* out, int N, int H, int W, int C, int x_pitch, int P, int Q,
+                        int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream);
+
+/* Weight gradient of a convolution / linear layer: gw[co][th][tw][ci] += sum over output pixels (n,i,j) of
+ * glin[n,i,j,co] * x[n, i*sh - ph + th*dh, j*sw - pw + tw*dw, ci]   (the autograd convolution_backward weight branch).
+ * glin [N,P,Q,g_pitch] (Cout used), x [N,H,W,x_pitch] (C used), gw [Cout][kh][kw][gw_cin] fp32, ZEROED BY THE CALLER
+ * (partial sums of pixel chunks are combined with atomics).  Pitches 0 = dense.  Exact fp32 products on
+ * v_mfma_f32_32x32x2_f32; a linear layer is the 1x1 case with N = 1, H = 1, W = rows. */
+int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, int N, int H, int W, int C, int x_pitch, int P, int Q,
+                      int Cout, int g_pitch, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int gw_cin,
+                      void* stream);
+
+/* out[c] += sum_r (a[r,c] - shift_a[c]) * (b ? b[r,c] - shift_b[c] : 1), C % 4 == 0, `out` zeroed by the caller: bias
+ * gradients (sum of glin) and the batch statistics / parameter gradients of BatchNormUncentered2d in training mode
+ * (batchnorm_uncentered.py:36-44: var = x.var((0,2,3), unbiased=False), two passes: mean, then centred squares). */
+int bcos_colsum(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out, int64_t rows, int C,
+                void* stream);
+
+/* out[r,c] = a[r,c] * sa[c] + (b[r,c] - mb[c]) * sb[c]   (b / mb / sb may be NULL: out = a * sa): the input gradient of the
+ * training-mode uncentered batch norm, gx = gy * w / std + (x - mean) * coef. */
+int bcos_channel_axpby(const float* a, const float* sa, const float* b, const float* mb, const float* sb, float* out,
+                       int64_t rows, int C, void* stream);
+
 /* -- transformer pieces (bcos_vit.hip) ---------------------------------------------------- */
 
 /* LayerNorm over the last dimension D of x [rows, D] (weight / bias may be NULL); rstd_out (NULL or [rows]) keeps

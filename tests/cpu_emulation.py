@@ -217,6 +217,56 @@ def ensure_absmax(t):
     return t
 
 
+# ---- training-mode backward (include/bcos_hip.h: bcos_train_scale_bwd ... bcos_channel_axpby) ----------------------------
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False):
+    nrm = norm.view(-1, 1)
+    if b == 2 and not force_pow:
+        glin = gy2d * 2 * s2d
+        dnorm = (gy2d * (-y2d / nrm)).sum(1)
+    else:
+        c = s2d.pow(1.0 / (b - 1))
+        ratio = (c - 1e-6).clamp(min=0) / c
+        glin = gy2d * s2d * (1 + (b - 1) * ratio)
+        dnorm = (gy2d * (-(b - 1) * y2d * ratio / nrm)).sum(1)
+    div = (norm - 1e-12).clamp(min=1e-30) if mode == BCOS_LINEAR_EPS else norm
+    return glin, dnorm / div
+
+
+def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation):
+    N, H, W, _ = x.shape
+    with torch.enable_grad():          # the transposed patch sum = adjoint of a convolution with a kernel of ones
+        z = torch.zeros(N, 1, H, W, requires_grad=True)
+        patch_sum = F.conv2d(z, torch.ones(1, 1, kernel[0], kernel[1]), None, stride, padding, dilation)
+        (t,) = torch.autograd.grad(patch_sum, z, rnorm[:, None].detach())
+    return x[..., :C_used] * t[:, 0, :, :, None]
+
+
+def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation):
+    xn = x[..., :C_used].permute(0, 3, 1, 2).double()
+    g = glin[..., :Cout].permute(0, 3, 1, 2).double()
+    with torch.enable_grad():          # called from inside autograd.Function.backward, where grad mode is off
+        w = torch.zeros(Cout, C_used, kernel[0], kernel[1], dtype=torch.float64, requires_grad=True)
+        (gw,) = torch.autograd.grad(F.conv2d(xn.detach(), w, None, stride, padding, dilation), w, g.detach())
+    return gw.permute(0, 2, 3, 1).float().contiguous()
+
+
+def colsum(a2d, b2d=None, shift_a=None, shift_b=None):
+    a = a2d.double() - (shift_a.double() if shift_a is not None else 0)
+    if b2d is not None:
+        a = a * (b2d.double() - (shift_b.double() if shift_b is not None else 0))
+    return a.sum(0).float()
+
+
+def channel_axpby(a, sa, b=None, mb=None, sb=None, out=None):
+    r = a * sa
+    if b is not None:
+        r = r + (b - (mb if mb is not None else 0)) * sb
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def tapconv_group(a, wts, geoms, *, out, addend=None, mul=None):
     for w, g in zip(wts, geoms):
         tapconv(a, w, g, out=out, addend=addend, mul=mul)
@@ -229,7 +279,8 @@ def install(monkeypatch):
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
                  "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
-                 "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax"):
+                 "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
+                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

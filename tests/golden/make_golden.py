@@ -186,6 +186,99 @@ def variant_cases():
 
 
 # --------------------------------------------------------------------------------------------------------
+# N4: training-mode gradients (dynamic scale NOT detached; weight / bias gradients; BNU batch statistics)
+# --------------------------------------------------------------------------------------------------------
+TRAIN_CONV_CASES = [
+    # name,          cin, cout, k, s, p, d, b,   bias,  H,  W      (B-cosified layers, max_out 1, groups 1)
+    ("t_c1x1",        16,  24,  1, 1, 0, 1, 2,   False, 9, 7),
+    ("t_c3x3",        16,  20,  3, 1, 1, 1, 2,   False, 9, 7),
+    ("t_c3x3_s2",     16,  20,  3, 2, 1, 1, 2,   False, 10, 9),
+    ("t_c1x1_s2",     16,  32,  1, 2, 0, 1, 2,   False, 10, 9),
+    ("t_c7x7_stem",    6,  16,  7, 2, 3, 1, 2,   False, 20, 18),
+    ("t_c3x3_bias",   12,  20,  3, 1, 1, 1, 2,   True,  8, 8),
+    ("t_c3x3_b1",     12,  20,  3, 1, 1, 1, 1,   True,  8, 8),
+    ("t_c3x3_b1p5",   12,  20,  3, 1, 1, 1, 1.5, False, 8, 8),
+    ("t_c3x3_dil2",   12,  20,  3, 1, 2, 2, 2,   False, 9, 9),
+    ("t_c1x1_wide",  160, 136,  1, 1, 0, 1, 2,   False, 6, 5),      # more than one 128-channel tile on both sides
+]
+TRAIN_LINEAR_CASES = [
+    # name,        cin, cout, b, bias, lead shape
+    ("t_l",         48,  40,  2,   False, (3, 7)),
+    ("t_l_bias",    48,  40,  2,   True,  (3, 7)),
+    ("t_l_odd",     30,  12,  2,   False, (6,)),
+    ("t_l_b1p5",    32,  24,  1.5, False, (2, 3)),
+]
+
+
+def train_cases():
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    for (name, cin, cout, k, s, p, d, b, bias, H, W) in TRAIN_CONV_CASES:
+        mod = R.bcosifyconv2d.BcosifyConv2d(cin, cout, k, s, p, d, 1, b=b, max_out=1, bias=bias)
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+        if bias:       # the constructor never creates one (bcosconv2d.py:117); from_standard_module attaches it (bcosifyconv2d.py:145-147)
+            mod.linear.bias = nn.Parameter(torch.randn(cout, generator=g) * 0.1)
+        mod.train()
+        x = torch.randn(2, cin, H, W, generator=g)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        params = [mod.linear.weight] + ([mod.linear.bias] if bias else [])
+        grads = torch.autograd.grad(y, [xr] + params, gy)
+        case = dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=grads[0], gw=grads[1])
+        if bias:
+            case.update(bias=mod.linear.bias.detach(), gb=grads[2])
+        for kk, vv in case.items():
+            out[f"{name}/{kk}"] = vv
+    for (name, cin, cout, b, bias, lead) in TRAIN_LINEAR_CASES:
+        mod = R.bcosifylinear.BcosifyLinear(cin, cout, b=b, max_out=1, bias=bias)
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+        if bias:
+            mod.linear.bias = nn.Parameter(torch.randn(cout, generator=g) * 0.1)
+        mod.train()
+        x = torch.randn(*lead, cin, generator=g)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        params = [mod.linear.weight] + ([mod.linear.bias] if bias else [])
+        grads = torch.autograd.grad(y, [xr] + params, gy)
+        case = dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=grads[0], gw=grads[1])
+        if bias:
+            case.update(bias=mod.linear.bias.detach(), gb=grads[2])
+        for kk, vv in case.items():
+            out[f"{name}/{kk}"] = vv
+    # BatchNormUncentered2d with batch statistics (batchnorm_uncentered.py:36-44), plain and with the variance detached
+    for name, detach in (("t_bnu", False), ("t_bnu_detach", True)):
+        import importlib
+        RefBNU = importlib.import_module("bcos.modules.norms.uncentered_norms.batchnorm_uncentered").BatchNormUncentered2d
+        assert RefBNU.__module__.startswith("bcos.") and "/root/reference" in sys.modules[RefBNU.__module__].__file__
+        bn = RefBNU(16, bias=True)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(16, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(16, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(16, generator=g) + 0.5)
+        bn.train()
+        bn.detach = detach
+        rv0 = bn.running_var.detach().clone()
+        x = torch.randn(3, 16, 5, 4, generator=g) * 2 + 0.7
+        xr = x.clone().requires_grad_(True)
+        y = bn(xr)
+        gy = torch.randn(y.shape, generator=g)
+        gx, gw, gb = torch.autograd.grad(y, [xr, bn.weight, bn.bias], gy)
+        for kk, vv in dict(x=x, weight=bn.weight.detach(), bias=bn.bias.detach(), running_var_before=rv0,
+                           running_var_after=bn.running_var.detach().clone(), y=y.detach(), gy=gy, gx=gx, gw=gw, gb=gb).items():
+            out[f"{name}/{kk}"] = vv
+    np.savez_compressed(os.path.join(HERE, "train_layers.npz"), **t2n(out))
+    meta = dict(conv=[dict(zip(("name", "cin", "cout", "k", "s", "p", "d", "b", "bias", "H", "W"), c)) for c in TRAIN_CONV_CASES],
+                linear=[dict(zip(("name", "cin", "cout", "b", "bias", "lead"), c)) for c in TRAIN_LINEAR_CASES],
+                bnu=[dict(name="t_bnu", detach=False), dict(name="t_bnu_detach", detach=True)])
+    with open(os.path.join(HERE, "train_layers.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+# --------------------------------------------------------------------------------------------------------
 # F2-F5: patch norms fast vs slow, BNU fold, add_channels, scale invariance
 # --------------------------------------------------------------------------------------------------------
 def small_invariants():
@@ -237,6 +330,35 @@ def reference_resnet(arch, seed=0):
     net = R.bcosify.BcosifyNetwork(std, cfg, add_channels=True, logit_layer=True)
     synth.finish_conversion(net, cfg, hip_pools=False)
     return net.eval()
+
+
+def resnet18_training_step():
+    """N4 end to end: one training-mode forward + backward of the B-cosified ResNet-18 (batch statistics in every
+    BatchNormUncentered2d, dynamic scales differentiated, BCE-with-logits loss as in the reference's ImageNet configs) on
+    4 images of 64 x 64: loss, the norm of every parameter gradient, three full gradients and the input gradient."""
+    net = reference_resnet("resnet18")
+    x = synth.synthetic_images(8)
+    synth.calibrate(net, x[:4])
+    xs = synth.synthetic_images(4, seed=31, size=64)
+    labels = torch.tensor([3, 500, 999, 17])
+    target = torch.nn.functional.one_hot(labels, 1000).float()
+    net.train()
+    xr = xs.clone().requires_grad_(True)
+    logits = net(xr)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, target)
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad(loss, [xr] + [p for _, p in net.named_parameters() if p.requires_grad])
+    out = dict(logits=logits.detach(), loss=loss.detach(), gx=grads[0],
+               grad_norms=torch.stack([g.norm() for g in grads[1:]]))
+    for keep in ("model.conv1.linear.weight", "model.layer2.0.conv1.linear.weight", "model.fc.linear.weight", "model.layer3.1.bn2.weight"):
+        out["grad/" + keep] = grads[1 + names.index(keep)]
+    rv = dict(net.named_buffers())
+    out["running_var/model.bn1"] = rv["model.bn1.running_var"].detach().clone()
+    out["running_var/model.layer4.1.bn2"] = rv["model.layer4.1.bn2.running_var"].detach().clone()
+    np.savez_compressed(os.path.join(HERE, "resnet18_train_step.npz"), **t2n(out))
+    with open(os.path.join(HERE, "resnet18_train_step.json"), "w") as f:
+        json.dump(dict(arch="resnet18", weight_seed=0, calib_images=4, image_seed=31, size=64, labels=labels.tolist(),
+                       param_names=names), f, indent=1)
 
 
 def state_checksum(sd):
@@ -533,7 +655,7 @@ def localisation_grid():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "variants", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
+    which = sys.argv[1:] or ["layers", "variants", "train", "train_r18", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -541,6 +663,10 @@ if __name__ == "__main__":
         layer_cases()
     if "variants" in which:
         variant_cases()
+    if "train" in which:
+        train_cases()
+    if "train_r18" in which:
+        resnet18_training_step()
     if "inv" in which:
         small_invariants()
     if "r18" in which:

@@ -114,3 +114,48 @@ def test_overlapped_gather_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+def _allreduce_worker(rank, world, port, q):
+    repo = os.path.dirname(HERE)
+    for p in (os.path.join(repo, "b-cosification_amd"), repo, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from bcos_hip import dist as bdist
+    bdist.init(backend="gloo")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 6, 7, 7), (64,), (128, 64, 3, 3), (1000, 512, 1, 1), (3,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(4))]   # the last has no grad
+    base = [torch.randn(s, generator=g) for s in shapes]
+    for p, b in zip(params, base):
+        p.grad = b * (rank + 1)                      # rank r holds (r + 1) * base
+    bdist.allreduce_gradients(params, bucket_bytes=256 << 10)        # several buckets
+    ok = params[-1].grad is None
+    for p, b in zip(params, base):
+        ok = ok and torch.allclose(p.grad, b * (sum(range(1, world + 1)) / world), rtol=1e-6, atol=1e-7)
+    for p, b in zip(params, base):
+        p.grad = b * (rank + 1)
+    bdist.allreduce_gradients(params, average=False)                  # one bucket, plain sum
+    for p, b in zip(params, base):
+        ok = ok and torch.allclose(p.grad, b * sum(range(1, world + 1)), rtol=1e-6, atol=1e-7)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    """N4: bucketed asynchronous gradient all-reduce (the collective of data-parallel training)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results

@@ -92,6 +92,61 @@ def test_learnable_b_variants_against_golden(lib, golden_dir):
         assert rel(y, data[f"{n}/y"]) <= 1e-5 and rel(gx, data[f"{n}/gx"]) <= 1e-5, n
 
 
+def test_training_mode_gradients_against_reference_golden(lib, golden_dir):
+    """N4 first slice on the device: input, weight and bias gradients of BcosifyConv2d / BcosifyLinear with the dynamic
+    scale differentiated (bcosconv2d.py:176-194 without detach), BatchNormUncentered2d with batch statistics
+    (batchnorm_uncentered.py:36-44) -- bcos_train_scale_bwd, bcos_patch_norm_bwd, bcos_conv2d_wgrad (fp32 MFMA),
+    bcos_colsum, bcos_channel_axpby -- against gradients recorded from the reference in train mode."""
+    from test_host_cpu import run_training_goldens
+    run_training_goldens(golden_dir, DEV, 1e-5)
+
+
+def test_resnet18_training_step_against_reference_golden(lib, golden_dir):
+    """N4 end to end: B-cosified ResNet-18 in train() mode -- batch statistics in all 20 BatchNormUncentered2d, every
+    dynamic scale differentiated, BCE-with-logits loss -- forward and backward through the per-layer HIP kernels against
+    the loss, input gradient and parameter gradients recorded from the reference's training-mode step."""
+    from bcos_hip import synth
+    net, _, _ = _golden_net(golden_dir, "resnet18_e2e")                     # the fixture's calibrated weights
+    meta = json.load(open(os.path.join(golden_dir, "resnet18_train_step.json")))
+    data = np.load(os.path.join(golden_dir, "resnet18_train_step.npz"))
+    x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV).requires_grad_(True)
+    target = F.one_hot(torch.tensor(meta["labels"]), 1000).float().to(DEV)
+    net.train()
+    logits = net(x)                                                          # training: the fused engine is bypassed
+    assert rel(logits, data["logits"]) <= 1e-4
+    loss = F.binary_cross_entropy_with_logits(logits, target)
+    assert abs(float(loss) - float(data["loss"])) <= 1e-5 * abs(float(data["loss"]))
+    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    assert [n for n, _ in named] == meta["param_names"]
+    grads = torch.autograd.grad(loss, [x] + [p for _, p in named])
+    # ReLU gates with ~1e-13 pre-activations open differently under another summation order (SURVEY.md H1): the same floor as
+    # the explanation maps applies to gradients that pass through them
+    assert rel(grads[0], data["gx"]) <= 2e-3
+    norms = torch.stack([g.norm() for g in grads[1:]]).cpu()
+    assert float(((norms - torch.from_numpy(data["grad_norms"])).abs() / torch.from_numpy(data["grad_norms"])).max()) <= 2e-3
+    names = [n for n, _ in named]
+    for key in [k for k in data.files if k.startswith("grad/")]:
+        assert rel(grads[1 + names.index(key[5:])], data[key]) <= 2e-3, key
+    bufs = dict(net.named_buffers())
+    for key in [k for k in data.files if k.startswith("running_var/")]:
+        assert rel(bufs[key[12:] + ".running_var"], data[key]) <= 1e-4, key
+
+
+def test_wgrad_kernel_on_resnet_shapes(lib):
+    """bcos_conv2d_wgrad at real layer sizes (several pixel chunks, atomically combined) against fp64 autograd."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(9)
+    for (N, Cin, H, Cout, k, s, p) in [(8, 64, 56, 64, 3, 1, 1), (8, 256, 14, 1024, 1, 1, 0), (4, 8, 64, 64, 7, 2, 3), (8, 128, 28, 128, 3, 2, 1)]:
+        x = torch.randn(N, Cin, H, H, generator=g)
+        Ho = (H + 2 * p - k) // s + 1
+        gl = torch.randn(N, Cout, Ho, Ho, generator=g)
+        w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(x.double(), w, None, s, p), w, gl.double())
+        gw = ops.conv2d_wgrad(gl.permute(0, 2, 3, 1).contiguous().to(DEV), x.permute(0, 2, 3, 1).contiguous().to(DEV), Cin, Cout,
+                              (k, k), (s, s), (p, p), (1, 1))
+        assert rel(gw.permute(0, 3, 1, 2), ref) <= 2e-6, (N, Cin, H, Cout, k, s, p)
+
+
 CONV_GEOMS = [  # N, Cin, H, W, Cout, k, s, p   (the distinct R18/R50 geometry classes at reduced size + ragged edges)
     (2, 64, 14, 14, 64, 1, 1, 0), (2, 64, 14, 14, 256, 1, 1, 0), (2, 256, 14, 14, 64, 1, 1, 0),
     (2, 64, 14, 14, 64, 3, 1, 1), (2, 128, 14, 14, 128, 3, 2, 1), (2, 256, 14, 14, 512, 1, 2, 0),

@@ -22,7 +22,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rel(a, b):
-    a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
 
 
@@ -257,14 +257,81 @@ def test_learnable_b_variants_match_reference_golden(monkeypatch, golden_dir):
         assert rel(y, data[f"{n}/y"]) <= 2e-6 and rel(gx, data[f"{n}/gx"]) <= 2e-6, n
 
 
-def test_training_mode_backward_is_refused(monkeypatch):
-    cpu_emulation.install(monkeypatch)
+def run_training_goldens(golden_dir, dev, tol):
+    """N4: B-cosified layers and BatchNormUncentered2d in TRAINING mode (scale not detached, batch statistics) against
+    outputs, input / weight / bias gradients and running statistics recorded from the reference."""
     from bcos.modules.bcosifyconv2d import BcosifyConv2d
-    m = BcosifyConv2d(8, 4, 3, padding=1, b=2)
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    from bcos.modules.norms import BatchNormUncentered2d
+    data = np.load(os.path.join(golden_dir, "train_layers.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "train_layers.json")))
+    t = lambda k: torch.from_numpy(data[k]).to(dev)      # noqa: E731
+    for c in meta["conv"] + meta["linear"]:
+        n = c["name"]
+        if "k" in c:
+            m = BcosifyConv2d(c["cin"], c["cout"], c["k"], c["s"], c["p"], c["d"], 1, b=c["b"], max_out=1)
+        else:
+            m = BcosifyLinear(c["cin"], c["cout"], b=c["b"], max_out=1)
+        with torch.no_grad():
+            m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+        if c["bias"]:
+            m.linear.bias = nn.Parameter(torch.from_numpy(data[f"{n}/bias"]).clone())
+        m = m.to(dev).train()
+        x = t(f"{n}/x").requires_grad_(True)
+        y = m(x)
+        params = [m.linear.weight] + ([m.linear.bias] if c["bias"] else [])
+        grads = torch.autograd.grad(y, [x] + params, t(f"{n}/gy"))
+        assert rel(y, data[f"{n}/y"]) <= tol, n
+        assert rel(grads[0], data[f"{n}/gx"]) <= tol, (n, "gx")
+        assert rel(grads[1], data[f"{n}/gw"]) <= tol, (n, "gw")
+        if c["bias"]:
+            assert rel(grads[2], data[f"{n}/gb"]) <= tol, (n, "gb")
+        # explanation mode keeps working on a module whose parameters require grad, and now also yields weight gradients
+        # with the scale held constant: d/dW of sum(gy * s.detach() * lin)
+        m.set_explanation_mode(True)
+        x2 = t(f"{n}/x").requires_grad_(True)
+        gx_e, gw_e = torch.autograd.grad(m(x2), [x2, m.linear.weight], t(f"{n}/gy"))
+        assert gw_e.shape == m.linear.weight.shape and torch.isfinite(gw_e).all()
+        if c["b"] == 1:                                   # no dynamic scale: both modes are the plain convolution
+            assert rel(gx_e, data[f"{n}/gx"]) <= tol and rel(gw_e, data[f"{n}/gw"]) <= tol, n
+    for c in meta["bnu"]:
+        n = c["name"]
+        bn = BatchNormUncentered2d(16, bias=True)
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+            bn.bias.copy_(torch.from_numpy(data[f"{n}/bias"]))
+            bn.running_var.copy_(torch.from_numpy(data[f"{n}/running_var_before"]))
+        bn = bn.to(dev).train()
+        bn.detach = c["detach"]
+        x = t(f"{n}/x").requires_grad_(True)
+        y = bn(x)
+        gx, gw, gb = torch.autograd.grad(y, [x, bn.weight, bn.bias], t(f"{n}/gy"))
+        assert rel(y, data[f"{n}/y"]) <= tol and rel(bn.running_var, data[f"{n}/running_var_after"]) <= tol, n
+        assert rel(gx, data[f"{n}/gx"]) <= tol and rel(gw, data[f"{n}/gw"]) <= tol and rel(gb, data[f"{n}/gb"]) <= tol, n
+        assert int(bn.num_batches_tracked) == 1
+
+
+def test_training_mode_gradients_match_reference_golden(monkeypatch, golden_dir):
+    cpu_emulation.install(monkeypatch)
+    run_training_goldens(golden_dir, "cpu", 2e-6)
+
+
+def test_training_mode_refusals(monkeypatch):
+    """What the first slice of N4 does not cover raises instead of training silently without (correct) gradients."""
+    cpu_emulation.install(monkeypatch)
+    from bcos.modules import BcosConv2d, BcosLinear
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
     x = torch.rand(1, 8, 5, 5, requires_grad=True)
-    y = m(x)           # not in explanation mode
-    with pytest.raises(NotImplementedError, match="explanation_mode"):
-        y.sum().backward()
+    with pytest.raises(NotImplementedError, match="max_out == 1"):                   # MaxOut outside explanation mode
+        BcosifyConv2d(8, 4, 3, padding=1, b=2, max_out=2).train()(x)
+    with pytest.raises(NotImplementedError, match="unit-norm"):                      # native layers: weight gradient would
+        BcosConv2d(8, 4, 3, padding=1, b=2).train()(x)                               # have to pass the unit-norm projection
+    with pytest.raises(NotImplementedError, match="unit-norm"):
+        BcosLinear(8, 4).train()(torch.rand(3, 8))
+    m = BcosConv2d(8, 4, 3, padding=1, b=2).eval()                                   # eval / explanation mode are unaffected
+    m.set_explanation_mode(True)
+    (g,) = torch.autograd.grad(m(x).sum(), x)
+    assert g.shape == x.shape
 
 
 @pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
