@@ -65,6 +65,7 @@ SIGNATURES = {
     "bcos_tapconv_ops": (C.c_int, [C.POINTER(Operands), C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
     "bcos_split_weights_f16x2_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights_f16x2": (C.c_int, [_P, _P, _I, _I, _P]),
+    "bcos_split_weights_f16x2_conv": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "bcos_rows_absmax": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "bcos_split_weights_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights": (C.c_int, [_P, _P, _I, _I, _P]),

@@ -76,17 +76,19 @@ def split_weights(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def split_weights_f16x2(w: torch.Tensor) -> torch.Tensor:
-    """Row-scaled 2-way fp16 split of w [rows, ...] in MFMA fragment order + inverse row scales
-    (include/bcos_hip.h: bcos_split_weights_f16x2)."""
+def split_weights_f16x2(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
+    """Row-scaled 2-way fp16 split of w [rows, taps * C] in MFMA fragment order + inverse row scales, stored in the K order
+    the kernel walks for a launch with `taps` taps (include/bcos_hip.h: bcos_split_weights_f16x2_conv)."""
     lib = _l.load()
     rows = w.shape[0]
     ktot = w.numel() // rows
+    if ktot % taps:
+        raise BcosHipError(f"split_weights_f16x2: K = {ktot} is not a multiple of taps = {taps}")
     nbytes = C.c_int64(0)
     _l.check(lib.bcos_split_weights_f16x2_bytes(rows, ktot, C.byref(nbytes)), "bcos_split_weights_f16x2_bytes")
     out = torch.empty(nbytes.value, device=w.device, dtype=torch.uint8)
-    _l.check(lib.bcos_split_weights_f16x2(_dev(w, "split_weights_f16x2.w"), C.c_void_p(out.data_ptr()), rows, ktot, _stream()),
-             "bcos_split_weights_f16x2")
+    _l.check(lib.bcos_split_weights_f16x2_conv(_dev(w, "split_weights_f16x2.w"), C.c_void_p(out.data_ptr()), rows, taps, ktot // taps,
+                                               _stream()), "bcos_split_weights_f16x2_conv")
     return out
 
 
@@ -227,7 +229,8 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         if (am_a is not None and static and am_a.numel() == int(g.N) * int(g.H) * int(g.W)
                 and (ktot >= F16X2_MIN_K or (int(g.C) <= 16 and ktot >= 128) or contraction == "f16x2")):
             o.a_absmax = am_a.data_ptr()
-            o.wt_f16x2 = _image_of(wt, "_bcos_wt2", split_weights_f16x2).data_ptr()
+            taps = int(g.TH) * int(g.TW)               # the image is stored in the K order of a launch with this tap count
+            o.wt_f16x2 = _image_of(wt, f"_bcos_wt2_t{taps}", lambda w: split_weights_f16x2(w, taps)).data_ptr()
         elif static:
             o.wt_bf16x3 = _image_of(wt, "_bcos_wt3", split_weights).data_ptr()
     elif mode == "bf16x3" and static:
@@ -239,7 +242,12 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     code = lib.bcos_tapconv_ops(C.byref(o), C.byref(g), C.byref(e), _stream())
     if timing is not None:
         ev1.record()
-        timing.append((ev0, ev1))
+        # algorithmic work of the launch: 2 M K N flops; bytes = A once + weights once + every output-sized epilogue tensor
+        m_rows = int(g.N) * int(g.P) * int(g.Q)
+        ktot = int(g.TH) * int(g.TW) * int(g.C)
+        epi_tensors = sum(1 for t in (out, out2, scale_out, addend, mul, mul2, gate2, relu_gate) if t is not None)
+        nbytes = 4 * (int(g.N) * int(g.H) * int(g.W) * int(g.C) + ktot * int(g.Cout) + m_rows * int(g.Cout) * epi_tensors)
+        timing.append((ev0, ev1, 2.0 * m_rows * ktot * int(g.Cout), nbytes))
     _l.check(code, "bcos_tapconv")
 
 
@@ -268,7 +276,11 @@ def tapconv_group(a: torch.Tensor, wts, geoms, *, out, addend=None, mul=None):
     code = lib.bcos_tapconv_group(_dev(a, "tapconv_group.a", contiguous=False), warr, garr, earr, n, _stream())
     if timing is not None:
         ev1.record()
-        timing.append((ev0, ev1))
+        fl = sum(2.0 * q["N"] * q["P"] * q["Q"] * q["TH"] * q["TW"] * q["C"] * q["Cout"] for q in geoms)
+        g0 = geoms[0]
+        rows_out = sum(q["N"] * q["P"] * q["Q"] for q in geoms)
+        nbytes = 4 * (g0["N"] * g0["H"] * g0["W"] * g0["C"] + rows_out * g0["Cout"] * (1 + (addend is not None) + (mul is not None)))
+        timing.append((ev0, ev1, fl, nbytes))
     _l.check(code, "bcos_tapconv_group")
 
 

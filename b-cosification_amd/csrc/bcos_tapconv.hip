@@ -222,8 +222,18 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
             if (e.ch_shift) csh4[q] = e.ch_shift[c];
             if (SCALED) cinv4[q] = p.wt2_cinv[c];
         }
-#pragma unroll 1
-        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
+        struct EpiIn { f32x4 ad[EPI_G], m1[EPI_G]; };
+        auto issue = [&](int p0, EpiIn& in) {
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                const int lrow = rbase + (p0 + u) * RPP;
+                const int64_t pix = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
+                const int64_t idx = (pix >= 0 ? pix : 0) * g.out_pitch + col;
+                in.ad[u] = (vec && e.addend) ? *reinterpret_cast<const f32x4*>(e.addend + idx) : zero4;
+                in.m1[u] = (vec && e.mul) ? *reinterpret_cast<const f32x4*>(e.mul + idx) : zero4;
+            }
+        };
+        auto process = [&](int p0, const EpiIn& in) {
             unsigned mx1[EPI_G], mx2[EPI_G];
             int64_t pixs[EPI_G];
 #pragma unroll
@@ -248,9 +258,9 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                     if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
                     rinv[u] = NORM ? sRinv[row] : 1.f;
                     nrm[u] = NORM ? sNorm[row] : 1.f;
-                    ad[u] = e.addend ? *reinterpret_cast<const f32x4*>(e.addend + idx[u]) : zero4;
+                    ad[u] = in.ad[u];
                     rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
-                    m1[u] = e.mul ? *reinterpret_cast<const f32x4*>(e.mul + idx[u]) : zero4;
+                    m1[u] = in.m1[u];
                     m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
                     g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
                 }
@@ -363,6 +373,14 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                     }
                 }
             }
+        };
+        // (requesting group g+1's inputs before group g is computed -- two register sets -- was measured: 30 more VGPRs and
+        //  the forward HBM-bound launches got 10 % SLOWER, 2.47 -> 2.77 ms for the four 64 -> 256 @ 56^2 layers; not kept)
+        EpiIn in;
+#pragma unroll 1
+        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
+            issue(p0, in);
+            process(p0, in);
         }
     }
 }
@@ -813,6 +831,13 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
 //     reads): the four waves share one copy instead of each fetching its own fragments through the texture path;
 //   * the activation split costs ~4 VALU per element (scale, 2 converts, 1 mixed FMA) instead of ~9;
 //   * tiles of 256 x 128 / 128 x 256 (8 accumulator tiles per wave) halve the bytes staged per MFMA.
+constexpr int H2_MAX_TAPS = 16;    // channel-chunk-major K walk for up to this many taps (offset table: taps x BM x 4 bytes of LDS)
+#ifndef H2_KO
+#define H2_KO 0                   // development knock-outs (timing only, wrong results): 1 no MFMA, 2 no split VALU, 4 no global loads in the loop, 8 no fragment reads
+#endif
+#ifndef H2_MFMA_ORDER
+#define H2_MFMA_ORDER 0           // 0 = product-major (consecutive MFMAs on different accumulators), 1 = accumulator-major
+#endif
 #ifndef H2_PIPE_SMALL
 #define H2_PIPE_SMALL 2           // pipeline of the <= 4-accumulator tiles: 2 = one 16-k step per barrier, 3 = two
 #endif
@@ -829,6 +854,7 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
     char* lds = reinterpret_cast<char*>(smem);
     constexpr int A_SPLIT = BM * X3_ROW, B_BASE = 2 * A_SPLIT;
     constexpr int BUF = B_BASE + NBLK * 1024;
+    constexpr int H2_NBUF = PIPE == 3 ? 4 : 2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -908,6 +934,27 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
         l_th = sub / g.TW;
         l_tw = sub - l_th * g.TW;
     }
+    // Multi-tap launches (3x3 convolutions and their input gradients) walk K channel-chunk-major: step ks covers tap
+    // ks % taps of the 16-channel chunk ks / taps (the pre-split weight image is stored in the same order,
+    // bcos_split_weights_f16x2_conv).  A workgroup then re-reads the same ~160 pixels x 64 B for nine consecutive steps -- they
+    // stay in L1 / L2 -- instead of streaming its whole row panel (164 KB at 256 channels) once per tap through a 4 MB L2
+    // that 64 co-resident workgroups share.  Per-(tap, row) source offsets live in LDS behind the staging buffers.
+    const int ntaps = g.TH * g.TW;
+    const bool kmajor = ntaps > 1 && ntaps <= H2_MAX_TAPS && uniform;
+    unsigned* s_tapoff = reinterpret_cast<unsigned*>(lds + H2_NBUF * BUF);         // [tap][BM] byte offsets (without the lane's chunk)
+    if (kmajor) {
+        for (int t = chunk; t < ntaps; t += 4) {
+            const int th = t / g.TW, tw = t - th * g.TW;
+            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                s_tapoff[t * BM + r0 + 64 * j] = ok ? a_nbase[j] - chunk * 16u + (unsigned)((ih * W + iw) * a_pitch) * 4u : OOB;
+            }
+        }
+    }
+    int s_tap = 0;
     int s_cc = 0, s_th = 0, s_tw = 0;
     unsigned a_cur[A_LD];
 #pragma unroll
@@ -918,7 +965,11 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
     // B: wave w copies blocks w, w + 4, ... of the step (block = (32-column tile c, plane sp) = 1 KB, lane-linear)
     const int b_tile0 = n0 >> 5;
     auto load_step = [&](int ks, f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
-        if (uniform) {
+        if (kmajor) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) ra[j] = ldq(a_rsrc, s_tapoff[s_tap * BM + r0 + 64 * j] + chunk * 16u, s_cc * 16);
+            if (++s_tap == ntaps) { s_tap = 0; s_cc += 4; }
+        } else if (uniform) {
             if (s_cc == 0) {
                 const int dh = s_th * g.dstep_h, dw = s_tw * g.dstep_w;
 #pragma unroll
@@ -986,6 +1037,10 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
                 rowss[j] = fmaf(ra[j][3], ra[j][3], rowss[j]);
             }
             f16x4 h, l;
+#if H2_KO & 2
+            h = __builtin_bit_cast(f16x4, __builtin_shufflevector(ra[j], ra[j], 0, 1));
+            l = __builtin_bit_cast(f16x4, __builtin_shufflevector(ra[j], ra[j], 2, 3));
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float xs = ra[j][q] * a_scale[j];
@@ -993,6 +1048,7 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
                 h[q] = hh;
                 l[q] = (_Float16)(xs - (float)hh);
             }
+#endif
             char* dst = base + (r0 + 64 * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4));
             *reinterpret_cast<f16x4*>(dst) = h;
             *reinterpret_cast<f16x4*>(dst + A_SPLIT) = l;
@@ -1022,24 +1078,49 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
         f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
+#if H2_KO & 8
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { af[sp][i] = f16x8{}; asm volatile("" : "+v"(af[sp][i])); }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { bf[sp][j] = f16x8{}; asm volatile("" : "+v"(bf[sp][j])); }
+#else
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 af[sp][i] = *reinterpret_cast<const f16x8*>(base + a_frag + sp * A_SPLIT + i * 32 * X3_ROW);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[sp][j] = *reinterpret_cast<const f16x8*>(base + b_frag + j * 2048 + sp * 1024);
+#endif
         }
+        // smallest terms first; product-major order, so that consecutive matrix instructions write DIFFERENT accumulators
+        // (a dependent v_mfma on the same accumulator waits for the previous one to retire)
+#if H2_MFMA_ORDER == 0
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                {
+#if H2_KO & 1
+                    asm volatile("" :: "v"(af[pr == 0 ? 1 : 0][i]), "v"(bf[pr == 1 ? 1 : 0][j]));
+#else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[pr == 0 ? 1 : 0][i], bf[pr == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+#endif
+                }
+#else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                // smallest terms first
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
             }
+#endif
     };
 
+    if (kmajor) __syncthreads();        // the (tap, row) offset table is complete
     if constexpr (PIPE == 2) {
         // same three-stage pipeline as tile_body_x3: loads of step ks+2 in flight, step ks+1 converted and written to the
         // other LDS buffer next to the MFMAs of step ks; two steps per trip so the register sets swap roles without copies
@@ -1050,11 +1131,15 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
         __syncthreads();
         int ks = 0;
         for (; ks + 3 < nk; ks += 2) {
+#if !(H2_KO & 4)
             load_step(ks + 2, ra1, rb1);
+#endif
             mma_step(0);
             store_step(ra0, rb0, 1);
             __syncthreads();
+#if !(H2_KO & 4)
             load_step(ks + 3, ra0, rb0);
+#endif
             mma_step(1);
             store_step(ra1, rb1, 0);
             __syncthreads();
@@ -1068,6 +1153,25 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
         if (ks < nk) tail_step(ks, ra1, rb1, ra0, rb0);
         if (ks + 1 < nk) tail_step(ks + 1, ra0, rb0, ra1, rb1);
         if (ks + 2 < nk) tail_step(ks + 2, ra1, rb1, ra0, rb0);
+    } else if constexpr (PIPE == 4) {
+        // three staging register sets: the loads of step ks+3 are issued at step ks and have three steps to arrive
+        f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD], ra2[A_LD], rb2[B_LD];
+        load_step(0, ra0, rb0);
+        store_step(ra0, rb0, 0);
+        if (nk > 1) load_step(1, ra1, rb1);
+        if (nk > 2) load_step(2, ra2, rb2);
+        __syncthreads();
+        auto body = [&](int k, f32x4 (&la)[A_LD], f32x4 (&lb)[B_LD], const f32x4 (&sa)[A_LD], const f32x4 (&sb)[B_LD]) {
+            if (k + 3 < nk) load_step(k + 3, la, lb);
+            mma_step(k & 1);
+            if (k + 1 < nk) store_step(sa, sb, (k + 1) & 1);
+            __syncthreads();
+        };
+        for (int ks = 0; ks < nk; ks += 3) {
+            body(ks, ra0, rb0, ra1, rb1);
+            if (ks + 1 < nk) body(ks + 1, ra1, rb1, ra2, rb2);
+            if (ks + 2 < nk) body(ks + 2, ra2, rb2, ra0, rb0);
+        }
     } else if constexpr (PIPE == 3) {
         // two 16-k sub-steps per barrier (four LDS sub-buffers): the loads of macro-step m+1 are issued before the 24 MFMAs
         // of macro-step m and written to the other buffer pair after them -- the same latency budget as the pipeline above
@@ -1216,7 +1320,7 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 constexpr size_t h2_staging_lds() {
     constexpr int nbuf = ((BM / WAVES_M) * (BN / WAVES_N) <= 64 * 64 && H2_PIPE_SMALL == 3) ? 4 : 2;
-    return nbuf * ((size_t)2 * BM * X3_ROW + (size_t)(BN / 32) * 2048);
+    return nbuf * ((size_t)2 * BM * X3_ROW + (size_t)(BN / 32) * 2048) + (size_t)H2_MAX_TAPS * BM * 4;
 }
 
 // split-f16 launches (their own tile configurations: only this loop is instantiated for them)
@@ -1337,7 +1441,7 @@ __global__ __launch_bounds__(256) void weight_rowscale_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void split_weights_h2_kernel(const float* __restrict__ wt, uint4* __restrict__ wt2,
                                                                const float* __restrict__ cinv, int rows, int Ktot, int nk,
-                                                               int64_t total) {
+                                                               int64_t total, int taps, int C) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (tile, ks, lane)
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -1345,7 +1449,8 @@ __global__ __launch_bounds__(256) void split_weights_h2_kernel(const float* __re
     const int ks = (int)(ts % nk);
     const int tile = (int)(ts / nk);
     const int row = tile * 32 + (lane & 31);
-    const int k0 = ks * 16 + 8 * (lane >> 5);
+    // k of the 8 elements: plain order, or (taps > 1) channel-chunk-major: step ks = tap ks % taps of 16-channel chunk ks / taps
+    const int k0 = taps > 1 ? (ks % taps) * C + (ks / taps) * 16 + 8 * (lane >> 5) : ks * 16 + 8 * (lane >> 5);
     const float scale = 1.0f / cinv[row];                             // exact: a power of two
     f16x8 h, l;
 #pragma unroll
@@ -1372,6 +1477,14 @@ extern "C" int bcos_split_weights_f16x2_bytes(int rows, int Ktot, int64_t* bytes
 }
 
 extern "C" int bcos_split_weights_f16x2(const float* wt, void* wt2, int rows, int Ktot, void* stream) {
+    return bcos_split_weights_f16x2_conv(wt, wt2, rows, 1, Ktot, stream);
+}
+
+extern "C" int bcos_split_weights_f16x2_conv(const float* wt, void* wt2, int rows, int taps, int C, void* stream) {
+    if (taps <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights_f16x2: bad argument");
+    const int Ktot = taps * C;
+    // the kernel walks K channel-chunk-major exactly when this holds (tile_body_h2: kmajor)
+    const int ktaps = (taps > 1 && taps <= H2_MAX_TAPS && C % 16 == 0) ? taps : 1;
     if (!wt || !wt2 || rows <= 0 || Ktot <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights_f16x2: bad argument");
     if (reinterpret_cast<uintptr_t>(wt2) & 15) return bcos_set_error(BCOS_E_INVAL, "bcos_split_weights_f16x2: image must be 16-byte aligned");
     const int nk = (Ktot + 15) / 16;
@@ -1381,7 +1494,7 @@ extern "C" int bcos_split_weights_f16x2(const float* wt, void* wt2, int rows, in
     hipLaunchKernelGGL(weight_rowscale_kernel, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, wt, cinv, rows, rows_pad, Ktot);
     const int64_t total = h2_tiles(rows) * nk * 64;
     hipLaunchKernelGGL(split_weights_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wt,
-                       reinterpret_cast<uint4*>(wt2), cinv, rows, Ktot, nk, total);
+                       reinterpret_cast<uint4*>(wt2), cinv, rows, Ktot, nk, total, ktaps, C);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("split_weights_f16x2 launch", err);
     return BCOS_OK;

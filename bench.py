@@ -42,7 +42,15 @@ ARCHS = {
     "clip_rn50": dict(gflop_fwd=10.756, family="clip", explain=True),    # explains the arg-max embedding coordinate
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the pipe the 6-product bf16x3 split runs on)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (the pipe the split contractions execute on)
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6 290 GB/s measured with a float4 copy)
+PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3}     # matrix instructions per algorithmic fp32 product, by contraction mode
+DTYPES = {
+    "f32": "f32",
+    "bf16x3": "f32 (contraction: exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products, fp32 accumulate)",
+    "f16x2": "f32 (contraction: row-scaled 2-way fp16 split of the fp32 operands, 3 f16 MFMA products, fp32 accumulate; "
+             "launches without operand maxima or with K < 512 use the exact 3-way bf16 split)",
+}
 
 
 def parse():
@@ -53,30 +61,47 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--arch", default="resnet50", choices=sorted(ARCHS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="images in the CPU-baseline sample (BASELINE.md section 4 asks "
+                    "for 256; smaller samples are scaled linearly and flagged)")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time the forward pass only")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (engine.CapturedPass) instead of launching eagerly; "
                          "measured 1 %% SLOWER than eager launches on ROCm 7.2 (6 667 vs 6 745 images/s), hence off")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: do not bracket the contraction launches with HIP events (roofline fields become null)")
-    ap.add_argument("--contraction", choices=("bf16x3", "f32"), default=None,
+    ap.add_argument("--contraction", choices=("f16x2", "bf16x3", "f32"), default=None,
                     help="arithmetic of the contraction kernel (include/bcos_hip.h: bcos_set_contraction_mode); default: "
-                         "the library default (bf16x3 = exact 3-way bf16 split, 6 products, fp32 accumulation)")
+                         "the library default (f16x2 = row-scaled 2-way fp16 split, 3 products, fp32 accumulation)")
     return ap.parse_args()
 
 
+def _host_description():
+    """CPU model / sockets / cores of the node from lscpu (stated with the baseline)."""
+    try:
+        import subprocess
+        info = {}
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            info[k.strip()] = v.strip()
+        return (f"{info.get('Model name', '?')}, {info.get('Socket(s)', '?')} socket(s) x {info.get('Core(s) per socket', '?')} cores, "
+                f"{info.get('CPU(s)', '?')} hardware threads")
+    except Exception:
+        return "lscpu unavailable"
+
+
 def cpu_baseline(net, arch, n_images):
-    """The oracle (kind 'port': PyTorch-CPU restatement of the reference path, pinned by tests/golden) on the
-    host cores: forward + explanation of `n_images` images, 1 warm-up + 2 timed passes."""
+    """The oracle (kind 'port': PyTorch-CPU restatement of the reference path, pinned by tests/golden) on the host cores,
+    following BASELINE.md section 4: all host threads, 3 warm-up passes, median of 5 timed passes of forward + explanation
+    over ONE batch of `n_images` images (256 asked for; a smaller sample is flagged as extrapolated -- throughput is per
+    image and the passes are batch-size independent above a few images)."""
     from bcos_hip import synth
     from oracle import bcos_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, int(os.environ.get("BCOS_CPU_BASELINE_THREADS", "32"))))   # oneDNN stops scaling (and
-    torch.set_num_threads(cores)                                       # oversubscribes badly) far below 256 threads
+    cores = max(1, int(os.environ.get("BCOS_CPU_BASELINE_THREADS", str(avail))))
+    torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     x = synth.synthetic_images(n_images, seed=321)
     if ARCHS[arch]["family"] == "vit":
@@ -84,22 +109,24 @@ def cpu_baseline(net, arch, n_images):
     else:
         fwd = lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach)  # noqa: E731
     t0 = time.perf_counter()
-    O.explain_batch(fwd, x[:2])                     # warm-up (oneDNN primitive creation) + cost probe
-    probe = time.perf_counter() - t0
-    # bounded sample: keep the whole baseline leg within ~30 s of CPU work
-    n_images = max(2, min(n_images, int(12.0 / max(probe / 2, 1e-3))))
+    O.explain_batch(fwd, x[:4])                     # first call: oneDNN primitive creation; also the cost probe
+    probe = (time.perf_counter() - t0) / 4
+    # bounded sample: 8 passes (3 warm-up + 5 timed) within ~30 s of CPU work
+    n_images = max(4, min(n_images, int(30.0 / 8 / max(probe / 3, 1e-3))))   # (the first call is ~3x slower than steady state)
     x = x[:n_images]
+    for _ in range(2):                              # two more warm-ups at the measured batch size
+        O.explain_batch(fwd, x)
     times = []
-    for _ in range(2):
+    for _ in range(5):
         t0 = time.perf_counter()
         O.explain_batch(fwd, x)
         times.append(time.perf_counter() - t0)
-        if sum(times) > 25.0:
-            break
-    best = min(times)
-    return dict(value=round(n_images / best, 3), unit="images/s", cores=cores, kind="port",
-                sample=f"forward+explanation of {n_images} images (1 batch), best of {len(times)} after warm-up, "
-                       f"torch {torch.__version__} CPU fp32, {cores} of {avail} hardware threads")
+    med = sorted(times)[len(times) // 2]
+    return dict(value=round(n_images / med, 3), unit="images/s", cores=cores, kind="port",
+                sample=f"forward+explanation of one batch of {n_images} images, median of 5 timed passes after 3 warm-ups "
+                       f"(min {n_images / max(times):.1f}, max {n_images / min(times):.1f} images/s), torch {torch.__version__} "
+                       f"CPU fp32 with {cores} threads on {_host_description()}"
+                       + ("" if n_images >= 256 else f"; extrapolated: BASELINE.md section 4 asks for batch 256, {n_images} timed"))
 
 
 def main():
@@ -200,30 +227,48 @@ def main():
     images = args.batch * world * args.steps
     value = images / elapsed
 
-    kernel_ms = sum(s.elapsed_time(e) for s, e in events)            # all contraction launches of the sampled steps
-    launches = len(events)
+    per_launch = [(e0.elapsed_time(e1), fl, nb) for (e0, e1, fl, nb) in events]   # (ms, algorithmic flops, algorithmic bytes)
+    kernel_ms = sum(ms for ms, _, _ in per_launch)                   # all contraction launches of the sampled steps
+    launches = len(per_launch)
     n_ev = max(len(event_steps), 1)
     gflop_step = spec["gflop_fwd"] * (1 if args.forward_only else 2) * args.batch
     achieved = gflop_step * n_ev / kernel_ms if kernel_ms > 0 else 0.0     # GFLOP/ms == TFLOP/s
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = os.path.join(REPO, "profiles", "traffic_latest.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = (f"profiles/traffic_latest.json ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; "
+                              "not measured by this run: counters need their own profiler passes)")
         except Exception:
             traffic = None
+    # both bounds of SURVEY.md section 8(d): a launch is counted HBM-bound when its algorithmic intensity is below the
+    # balance of what the contraction sustains (~250 TFLOP/s fp32-equivalent against ~5 TB/s => 50 FLOP/B)
+    hbm = [(ms, fl, nb) for ms, fl, nb in per_launch if fl / max(nb, 1) < 50.0]
+    mfma = [(ms, fl, nb) for ms, fl, nb in per_launch if fl / max(nb, 1) >= 50.0]
+    hbm_ms, mfma_ms = sum(m for m, _, _ in hbm), sum(m for m, _, _ in mfma)
+    hbm_gbps = sum(nb for _, _, nb in hbm) / hbm_ms / 1e6 if hbm_ms > 0 else 0.0
+    mfma_tf = sum(fl for _, fl, _ in mfma) / mfma_ms / 1e9 if mfma_ms > 0 else 0.0
+    prod = PRODUCTS[contraction]
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                    frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                     kernel="tapconv_kernel (all instantiations) + skinny_kernel", launches_per_step=launches // n_ev,
                     avg_launch_us=round(1e3 * kernel_ms / max(launches, 1), 2),
                     kernel_ms_per_step=round(kernel_ms / n_ev, 3), steps_with_events=len(event_steps),
-                    algorithmic_gflop_per_step=round(gflop_step, 1))
-    if contraction == "bf16x3":
-        # the same launches priced against the pipe they execute on: 6 bf16 products per algorithmic fp32 product
-        roofline["frac_of_bf16_pipe"] = round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4)
-        roofline["note"] = ("peak/frac: dense fp32 MFMA peak (fp32 is the arithmetic contract of the path); the default "
-                            "contraction evaluates each fp32 product as 6 exact bf16 MFMA products, frac_of_bf16_pipe "
-                            "prices those against the dense bf16 peak")
+                    algorithmic_gflop_per_step=round(gflop_step, 1),
+                    frac_of_executing_pipe=round(prod * achieved / (PEAK_16BIT_MFMA_TFLOPS if prod > 1 else PEAK_FP32_MFMA_TFLOPS), 4),
+                    by_bound=dict(
+                        mfma=dict(launches_per_step=len(mfma) // n_ev, ms_per_step=round(mfma_ms / n_ev, 3),
+                                  achieved_tflops=round(mfma_tf, 1), frac_of_fp32_peak=round(mfma_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                  frac_of_executing_pipe=round(prod * mfma_tf / (PEAK_16BIT_MFMA_TFLOPS if prod > 1 else PEAK_FP32_MFMA_TFLOPS), 4)),
+                        hbm=dict(launches_per_step=len(hbm) // n_ev, ms_per_step=round(hbm_ms / n_ev, 3),
+                                 achieved_gbps=round(hbm_gbps, 1), peak_gbps=PEAK_HBM_GBPS, frac=round(hbm_gbps / PEAK_HBM_GBPS, 4),
+                                 note="algorithmic bytes (A once, weights once, every epilogue tensor once) / launch time")),
+                    note=("peak / frac: the dense fp32 MFMA peak, the denominator BASELINE.md section 3 fixes for this metric (fp32 "
+                          f"is the arithmetic contract of the path).  The {contraction} contraction evaluates each fp32 product with "
+                          f"{prod} matrix instruction(s) on the {'16-bit' if prod > 1 else 'fp32'} pipe: frac_of_executing_pipe prices "
+                          "the same launches against that pipe's dense peak, so frac may exceed what the fp32 pipe could deliver"))
 
     result = {
         "metric": ("images/sec (fwd+explanation) B-cos ResNet-50 @224, batch 256, 1/2/4/8 MI355X"
@@ -239,7 +284,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if contraction == "f32" else "f32 (contraction: exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products, fp32 accumulate)",
+        "dtype": DTYPES[contraction],
         "data": "synthetic",
         "config": {"workload": f"B-cosified {args.arch} {'forward' if args.forward_only else 'forward+explanation'}, "
                                f"batch {args.batch} per GPU, 224x224x6 (AddInverse), calibrated random-init weights",

@@ -191,6 +191,11 @@ int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
  * 128, k to a multiple of 16) followed by float[padded rows] inverse row scales.  Copied verbatim into LDS by the kernel. */
 int bcos_split_weights_f16x2_bytes(int rows, int Ktot, int64_t* bytes);
 int bcos_split_weights_f16x2(const float* wt, void* image, int rows, int Ktot, void* stream);
+/* ... of convolution weights [rows][taps][C] (Ktot = taps * C).  For 1 < taps <= 16 and C % 16 == 0 the image stores K
+ * channel-chunk-major (16-k step ks = tap ks % taps of channel chunk ks / taps), the order in which the kernel then walks
+ * the taps so that a workgroup's input pixels stay cache-resident across the taps; a launch must be given the image
+ * made with ITS tap count and C (bcos_tapconv_geom.TH * TW, C). */
+int bcos_split_weights_f16x2_conv(const float* wt, void* image, int rows, int taps, int C, void* stream);
 
 /* out[r] = fp32 bit pattern of max_c |x[r*pitch + c]|, c < C (C % 4 == 0; pitch 0 = C): the `a_absmax` of a tensor whose
  * producer is not a bcos_tapconv epilogue (network input, pooling, attention ...).  One pass over x. */
