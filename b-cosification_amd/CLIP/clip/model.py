@@ -1,71 +1,73 @@
-"""CLIP ModifiedResNet topology with the module / state-dict names of the reference's vendored OpenAI CLIP
-(CLIP/clip/model.py: Bottleneck :10-55, AttentionPool2d :58-91, ModifiedResNet :94-154): 3-convolution stem with an
-average pool, anti-aliased strides (AvgPool2d before the strided 1x1 convs, all convolutions stride 1) and a QKV
-attention pool as the head.  Plain torch modules only -- `bcosify.py` converts them (clip_kd configuration).
+"""CLIP "ModifiedResNet" image-encoder topology, built from a stage table.
+
+What has to match the reference's vendored OpenAI file (CLIP/clip/model.py:10-154) is the STATE-DICT CONTRACT, because
+B-cosified CLIP checkpoints must load unchanged: module names conv{1,2,3} / bn{1,2,3} / relu{1,2,3} /
+avgpool / layer{1..4}.<i>.{conv,bn,relu}{1,2,3} / downsample."-1","0","1" / attnpool.{q,k,v,c}_proj, and the tensor
+shapes behind them.  The forward passes below are written against that naming scheme (units are looked up by index),
+not transcribed; the plain attention pool never runs in this package -- `bcosify.py` replaces it by
+BcosAttentionPool2d (clip_kd configuration) before any forward -- so it only carries its parameters.
 """
 from collections import OrderedDict
 
 import torch
-import torch.nn.functional as F
 from torch import nn
+
+# (unit index, kernel size, stride, output width as a multiple of `planes`) of the three conv/bn/relu units of a block;
+# the strided variant keeps every convolution at stride 1 and average-pools instead (anti-aliasing)
+_BLOCK_UNITS = ((1, 1, 1), (2, 3, 1), (3, 1, 4))
+
+
+def _add_unit(module: nn.Module, idx: int, cin: int, cout: int, k: int, stride: int = 1):
+    """registers conv<idx> / bn<idx> / relu<idx> on `module`"""
+    setattr(module, f"conv{idx}", nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False))
+    setattr(module, f"bn{idx}", nn.BatchNorm2d(cout))
+    setattr(module, f"relu{idx}", nn.ReLU(inplace=True))
+
+
+def _run_unit(module: nn.Module, idx: int, x: torch.Tensor, act: bool = True) -> torch.Tensor:
+    x = getattr(module, f"bn{idx}")(getattr(module, f"conv{idx}")(x))
+    return getattr(module, f"relu{idx}")(x) if act else x
 
 
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1):
+    def __init__(self, inplanes: int, planes: int, stride: int = 1):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.relu1 = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.relu2 = nn.ReLU(inplace=True)
-        self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
-        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
-        self.relu3 = nn.ReLU(inplace=True)
-        self.downsample = None
+        width_in = inplanes
+        for idx, k, mult in _BLOCK_UNITS:
+            _add_unit(self, idx, width_in, planes * mult, k)
+            width_in = planes * mult
+            if idx == 2:        # the stride of the block, applied as a pool between units 2 and 3
+                self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
         self.stride = stride
-        if stride > 1 or inplanes != planes * Bottleneck.expansion:
-            self.downsample = nn.Sequential(OrderedDict([
-                ("-1", nn.AvgPool2d(stride)),
-                ("0", nn.Conv2d(inplanes, planes * self.expansion, 1, stride=1, bias=False)),
-                ("1", nn.BatchNorm2d(planes * self.expansion)),
-            ]))
+        self.downsample = None
+        if stride > 1 or inplanes != width_in:
+            self.downsample = nn.Sequential(OrderedDict((("-1", nn.AvgPool2d(stride)),
+                                                         ("0", nn.Conv2d(inplanes, width_in, 1, stride=1, bias=False)),
+                                                         ("1", nn.BatchNorm2d(width_in)))))
 
-    def forward(self, x: torch.Tensor):
-        identity = x
-        out = self.relu1(self.bn1(self.conv1(x)))
-        out = self.relu2(self.bn2(self.conv2(out)))
-        out = self.avgpool(out)
-        out = self.bn3(self.conv3(out))
-        if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu3(out + identity)
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = _run_unit(self, 2, _run_unit(self, 1, x))
+        y = _run_unit(self, 3, self.avgpool(y), act=False)
+        return self.relu3(y + shortcut)
 
 
 class AttentionPool2d(nn.Module):
+    """Parameter container of CLIP's QKV attention pool (positional embedding + q/k/v/c projections with biases).
+    `bcosify.BcosifyNetwork` turns it into `bcos.modules.BcosAttentionPool2d`, which owns the forward pass."""
+
     def __init__(self, spacial_dim: int, embed_dim: int, num_heads: int, output_dim: int = None):
         super().__init__()
         self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
-        self.k_proj = nn.Linear(embed_dim, embed_dim)
-        self.q_proj = nn.Linear(embed_dim, embed_dim)
-        self.v_proj = nn.Linear(embed_dim, embed_dim)
-        self.c_proj = nn.Linear(embed_dim, output_dim or embed_dim)
+        for name, width in (("k_proj", embed_dim), ("q_proj", embed_dim), ("v_proj", embed_dim), ("c_proj", output_dim or embed_dim)):
+            setattr(self, name, nn.Linear(embed_dim, width))
         self.num_heads = num_heads
 
     def forward(self, x):
-        x = x.flatten(start_dim=2).permute(2, 0, 1)
-        x = torch.cat([x.mean(dim=0, keepdim=True), x], dim=0)
-        x = x + self.positional_embedding[:, None, :].to(x.dtype)
-        x, _ = F.multi_head_attention_forward(
-            query=x[:1], key=x, value=x, embed_dim_to_check=x.shape[-1], num_heads=self.num_heads,
-            q_proj_weight=self.q_proj.weight, k_proj_weight=self.k_proj.weight, v_proj_weight=self.v_proj.weight,
-            in_proj_weight=None, in_proj_bias=torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]),
-            bias_k=None, bias_v=None, add_zero_attn=False, dropout_p=0, out_proj_weight=self.c_proj.weight,
-            out_proj_bias=self.c_proj.bias, use_separate_proj_weight=True, training=self.training, need_weights=False)
-        return x.squeeze(0)
+        raise NotImplementedError("the un-converted CLIP attention pool is not part of the MI355X hot path: convert the "
+                                  "model with bcosify.BcosifyNetwork (bcosify_args['clip_kd']) first")
 
 
 class ModifiedResNet(nn.Module):
@@ -73,35 +75,24 @@ class ModifiedResNet(nn.Module):
         super().__init__()
         self.output_dim = output_dim
         self.input_resolution = input_resolution
-        self.conv1 = nn.Conv2d(3, width // 2, kernel_size=3, stride=2, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(width // 2)
-        self.relu1 = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(width // 2, width // 2, kernel_size=3, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(width // 2)
-        self.relu2 = nn.ReLU(inplace=True)
-        self.conv3 = nn.Conv2d(width // 2, width, kernel_size=3, padding=1, bias=False)
-        self.bn3 = nn.BatchNorm2d(width)
-        self.relu3 = nn.ReLU(inplace=True)
+        # stem: three 3x3 units (the first one strided) and a 2x2 average pool
+        for idx, (cin, cout, stride) in enumerate(((3, width // 2, 2), (width // 2, width // 2, 1), (width // 2, width, 1)), start=1):
+            _add_unit(self, idx, cin, cout, 3, stride)
         self.avgpool = nn.AvgPool2d(2)
-        self._inplanes = width
-        self.layer1 = self._make_layer(width, layers[0])
-        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
-        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
-        self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
-        embed_dim = width * 32
-        self.attnpool = AttentionPool2d(input_resolution // 32, embed_dim, heads, output_dim)
-
-    def _make_layer(self, planes, blocks, stride=1):
-        layers = [Bottleneck(self._inplanes, planes, stride)]
-        self._inplanes = planes * Bottleneck.expansion
-        layers += [Bottleneck(self._inplanes, planes) for _ in range(1, blocks)]
-        return nn.Sequential(*layers)
+        inplanes = width
+        for stage, (planes, depth) in enumerate(zip((width, width * 2, width * 4, width * 8), layers), start=1):
+            blocks = []
+            for b in range(depth):
+                blocks.append(Bottleneck(inplanes, planes, stride=2 if (b == 0 and stage > 1) else 1))
+                inplanes = planes * Bottleneck.expansion
+            setattr(self, f"layer{stage}", nn.Sequential(*blocks))
+        self.attnpool = AttentionPool2d(input_resolution // 32, inplanes, heads, output_dim)
 
     def forward(self, x):
         x = x.type(self.conv1.weight.dtype)
-        x = self.relu1(self.bn1(self.conv1(x)))
-        x = self.relu2(self.bn2(self.conv2(x)))
-        x = self.relu3(self.bn3(self.conv3(x)))
+        for idx in (1, 2, 3):
+            x = _run_unit(self, idx, x)
         x = self.avgpool(x)
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        for stage in (1, 2, 3, 4):
+            x = getattr(self, f"layer{stage}")(x)
         return self.attnpool(x)

@@ -5,7 +5,7 @@ export MKN=${MKN:-50176,2304,256}
 TAG=${1:-pmc}
 for c in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
   d=$R/gpurun_out/${TAG}_$(echo $c | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 $R/scripts/pmc_gemm.py > /dev/null 2>$d.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 $R/scripts/${PMC_SCRIPT:-pmc_gemm.py} > /dev/null 2>$d.err
   f=$(find $d -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv,sys

@@ -1,0 +1,74 @@
+/* Host-side argument validation of the C ABI under AddressSanitizer (SURVEY.md section 5 "sanitizers"; CPU build only --
+ * GPU ASan is not available on the pool).  Linked against a host-sanitised build of libbcos_hip (device code
+ * unsanitised, -fno-gpu-sanitize); every call below must be REJECTED by the library's own checks before any HIP call,
+ * so it runs without a GPU.  Exit code 0 = every call returned the expected error and ASan saw no bad access. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "bcos_hip.h"
+
+static int failures = 0;
+#define EXPECT(call, code)                                                                              \
+    do {                                                                                                \
+        int rc_ = (call);                                                                               \
+        if (rc_ != (code)) { printf("FAIL %s -> %d (expected %d)\n", #call, rc_, (code)); ++failures; } \
+        else if ((code) != BCOS_OK && strlen(bcos_last_error_string()) == 0) {                          \
+            printf("FAIL %s: no error message\n", #call); ++failures; }                                 \
+    } while (0)
+
+int main(void) {
+    if (bcos_version() != BCOS_ABI_VERSION) { printf("ABI version mismatch\n"); return 2; }
+    /* 16-byte aligned host buffers stand in for device pointers: validation never dereferences them */
+    float* buf = (float*)aligned_alloc(64, 4096);
+    uint32_t* am = (uint32_t*)aligned_alloc(64, 4096);
+    bcos_tapconv_geom g;
+    bcos_epilogue e;
+    bcos_operands o;
+    memset(&g, 0, sizeof g); memset(&e, 0, sizeof e); memset(&o, 0, sizeof o);
+    g.N = 1; g.H = 4; g.W = 4; g.C = 8; g.P = 4; g.Q = 4; g.in_sh = g.in_sw = 1; g.dstep_h = g.dstep_w = 1; g.TH = g.TW = 1;
+    g.OH = 4; g.OW = 4; g.out_sh = g.out_sw = 1; g.Cout = 8;
+    e.out = buf; e.b = 2.0f;
+    o.a = buf; o.wt = buf;
+    EXPECT(bcos_tapconv_ops(NULL, &g, &e, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_tapconv_ops(&o, NULL, &e, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_tapconv_ops(&o, &g, NULL, NULL), BCOS_E_INVAL);
+    o.a = NULL;        EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); o.a = buf;
+    o.contraction = 7; EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); o.contraction = 0;
+    g.C = 6;           EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.C = 8;       /* C % 4 */
+    g.Cout = 0;        EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.Cout = 8;
+    o.a = buf + 1;     EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); o.a = buf;    /* misaligned operand */
+    e.out = NULL;      EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); e.out = buf;  /* no output */
+    g.out_h0 = 9;      EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.out_h0 = 0; /* mapping outside [OH,OW] */
+    g.a_pitch = 6;     EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.a_pitch = 0;
+    g.out_pitch = 4;   EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.out_pitch = 0;
+    EXPECT(bcos_tapconv(NULL, buf, &g, &e, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_tapconv_presplit(buf, NULL, NULL, &g, &e, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_tapconv_group(buf, NULL, &g, &e, 1, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_set_contraction_mode(5), BCOS_E_INVAL);
+    { int64_t nb = 0;
+      EXPECT(bcos_split_weights_bytes(0, 16, &nb), BCOS_E_INVAL);
+      EXPECT(bcos_split_weights_bytes(64, 64, &nb), BCOS_OK);
+      if (nb != 4 * 4 * 3 * 1024) { printf("FAIL split bytes %lld\n", (long long)nb); ++failures; }
+      EXPECT(bcos_split_weights_f16x2_bytes(64, 64, NULL), BCOS_E_INVAL);
+      EXPECT(bcos_split_weights_f16x2_bytes(200, 72, &nb), BCOS_OK);
+      if (nb != 8 * 5 * 2 * 1024 + 8 * 32 * 4) { printf("FAIL f16x2 bytes %lld\n", (long long)nb); ++failures; } }
+    EXPECT(bcos_split_weights(buf, (char*)buf + 4, 8, 16, NULL), BCOS_E_INVAL);                   /* misaligned image */
+    EXPECT(bcos_split_weights_f16x2_conv(buf, buf, 8, 0, 16, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_rows_absmax(buf, am, 4, 6, 0, NULL), BCOS_E_INVAL);                               /* C % 4 */
+    EXPECT(bcos_rows_absmax(NULL, am, 4, 8, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_conv2d_fwd(buf, buf, NULL, buf, NULL, NULL, 1, 8, 4, 4, 8, 3, 3, 0, 1, 1, 1, 1, 1, 2.0f, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_conv2d_fwd(NULL, buf, NULL, buf, NULL, NULL, 1, 8, 4, 4, 8, 3, 3, 1, 1, 1, 1, 1, 1, 2.0f, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_linear_fwd(buf, NULL, NULL, buf, NULL, NULL, 4, 8, 8, 2.0f, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, 4, 6, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, 4, 8, BCOS_NONE, 2.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, 4, 8, BCOS_CONV_EPS, 1.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_patch_norm_bwd(buf, buf, NULL, 1, 4, 4, 8, 0, 4, 4, 1, 1, 1, 1, 0, 0, 1, 1, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_conv2d_wgrad(buf, buf, buf, 1, 4, 4, 8, 6, 4, 4, 8, 0, 1, 1, 1, 1, 0, 0, 1, 1, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_colsum(buf, NULL, NULL, NULL, buf, 4, 6, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_channel_axpby(buf, buf, buf, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);
+    free(buf); free(am);
+    if (failures) { printf("%d failure(s)\n", failures); return 1; }
+    printf("abi_validation: ok\n");
+    return 0;
+}
