@@ -62,7 +62,7 @@ def test_abi_argument_validation_under_address_sanitizer():
     """SURVEY.md section 5 "sanitizers": the host side of the C ABI built with -fsanitize=address (device code unsanitised,
     GPU ASan is not available on the pool) rejects ~40 malformed calls without a bad access (tests/asan/abi_validation.c)."""
     import subprocess
-    script = os.path.join(os.path.dirname(HERE), "scripts", "asan_host_check.sh")
+    script = os.path.join(REPO, "scripts", "asan_host_check.sh")
     proc = subprocess.run(["bash", script], capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0 and "abi_validation: ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
 
