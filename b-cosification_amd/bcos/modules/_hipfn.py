@@ -137,6 +137,11 @@ class BcosConv2dFn(Function):
                 "BcosConv2d: weight gradients / training-mode gradients are built for max_out == 1, groups == 1 "
                 "(SURVEY.md section 8(f) N4); MaxOut and grouped layers support explanation-mode input gradients only")
         want_scale = bool((need_grad or need_w or need_b) and b != 1.0)
+        # MaxOut over 2 or 4 filters is taken inside the contraction's epilogue (one launch, bcosconv2d.py:166-170); other
+        # unit sizes and grouped layers go through the general path (full-width lin + bcos_maxout_scale)
+        mo_fused = max_out in (2, 4) and groups == 1 and Cout_all % 4 == 0
+        if mo_fused:
+            return BcosConv2dFn._forward_maxout(ctx, x, xh, wk, w_eff, bias, cfg, (N, Cin, H, W), (kh, kw, Ho, Wo), Cout_all, need_grad)
         fused = max_out == 1
         y_cl, y = empty_cl(N, Cout_all, Ho, Wo, x.device)
         scale = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if (want_scale and fused) else None
@@ -173,12 +178,33 @@ class BcosConv2dFn(Function):
         ctx.in_shape = (N, Cin, H, W)
         ctx.w_eff = w_eff
         ctx.train = bool(train)
+        ctx.mo_fused = False
         ctx.geom = (kh, kw, Ho, Wo)
         keep_x = xh if (train or need_w) else None                  # the padded NHWC input: weight gradient / norm term
         keep_y = y_cl if train else None
         keep_n = norm if train else None
         ctx.save_for_backward(*(t for t in (scale, argmax, keep_x, keep_y, keep_n) if t is not None))
         ctx.has = (scale is not None, argmax is not None, keep_x is not None, keep_y is not None, keep_n is not None)
+        return y_cl
+
+    @staticmethod
+    def _forward_maxout(ctx, x, xh, wk, w_eff, bias, cfg, in_shape, geom, Cout_all, need_grad):
+        """one launch: contraction + max over the M filters of each unit + B-cos scale; the stored multiplier keeps the
+        contraction's width with the scale at the winning filter and zeros elsewhere (= d out / d lin)."""
+        N, Cin, H, W = in_shape
+        kh, kw, Ho, Wo = geom
+        b, M = float(cfg["b"]), cfg["max_out"]
+        stride, padding, dilation = cfg["stride"], cfg["padding"], cfg["dilation"]
+        Cout = Cout_all // M
+        y_cl, y = empty_cl(N, Cout, Ho, Wo, x.device)
+        t_full = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if need_grad else None
+        gm = ops.fwd_geom(N, H, W, wk.shape[3], Cout_all, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1])
+        ops.tapconv(xh, wk, gm, out=y, scale_out=t_full, bias=bias, bcos_mode=BCOS_NONE if b == 1.0 else BCOS_CONV_EPS, b=b,
+                    flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0, max_out=M)
+        ctx.cfg, ctx.in_shape, ctx.w_eff, ctx.train, ctx.geom = cfg, in_shape, w_eff, False, geom
+        ctx.save_for_backward(*(t for t in (t_full,) if t is not None))
+        ctx.has = (t_full is not None, False, False, False, False)
+        ctx.mo_fused = True
         return y_cl
 
     @staticmethod
@@ -205,6 +231,9 @@ class BcosConv2dFn(Function):
             glin = glin.view(N, Ho, Wo, Cout)
             if need_x:      # gradient through calc_patch_norms: x * PatchSum^T(dL/dnorm / norm), added by the dgrad epilogue
                 addend = ops.patch_norm_bwd(xh, rnorm.view(N, Ho, Wo), Cin, (kh, kw), cfg["stride"], cfg["padding"], cfg["dilation"])
+        elif ctx.mo_fused:      # the gradient goes to the winning filter of each unit, times its scale
+            Cn = g.shape[3]
+            glin = ops.maxout_expand(g.reshape(-1, Cn), scale.view(-1, Cn * max_out), max_out).view(N, Ho, Wo, Cn * max_out)
         else:
             glin = ops.mul(g, scale) if scale is not None else g
         gw = gb = None
@@ -258,7 +287,16 @@ class BcosLinearFn(Function):
         Cout_all = w_eff.shape[0]
         argmax = None
         norm = None
-        if max_out == 1:
+        mo_fused = max_out in (2, 4) and Cout_all % 4 == 0
+        if mo_fused:
+            rows = x2.shape[0]
+            y = torch.empty((rows, Cout_all // max_out), device=x.device, dtype=torch.float32)
+            scale = torch.empty((rows, Cout_all), device=x.device, dtype=torch.float32) if need_grad else None
+            g = dict(N=1, H=1, W=rows, C=x2.shape[1], P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
+                     TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout_all)
+            ops.tapconv(x2, wk, g, out=y, scale_out=scale, bias=bias, bcos_mode=BCOS_NONE if b == 1.0 else BCOS_LINEAR_EPS, b=b,
+                        flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0, max_out=max_out)
+        elif max_out == 1:
             y, scale, norm = ops.linear_fwd(x2, wk, bias=bias, b=b, want_scale=want_scale, want_norm=train,
                                             flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0)
         else:
@@ -275,6 +313,7 @@ class BcosLinearFn(Function):
         ctx.w_eff = w_eff
         ctx.in_shape = tuple(x.shape)
         ctx.train = bool(train)
+        ctx.mo_fused = bool(mo_fused)
         keep_x = x2 if (train or need_w) else None
         keep_y = y if train else None
         keep_n = norm if train else None
@@ -304,6 +343,8 @@ class BcosLinearFn(Function):
             if need_x:      # gradient through ||x||: x * dL/dnorm / ||x||, added by the dgrad epilogue
                 rows = x2.shape[0]
                 addend = ops.patch_norm_bwd(x2.view(1, 1, rows, x2.shape[1]), rnorm.view(1, 1, rows), Cin, (1, 1), (1, 1), (0, 0), (1, 1))
+        elif ctx.mo_fused:
+            glin = ops.maxout_expand(g2, scale, max_out)
         else:
             glin = ops.mul(g2, scale) if scale is not None else g2
         gw = gb = None

@@ -44,7 +44,7 @@ class Epilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2", "relu_gate",
         "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax")] + [
-        ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32)]
+        ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32), ("max_out", C.c_int32)]
 
 
 class Operands(C.Structure):
@@ -83,6 +83,7 @@ SIGNATURES = {
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_maxout_scale": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
+    "bcos_maxout_expand": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "bcos_prep_input": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bcos_finalize_explanation": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bcos_contrib_map": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),

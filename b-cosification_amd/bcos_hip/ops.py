@@ -188,7 +188,7 @@ def _out_absmax(t: Optional[torch.Tensor], pixels: int):
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
             gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0, contraction=None,
-            track_absmax=None, track_absmax2=None):
+            track_absmax=None, track_absmax2=None, max_out=1):
     """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv_ops).
     `contraction`: None = the library default, or 'f32' / 'bf16x3' / 'f16x2' for this call.
     `track_absmax` / `track_absmax2`: emit the per-pixel maxima of out / out2 (default: whenever the f16x2 contraction is
@@ -209,6 +209,9 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     e.relu = int(relu)          # 0 none, 1 ReLU, 2 GELU with constant gate
     e.b = float(b)
     e.flags = int(flags)
+    e.max_out = int(max_out)
+    if e.max_out > 1:                    # fused MaxOut: plain forward epilogue, no operand maxima of the (narrow) output
+        track_absmax = track_absmax2 = False
     mode = contraction if contraction is not None else _l.get_contraction_mode()
     o = _l.Operands()
     o.a = _dev(a, "tapconv.a", contiguous=False).value
@@ -462,6 +465,16 @@ def mul(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)
     _l.check(lib.bcos_mul(_dev(a, "a"), _dev(b, "b"), _dev(out, "out"), a.numel(), _stream()), "bcos_mul")
+    return out
+
+
+def maxout_expand(gy2d, t2d, max_out):
+    """glin[r, c] = gy[r, c // M] * t[r, c]: backward of the fused MaxOut (include/bcos_hip.h: bcos_maxout_expand)."""
+    lib = _l.load()
+    rows, Cout = t2d.shape
+    out = torch.empty_like(t2d)
+    _l.check(lib.bcos_maxout_expand(_dev(gy2d, "gy"), _dev(t2d, "t"), _dev(out, "glin"), rows, Cout, int(max_out), _stream()),
+             "bcos_maxout_expand")
     return out
 
 

@@ -321,6 +321,31 @@ extern "C" int bcos_mul(const float* a, const float* b, float* out, int64_t n, v
     return check_launch("mul_kernel");
 }
 
+namespace {
+__global__ __launch_bounds__(TPB) void maxout_expand_kernel(const float* __restrict__ gy, const float* __restrict__ t,
+                                                            float* __restrict__ glin, int64_t n4, int c4, int Cn, int M) {
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += stride) {
+        const int64_t r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        f32x4 tv = reinterpret_cast<const f32x4*>(t)[i];
+        const float* g = gy + r * Cn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tv[q] *= g[(c + q) / M];
+        reinterpret_cast<f32x4*>(glin)[i] = tv;
+    }
+}
+}  // namespace
+
+extern "C" int bcos_maxout_expand(const float* gy, const float* t, float* glin, int64_t rows, int Cout, int max_out, void* stream) {
+    if (!gy || !t || !glin || rows <= 0 || Cout <= 0 || max_out <= 0 || Cout % 4 != 0 || Cout % max_out != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_maxout_expand: bad argument");
+    const int64_t n4 = rows * (Cout / 4);
+    hipLaunchKernelGGL(maxout_expand_kernel, dim3(grid_for(n4)), dim3(TPB), 0, STREAM(stream), gy, t, glin, n4, Cout / 4,
+                       Cout / max_out, max_out);
+    return check_launch("maxout_expand_kernel");
+}
+
 extern "C" int bcos_maxout_scale(const float* lin, const float* norm, float* y, float* scale_out,
                                  int32_t* argmax_out, int64_t rows, int Cout, int max_out, int norm_stride, float b,
                                  void* stream) {

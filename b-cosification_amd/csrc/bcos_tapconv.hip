@@ -242,7 +242,35 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                 mx1[u] = 0u; mx2[u] = 0u;
                 pixs[u] = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
             }
-            if (vec) {
+            if (e.max_out > 1) {
+                // MaxOut (bcosconv2d.py:166-170): the accumulator columns are the M filters of each output unit, adjacent;
+                // a thread's 4 columns hold 4 / M whole units.  out is [pixels, Cout / M] (pitch out_pitch), scale_out keeps
+                // the contraction's width (pitch Cout): the scale at the winning filter, 0 at the others -- d out / d lin.
+                // (the host only takes this path for M in {2, 4}, Cout % 4 == 0 and plain forward epilogues)
+                const int M_ = e.max_out;
+#pragma unroll
+                for (int u = 0; u < EPI_G; ++u) {
+                    const int lrow = rbase + (p0 + u) * RPP;
+                    const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
+                    const int64_t pix = pixs[u];
+                    if (pix < 0 || col >= Cout) continue;
+                    f32x4 val = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
+                    if (SCALED) val = val * sAinv[row] * cinv4;
+                    val += bias4;
+                    f32x4 tf = {0.f, 0.f, 0.f, 0.f};
+                    for (int u0 = 0; u0 < 4; u0 += M_) {
+                        int arg = u0;
+                        for (int q = u0 + 1; q < u0 + M_; ++q) arg = val[q] > val[arg] ? q : arg;      // first maximum wins
+                        const float m = val[arg];
+                        float sc = 1.f;
+                        if (NORM && !norm_only)
+                            sc = b_is_2 ? fabsf(m) * sRinv[row] : powf(fabsf(m / sNorm[row]) + 1e-6f, bm1);
+                        if (e.out) e.out[pix * g.out_pitch + (col + u0) / M_] = m * sc;
+                        tf[arg] = sc;
+                    }
+                    if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + pix * (int64_t)Cout + col) = tf;
+                }
+            } else if (vec) {
                 f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
                 int64_t idx[EPI_G];
                 bool ok[EPI_G];
@@ -1574,6 +1602,16 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     if (M64 >= (int64_t)1 << 31) return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: more than 2^31 rows");
     if (!epi->out && !epi->out2 && !epi->scale_out)
         return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: no output buffer");
+    if (epi->max_out < 0) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: negative max_out");
+    if (epi->max_out > 1) {
+        if ((epi->max_out != 2 && epi->max_out != 4) || g.Cout % 4 != 0)
+            return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: fused MaxOut needs max_out in {2, 4} and Cout % 4 == 0");
+        if (epi->addend || epi->mul || epi->mul2 || epi->gate2 || epi->relu_gate || epi->out2 || epi->ch_scale || epi->ch_shift ||
+            epi->relu || epi->out_absmax || epi->out2_absmax || (epi->flags & ~(BCOS_EPI_FORCE_POW)))
+            return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: fused MaxOut supports bias, the B-cos scale, out, scale_out and norm_out only");
+        if ((reinterpret_cast<uintptr_t>(epi->scale_out) & 15))
+            return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: scale_out must be 16-byte aligned");
+    }
     // the last row/col written must be inside the output tensor
     if ((g.P - 1) * g.out_sh + g.out_h0 >= g.OH || (g.Q - 1) * g.out_sw + g.out_w0 >= g.OW || g.out_h0 < 0 ||
         g.out_w0 < 0)
@@ -1587,7 +1625,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     if (p.g.out_pitch == 0) p.g.out_pitch = g.Cout;
     if (p.g.norm_pitch == 0) p.g.norm_pitch = 1;
     if (p.g.a_pitch % 4 != 0 || p.g.a_pitch < g.C) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad a_pitch");
-    if (p.g.out_pitch < g.Cout) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad out_pitch");
+    if (epi->max_out > 1 && g.out_pitch == 0) p.g.out_pitch = g.Cout / epi->max_out;
+    if (p.g.out_pitch < g.Cout / (epi->max_out > 1 ? epi->max_out : 1)) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad out_pitch");
     p.e = *epi;
     p.M = (int)M64;
     p.PQ = g.P * g.Q;
@@ -1659,7 +1698,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g.Cout <= 8 && !epi->out_absmax && !epi->out2_absmax) {
+    if (g.Cout <= 8 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1) {
         const int handled = bcos_try_skinny(a, wt, p.g, p.e, p.M, s);
         if (handled != 0) return handled < 0 ? handled : BCOS_OK;
     }

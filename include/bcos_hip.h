@@ -122,6 +122,11 @@ typedef struct bcos_epilogue {
     int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */
     int32_t flags;          /* BCOS_EPI_* bits                            */
+    int32_t max_out;        /* 0 / 1: off.  2 or 4 (Cout % 4 == 0): MaxOut fused (bcosconv2d.py:166-170): the Cout accumulator
+                               columns are the M adjacent filters of Cout / M units; v = max over each unit before the B-cos
+                               scale; out is [pixels, Cout / M] (out_pitch 0 = Cout / M); scale_out keeps width Cout and holds s at
+                               the winning filter (first maximum) and 0 elsewhere, i.e. d out / d lin.  Only with bias, the scale,
+                               out, scale_out, norm_out.                                                          */
 } bcos_epilogue;
 
 /* compute the patch norms (norm_out) but leave v unscaled: used by the MaxOut / grouped
@@ -271,6 +276,10 @@ int bcos_weight_rownorm_scale(const float* w, const float* gain, float* w_out,
 
 /* out[i] = a[i] * b[i] */
 int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* Backward of the fused MaxOut: glin[r, c] = gy[r, c / M] * t[r, c] with t = the scale_out of a max_out launch
+ * (gy [rows, Cout / M], t and glin [rows, Cout], Cout % 4 == 0): routes the gradient to the winning filter. */
+int bcos_maxout_expand(const float* gy, const float* t, float* glin, int64_t rows, int Cout, int max_out, void* stream);
 
 /* MaxOut + B-cos scaling for the non-fused general path (max_out > 1, groups > 1):
  * lin [rows, Cout*max_out] -> y [rows, Cout] with per-row norms given (bcosconv2d.py:166-194). */

@@ -14,7 +14,7 @@ from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM
 
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
             ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
-            b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None):
+            b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None, max_out=1):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
     g = dict(a_pitch=0, out_pitch=0, norm_pitch=0)
@@ -40,6 +40,23 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
     v = acc
     if bias is not None:
         v = v + bias.double()
+    if max_out > 1:       # fused MaxOut (include/bcos_hip.h: bcos_epilogue.max_out): out narrow, scale_out at the winner
+        M = max_out
+        vm, arg = v.view(N, P, Q, Cout // M, M).max(-1)            # first maximum, like torch.max
+        sm = torch.ones_like(vm)
+        if bcos_mode != BCOS_NONE:
+            nrm = ss.sqrt() + 1e-12 if bcos_mode == BCOS_LINEAR_EPS else (ss + 1e-6).sqrt()
+            sm = vm.abs() / nrm[..., None] if (b == 2.0 and not (flags & BCOS_EPI_FORCE_POW)) else \
+                ((vm / nrm[..., None]).abs() + 1e-6).pow(b - 1)
+            if norm_out is not None:
+                norm_out.view(N, P, Q)[...] = nrm.to(norm_out.dtype)
+        if out is not None:
+            out.view(N, P, Q, -1)[..., :Cout // M] = (vm * sm).to(out.dtype)
+        if scale_out is not None:
+            t = torch.zeros(N, P, Q, Cout // M, M, dtype=torch.float64)
+            t.scatter_(-1, arg[..., None], sm[..., None])
+            scale_out.view(N, P, Q, Cout)[...] = t.view(N, P, Q, Cout).to(scale_out.dtype)
+        return
     s = torch.ones_like(v)
     nrm = None
     if bcos_mode != BCOS_NONE:
@@ -217,6 +234,10 @@ def ensure_absmax(t):
     return t
 
 
+def maxout_expand(gy2d, t2d, max_out):
+    return t2d * gy2d.repeat_interleave(max_out, dim=1)
+
+
 # ---- training-mode backward (include/bcos_hip.h: bcos_train_scale_bwd ... bcos_channel_axpby) ----------------------------
 def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False):
     nrm = norm.view(-1, 1)
@@ -280,7 +301,7 @@ def install(monkeypatch):
                  "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
-                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby"):
+                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn
