@@ -24,10 +24,16 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_SCALE_GATE_LSB, BCOS_NONE,
-                  BcosHipError)
+from .lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_MUL_FROM_ACT, BCOS_EPI_SCALE_GATE_LSB,
+                  BCOS_NONE, BcosHipError)
 
 _GATE_TENSOR = bool(os.environ.get("BCOS_GATE_TENSOR"))   # development switch: ReLU gates as tensors, not as the bit in t
+# Rebuilding a layer's multiplier t from its kept activation (BCOS_EPI_MUL_FROM_ACT) instead of storing it saves one
+# output-sized write in the forward launches of conv1 / conv2 of every block (-0.57 ms of HBM-bound launch time per step at
+# ResNet-50 batch 256), but the input-gradient launches that rebuild it are instruction-issue bound in their epilogue and lose
+# +0.76 ms (measured on one node, interleaved runs: 6 963 vs 6 992 images/s).  Stored t stays the default; BCOS_REBUILD_T=1
+# selects the rebuild (same results: tests run both).
+_STORE_T = not bool(os.environ.get("BCOS_REBUILD_T"))
 
 
 def _pair(v):
@@ -100,15 +106,37 @@ class _Conv:
         """largest K of the input-gradient launches (their A operand is the gradient w.r.t. this layer's `lin`)."""
         return self.cout * self.k[0] * self.k[1]
 
-    def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None, flags=0, track=None):
+    def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None, flags=0, track=None, keep_act=False):
+        """-> (y, t).  `keep_act` (explanation state of a layer whose output stays alive anyway is cheaper to REBUILD than to
+        store): when the layer allows it -- B = 2, plain |lin| / norm scale, own ReLU decided by the value, no residual -- t
+        is not written; the returned `t` is then an _ActScale record (activation, patch norms, BN scale / shift) from which
+        the consuming input-gradient launch rebuilds the multiplier (BCOS_EPI_MUL_FROM_ACT)."""
         gate = gates.pop(0) if (relu and gates is not None) else None
-        y, t, _ = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
-                                 bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
-                                 ch_shift=self.ch_shift, addend=addend, relu=relu, relu_gate=gate,
-                                 want_scale=want_scale, flags=flags | (BCOS_EPI_FORCE_POW if self.force_pow else 0),
-                                 track_absmax=track)
+        rebuild = (keep_act and want_scale and relu and gate is None and addend is None and self.b == 2.0 and not self.force_pow)
+        y, t, nrm = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
+                                   bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
+                                   ch_shift=self.ch_shift, addend=addend, relu=relu, relu_gate=gate,
+                                   want_scale=want_scale and not rebuild, want_norm=rebuild,
+                                   flags=flags | (BCOS_EPI_FORCE_POW if self.force_pow else 0), track_absmax=track)
         self.last_gate = gate       # the replayed gate tensor, if any (else the output itself encodes the gate)
+        if rebuild:
+            t = _ActScale(y, nrm, self.ch_scale, self.ch_shift)
         return y, t
+
+
+class _ActScale:
+    """What the explanation pass needs to rebuild t = s * bn_scale * relu_gate of a layer from its kept activation."""
+
+    def __init__(self, act, norm, ch_scale, ch_shift):
+        self.act, self.norm, self.ch_scale, self.ch_shift = act, norm, ch_scale, ch_shift
+
+    def kwargs(self):
+        return dict(mul=self.act, mul_norm=self.norm, mul_csc=self.ch_scale, mul_csh=self.ch_shift, flags=BCOS_EPI_MUL_FROM_ACT)
+
+
+def _mul_kwargs(t):
+    """epilogue arguments that multiply a gradient by the layer multiplier `t` (stored tensor or _ActScale record)"""
+    return t.kwargs() if isinstance(t, _ActScale) else dict(mul=t)
 
 
 class _Block:
@@ -292,7 +320,7 @@ class ResNetEngine:
             for ci, c in enumerate(blk.convs[:-1]):
                 hws.append((h.shape[1], h.shape[2]))
                 pooled_next = blk.pool and ci == len(blk.convs) - 2              # a pool sits between this conv and the next
-                h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates,
+                h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates, keep_act=not pooled_next and not _STORE_T,
                              track=need(blk.convs[ci + 1].k_fwd) and not pooled_next)
                 ts.append(t)
             pre_pool_hw = (h.shape[1], h.shape[2])
@@ -458,8 +486,8 @@ class ResNetEngine:
                     if convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K:
                         ops.ensure_absmax(gl)
                 else:
-                    gl = convs[ci].dgrad.run(gl, h, w, mul=rec["ts"][ci - 1],
-                                             track_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K)
+                    gl = convs[ci].dgrad.run(gl, h, w, track_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K,
+                                             **_mul_kwargs(rec["ts"][ci - 1]))
                 if consume:
                     rec["ts"][ci - 1] = None
             consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc, blk.shortcut_pool)

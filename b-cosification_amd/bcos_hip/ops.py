@@ -129,7 +129,24 @@ class AbsmaxArena:
 
 
 _ARENA: Optional[AbsmaxArena] = None
+DEFAULT_TRACK_ABSMAX = True    # what tapconv(track_absmax=None) means while the f16x2 contraction is selected (see no_absmax)
 F16X2_MIN_K = 512     # csrc/bcos_tapconv.hip: below this K a launch is HBM-bound and keeps the bf16x3 loop (no operand maxima needed)
+
+
+class no_absmax:
+    """Context: launches inside do not emit per-pixel maxima unless asked to, so their readers keep the bf16x3 loop.  Used by
+    plans whose contractions are too small-K for the f16x2 loop to pay (SimpleViT: K = 192 / 768 linears -- measured
+    15.2 k images/s with bf16x3 against 14.5 k with maxima + f16x2 at batch 512)."""
+
+    def __enter__(self):
+        global DEFAULT_TRACK_ABSMAX
+        self._prev = DEFAULT_TRACK_ABSMAX
+        DEFAULT_TRACK_ABSMAX = False
+
+    def __exit__(self, *exc):
+        global DEFAULT_TRACK_ABSMAX
+        DEFAULT_TRACK_ABSMAX = self._prev
+        return False
 
 
 def set_absmax_arena(arena: Optional[AbsmaxArena]):
@@ -188,7 +205,7 @@ def _out_absmax(t: Optional[torch.Tensor], pixels: int):
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
             gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0, contraction=None,
-            track_absmax=None, track_absmax2=None, max_out=1):
+            track_absmax=None, track_absmax2=None, max_out=1, mul_norm=None, mul_csc=None, mul_csh=None):
     """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv_ops).
     `contraction`: None = the library default, or 'f32' / 'bf16x3' / 'f16x2' for this call.
     `track_absmax` / `track_absmax2`: emit the per-pixel maxima of out / out2 (default: whenever the f16x2 contraction is
@@ -201,7 +218,8 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         setattr(g, k, int(v))
     e = Epilogue()
     tensors = dict(bias=bias, ch_scale=ch_scale, ch_shift=ch_shift, addend=addend, mul=mul, mul2=mul2,
-                   gate2=gate2, relu_gate=relu_gate, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out)
+                   gate2=gate2, relu_gate=relu_gate, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out,
+                   mul_norm=mul_norm, mul_csc=mul_csc, mul_csh=mul_csh)
     for k, t in tensors.items():
         p = _dev(t, f"tapconv.{k}", contiguous=False)
         setattr(e, k, p.value if p is not None else None)
@@ -223,7 +241,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         # outputs carry their per-pixel maxima for the launch that will read them as its A operand
         pixels = int(g.N) * int(g.OH) * int(g.OW)
         for name, t, want in (("out_absmax", out, track_absmax), ("out2_absmax", out2, track_absmax2)):
-            am = _out_absmax(t, pixels) if (want is None or want) else None
+            am = _out_absmax(t, pixels) if (DEFAULT_TRACK_ABSMAX if want is None else want) else None
             if am is not None:
                 setattr(e, name, am.data_ptr())
                 keep.append(am)

@@ -178,6 +178,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
     const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
     const bool gate_lsb = (e.flags & BCOS_EPI_SCALE_GATE_LSB) != 0;
     const bool gate_mul = (e.flags & BCOS_EPI_GATE2_FROM_MUL) != 0 && e.mul != nullptr;
+    const bool mul_from_act = (e.flags & BCOS_EPI_MUL_FROM_ACT) != 0 && e.mul != nullptr && e.mul_norm != nullptr;
     const bool want_max = e.out_absmax != nullptr || e.out2_absmax != nullptr;
     const float bm1 = e.b - 1.0f;
     const int Cout = g.Cout;
@@ -222,6 +223,24 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
             if (e.ch_shift) csh4[q] = e.ch_shift[c];
             if (SCALED) cinv4[q] = p.wt2_cinv[c];
         }
+        f32x4 mcsc4 = {1.f, 1.f, 1.f, 1.f}, mcsh4 = {0.f, 0.f, 0.f, 0.f};
+        if (mul_from_act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = col + q < Cout ? col + q : 0;
+                if (e.mul_csc) mcsc4[q] = e.mul_csc[c];
+                if (e.mul_csh) mcsh4[q] = e.mul_csh[c];
+            }
+        }
+        // `mul` given as the kept ACTIVATION a = relu(lin s csc + csh) of the layer below (B = 2, s = |lin| / norm) instead of its
+        // stored multiplier t = s csc gate: |lin|^2 = |a - csh| norm / |csc|, so t = csc sqrt(|a - csh| / (|csc| norm)) where a > 0
+        auto rebuild_t = [&](float a, float nrm, float csc, float csh) {
+            const float z = fabsf(a - csh);
+            const float den = fabsf(csc) * nrm;
+            // hardware reciprocal / square root (1 ulp each): the IEEE division + sqrt sequences are ~20 instructions per
+            // element in an epilogue that is issue-bound, and t enters a product whose other factor carries fp32 rounding anyway
+            return (a > 0.f && den > 0.f) ? csc * __builtin_amdgcn_sqrtf(z * __builtin_amdgcn_rcpf(den)) : 0.f;
+        };
         struct EpiIn { f32x4 ad[EPI_G], m1[EPI_G]; };
         auto issue = [&](int p0, EpiIn& in) {
 #pragma unroll
@@ -289,6 +308,11 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                     ad[u] = in.ad[u];
                     rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
                     m1[u] = in.m1[u];
+                    if (mul_from_act) {
+                        const float mn = e.mul_norm[ok[u] ? pix : 0];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) m1[u][q] = rebuild_t(m1[u][q], mn, mcsc4[q], mcsh4[q]);
+                    }
                     m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
                     g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
                 }
@@ -373,7 +397,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                             s *= gate;
                             v *= gate;
                         }
-                        const float o1 = e.mul ? v * e.mul[idx] : v;
+                        const float o1 = e.mul ? v * (mul_from_act ? rebuild_t(e.mul[idx], e.mul_norm[pix], mcsc4[q], mcsh4[q]) : e.mul[idx]) : v;
                         if (e.out) e.out[idx] = o1;
                         mx1[u] = max(mx1[u], __float_as_uint(o1) & 0x7fffffffu);
                         if (e.out2) {
@@ -1603,6 +1627,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     if (!epi->out && !epi->out2 && !epi->scale_out)
         return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: no output buffer");
     if (epi->max_out < 0) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: negative max_out");
+    if ((epi->flags & BCOS_EPI_MUL_FROM_ACT) && (!epi->mul || !epi->mul_norm || (epi->flags & BCOS_EPI_GATE2_FROM_MUL)))
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: BCOS_EPI_MUL_FROM_ACT needs mul and mul_norm and excludes GATE2_FROM_MUL");
     if (epi->max_out > 1) {
         if ((epi->max_out != 2 && epi->max_out != 4) || g.Cout % 4 != 0)
             return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: fused MaxOut needs max_out in {2, 4} and Cout % 4 == 0");
@@ -1660,6 +1686,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 float** cout[] = {&e2.out, &e2.out2, &e2.scale_out};
                 for (float** q : cout) if (*q) *q += opix * p.g.out_pitch;
                 if (e2.norm_out) e2.norm_out += opix * p.g.norm_pitch;
+                if (e2.mul_norm) e2.mul_norm += opix;
                 if (e2.out_absmax) e2.out_absmax += opix;
                 if (e2.out2_absmax) e2.out2_absmax += opix;
                 bcos_operands o2 = *ops;

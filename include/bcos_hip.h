@@ -118,6 +118,9 @@ typedef struct bcos_epilogue {
     float* norm_out;
     uint32_t* out_absmax;   /* NULL or [N*OH*OW] */
     uint32_t* out2_absmax;  /* NULL or [N*OH*OW] */
+    const float* mul_norm;  /* BCOS_EPI_MUL_FROM_ACT: patch norms [N*OH*OW] of the layer whose activation `mul` holds */
+    const float* mul_csc;   /* ... its ch_scale [Cout] (NULL = 1) */
+    const float* mul_csh;   /* ... its ch_shift [Cout] (NULL = 0) */
     int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
     int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */
@@ -142,6 +145,13 @@ typedef struct bcos_epilogue {
 #define BCOS_EPI_SCALE_GATE_LSB 4
 /* out2 = v [* mul2] gated by that bit of `mul` (instead of gate2 > 0): saves one output-sized read per launch. */
 #define BCOS_EPI_GATE2_FROM_MUL 8
+
+/* `mul` holds the kept forward ACTIVATION a = relu(lin s ch_scale + ch_shift) of the layer below (B = 2, s = |lin| / norm, no
+ * residual addend) instead of its stored multiplier t = s ch_scale gate; the epilogue rebuilds
+ *     t = ch_scale sqrt(|a - ch_shift| / (|ch_scale| norm))  where a > 0, else 0
+ * from mul_norm / mul_csc / mul_csh.  The forward launch of such a layer then writes out + norm_out only: one
+ * output-sized HBM write less (the explanation pass reads `a` where it would have read t). */
+#define BCOS_EPI_MUL_FROM_ACT 16
 
 /* -- library -------------------------------------------------------------------------- */
 

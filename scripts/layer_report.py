@@ -45,8 +45,20 @@ for (e0, e1, M, K, Nn, TH, ins, outs, nbytes, kind, fl) in records:
     key = (kind, M, K, Nn, TH, ins, outs)
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl; a[3] += nbytes
     tot += ms; totf += fl
+rows_csv = []
 print(f"{'kind':4} {'M':>8} {'K':>6} {'N':>5} k s/os  cnt    ms     TF/s    GB/s   %time")
 for key, (cnt, ms, fl, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     kind, M, K, Nn, TH, ins, outs = key
     print(f"{kind:4} {M:8d} {K:6d} {Nn:5d} {TH} {ins}/{outs} {cnt:4d} {ms:7.3f} {fl/ms/1e9:7.1f} {nb/ms/1e6:7.0f} {100*ms/tot:6.1f}")
+    tf, gbs = fl / ms / 1e9, nb / ms / 1e6
+    bound = "hbm" if fl / max(nb, 1) < 50.0 else "mfma"       # same rule as bench.py: algorithmic FLOP/B against ~50
+    rows_csv.append(dict(kind=kind, M=M, K=K, N=Nn, taps_h=TH, in_stride=ins, out_stride=outs, launches=cnt, ms=round(ms, 4),
+                         tflops=round(tf, 1), gbps=round(gbs, 0), bound=bound, frac_of_fp32_mfma_peak=round(tf / 157.3, 3),
+                         hbm_frac_of_8TBps=round(gbs / 8000.0, 3), pct_of_contraction_time=round(100 * ms / tot, 2)))
+if os.environ.get("LAYERS_CSV"):
+    import csv
+    with open(os.environ["LAYERS_CSV"], "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=list(rows_csv[0].keys()))
+        wr.writeheader()
+        wr.writerows(rows_csv)
 print(f"total tapconv {tot:.2f} ms, {totf/1e9:.0f} GFLOP executed ({totf/tot/1e9:.1f} TF/s executed); algorithmic {17.22*B:.0f} GFLOP -> {17.22*B/tot:.1f} TF/s")

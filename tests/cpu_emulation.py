@@ -8,13 +8,14 @@ include/bcos_hip.h documents for each entry point.  Nothing here is reachable fr
 import torch
 import torch.nn.functional as F
 
-from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_NORM_ONLY,
+from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM_MUL, BCOS_EPI_MUL_FROM_ACT, BCOS_EPI_NORM_ONLY,
                           BCOS_EPI_SCALE_GATE_LSB, BCOS_LINEAR_EPS, BCOS_NONE)
 
 
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
             ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
-            b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None, max_out=1):
+            b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None, max_out=1,
+            mul_norm=None, mul_csc=None, mul_csh=None):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
     g = dict(a_pitch=0, out_pitch=0, norm_pitch=0)
@@ -97,8 +98,16 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
         if flags & BCOS_EPI_SCALE_GATE_LSB:       # gate decision in the low mantissa bit of the stored fp32 multiplier
             bits = s.float().contiguous().view(torch.int32)
             s = torch.where(open_gate, (bits | 1).view(torch.float32).double(), torch.zeros_like(s))
+    mul_val = rd(mul) if mul is not None else None
+    if mul is not None and (flags & BCOS_EPI_MUL_FROM_ACT):        # `mul` is the kept activation: rebuild t (include/bcos_hip.h)
+        a = mul_val
+        csc = mul_csc.double() if mul_csc is not None else torch.ones(Cout, dtype=torch.float64)
+        csh = mul_csh.double() if mul_csh is not None else torch.zeros(Cout, dtype=torch.float64)
+        mn = (mul_norm if mul_norm.dim() == 4 else mul_norm.view(N, g["OH"], g["OW"], 1))[:, oh][:, :, ow][..., :1].double()
+        den = csc.abs() * mn
+        mul_val = torch.where((a > 0) & (den > 0), csc * ((a - csh).abs() / den.clamp_min(1e-300)).sqrt(), torch.zeros_like(a))
     if out is not None:
-        wr(out, v * rd(mul) if mul is not None else v)
+        wr(out, v * mul_val if mul is not None else v)
     if out2 is not None:
         o2 = v
         if mul2 is not None:

@@ -337,6 +337,7 @@ def _gate_flips(net, eng, x, arch):
     ours = list(st["stem_ts"]) + [t for rec in st["blocks"] for t in rec["ts"]]
     flips, total, worst = 0, 0, 0.0
     for p, t in zip(pre, ours):
+        t = t.act if hasattr(t, "act") else t           # layers whose multiplier is rebuilt keep their activation instead
         open_ref = (p > 0)
         open_hip = (t.permute(0, 3, 1, 2).cpu() != 0)   # t = s * bn_scale * gate
         diff = open_ref != open_hip
@@ -445,6 +446,24 @@ def test_determinism_and_batch_independence(lib, golden_dir):
     c = eng.explain(x[1:3])
     assert torch.equal(c["logits"], a["logits"][1:3])
     assert torch.equal(c["dynamic_linear_weights"], a["dynamic_linear_weights"][1:3])
+
+
+def test_rebuilt_multipliers_match_stored_ones(lib, golden_dir, monkeypatch):
+    """BCOS_EPI_MUL_FROM_ACT: the explanation pass with the multipliers t of the inner block convolutions REBUILT from the
+    kept activations and patch norms (no t written in the forward) equals the stored-t pass -- gates pinned to the same
+    oracle decisions, 1e-5; and the free-gate maps stay within the ResNet-18 floor of the reference fixture."""
+    from bcos_hip import engine, synth
+    net, meta, data = _golden_net(golden_dir, "resnet18_e2e")
+    x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+    eng = engine.attach(net)
+    stored = eng.explain(x)
+    monkeypatch.setattr(engine, "_STORE_T", False)
+    rebuilt = eng.explain(x)
+    _, st = eng._run_forward(x[:2], keep=True)
+    assert any(isinstance(t, engine._ActScale) for rec in st["blocks"] for t in rec["ts"])      # the rebuild path is taken
+    assert torch.equal(rebuilt["logits"], stored["logits"])
+    assert rel(rebuilt["dynamic_linear_weights"], stored["dynamic_linear_weights"]) <= 1e-5
+    assert rel(rebuilt["contribution_map"], data["contribution_map"]) <= 2e-3
 
 
 def test_resnet50_batch256_properties(lib):
