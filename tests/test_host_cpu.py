@@ -112,6 +112,34 @@ def test_constructor_surface_and_state_dict_keys():
     assert "B=2" in repr(c)
 
 
+def test_torchvision_resnet_topology_facts():
+    """The oracle's torchvision stand-in IS the product's `_tv_resnet.py` (oracle/refimport.py), so an error in that
+    restatement would be invisible to fixtures, oracle and product alike.  This pins it against facts that come from
+    torchvision 0.17.1 itself, not from this repository: the published parameter counts of resnet18 / resnet50
+    (11 689 512 / 25 557 032), their state-dict sizes (122 / 320 entries), key names, the v1.5 placement of the stride on
+    the 3x3 convolution, and the B-cosified key list SURVEY.md T3 records from the reference run."""
+    from bcos_hip import synth
+    facts = {"resnet18": (11_689_512, 122, (1000, 512), (512, 256, 1, 1)), "resnet50": (25_557_032, 320, (1000, 2048), (2048, 1024, 1, 1))}
+    for arch, (n_params, n_entries, fc_shape, ds_shape) in facts.items():
+        std = synth.standard_resnet(arch)
+        sd = std.state_dict()
+        assert sum(p.numel() for p in std.parameters()) == n_params, arch
+        assert len(sd) == n_entries, arch
+        assert sd["conv1.weight"].shape == (64, 3, 7, 7) and sd["fc.weight"].shape == fc_shape and sd["fc.bias"].shape == (1000,)
+        assert sd["layer4.0.downsample.0.weight"].shape == ds_shape and "layer4.0.downsample.1.running_var" in sd
+        assert "layer1.0.downsample.0.weight" in sd if arch == "resnet50" else "layer1.0.downsample.0.weight" not in sd
+        assert "bn1.num_batches_tracked" in sd and isinstance(std.maxpool, nn.MaxPool2d) and std.maxpool.kernel_size == 3
+    r50 = synth.standard_resnet("resnet50")
+    assert r50.layer2[0].conv1.stride == (1, 1) and r50.layer2[0].conv2.stride == (2, 2)          # ResNet v1.5
+    assert r50.layer2[0].downsample[0].stride == (2, 2) and r50.layer1[0].conv2.stride == (1, 1)
+    # B-cosified key list (SURVEY.md T3, recorded from the reference): 101 tensors / 11.70 M elements for ResNet-18, no bias keys
+    net = synth.build_bcosified_resnet("resnet18")
+    bsd = net.state_dict()
+    assert len(bsd) == 101 and abs(sum(v.numel() for v in bsd.values()) / 1e6 - 11.70) < 0.01
+    assert bsd["model.conv1.linear.weight"].shape == (64, 6, 7, 7) and bsd["model.fc.linear.weight"].shape == (1000, 512, 1, 1)
+    assert not any(k.endswith(".bias") for k in bsd) and "model.layer2.0.downsample.0.linear.weight" in bsd
+
+
 def test_from_standard_module_and_model_config_keys():
     from bcos.modules.bcosifyconv2d import BcosifyConv2d
     from bcos.modules.bcosifylinear import BcosifyLinear
