@@ -97,7 +97,7 @@ template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
 // row scales, p.wt2_cinv the inverse column scales.
 // Tiles larger than 128 x 128 are drained in 128 x 128 parts (one part = the accumulators of two of the four waves) so
 // that the LDS transpose buffer stays at 66 KB and two workgroups fit a CU.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT = NTHREADS>
 __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
                                               const float* ss, const float* ROWSS, const float* AINV, const int m0, const int n0,
                                               const int tile_n) {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
     float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
     float* sAinv = sRinv + BM;                                     // [BM] inverse operand scale of the row (SCALED)
     const bcos_epilogue& e = p.e;
-    for (int r = tid; r < BM; r += NTHREADS) {
+    for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         int64_t pix = -1;
         if (m < p.M) {
@@ -154,15 +154,16 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
             }
         }
     } else if (NORM) {
-        // row sums of squares in staging layout (split kernels): thread (r0 + 64 j, chunk), 4 chunk-lanes per row
+        // row sums of squares in staging layout (split kernels): thread (r0 + RP j, chunk), 4 chunk-lanes per row
+        constexpr int RP = NT / 4;
 #pragma unroll
-        for (int j = 0; j < BM / 64; ++j) {
+        for (int j = 0; j < BM / RP; ++j) {
             float t = ROWSS[j];
             t += __shfl_xor(t, 1);
             t += __shfl_xor(t, 2);
             if ((tid & 3) == 0) {
                 float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
-                const int row = (tid >> 2) + 64 * j;
+                const int row = (tid >> 2) + RP * j;
                 sNorm[row] = nrm;
                 sRinv[row] = 1.0f / nrm;
             }
@@ -170,8 +171,8 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
     }
     if (SCALED) {
 #pragma unroll
-        for (int j = 0; j < BM / 64; ++j)
-            if ((tid & 3) == 0) sAinv[(tid >> 2) + 64 * j] = AINV[j];
+        for (int j = 0; j < BM / (NT / 4); ++j)
+            if ((tid & 3) == 0) sAinv[(tid >> 2) + (NT / 4) * j] = AINV[j];
     }
 
     const bool b_is_2 = e.b == 2.0f && !(e.flags & BCOS_EPI_FORCE_POW);
@@ -183,9 +184,9 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
     const float bm1 = e.b - 1.0f;
     const int Cout = g.Cout;
     constexpr int CPR = SBN / 4;             // 16-byte chunks per part row
-    constexpr int RPP = NTHREADS / CPR;      // rows per pass
+    constexpr int RPP = NT / CPR;            // rows per pass
     constexpr int PASSES = SBM / RPP;
-    constexpr int EPI_G = 4;                 // chunks whose loads are in flight together
+    constexpr int EPI_G = NT > 256 ? 2 : 4;  // chunks whose loads are in flight together (half the registers per wave at 8 waves)
     static_assert(PASSES % EPI_G == 0, "epilogue grouping");
     const int cq = tid % CPR;
     const int rbase = tid / CPR;
@@ -207,7 +208,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                 }
         __syncthreads();                         // (part 0: also publishes the row metadata written above)
         if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
-            for (int r = tid; r < BM; r += NTHREADS) {
+            for (int r = tid; r < BM; r += NT) {
                 const int64_t pix = sPix[r];
                 if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[r];
             }
@@ -896,13 +897,17 @@ constexpr int H2_MAX_TAPS = 16;    // channel-chunk-major K walk for up to this 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int PIPE = ((BM / WAVES_M) * (BN / WAVES_N) <= 64 * 64 ? H2_PIPE_SMALL : 1)>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NT = NTHREADS,
+          int PIPE = ((BM / WAVES_M) * (BN / WAVES_N) <= 64 * 64 ? H2_PIPE_SMALL : 1)>
 __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_LD = BM / 64;                   // float4 loads per thread per 16-k step
+    constexpr int NW = NT / 64;                     // wavefronts of the workgroup (4, or 8 for the 512-thread variant)
+    constexpr int RP = NT / 4;                      // staging rows per pass
+    static_assert(WAVES_M * WAVES_N == NW && BM % RP == 0, "wave layout");
+    constexpr int A_LD = BM / RP;                   // float4 loads per thread per 16-k step
     constexpr int NBLK = (BN / 32) * 2;             // 1-KB fragment blocks of B per step: (32-column tile, plane)
-    constexpr int B_LD = (NBLK + 3) / 4;            // blocks per wave
+    constexpr int B_LD = (NBLK + NW - 1) / NW;      // blocks per wave
     char* lds = reinterpret_cast<char*>(smem);
     constexpr int A_SPLIT = BM * X3_ROW, B_BASE = 2 * A_SPLIT;
     constexpr int BUF = B_BASE + NBLK * 1024;
@@ -913,7 +918,7 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int chunk = tid & 3;       // 16-byte chunk (4 k) within the 16-k step
-    const int r0 = tid >> 2;         // staging row 0..63 (+64 per pass)
+    const int r0 = tid >> 2;         // staging row 0..RP-1 (+RP per pass)
     const bcos_tapconv_geom& g = p.g;
     const int H = g.H, W = g.W;
     const int a_pitch = g.a_pitch;
@@ -931,7 +936,7 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
         int pix0[A_LD];
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
-            const int m = m0 + r0 + 64 * j;
+            const int m = m0 + r0 + RP * j;
             rmax[j] = 0u;
             if (m < p.M) {
                 const int n = m / p.PQ;
@@ -1002,7 +1007,7 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
             for (int j = 0; j < A_LD; ++j) {
                 const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
                 const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                s_tapoff[t * BM + r0 + 64 * j] = ok ? a_nbase[j] - chunk * 16u + (unsigned)((ih * W + iw) * a_pitch) * 4u : OOB;
+                s_tapoff[t * BM + r0 + RP * j] = ok ? a_nbase[j] - chunk * 16u + (unsigned)((ih * W + iw) * a_pitch) * 4u : OOB;
             }
         }
     }
@@ -1019,7 +1024,7 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
     auto load_step = [&](int ks, f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
         if (kmajor) {
 #pragma unroll
-            for (int j = 0; j < A_LD; ++j) ra[j] = ldq(a_rsrc, s_tapoff[s_tap * BM + r0 + 64 * j] + chunk * 16u, s_cc * 16);
+            for (int j = 0; j < A_LD; ++j) ra[j] = ldq(a_rsrc, s_tapoff[s_tap * BM + r0 + RP * j] + chunk * 16u, s_cc * 16);
             if (++s_tap == ntaps) { s_tap = 0; s_cc += 4; }
         } else if (uniform) {
             if (s_cc == 0) {
@@ -1068,16 +1073,16 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            const int blk = wave + 4 * j;
-            if (NBLK % 4 == 0 || blk < NBLK) {
+            const int blk = wave + NW * j;
+            if (NBLK % NW == 0 || blk < NBLK) {
                 const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
                 rb[j] = ldq(b_rsrc, lane * 16, soff);
             }
         }
     };
-    float rowss[BM / 32];
+    float rowss[A_LD];
 #pragma unroll
-    for (int j = 0; j < BM / 32; ++j) rowss[j] = 0.f;
+    for (int j = 0; j < A_LD; ++j) rowss[j] = 0.f;
     auto store_step = [&](const f32x4 (&ra)[A_LD], const f32x4 (&rb)[B_LD], int buf) {
         char* base = lds + buf * BUF;
 #pragma unroll
@@ -1101,14 +1106,14 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
                 l[q] = (_Float16)(xs - (float)hh);
             }
 #endif
-            char* dst = base + (r0 + 64 * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4));
+            char* dst = base + (r0 + RP * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4));
             *reinterpret_cast<f16x4*>(dst) = h;
             *reinterpret_cast<f16x4*>(dst + A_SPLIT) = l;
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            const int blk = wave + 4 * j;
-            if (NBLK % 4 == 0 || blk < NBLK) *reinterpret_cast<f32x4*>(base + B_BASE + blk * 1024 + lane * 16) = rb[j];
+            const int blk = wave + NW * j;
+            if (NBLK % NW == 0 || blk < NBLK) *reinterpret_cast<f32x4*>(base + B_BASE + blk * 1024 + lane * 16) = rb[j];
         }
     };
 
@@ -1262,7 +1267,7 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
             __syncthreads();
         }
     }
-    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n);
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n);
 }
 
 // XCD-aware id remap: the 8 XCDs (private L2s) each get a contiguous range of `nt` work items (bijective for any nt)
@@ -1305,6 +1310,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void tapconv_kernel(const KArgs p) {
     }
 }
 
+// (An 8-wavefront / 512-thread form of the split-f16 loop -- same tile and LDS images, eight waves of 64 x 32 with 32
+//  accumulator registers, four waves per SIMD -- was measured on the ResNet-50 shapes: 186 vs 211 TFLOP/s at M = 50 176,
+//  K = 2304 and within +-3 % elsewhere.  More waves per SIMD do not lift the loop; tile_body_h2 keeps its thread-count
+//  parameter, the kernel variant was dropped.)
 constexpr int SLOTS = 512;   // 256 CUs x 2 resident workgroups (LDS- and VGPR-limited)
 
 // tile counts of a launch: n_big tiles of BM rows, then n_small half-height tiles (see tapconv_kernel)
