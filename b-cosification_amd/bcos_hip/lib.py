@@ -28,6 +28,7 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 ABI_VERSION = 2
+TAPCONV_PARTS = 4
 
 
 class BcosHipError(RuntimeError):
@@ -118,11 +119,32 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             return LIB_PATH
     LIB_PATH.parent.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           f"-I{INCLUDE}", f"-I{CSRC}"] + [str(s) for s in srcs] + ["-o", str(LIB_PATH)]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    # one object per (source, part) compiled in parallel, then one link: bcos_tapconv.hip is compiled in TAPCONV_PARTS slices
+    # (-DBCOS_TAPCONV_PART=k selects which kernel instantiations a slice carries) because its ~30 kernels dominate the build
+    objdir = LIB_PATH.parent / "obj"
+    objdir.mkdir(parents=True, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+    flags += os.environ.get("BCOS_HIPCC_FLAGS", "").split()
+    jobs = []
+    for s in srcs:
+        parts = range(TAPCONV_PARTS) if s.name == "bcos_tapconv.hip" else [None]
+        for k in parts:
+            obj = objdir / (s.stem + ("" if k is None else f"_p{k}") + ".o")
+            extra = [] if k is None else [f"-DBCOS_TAPCONV_PART={k}"]
+            stale = force or not obj.exists() or any(obj.stat().st_mtime < d.stat().st_mtime for d in (s, deps[-2], deps[-1]))
+            jobs.append((obj, [hipcc] + flags + extra + ["-c", str(s), "-o", str(obj)], stale))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(job):
+        obj, cmd, stale = job
+        if stale:
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(run, jobs))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [str(o) for o in objs] + ["-o", str(LIB_PATH)], check=True)
     return LIB_PATH
 
 

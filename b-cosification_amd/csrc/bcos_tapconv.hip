@@ -73,6 +73,8 @@ struct KArgs {
     int x3;          // contraction on split-bf16 MFMA (see tile_body_x3) instead of fp32 MFMA
     int uniform_tap; // C % 32 == 0: every K-step lies inside one tap
     int vec_ok;     // every per-element epilogue tensor is 16-byte addressable (pitch % 4 == 0, aligned bases)
+    int epi_kind;   // 0 = general epilogue, k + 1 = specialisation k of EPI_KINDS_FWD (norm launches) / EPI_KINDS_BWD (tile_epilogue_fast)
+    unsigned out_bytes;   // size of the [N*OH*OW][out_pitch] epilogue tensors (epi_kind > 0: < 2 GiB)
 };
 
 // max over groups of G consecutive lanes (G = 8, 16, 32; groups aligned to G) on the vector ALU (DPP), no LDS traffic.
@@ -91,44 +93,53 @@ __device__ __forceinline__ unsigned group_max_u32(unsigned v) {
 }
 template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
 
-// Fused epilogue of one tile (include/bcos_hip.h: bcos_epilogue), shared by the fp32, split-bf16 and split-f16 main loops.
-// `ss` = per-lane partial row sums in MFMA fragment layout, or `ROWSS` = partial row sums in staging layout.
-// SCALED (split-f16 loop): accumulators carry the power-of-two operand scales; `AINV` (staging layout) holds the inverse
-// row scales, p.wt2_cinv the inverse column scales.
-// Tiles larger than 128 x 128 are drained in 128 x 128 parts (one part = the accumulators of two of the four waves) so
-// that the LDS transpose buffer stays at 66 KB and two workgroups fit a CU.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT = NTHREADS>
-__device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
-                                              const float* ss, const float* ROWSS, const float* AINV, const int m0, const int n0,
-                                              const int tile_n) {
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    // part (pm, pn) = accumulator tiles i in [pm*TM/PM, ...), j in [pn*TN/PN, ...) of EVERY wave, so each wave retires half
-    // of its accumulator registers per part; local row l of a part is tile row (l / HM) * WM + pm * HM + l % HM
-    constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
-    constexpr int PN = BN > 128 ? BN / 128 : 1;                                   // parts
-    constexpr int SBM = BM / PM, SBN = BN / PN;                                   // part size
-    constexpr int HM = WM / PM, HN = WN / PN;                                     // rows / columns of one wave per part
-    constexpr int TMP = TM / PM, TNP = TN / PN;
-    static_assert(TM % PM == 0 && TN % PN == 0 && HN % 4 == 0, "parts split the wave tile evenly");
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const bcos_tapconv_geom& g = p.g;
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // (all waves are past the last barrier: the staging buffers are free)
-    // 1. accumulators -> LDS tile sC[SBM][SBN+4] (MFMA layout: lane = column, 16 rows per lane);
-    // 2. every thread then owns 16-byte column chunks of whole rows: wave-wide accesses are 2..8 full rows of
-    //    SBN*4 contiguous bytes, all epilogue tensors move as dwordx4, and the loads of a group of EPI_G chunks are
-    //    issued together before any of them is consumed (the streaming layers 64<->256 @56^2 are HBM-bound here).
-    constexpr int LDC = SBN + 4;
+// tile / part geometry of an epilogue (shared by the functions below)
+// part (pm, pn) = accumulator tiles i in [pm*TM/PM, ...), j in [pn*TN/PN, ...) of EVERY wave, so each wave retires half
+// of its accumulator registers per part; local row l of a part is tile row (l / HM) * WM + pm * HM + l % HM
+#define BCOS_EPI_SHAPE                                                                                                     \
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;                                                                    \
+    constexpr int TM = WM / 32, TN = WN / 32;                                                                              \
+    constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;                \
+    constexpr int PN = BN > 128 ? BN / 128 : 1;                                                                            \
+    constexpr int SBM = BM / PM, SBN = BN / PN;                                                                            \
+    constexpr int HM = WM / PM, HN = WN / PN;                                                                              \
+    constexpr int TMP = TM / PM, TNP = TN / PN;                                                                            \
+    static_assert(TM % PM == 0 && TN % PN == 0 && HN % 4 == 0, "parts split the wave tile evenly");                        \
+    constexpr int LDC = SBN + 4;                                                                                           \
+    const int tid = threadIdx.x;                                                                                           \
+    const int lane = tid & 63;                                                                                             \
+    const int wave = tid >> 6;                                                                                             \
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;                                                            \
+    (void)TM; (void)TN; (void)SBM; (void)HM; (void)HN; (void)TMP; (void)TNP; (void)LDC; (void)lane; (void)wave_m; (void)wave_n;
+// The epilogue reads the launch descriptor through a laundered pointer to the kernel-argument segment: its ~60 scalars
+// (20 tensor pointers, pitches, flags) are then loaded HERE, by scalar loads, instead of at kernel entry.  Loaded at
+// entry they are live across the whole main loop, the kernel exceeds the 102 scalar registers by > 100, and every
+// use of a spilled pointer inside the per-element loop becomes a v_readlane on the vector ALU.
+// (KArgs is the kernel's only explicit argument, so it sits at offset 0 of the segment.)
+#define BCOS_EPI_KARGS                                                                                                     \
+    const __attribute__((address_space(4))) KArgs* kp =                                                                    \
+        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();                            \
+    asm volatile("" : "+s"(kp));                                                                                           \
+    const __attribute__((address_space(4))) KArgs& p = *kp;                                                                \
+    const auto& g = p.g;                                                                                                   \
+    const auto& e = p.e;                                                                                                   \
+    (void)g; (void)e;
+
+// General epilogue (include/bcos_hip.h: bcos_epilogue), every feature decided at run time; shared by the fp32, split-bf16 and
+// split-f16 main loops.  `ss` = per-lane partial row sums in MFMA fragment layout, or `ROWSS` = partial row sums in staging
+// layout.  SCALED (split-f16 loop): accumulators carry the power-of-two operand scales; `AINV` (staging layout) holds the
+// inverse row scales, p.wt2_cinv the inverse column scales.
+//   epi_rows_generic: per-row metadata (output pixel, patch norm, inverse scales) into LDS behind the transpose buffer;
+//   epi_part_generic: one part of the tile, LDS transpose buffer -> epilogue math -> tensors.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
+__device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0) {
+    BCOS_EPI_SHAPE
+    BCOS_EPI_KARGS
     float* sC = smem;
     int64_t* sPix = reinterpret_cast<int64_t*>(smem + SBM * LDC);  // [BM] output pixel index or -1
     float* sNorm = reinterpret_cast<float*>(sPix + BM);            // [BM] patch norm
     float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
     float* sAinv = sRinv + BM;                                     // [BM] inverse operand scale of the row (SCALED)
-    const bcos_epilogue& e = p.e;
     for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         int64_t pix = -1;
@@ -175,6 +186,17 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
             if ((tid & 3) == 0) sAinv[(tid >> 2) + (NT / 4) * j] = AINV[j];
     }
 
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
+__device__ __forceinline__ void epi_part_generic(float* smem, const int pm, const int pn, const int part, const int n0, const int tile_n) {
+    BCOS_EPI_SHAPE
+    BCOS_EPI_KARGS
+    float* sC = smem;
+    int64_t* sPix = reinterpret_cast<int64_t*>(smem + SBM * LDC);  // [BM] output pixel index or -1
+    float* sNorm = reinterpret_cast<float*>(sPix + BM);            // [BM] patch norm
+    float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
+    float* sAinv = sRinv + BM;                                     // [BM] inverse operand scale of the row (SCALED)
     const bool b_is_2 = e.b == 2.0f && !(e.flags & BCOS_EPI_FORCE_POW);
     const bool norm_only = (e.flags & BCOS_EPI_NORM_ONLY) != 0;
     const bool gate_lsb = (e.flags & BCOS_EPI_SCALE_GATE_LSB) != 0;
@@ -192,9 +214,464 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
     const int rbase = tid / CPR;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
+        for (int r = tid; r < BM; r += NT) {
+            const int64_t pix = sPix[r];
+            if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[r];
+        }
+    }
+    const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
+    const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-    for (int part = 0; part < PM * PN; ++part) {
-        const int pm = part / PN, pn = part - pm * PN;
+    for (int q = 0; q < 4; ++q) {
+        const int c = col + q < Cout ? col + q : 0;
+        if (e.bias) bias4[q] = e.bias[c];
+        if (e.ch_scale) csc4[q] = e.ch_scale[c];
+        if (e.ch_shift) csh4[q] = e.ch_shift[c];
+        if (SCALED) cinv4[q] = p.wt2_cinv[c];
+    }
+    f32x4 mcsc4 = {1.f, 1.f, 1.f, 1.f}, mcsh4 = {0.f, 0.f, 0.f, 0.f};
+    if (mul_from_act) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = col + q < Cout ? col + q : 0;
+            if (e.mul_csc) mcsc4[q] = e.mul_csc[c];
+            if (e.mul_csh) mcsh4[q] = e.mul_csh[c];
+        }
+    }
+    // `mul` given as the kept ACTIVATION a = relu(lin s csc + csh) of the layer below (B = 2, s = |lin| / norm) instead of its
+    // stored multiplier t = s csc gate: |lin|^2 = |a - csh| norm / |csc|, so t = csc sqrt(|a - csh| / (|csc| norm)) where a > 0
+    auto rebuild_t = [&](float a, float nrm, float csc, float csh) {
+        const float z = fabsf(a - csh);
+        const float den = fabsf(csc) * nrm;
+        // hardware reciprocal / square root (1 ulp each): the IEEE division + sqrt sequences are ~20 instructions per
+        // element in an epilogue that is issue-bound, and t enters a product whose other factor carries fp32 rounding anyway
+        return (a > 0.f && den > 0.f) ? csc * __builtin_amdgcn_sqrtf(z * __builtin_amdgcn_rcpf(den)) : 0.f;
+    };
+    struct EpiIn { f32x4 ad[EPI_G], m1[EPI_G]; };
+    auto issue = [&](int p0, EpiIn& in) {
+#pragma unroll
+        for (int u = 0; u < EPI_G; ++u) {
+            const int lrow = rbase + (p0 + u) * RPP;
+            const int64_t pix = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
+            const int64_t idx = (pix >= 0 ? pix : 0) * g.out_pitch + col;
+            in.ad[u] = (vec && e.addend) ? *reinterpret_cast<const f32x4*>(e.addend + idx) : zero4;
+            in.m1[u] = (vec && e.mul) ? *reinterpret_cast<const f32x4*>(e.mul + idx) : zero4;
+        }
+    };
+    auto process = [&](int p0, const EpiIn& in) {
+        unsigned mx1[EPI_G], mx2[EPI_G];
+        int64_t pixs[EPI_G];
+#pragma unroll
+        for (int u = 0; u < EPI_G; ++u) {
+            const int lrow = rbase + (p0 + u) * RPP;
+            mx1[u] = 0u; mx2[u] = 0u;
+            pixs[u] = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
+        }
+        if (e.max_out > 1) {
+            // MaxOut (bcosconv2d.py:166-170): the accumulator columns are the M filters of each output unit, adjacent;
+            // a thread's 4 columns hold 4 / M whole units.  out is [pixels, Cout / M] (pitch out_pitch), scale_out keeps
+            // the contraction's width (pitch Cout): the scale at the winning filter, 0 at the others -- d out / d lin.
+            // (the host only takes this path for M in {2, 4}, Cout % 4 == 0 and plain forward epilogues)
+            const int M_ = e.max_out;
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                const int lrow = rbase + (p0 + u) * RPP;
+                const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
+                const int64_t pix = pixs[u];
+                if (pix < 0 || col >= Cout) continue;
+                f32x4 val = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
+                if (SCALED) val = val * sAinv[row] * cinv4;
+                val += bias4;
+                f32x4 tf = {0.f, 0.f, 0.f, 0.f};
+                for (int u0 = 0; u0 < 4; u0 += M_) {
+                    int arg = u0;
+                    for (int q = u0 + 1; q < u0 + M_; ++q) arg = val[q] > val[arg] ? q : arg;      // first maximum wins
+                    const float m = val[arg];
+                    float sc = 1.f;
+                    if (NORM && !norm_only)
+                        sc = b_is_2 ? fabsf(m) * sRinv[row] : powf(fabsf(m / sNorm[row]) + 1e-6f, bm1);
+                    if (e.out) e.out[pix * g.out_pitch + (col + u0) / M_] = m * sc;
+                    tf[arg] = sc;
+                }
+                if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + pix * (int64_t)Cout + col) = tf;
+            }
+        } else if (vec) {
+            f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
+            int64_t idx[EPI_G];
+            bool ok[EPI_G];
+            float rinv[EPI_G], nrm[EPI_G];
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                const int lrow = rbase + (p0 + u) * RPP;
+                const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
+                const int64_t pix = pixs[u];
+                ok[u] = pix >= 0;
+                idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
+                v[u] = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
+                if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
+                rinv[u] = NORM ? sRinv[row] : 1.f;
+                nrm[u] = NORM ? sNorm[row] : 1.f;
+                ad[u] = in.ad[u];
+                rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
+                m1[u] = in.m1[u];
+                if (mul_from_act) {
+                    const float mn = e.mul_norm[ok[u] ? pix : 0];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) m1[u][q] = rebuild_t(m1[u][q], mn, mcsc4[q], mcsh4[q]);
+                }
+                m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
+                g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                f32x4 val = v[u] + bias4;
+                f32x4 s = {1.f, 1.f, 1.f, 1.f};
+                if (NORM && !norm_only) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        s[q] = b_is_2 ? fabsf(val[q]) * rinv[u] : powf(fabsf(val[q] / nrm[u]) + 1e-6f, bm1);
+                    val *= s;
+                }
+                val = val * csc4 + csh4;
+                s *= csc4;
+                if (e.addend) val += ad[u];
+                if (e.relu == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
+                        s[q] = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s[q]) | 1u) : s[q]) : 0.f;
+                        val[q] = open_gate ? val[q] : 0.f;
+                    }
+                } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
+                        s[q] *= gate;
+                        val[q] *= gate;
+                    }
+                }
+                if (ok[u]) {
+                    const f32x4 o1 = e.mul ? val * m1[u] : val;
+                    if (e.out) *reinterpret_cast<f32x4*>(e.out + idx[u]) = o1;
+                    if (want_max)
+                        mx1[u] = max(max(__float_as_uint(o1[0]) & 0x7fffffffu, __float_as_uint(o1[1]) & 0x7fffffffu),
+                                     max(__float_as_uint(o1[2]) & 0x7fffffffu, __float_as_uint(o1[3]) & 0x7fffffffu));
+                    if (e.out2) {
+                        f32x4 o2 = val;
+                        if (e.mul2) o2 *= m2[u];
+                        if (gate_mul) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o2[q] = (__float_as_uint(m1[u][q]) & 1u) ? o2[q] : 0.f;
+                        } else if (e.gate2) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(e.out2 + idx[u]) = o2;
+                        if (want_max)
+                            mx2[u] = max(max(__float_as_uint(o2[0]) & 0x7fffffffu, __float_as_uint(o2[1]) & 0x7fffffffu),
+                                         max(__float_as_uint(o2[2]) & 0x7fffffffu, __float_as_uint(o2[3]) & 0x7fffffffu));
+                    }
+                    if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + idx[u]) = s;
+                }
+            }
+        } else if (col < Cout) {
+            // ragged right edge (Cout % 4 != 0) or unaligned tensors: same math, element by element
+            for (int u = 0; u < EPI_G; ++u) {
+                const int lrow = rbase + (p0 + u) * RPP;
+                const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
+                const int64_t pix = pixs[u];
+                if (pix < 0) continue;
+                for (int q = 0; q < 4 && col + q < Cout; ++q) {
+                    const int64_t idx = pix * g.out_pitch + col + q;
+                    float v = sC[lrow * LDC + cq * 4 + q];
+                    if (SCALED) v = v * sAinv[row] * cinv4[q];
+                    v += bias4[q];
+                    float s = 1.f;
+                    if (NORM && !norm_only) {
+                        s = b_is_2 ? fabsf(v) * sRinv[row] : powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
+                        v *= s;
+                    }
+                    v = v * csc4[q] + csh4[q];
+                    s *= csc4[q];
+                    if (e.addend) v += e.addend[idx];
+                    if (e.relu == 1) {
+                        const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
+                        s = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s) | 1u) : s) : 0.f;
+                        v = open_gate ? v : 0.f;
+                    } else if (e.relu == 2) {
+                        const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
+                        s *= gate;
+                        v *= gate;
+                    }
+                    const float o1 = e.mul ? v * (mul_from_act ? rebuild_t(e.mul[idx], e.mul_norm[pix], mcsc4[q], mcsh4[q]) : e.mul[idx]) : v;
+                    if (e.out) e.out[idx] = o1;
+                    mx1[u] = max(mx1[u], __float_as_uint(o1) & 0x7fffffffu);
+                    if (e.out2) {
+                        float o2 = v;
+                        if (e.mul2) o2 *= e.mul2[idx];
+                        if (gate_mul) o2 = (__float_as_uint(e.mul[idx]) & 1u) ? o2 : 0.f;
+                        else if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
+                        e.out2[idx] = o2;
+                        mx2[u] = max(mx2[u], __float_as_uint(o2) & 0x7fffffffu);
+                    }
+                    if (e.scale_out) e.scale_out[idx] = s;
+                }
+            }
+        }
+        if (want_max) {
+            // per-pixel max |value| of what this tile wrote (bit pattern: monotonic for non-negative floats), for the
+            // operand scaling of the split-f16 contraction in the layer that reads the tensor; all lanes are active here
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                unsigned a1 = e.out_absmax ? group_max_u32<CPR>(mx1[u]) : 0u;
+                unsigned a2 = e.out2_absmax ? group_max_u32<CPR>(mx2[u]) : 0u;
+                if (cq == group_max_lane<CPR>() && pixs[u] >= 0) {
+                    if (e.out_absmax && a1) atomicMax(e.out_absmax + pixs[u], a1);
+                    if (e.out2_absmax && a2) atomicMax(e.out2_absmax + pixs[u], a2);
+                }
+            }
+        }
+    };
+    // (requesting group g+1's inputs before group g is computed -- two register sets -- was measured: 30 more VGPRs and
+    //  the forward HBM-bound launches got 10 % SLOWER, 2.47 -> 2.77 ms for the four 64 -> 256 @ 56^2 layers; not kept)
+    EpiIn in;
+#pragma unroll 1
+    for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
+        issue(p0, in);
+        process(p0, in);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Specialised epilogues.  The layers around the 4x-wide block tensors (K <= 256) move ~2.7 GB per launch through the
+// epilogue and are bound by instruction issue there, not by the contraction: the general
+// epilogue above decides every feature at run time and spends ~210 vector instructions per 4 output elements.  The
+// launches of a ResNet-style forward + explanation pass use a handful of feature sets; for those the host selects a
+// compile-time specialisation (KArgs.epi_kind) that
+//   * knows its tensors at compile time (EF_* bits), computes the same expressions in the same order as the general
+//     epilogue (bit-identical results; tests/test_gpu_parity.py::test_fast_epilogue_bit_identical),
+//   * addresses every tensor through raw buffer descriptors with 32-bit byte offsets (tensors < 2 GiB): rows beyond M and
+//     columns beyond Cout carry an out-of-range offset, the hardware bounds check drops their stores and zero-fills their
+//     loads, so the loop body has no predicates,
+//   * keeps the per-row values (output offset, 1 / norm, inverse operand scale, pixel index) as one 16-byte LDS record.
+// Anything else (MaxOut, B != 2, GELU, replayed gates, ragged Cout, tensors >= 2 GiB, ...) takes the general epilogue.
+enum : int { EF_ADDEND = 1, EF_RELU = 2, EF_SCALE_OUT = 4, EF_MUL = 8, EF_OUT2 = 16, EF_MUL2 = 32 };
+// forward kinds (NORM kernels): B = 2 scale, optional bias / channel affine;  backward kinds (no norm): gradient multipliers
+constexpr int EPI_KINDS_FWD[] = {EF_RELU | EF_SCALE_OUT, EF_RELU | EF_SCALE_OUT | EF_ADDEND, EF_SCALE_OUT, EF_RELU, EF_RELU | EF_ADDEND, 0};
+constexpr int EPI_KINDS_BWD[] = {EF_MUL, EF_MUL | EF_ADDEND | EF_OUT2, EF_MUL | EF_ADDEND | EF_OUT2 | EF_MUL2, 0, EF_ADDEND, EF_MUL | EF_OUT2};
+constexpr int N_EPI_KINDS = 6;
+
+struct __attribute__((aligned(16))) EpiRow { unsigned off; float rinv; float ainv; int pix; };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
+__device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0) {
+    BCOS_EPI_SHAPE
+    BCOS_EPI_KARGS
+    constexpr unsigned OOB = 0x80000000u;
+    float* sC = smem;
+    EpiRow* sRow = reinterpret_cast<EpiRow*>(smem + SBM * LDC);    // [BM]
+    float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
+    const int out_pitch = g.out_pitch;
+    for (int r = tid; r < BM; r += NT) {
+        const int m = m0 + r;
+        int pix = -1;
+        if (m < p.M) {
+            const int n = m / p.PQ;
+            const int rem = m - n * p.PQ;
+            const int i = rem / g.Q;
+            const int jj = rem - i * g.Q;
+            pix = (n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+        }
+        sRow[r].pix = pix;
+        sRow[r].off = pix >= 0 ? (unsigned)pix * (unsigned)out_pitch * 4u : OOB;
+    }
+    if (NORM && ROWSS == nullptr) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float t = ss[i] + __shfl_xor(ss[i], 32);
+            if (wave_n == 0 && lane < 32) {
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
+                const int row = wave_m * WM + i * 32 + lane;
+                sNorm[row] = nrm;
+                sRow[row].rinv = 1.0f / nrm;
+            }
+        }
+    } else if (NORM) {
+        constexpr int RP = NT / 4;
+#pragma unroll
+        for (int j = 0; j < BM / RP; ++j) {
+            float t = ROWSS[j];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            if ((tid & 3) == 0) {
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
+                const int row = (tid >> 2) + RP * j;
+                sNorm[row] = nrm;
+                sRow[row].rinv = 1.0f / nrm;
+            }
+        }
+    }
+    if (SCALED) {
+#pragma unroll
+        for (int j = 0; j < BM / (NT / 4); ++j)
+            if ((tid & 3) == 0) sRow[(tid >> 2) + (NT / 4) * j].ainv = AINV[j];
+    }
+
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT, int EF>
+__device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const int pn, const int part, const int n0, const int tile_n) {
+    BCOS_EPI_SHAPE
+    BCOS_EPI_KARGS
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr bool ADDEND = (EF & EF_ADDEND) != 0, RELU = (EF & EF_RELU) != 0, SCALE_OUT = (EF & EF_SCALE_OUT) != 0;
+    constexpr bool MUL = (EF & EF_MUL) != 0, OUT2 = (EF & EF_OUT2) != 0, MUL2 = (EF & EF_MUL2) != 0;
+    static_assert(NORM ? !(MUL || OUT2 || MUL2) : !(RELU || SCALE_OUT), "forward kinds scale, backward kinds multiply");
+    float* sC = smem;
+    EpiRow* sRow = reinterpret_cast<EpiRow*>(smem + SBM * LDC);    // [BM]
+    float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
+    const unsigned lsb = (RELU && SCALE_OUT && (e.flags & BCOS_EPI_SCALE_GATE_LSB)) ? 1u : 0u;
+    const bool want_max1 = e.out_absmax != nullptr, want_max2 = OUT2 && e.out2_absmax != nullptr;
+    const int Cout = g.Cout;
+    const unsigned tbytes = p.out_bytes;
+    auto rsrc = [&](const void* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q), 0, tbytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t r_out = rsrc(e.out);
+    const __amdgpu_buffer_rsrc_t r_ad = rsrc(ADDEND ? e.addend : e.out);
+    const __amdgpu_buffer_rsrc_t r_mul = rsrc(MUL ? e.mul : e.out);
+    const __amdgpu_buffer_rsrc_t r_mul2 = rsrc(MUL2 ? e.mul2 : e.out);
+    const __amdgpu_buffer_rsrc_t r_out2 = rsrc(OUT2 ? e.out2 : e.out);
+    const __amdgpu_buffer_rsrc_t r_sc = rsrc(SCALE_OUT ? e.scale_out : e.out);
+    auto ldq = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+    };
+    auto stq = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, const f32x4& v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, 0, 0);
+    };
+    auto absmax4 = [](const f32x4& o) {
+        return max(max(__float_as_uint(o[0]) & 0x7fffffffu, __float_as_uint(o[1]) & 0x7fffffffu),
+                   max(__float_as_uint(o[2]) & 0x7fffffffu, __float_as_uint(o[3]) & 0x7fffffffu));
+    };
+    constexpr int CPR = SBN / 4;
+    constexpr int RPP = NT / CPR;
+    constexpr int PASSES = SBM / RPP;
+    constexpr int NIN = (ADDEND ? 1 : 0) + (MUL ? 1 : 0) + (MUL2 ? 1 : 0);
+    constexpr int G = (NIN <= 1 && PASSES % 8 == 0 && NT <= 256 && PM * PN == 1) ? 8 : (PASSES % 4 == 0 ? 4 : 2);
+    static_assert(PASSES % G == 0, "epilogue grouping");
+    const int cq = tid % CPR;
+    const int rbase = tid / CPR;
+
+    if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
+        for (int r = tid; r < BM; r += NT) {
+            const int pix = sRow[r].pix;
+            if (pix >= 0) e.norm_out[(int64_t)pix * g.norm_pitch] = sNorm[r];
+        }
+    }
+    const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
+    const bool col_ok = col < Cout;                       // Cout % 4 == 0 (host): the whole chunk is inside or outside
+    const unsigned coloff = col_ok ? (unsigned)col * 4u : OOB;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
+    if (col_ok) {
+        if (NORM && e.bias) bias4 = *reinterpret_cast<const f32x4*>(e.bias + col);
+        if (NORM && e.ch_scale) csc4 = *reinterpret_cast<const f32x4*>(e.ch_scale + col);
+        if (NORM && e.ch_shift) csh4 = *reinterpret_cast<const f32x4*>(e.ch_shift + col);
+    }
+    if (SCALED) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cinv4[q] = p.wt2_cinv[col_ok ? col + q : 0];
+    }
+#pragma unroll 1
+    for (int p0 = 0; p0 < PASSES; p0 += G) {
+        EpiRow rw[G];
+        unsigned voff[G];
+        f32x4 ad[G], m1[G], m2[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int lrow = rbase + (p0 + u) * RPP;
+            rw[u] = sRow[(lrow / HM) * WM + pm * HM + lrow % HM];
+            voff[u] = (rw[u].off + coloff) | ((rw[u].off | coloff) & OOB);
+            if (ADDEND) ad[u] = ldq(r_ad, voff[u]);
+            if (MUL) m1[u] = ldq(r_mul, voff[u]);
+            if (MUL2) m2[u] = ldq(r_mul2, voff[u]);
+        }
+        unsigned mx1[G], mx2[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int lrow = rbase + (p0 + u) * RPP;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
+            if (SCALED) v = v * rw[u].ainv * cinv4;
+            f32x4 val = v + bias4;
+            f32x4 s = {1.f, 1.f, 1.f, 1.f};
+            if (NORM) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] = fabsf(val[q]) * rw[u].rinv;
+                val *= s;
+            }
+            val = val * csc4 + csh4;
+            s *= csc4;
+            if (ADDEND) val += ad[u];
+            if (RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool open_gate = val[q] > 0.f;
+                    s[q] = open_gate ? __uint_as_float(__float_as_uint(s[q]) | lsb) : 0.f;
+                    val[q] = open_gate ? val[q] : 0.f;
+                }
+            }
+            const f32x4 o1 = MUL ? val * m1[u] : val;
+            stq(r_out, voff[u], o1);
+            mx1[u] = want_max1 ? absmax4(o1) : 0u;
+            if (OUT2) {
+                f32x4 o2 = val;
+                if (MUL2) o2 *= m2[u];
+                if (MUL && (e.flags & BCOS_EPI_GATE2_FROM_MUL)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o2[q] = (__float_as_uint(m1[u][q]) & 1u) ? o2[q] : 0.f;
+                }
+                stq(r_out2, voff[u], o2);
+                mx2[u] = want_max2 ? absmax4(o2) : 0u;
+            }
+            if (SCALE_OUT) stq(r_sc, voff[u], s);
+        }
+        if (want_max1 || want_max2) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                // lanes outside the tensor hold zeros or values whose stores were dropped: keep them out of the maxima
+                const bool live = (int)voff[u] >= 0;
+                const unsigned a1 = want_max1 ? group_max_u32<CPR>(live ? mx1[u] : 0u) : 0u;
+                const unsigned a2 = want_max2 ? group_max_u32<CPR>(live ? mx2[u] : 0u) : 0u;
+                if (cq == group_max_lane<CPR>() && rw[u].pix >= 0) {
+                    if (want_max1 && a1) atomicMax(e.out_absmax + rw[u].pix, a1);
+                    if (want_max2 && a2) atomicMax(e.out2_absmax + rw[u].pix, a2);
+                }
+            }
+        }
+    }
+}
+
+// Epilogue of one tile: row metadata, then per part: accumulators -> LDS transpose buffer sC[SBM][SBN+4] (MFMA layout:
+// lane = column, 16 rows per lane) and the specialisation the host selected for this launch, or the general code.  The
+// accumulators are only touched HERE: the (large) part functions take no reference to them, so the registers of the
+// parts still waiting stay put while one part is drained.
+// Tiles larger than 128 x 128 are drained in 128 x 128 parts (one part = half the accumulators of every wave) so that the
+// LDS transpose buffer stays at 66 KB and two workgroups fit a CU.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT = NTHREADS>
+__device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
+                                              const float* ss, const float* ROWSS, const float* AINV, const int m0, const int n0,
+                                              const int tile_n) {
+    BCOS_EPI_SHAPE
+    const int kind = p.epi_kind;
+    // (all waves are past the last barrier of the main loop: the staging buffers are free)
+    if (kind) epi_rows_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0);
+    else epi_rows_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0);
+    float* sC = smem;
+    // (the parts are expanded at compile time: a loop the optimiser declines to unroll would index the accumulators at run time)
+    auto drain = [&](auto part_c) {
+        constexpr int part = decltype(part_c)::value;
+        constexpr int pm = part / PN, pn = part - pm * PN;
         if (part > 0) __syncthreads();           // the previous part's sC has been consumed
 #pragma unroll
         for (int ii = 0; ii < TMP; ++ii)
@@ -207,235 +684,22 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
                     sC[row * LDC + colt] = acc[pm * TMP + ii][pn * TNP + jj][r];
                 }
         __syncthreads();                         // (part 0: also publishes the row metadata written above)
-        if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
-            for (int r = tid; r < BM; r += NT) {
-                const int64_t pix = sPix[r];
-                if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[r];
-            }
+#define BCOS_EPI_CASE(I)                                                                                                     \
+    case I + 1:                                                                                                              \
+        epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, (NORM ? EPI_KINDS_FWD[I] : EPI_KINDS_BWD[I])>(smem, pm, pn, part, \
+                                                                                                                n0, tile_n); \
+        break;
+        switch (kind) {
+            BCOS_EPI_CASE(0) BCOS_EPI_CASE(1) BCOS_EPI_CASE(2) BCOS_EPI_CASE(3) BCOS_EPI_CASE(4) BCOS_EPI_CASE(5)
+            default: epi_part_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, pm, pn, part, n0, tile_n);
         }
-        const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
-        const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = col + q < Cout ? col + q : 0;
-            if (e.bias) bias4[q] = e.bias[c];
-            if (e.ch_scale) csc4[q] = e.ch_scale[c];
-            if (e.ch_shift) csh4[q] = e.ch_shift[c];
-            if (SCALED) cinv4[q] = p.wt2_cinv[c];
-        }
-        f32x4 mcsc4 = {1.f, 1.f, 1.f, 1.f}, mcsh4 = {0.f, 0.f, 0.f, 0.f};
-        if (mul_from_act) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = col + q < Cout ? col + q : 0;
-                if (e.mul_csc) mcsc4[q] = e.mul_csc[c];
-                if (e.mul_csh) mcsh4[q] = e.mul_csh[c];
-            }
-        }
-        // `mul` given as the kept ACTIVATION a = relu(lin s csc + csh) of the layer below (B = 2, s = |lin| / norm) instead of its
-        // stored multiplier t = s csc gate: |lin|^2 = |a - csh| norm / |csc|, so t = csc sqrt(|a - csh| / (|csc| norm)) where a > 0
-        auto rebuild_t = [&](float a, float nrm, float csc, float csh) {
-            const float z = fabsf(a - csh);
-            const float den = fabsf(csc) * nrm;
-            // hardware reciprocal / square root (1 ulp each): the IEEE division + sqrt sequences are ~20 instructions per
-            // element in an epilogue that is issue-bound, and t enters a product whose other factor carries fp32 rounding anyway
-            return (a > 0.f && den > 0.f) ? csc * __builtin_amdgcn_sqrtf(z * __builtin_amdgcn_rcpf(den)) : 0.f;
-        };
-        struct EpiIn { f32x4 ad[EPI_G], m1[EPI_G]; };
-        auto issue = [&](int p0, EpiIn& in) {
-#pragma unroll
-            for (int u = 0; u < EPI_G; ++u) {
-                const int lrow = rbase + (p0 + u) * RPP;
-                const int64_t pix = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
-                const int64_t idx = (pix >= 0 ? pix : 0) * g.out_pitch + col;
-                in.ad[u] = (vec && e.addend) ? *reinterpret_cast<const f32x4*>(e.addend + idx) : zero4;
-                in.m1[u] = (vec && e.mul) ? *reinterpret_cast<const f32x4*>(e.mul + idx) : zero4;
-            }
-        };
-        auto process = [&](int p0, const EpiIn& in) {
-            unsigned mx1[EPI_G], mx2[EPI_G];
-            int64_t pixs[EPI_G];
-#pragma unroll
-            for (int u = 0; u < EPI_G; ++u) {
-                const int lrow = rbase + (p0 + u) * RPP;
-                mx1[u] = 0u; mx2[u] = 0u;
-                pixs[u] = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
-            }
-            if (e.max_out > 1) {
-                // MaxOut (bcosconv2d.py:166-170): the accumulator columns are the M filters of each output unit, adjacent;
-                // a thread's 4 columns hold 4 / M whole units.  out is [pixels, Cout / M] (pitch out_pitch), scale_out keeps
-                // the contraction's width (pitch Cout): the scale at the winning filter, 0 at the others -- d out / d lin.
-                // (the host only takes this path for M in {2, 4}, Cout % 4 == 0 and plain forward epilogues)
-                const int M_ = e.max_out;
-#pragma unroll
-                for (int u = 0; u < EPI_G; ++u) {
-                    const int lrow = rbase + (p0 + u) * RPP;
-                    const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
-                    const int64_t pix = pixs[u];
-                    if (pix < 0 || col >= Cout) continue;
-                    f32x4 val = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
-                    if (SCALED) val = val * sAinv[row] * cinv4;
-                    val += bias4;
-                    f32x4 tf = {0.f, 0.f, 0.f, 0.f};
-                    for (int u0 = 0; u0 < 4; u0 += M_) {
-                        int arg = u0;
-                        for (int q = u0 + 1; q < u0 + M_; ++q) arg = val[q] > val[arg] ? q : arg;      // first maximum wins
-                        const float m = val[arg];
-                        float sc = 1.f;
-                        if (NORM && !norm_only)
-                            sc = b_is_2 ? fabsf(m) * sRinv[row] : powf(fabsf(m / sNorm[row]) + 1e-6f, bm1);
-                        if (e.out) e.out[pix * g.out_pitch + (col + u0) / M_] = m * sc;
-                        tf[arg] = sc;
-                    }
-                    if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + pix * (int64_t)Cout + col) = tf;
-                }
-            } else if (vec) {
-                f32x4 v[EPI_G], ad[EPI_G], m1[EPI_G], m2[EPI_G], g2[EPI_G], rg[EPI_G];
-                int64_t idx[EPI_G];
-                bool ok[EPI_G];
-                float rinv[EPI_G], nrm[EPI_G];
-#pragma unroll
-                for (int u = 0; u < EPI_G; ++u) {
-                    const int lrow = rbase + (p0 + u) * RPP;
-                    const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
-                    const int64_t pix = pixs[u];
-                    ok[u] = pix >= 0;
-                    idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
-                    v[u] = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
-                    if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
-                    rinv[u] = NORM ? sRinv[row] : 1.f;
-                    nrm[u] = NORM ? sNorm[row] : 1.f;
-                    ad[u] = in.ad[u];
-                    rg[u] = e.relu_gate ? *reinterpret_cast<const f32x4*>(e.relu_gate + idx[u]) : zero4;
-                    m1[u] = in.m1[u];
-                    if (mul_from_act) {
-                        const float mn = e.mul_norm[ok[u] ? pix : 0];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) m1[u][q] = rebuild_t(m1[u][q], mn, mcsc4[q], mcsh4[q]);
-                    }
-                    m2[u] = e.mul2 ? *reinterpret_cast<const f32x4*>(e.mul2 + idx[u]) : zero4;
-                    g2[u] = e.gate2 ? *reinterpret_cast<const f32x4*>(e.gate2 + idx[u]) : zero4;
-                }
-#pragma unroll
-                for (int u = 0; u < EPI_G; ++u) {
-                    f32x4 val = v[u] + bias4;
-                    f32x4 s = {1.f, 1.f, 1.f, 1.f};
-                    if (NORM && !norm_only) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            s[q] = b_is_2 ? fabsf(val[q]) * rinv[u] : powf(fabsf(val[q] / nrm[u]) + 1e-6f, bm1);
-                        val *= s;
-                    }
-                    val = val * csc4 + csh4;
-                    s *= csc4;
-                    if (e.addend) val += ad[u];
-                    if (e.relu == 1) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool open_gate = e.relu_gate ? rg[u][q] > 0.f : val[q] > 0.f;
-                            s[q] = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s[q]) | 1u) : s[q]) : 0.f;
-                            val[q] = open_gate ? val[q] : 0.f;
-                        }
-                    } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
-                            s[q] *= gate;
-                            val[q] *= gate;
-                        }
-                    }
-                    if (ok[u]) {
-                        const f32x4 o1 = e.mul ? val * m1[u] : val;
-                        if (e.out) *reinterpret_cast<f32x4*>(e.out + idx[u]) = o1;
-                        if (want_max)
-                            mx1[u] = max(max(__float_as_uint(o1[0]) & 0x7fffffffu, __float_as_uint(o1[1]) & 0x7fffffffu),
-                                         max(__float_as_uint(o1[2]) & 0x7fffffffu, __float_as_uint(o1[3]) & 0x7fffffffu));
-                        if (e.out2) {
-                            f32x4 o2 = val;
-                            if (e.mul2) o2 *= m2[u];
-                            if (gate_mul) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) o2[q] = (__float_as_uint(m1[u][q]) & 1u) ? o2[q] : 0.f;
-                            } else if (e.gate2) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) o2[q] = g2[u][q] > 0.f ? o2[q] : 0.f;
-                            }
-                            *reinterpret_cast<f32x4*>(e.out2 + idx[u]) = o2;
-                            if (want_max)
-                                mx2[u] = max(max(__float_as_uint(o2[0]) & 0x7fffffffu, __float_as_uint(o2[1]) & 0x7fffffffu),
-                                             max(__float_as_uint(o2[2]) & 0x7fffffffu, __float_as_uint(o2[3]) & 0x7fffffffu));
-                        }
-                        if (e.scale_out) *reinterpret_cast<f32x4*>(e.scale_out + idx[u]) = s;
-                    }
-                }
-            } else if (col < Cout) {
-                // ragged right edge (Cout % 4 != 0) or unaligned tensors: same math, element by element
-                for (int u = 0; u < EPI_G; ++u) {
-                    const int lrow = rbase + (p0 + u) * RPP;
-                    const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
-                    const int64_t pix = pixs[u];
-                    if (pix < 0) continue;
-                    for (int q = 0; q < 4 && col + q < Cout; ++q) {
-                        const int64_t idx = pix * g.out_pitch + col + q;
-                        float v = sC[lrow * LDC + cq * 4 + q];
-                        if (SCALED) v = v * sAinv[row] * cinv4[q];
-                        v += bias4[q];
-                        float s = 1.f;
-                        if (NORM && !norm_only) {
-                            s = b_is_2 ? fabsf(v) * sRinv[row] : powf(fabsf(v / sNorm[row]) + 1e-6f, bm1);
-                            v *= s;
-                        }
-                        v = v * csc4[q] + csh4[q];
-                        s *= csc4[q];
-                        if (e.addend) v += e.addend[idx];
-                        if (e.relu == 1) {
-                            const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
-                            s = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s) | 1u) : s) : 0.f;
-                            v = open_gate ? v : 0.f;
-                        } else if (e.relu == 2) {
-                            const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
-                            s *= gate;
-                            v *= gate;
-                        }
-                        const float o1 = e.mul ? v * (mul_from_act ? rebuild_t(e.mul[idx], e.mul_norm[pix], mcsc4[q], mcsh4[q]) : e.mul[idx]) : v;
-                        if (e.out) e.out[idx] = o1;
-                        mx1[u] = max(mx1[u], __float_as_uint(o1) & 0x7fffffffu);
-                        if (e.out2) {
-                            float o2 = v;
-                            if (e.mul2) o2 *= e.mul2[idx];
-                            if (gate_mul) o2 = (__float_as_uint(e.mul[idx]) & 1u) ? o2 : 0.f;
-                            else if (e.gate2) o2 = e.gate2[idx] > 0.f ? o2 : 0.f;
-                            e.out2[idx] = o2;
-                            mx2[u] = max(mx2[u], __float_as_uint(o2) & 0x7fffffffu);
-                        }
-                        if (e.scale_out) e.scale_out[idx] = s;
-                    }
-                }
-            }
-            if (want_max) {
-                // per-pixel max |value| of what this tile wrote (bit pattern: monotonic for non-negative floats), for the
-                // operand scaling of the split-f16 contraction in the layer that reads the tensor; all lanes are active here
-#pragma unroll
-                for (int u = 0; u < EPI_G; ++u) {
-                    unsigned a1 = e.out_absmax ? group_max_u32<CPR>(mx1[u]) : 0u;
-                    unsigned a2 = e.out2_absmax ? group_max_u32<CPR>(mx2[u]) : 0u;
-                    if (cq == group_max_lane<CPR>() && pixs[u] >= 0) {
-                        if (e.out_absmax && a1) atomicMax(e.out_absmax + pixs[u], a1);
-                        if (e.out2_absmax && a2) atomicMax(e.out2_absmax + pixs[u], a2);
-                    }
-                }
-            }
-        };
-        // (requesting group g+1's inputs before group g is computed -- two register sets -- was measured: 30 more VGPRs and
-        //  the forward HBM-bound launches got 10 % SLOWER, 2.47 -> 2.77 ms for the four 64 -> 256 @ 56^2 layers; not kept)
-        EpiIn in;
-#pragma unroll 1
-        for (int p0 = 0; p0 < PASSES; p0 += EPI_G) {
-            issue(p0, in);
-            process(p0, in);
-        }
-    }
+#undef BCOS_EPI_CASE
+    };
+    static_assert(PM * PN <= 4, "parts");
+    drain(std::integral_constant<int, 0>{});
+    if constexpr (PM * PN > 1) drain(std::integral_constant<int, 1>{});
+    if constexpr (PM * PN > 2) drain(std::integral_constant<int, 2>{});
+    if constexpr (PM * PN > 3) drain(std::integral_constant<int, 3>{});
 }
 
 // One output tile [m0, m0+BM) x [n0, n0+BN): main loop + epilogue.  `tile_n` only tells whether this block is the one
@@ -1413,6 +1677,37 @@ int launch_h2(const KArgs& base, bool norm, hipStream_t stream) {
 
 }  // namespace
 
+// The file is compiled either whole or in slices (-DBCOS_TAPCONV_PART=k, bcos_hip/lib.py: build): slice 0 carries the C ABI
+// and the small tile configurations, slices 1.. the kernel instantiations of one or two tile configurations each.  The
+// launchers cross slices as plain functions taking the launch descriptor by address (every slice compiles the same KArgs).
+#ifndef BCOS_TAPCONV_PART
+#define BCOS_TAPCONV_PART -1
+#endif
+#define BCOS_TC_IN(k) (BCOS_TAPCONV_PART == -1 || BCOS_TAPCONV_PART == (k))
+#define BCOS_TC_LAUNCHER(name) __attribute__((visibility("hidden"))) int name(const void* kargs, int norm, hipStream_t s)
+BCOS_TC_LAUNCHER(bcos_tc_cfg_128x128);
+BCOS_TC_LAUNCHER(bcos_tc_cfg_128x64);
+BCOS_TC_LAUNCHER(bcos_tc_cfg_128x32);
+BCOS_TC_LAUNCHER(bcos_tc_h2_128x256);
+BCOS_TC_LAUNCHER(bcos_tc_h2_128x128);
+BCOS_TC_LAUNCHER(bcos_tc_h2_128x64);
+BCOS_TC_LAUNCHER(bcos_tc_h2_128x32);
+#define BCOS_TC_DEFINE(name, call) BCOS_TC_LAUNCHER(name) { return call(*static_cast<const KArgs*>(kargs), norm != 0, s); }
+#if BCOS_TC_IN(1)
+BCOS_TC_DEFINE(bcos_tc_cfg_128x128, (launch_cfg<128, 128, 2, 2>))
+#endif
+#if BCOS_TC_IN(2)
+BCOS_TC_DEFINE(bcos_tc_cfg_128x64, (launch_cfg<128, 64, 2, 2>))
+BCOS_TC_DEFINE(bcos_tc_cfg_128x32, (launch_cfg<128, 32, 4, 1>))
+#endif
+#if BCOS_TC_IN(3)
+BCOS_TC_DEFINE(bcos_tc_h2_128x256, (launch_h2<128, 256, 2, 2>))
+BCOS_TC_DEFINE(bcos_tc_h2_128x128, (launch_h2<128, 128, 2, 2>))
+#endif
+#if BCOS_TC_IN(0)
+BCOS_TC_DEFINE(bcos_tc_h2_128x64, (launch_h2<128, 64, 2, 2>))
+BCOS_TC_DEFINE(bcos_tc_h2_128x32, (launch_h2<128, 32, 4, 1>))
+
 extern "C" int bcos_set_contraction_mode(int mode) {
     if (mode < 0 || mode > 2)
         return bcos_set_error(BCOS_E_INVAL, "bcos_set_contraction_mode: 0 = fp32 MFMA, 1 = split-bf16 MFMA, 2 = split-f16 MFMA");
@@ -1732,6 +2027,32 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);
         p.vec_ok = ((bits & 15) == 0 && p.g.out_pitch % 4 == 0) ? 1 : 0;
     }
+    {   // specialised epilogue (tile_epilogue_fast) when the launch's feature set is one of the compiled kinds
+        p.epi_kind = 0;
+        p.out_bytes = 0;
+        const bcos_epilogue& e = *epi;
+        const int64_t obytes = (int64_t)g.N * g.OH * g.OW * p.g.out_pitch * 4;
+        const bool norm_l = e.bcos_mode != BCOS_NONE;
+        const bool off = getenv("BCOS_EPI_GENERIC") != nullptr;                 // development / test switch (read per call)
+        bool ok = !off && p.vec_ok && g.Cout % 4 == 0 && obytes < ((int64_t)1 << 31) && e.max_out <= 1 && e.out != nullptr &&
+                  !e.gate2 && !e.relu_gate && !(e.flags & (BCOS_EPI_NORM_ONLY | BCOS_EPI_FORCE_POW | BCOS_EPI_MUL_FROM_ACT)) &&
+                  ((reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.ch_scale) | reinterpret_cast<uintptr_t>(e.ch_shift)) & 15) == 0;
+        int ef = 0;
+        if (norm_l) {
+            ok = ok && e.b == 2.0f && (e.relu == 0 || e.relu == 1) && !e.mul && !e.mul2 && !e.out2 && !e.out2_absmax;
+            ef = (e.addend ? EF_ADDEND : 0) | (e.relu == 1 ? EF_RELU : 0) | (e.scale_out ? EF_SCALE_OUT : 0);
+        } else {
+            ok = ok && e.relu == 0 && !e.bias && !e.ch_scale && !e.ch_shift && !e.scale_out && (!e.mul2 || e.out2) &&
+                 (!e.out2 || e.mul) && (!e.out2_absmax || e.out2);
+            // out2 is either ungated or gated by the low bit of mul (BCOS_EPI_GATE2_FROM_MUL): both are what the kinds compute
+            ef = (e.addend ? EF_ADDEND : 0) | (e.mul ? EF_MUL : 0) | (e.out2 ? EF_OUT2 : 0) | (e.mul2 ? EF_MUL2 : 0);
+        }
+        if (ok) {
+            const int* kinds = norm_l ? EPI_KINDS_FWD : EPI_KINDS_BWD;
+            for (int k = 0; k < N_EPI_KINDS; ++k)
+                if (kinds[k] == ef) { p.epi_kind = k + 1; p.out_bytes = (unsigned)obytes; break; }
+        }
+    }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g.Cout <= 8 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1) {
@@ -1748,15 +2069,15 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             const int64_t c1 = (t1 + SLOTS - 1) / SLOTS, c2 = 2 * ((t2 + SLOTS - 1) / SLOTS);
             bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && p.Ktot >= 1024));
             if (force) wide = g.Cout > 128 && force[4] == '2';
-            if (wide) return launch_h2<128, 256, 2, 2>(p, norm, s);
-            return launch_h2<128, 128, 2, 2>(p, norm, s);
+            if (wide) return bcos_tc_h2_128x256(&p, norm, s);
+            return bcos_tc_h2_128x128(&p, norm, s);
         }
-        if (g.Cout > 32) return launch_h2<128, 64, 2, 2>(p, norm, s);
-        return launch_h2<128, 32, 4, 1>(p, norm, s);
+        if (g.Cout > 32) return bcos_tc_h2_128x64(&p, norm, s);
+        return bcos_tc_h2_128x32(&p, norm, s);
     }
-    if (g.Cout > 64) return launch_cfg<128, 128, 2, 2>(p, norm, s);
-    if (g.Cout > 32) return launch_cfg<128, 64, 2, 2>(p, norm, s);
-    return launch_cfg<128, 32, 4, 1>(p, norm, s);
+    if (g.Cout > 64) return bcos_tc_cfg_128x128(&p, norm, s);
+    if (g.Cout > 32) return bcos_tc_cfg_128x64(&p, norm, s);
+    return bcos_tc_cfg_128x32(&p, norm, s);
 }
 
 
@@ -1772,3 +2093,4 @@ extern "C" int bcos_tapconv_group(const float* a, const float* const* wts, const
     }
     return BCOS_OK;
 }
+#endif  // BCOS_TC_IN(0)

@@ -905,6 +905,89 @@ def test_presplit_weights_bit_identical(lib):
         assert torch.equal(y2, y3)
 
 
+def test_fast_epilogue_bit_identical(lib, golden_dir, monkeypatch):
+    """The specialised epilogues (csrc/bcos_tapconv.hip: tile_epilogue_fast, selected per launch from the feature set)
+    evaluate the same expressions in the same order as the general one: every tensor they write is identical bit for bit
+    to the BCOS_EPI_GENERIC=1 run -- single launches of every compiled kind on ragged shapes (rows not a multiple of the
+    tile, Cout not a multiple of the column tile, strided output mapping), in every contraction mode, and a whole
+    ResNet-18 / ResNet-50 forward + explanation pass."""
+    from bcos_hip import engine, ops, synth
+    from bcos_hip import lib as blib
+    g = torch.Generator().manual_seed(23)
+
+    def both(fn):
+        monkeypatch.delenv("BCOS_EPI_GENERIC", raising=False)
+        fast = fn()
+        monkeypatch.setenv("BCOS_EPI_GENERIC", "1")
+        gen = fn()
+        monkeypatch.delenv("BCOS_EPI_GENERIC", raising=False)
+        return fast, gen
+
+    def same(fast, gen, what):
+        for i, (a, b) in enumerate(zip(fast, gen)):
+            if a is None:
+                assert b is None
+                continue
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (what, i, rel(a, b))
+
+    prev = blib.get_contraction_mode()
+    try:
+        for mode in ("f16x2", "bf16x3", "f32"):
+            blib.set_contraction_mode(mode)
+            for (N, H, Cin, Cout, k, st, pd) in [(3, 13, 64, 200, 1, 1, 0), (2, 15, 32, 52, 3, 2, 1), (1, 9, 256, 24, 1, 1, 0),
+                                                 (2, 28, 128, 512, 1, 1, 0), (5, 7, 512, 384, 3, 1, 1)]:
+                x = ops.ensure_absmax(torch.randn(N, H, H, Cin, generator=g).to(DEV))
+                w = ops.mark_static((torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV))
+                bias = torch.randn(Cout, generator=g).to(DEV) * 0.1
+                csc = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+                csh = torch.randn(Cout, generator=g).to(DEV) * 0.1
+                Ho = ops.conv_out_size(H, k, st, pd)
+                add = torch.randn(N, Ho, Ho, Cout, generator=g).to(DEV)
+                for relu in (False, True):
+                    for addend in (None, add):
+                        for want_scale in (False, True):
+                            for flags in ((0, 4) if (relu and want_scale) else (0,)):
+                                def run():
+                                    y, sc, nrm = ops.conv2d_fwd(x, w, stride=(st, st), padding=(pd, pd), bias=bias, ch_scale=csc,
+                                                                ch_shift=csh, addend=addend, relu=relu, want_scale=want_scale,
+                                                                want_norm=True, flags=flags, track_absmax=True)
+                                    return y, sc, nrm, ops.absmax_of(y)
+                                same(*both(run), (mode, "fwd", N, H, Cin, Cout, k, relu, addend is not None, want_scale, flags))
+                # input-gradient launches: out = (acc [+ addend]) * mul, out2 = (acc [+ addend]) [* mul2] gated by the low bit of mul
+                plan = ops.DgradPlan(w.permute(0, 3, 1, 2).contiguous(), (st, st), (pd, pd))
+                gl = ops.ensure_absmax(torch.randn(N, Ho, Ho, Cout, generator=g).to(DEV))
+                mul = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+                mul2 = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+                add_in = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+                for kw in (dict(), dict(addend=add_in), dict(mul=mul), dict(mul=mul, addend=add_in, want2=True, flags=8),
+                           dict(mul=mul, addend=add_in, mul2=mul2, want2=True, flags=8), dict(mul=mul, want2=True), dict(mul=mul, want2=True, flags=8)):
+                    def run():
+                        kw2 = dict(kw)
+                        out2 = torch.full((N, H, H, Cin), float("nan"), device=DEV) if kw2.pop("want2", False) else None
+                        if out2 is not None:
+                            kw2["out2"] = out2
+                        out = plan.run(gl, H, H, track_absmax=True, track_absmax2=out2 is not None, **kw2)
+                        return out, out2, ops.absmax_of(out), (ops.absmax_of(out2) if out2 is not None else None)
+                    same(*both(run), (mode, "bwd", N, H, Cin, Cout, k, sorted(kw)))
+        blib.set_contraction_mode(prev)
+        net, meta, data = _golden_net(golden_dir, "resnet18_e2e")
+        x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+        eng = engine.attach(net)
+        fast, gen = both(lambda: eng.explain(x))
+        for key in ("logits", "dynamic_linear_weights", "contribution_map"):
+            assert torch.equal(fast[key], gen[key]), key
+        net50 = synth.build_bcosified_resnet("resnet50").to(DEV)
+        x50 = synth.synthetic_images(6, seed=5).to(DEV)
+        with torch.no_grad():
+            synth.calibrate(net50, x50)
+        eng50 = engine.attach(net50)
+        fast, gen = both(lambda: eng50.explain(x50))
+        for key in ("logits", "dynamic_linear_weights", "contribution_map"):
+            assert torch.equal(fast[key], gen[key]), key
+    finally:
+        blib.set_contraction_mode(prev)
+
+
 # ------------------------------------------------------------------------------------------ both contraction modes
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
 def test_contraction_modes_parity(lib, golden_dir, mode):
