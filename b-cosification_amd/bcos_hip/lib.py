@@ -27,7 +27,7 @@ BCOS_EPI_FORCE_POW = 2
 BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 TAPCONV_PARTS = 4
 
 
@@ -39,7 +39,7 @@ class TapconvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "C", "P", "Q", "in_sh", "in_sw", "dh0", "dw0", "dstep_h", "dstep_w",
         "TH", "TW", "OH", "OW", "out_sh", "out_sw", "out_h0", "out_w0", "Cout",
-        "a_pitch", "out_pitch", "norm_pitch")]
+        "a_pitch", "out_pitch", "norm_pitch", "out_cgroup")]
 
 
 class Epilogue(C.Structure):

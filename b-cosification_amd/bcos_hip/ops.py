@@ -53,6 +53,7 @@ def conv_out_size(size, k, s, p, d=1):
 
 _NO_PRESPLIT = bool(os.environ.get("BCOS_NO_PRESPLIT"))     # development switch: always split inside the kernel
 _NO_GROUP = bool(os.environ.get("BCOS_NO_GROUP"))           # development switch: one launch per parity class
+_NO_D2S = bool(os.environ.get("BCOS_NO_D2S"))               # development switch: narrow strided gradients on the grouped direct kernel
 
 
 def mark_static(w: torch.Tensor) -> torch.Tensor:
@@ -212,7 +213,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     selected; a caller that knows the reader of a tensor will not use them -- K < F16X2_MIN_K -- passes False)."""
     lib = _l.load()
     g = TapconvGeom()
-    for k in ("a_pitch", "out_pitch", "norm_pitch"):
+    for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup"):
         setattr(g, k, 0)
     for k, v in geom.items():
         setattr(g, k, int(v))
@@ -281,7 +282,7 @@ def tapconv_group(a: torch.Tensor, wts, geoms, *, out, addend=None, mul=None):
     earr = (Epilogue * n)()
     warr = (C.c_void_p * n)()
     for i, (w, geom) in enumerate(zip(wts, geoms)):
-        for k in ("a_pitch", "out_pitch", "norm_pitch"):
+        for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup"):
             setattr(garr[i], k, 0)
         for k, v in geom.items():
             setattr(garr[i], k, int(v))
@@ -392,6 +393,31 @@ class DgradPlan:
                 mark_static(wt)     # a DgradPlan is built once per weight version (engine plan / WeightCache)
                 self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
         self.has_empty = any(c[8] is None for c in self.classes)
+        self._d2s = {}        # channel pitch -> (weights [sh*sw*pitch, TH, TW, Cout], TH, TW, dh0, dw0), see _depth_to_space
+
+    def _depth_to_space(self, pitch: int):
+        """All parity classes of a narrow strided input gradient as ONE contraction (bcos_tapconv_geom.out_cgroup): rows =
+        coarse positions (i, j), columns = (parity class, channel), taps = the union of the classes' tap windows over the
+        gradient, with zero weights where a class does not use a tap.  The 2 x 2 classes of the 7x7 / 2 stem gradient
+        (16 / 12 / 12 / 9 taps over 64 channels) become one K = 1024, N = 32 launch on the MFMA tiles instead of four
+        6-column launches."""
+        hit = self._d2s.get(pitch)
+        if hit is not None:
+            return hit
+        sh, sw = self.stride
+        live = [c for c in self.classes if c[8] is not None]
+        dh0 = min(c[4] for c in live)
+        dw0 = min(c[5] for c in live)
+        TH = max(c[4] + c[2] for c in live) - dh0
+        TW = max(c[5] + c[3] for c in live) - dw0
+        ref = live[0][8]
+        wc = torch.zeros((sh * sw * pitch, TH, TW, self.Cout), device=ref.device, dtype=ref.dtype)
+        for (rh, rw, th, tw, h0, w0, _, _, wt) in live:
+            base = (rh * sw + rw) * pitch
+            wc[base:base + self.Cin, h0 - dh0:h0 - dh0 + th, w0 - dw0:w0 - dw0 + tw] = wt
+        mark_static(wc)
+        self._d2s[pitch] = (wc, TH, TW, dh0, dw0)
+        return self._d2s[pitch]
 
     @staticmethod
     def _taps(rho, s, p, k, d):
@@ -421,8 +447,17 @@ class DgradPlan:
                 out = torch.empty((N, H, W, self.Cin), device=glin.device, dtype=torch.float32)
         pitch = out.shape[-1]
         sh, sw = self.stride
-        if (self.Cin <= 8 and len(self.classes) > 1 and not self.has_empty and set(epi) <= {"addend", "mul"}
-                and not _NO_GROUP):
+        narrow = (self.Cin <= 8 and len(self.classes) > 1 and not self.has_empty and set(epi) <= {"addend", "mul"}
+                  and self.dilation == (1, 1))
+        if narrow and not _NO_D2S and pitch % 4 == 0 and pitch <= 16 and H % sh == 0 and W % sw == 0:
+            # one launch for all parity classes: columns = (class, channel), depth-to-space output mapping
+            wc, TH, TW, dh0, dw0 = self._depth_to_space(pitch)
+            g = dict(N=N, H=Ho, W=Wo, C=Cout, P=H // sh, Q=W // sw, in_sh=1, in_sw=1, dh0=dh0, dw0=dw0, dstep_h=1, dstep_w=1,
+                     TH=TH, TW=TW, OH=H, OW=W, out_sh=sh, out_sw=sw, out_h0=0, out_w0=0, Cout=sh * sw * pitch, out_pitch=pitch,
+                     out_cgroup=pitch)
+            tapconv(glin, wc, g, out=out, track_absmax=False, track_absmax2=False, **epi)
+            return out
+        if narrow and not _NO_GROUP:
             # narrow output (the stem gradient): all parity classes in one launch, the input patch staged once
             geoms, wts = [], []
             for (rh, rw, TH, TW, dh0, dw0, step_h, step_w, wt) in self.classes:

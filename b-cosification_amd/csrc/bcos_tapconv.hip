@@ -222,6 +222,13 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
     }
     const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
     const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
+    // depth-to-space launches (bcos_tapconv_geom.out_cgroup): the column chunk is channel colc of the pixel colpix further on
+    int colpix = 0, colc = col;
+    if (g.out_cgroup > 0) {
+        const int cls = col / g.out_cgroup;
+        colc = col - cls * g.out_cgroup;
+        colpix = (cls / g.out_sw) * g.OW + cls % g.out_sw;
+    }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -255,7 +262,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
         for (int u = 0; u < EPI_G; ++u) {
             const int lrow = rbase + (p0 + u) * RPP;
             const int64_t pix = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
-            const int64_t idx = (pix >= 0 ? pix : 0) * g.out_pitch + col;
+            const int64_t idx = ((pix >= 0 ? pix : 0) + colpix) * g.out_pitch + colc;
             in.ad[u] = (vec && e.addend) ? *reinterpret_cast<const f32x4*>(e.addend + idx) : zero4;
             in.m1[u] = (vec && e.mul) ? *reinterpret_cast<const f32x4*>(e.mul + idx) : zero4;
         }
@@ -308,7 +315,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                 const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
                 const int64_t pix = pixs[u];
                 ok[u] = pix >= 0;
-                idx[u] = (ok[u] ? pix : 0) * g.out_pitch + col;
+                idx[u] = ((ok[u] ? pix : 0) + colpix) * g.out_pitch + colc;
                 v[u] = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
                 if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
                 rinv[u] = NORM ? sRinv[row] : 1.f;
@@ -572,7 +579,11 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     }
     const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
     const bool col_ok = col < Cout;                       // Cout % 4 == 0 (host): the whole chunk is inside or outside
-    const unsigned coloff = col_ok ? (unsigned)col * 4u : OOB;
+    unsigned coloff = col_ok ? (unsigned)col * 4u : OOB;
+    if (g.out_cgroup > 0 && col_ok) {      // depth to space: column block (dh, dw) is the pixel dh * OW + dw further on
+        const int cls = col / g.out_cgroup;
+        coloff = (unsigned)(((cls / g.out_sw) * g.OW + cls % g.out_sw) * g.out_pitch + (col - cls * g.out_cgroup)) * 4u;
+    }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
     if (col_ok) {
         if (NORM && e.bias) bias4 = *reinterpret_cast<const f32x4*>(e.bias + col);
@@ -1946,17 +1957,29 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     if ((g.P - 1) * g.out_sh + g.out_h0 >= g.OH || (g.Q - 1) * g.out_sw + g.out_w0 >= g.OW || g.out_h0 < 0 ||
         g.out_w0 < 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: output mapping outside [OH,OW]");
+    if (g.out_cgroup != 0) {     // depth to space: columns = (output parity class, channel)
+        if (g.out_cgroup < 0 || g.out_cgroup % 4 != 0 || g.out_sh <= 0 || g.out_sw <= 0 || g.out_h0 != 0 || g.out_w0 != 0 ||
+            g.Cout != g.out_sh * g.out_sw * g.out_cgroup || g.P * g.out_sh > g.OH || g.Q * g.out_sw > g.OW ||
+            (g.out_pitch != 0 && g.out_pitch < g.out_cgroup))
+            return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: out_cgroup needs Cout == out_sh * out_sw * out_cgroup, out_cgroup % 4 == 0, "
+                                                "zero output offsets, P * out_sh <= OH, Q * out_sw <= OW and out_pitch >= out_cgroup");
+        if (epi->max_out > 1 || epi->out_absmax || epi->out2_absmax || epi->norm_out || epi->bias || epi->ch_scale || epi->ch_shift ||
+            (epi->flags & BCOS_EPI_MUL_FROM_ACT) || epi->bcos_mode != BCOS_NONE)
+            return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: out_cgroup launches are plain gradient launches (addend / mul / mul2 / "
+                                                "gate2 / out / out2 only)");
+    }
 
     KArgs p;
     p.a = a;
     p.wt = wt;
     p.g = g;
     if (p.g.a_pitch == 0) p.g.a_pitch = g.C;
-    if (p.g.out_pitch == 0) p.g.out_pitch = g.Cout;
+    if (p.g.out_pitch == 0) p.g.out_pitch = g.out_cgroup > 0 ? g.out_cgroup : g.Cout;
     if (p.g.norm_pitch == 0) p.g.norm_pitch = 1;
     if (p.g.a_pitch % 4 != 0 || p.g.a_pitch < g.C) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad a_pitch");
     if (epi->max_out > 1 && g.out_pitch == 0) p.g.out_pitch = g.Cout / epi->max_out;
-    if (p.g.out_pitch < g.Cout / (epi->max_out > 1 ? epi->max_out : 1)) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad out_pitch");
+    if (g.out_cgroup == 0 && p.g.out_pitch < g.Cout / (epi->max_out > 1 ? epi->max_out : 1))
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad out_pitch");
     p.e = *epi;
     p.M = (int)M64;
     p.PQ = g.P * g.Q;
@@ -2026,6 +2049,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         const void* ptrs[] = {epi->addend, epi->mul, epi->mul2, epi->gate2, epi->relu_gate, epi->out, epi->out2, epi->scale_out};
         for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);
         p.vec_ok = ((bits & 15) == 0 && p.g.out_pitch % 4 == 0) ? 1 : 0;
+        if (g.out_cgroup > 0 && !p.vec_ok)
+            return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: out_cgroup needs 16-byte addressable epilogue tensors");
     }
     {   // specialised epilogue (tile_epilogue_fast) when the launch's feature set is one of the compiled kinds
         p.epi_kind = 0;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 2
+#define BCOS_ABI_VERSION 3
 
 enum {
     BCOS_OK = 0,
@@ -59,7 +59,8 @@ enum { BCOS_NONE = 0, BCOS_CONV_EPS = 1, BCOS_LINEAR_EPS = 2 };
  * A forward convolution (stride s, padding p, dilation d) is
  *     in_s = s, dh0 = -p, dstep = d, TH x TW = kernel, P x Q = OH x OW, out_s = 1, out_0 = 0.
  * The input-gradient ("dgrad") of a strided convolution is one launch per output parity
- * class with the matching sub-kernel, in_s = 1 and out_s = stride (bcos_hip/ops.py: DgradPlan).
+ * class with the matching sub-kernel, in_s = 1 and out_s = stride (bcos_hip/ops.py: DgradPlan),
+ * or -- narrow outputs -- ONE launch whose columns are (parity class, channel), see out_cgroup.
  */
 typedef struct bcos_tapconv_geom {
     int32_t N, H, W, C;          /* A operand: NHWC, C % 4 == 0                      */
@@ -77,6 +78,12 @@ typedef struct bcos_tapconv_geom {
     int32_t out_pitch;           /* floats between consecutive output pixels (0 = Cout); every
                                     per-element epilogue tensor uses the same pitch  */
     int32_t norm_pitch;          /* floats between consecutive pixels of norm_out (0 = 1) */
+    int32_t out_cgroup;          /* 0: off.  G > 0 ("depth to space"): Cout = out_sh * out_sw * G and column
+                                    (dh * out_sw + dw) * G + c of row (n, i, j) is channel c of output pixel
+                                    (n, i*out_sh + dh, j*out_sw + dw): ALL parity classes of a strided input
+                                    gradient in one launch over the union of their taps (weights of taps a class
+                                    does not use are zero; bcos_hip/ops.py: DgradPlan).  Needs G % 4 == 0,
+                                    out_h0 == out_w0 == 0, 16-byte addressable tensors, no max_out, no *_absmax */
 } bcos_tapconv_geom;
 
 /*

@@ -18,7 +18,7 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
             mul_norm=None, mul_csc=None, mul_csh=None):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
-    g = dict(a_pitch=0, out_pitch=0, norm_pitch=0)
+    g = dict(a_pitch=0, out_pitch=0, norm_pitch=0, out_cgroup=0)
     g.update(geom)
     N, H, W, C = g["N"], g["H"], g["W"], g["C"]
     P, Q, TH, TW, Cout = g["P"], g["Q"], g["TH"], g["TW"], g["Cout"]
@@ -79,11 +79,25 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
     def v4(t):
         return t if t.dim() == 4 else t.view(N, g["OH"], g["OW"], -1)
 
-    def rd(t):
-        return v4(t)[:, oh][:, :, ow][..., :Cout].double()
+    cg = g["out_cgroup"]
+    if cg:      # depth to space (include/bcos_hip.h: out_cgroup): column (dh * out_sw + dw) * cg + c -> pixel (i*out_sh + dh, j*out_sw + dw), channel c
+        osh, osw = g["out_sh"], g["out_sw"]
 
-    def wr(t, val):
-        v4(t)[:, oh[:, None], ow[None, :], :Cout] = val.to(t.dtype)
+        def d2s_view(t):
+            return v4(t)[:, :P * osh, :Q * osw, :cg].reshape(N, P, osh, Q, osw, cg)
+
+        def rd(t):
+            return d2s_view(t).permute(0, 1, 3, 2, 4, 5).reshape(N, P, Q, Cout).double()
+
+        def wr(t, val):
+            v4(t)[:, :P * osh, :Q * osw, :cg] = val.to(t.dtype).view(N, P, Q, osh, osw, cg).permute(0, 1, 3, 2, 4, 5).reshape(
+                N, P * osh, Q * osw, cg)
+    else:
+        def rd(t):
+            return v4(t)[:, oh][:, :, ow][..., :Cout].double()
+
+        def wr(t, val):
+            v4(t)[:, oh[:, None], ow[None, :], :Cout] = val.to(t.dtype)
 
     if addend is not None:
         v = v + rd(addend)
@@ -113,7 +127,7 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
         if mul2 is not None:
             o2 = o2 * rd(mul2)
         if (flags & BCOS_EPI_GATE2_FROM_MUL) and mul is not None:
-            mbits = v4(mul)[:, oh][:, :, ow][..., :Cout].float().contiguous().view(torch.int32)
+            mbits = rd(mul).float().contiguous().view(torch.int32)
             o2 = torch.where((mbits & 1).bool(), o2, torch.zeros_like(o2))
         elif gate2 is not None:
             o2 = torch.where(rd(gate2) > 0, o2, torch.zeros_like(o2))

@@ -454,11 +454,21 @@ def resnet50_logits_small():
     REPORT["r50/oracle_weights"] = rel(oe["dynamic_linear_weights"], wts)
     contrib = (x[:2] * wts).sum(1)
     rec_np = {f"calib/{k}": v.numpy() for k, v in record.items()}
+    # ReLU gates of both images (NHWC order, bit-packed) recorded with the oracle, whose forward and W(x) are bit-identical
+    # to the reference's on this host (r50/oracle_logits == r50/oracle_weights == 0): the GPU test replays the REFERENCE's
+    # gate decisions and then holds the 54-layer maps and W(x) to 1e-4 instead of the reference's own free-gate floor
+    log = []
+    with torch.no_grad():
+        lg = O.resnet_logits(sd, x[:2], arch, detach=True, gate_log=log)
+    assert torch.equal(lg, logits) and REPORT["r50/oracle_weights"][0] == 0.0
+    gate_np = {f"gate/{i:02d}": np.packbits((p > 0).permute(0, 2, 3, 1).contiguous().numpy().reshape(-1)) for i, p in enumerate(log)}
+    gate_shapes = [list(p.permute(0, 2, 3, 1).shape) for p in log]
     np.savez_compressed(os.path.join(HERE, "resnet50_small.npz"), logits=logits.numpy(),
-                        prediction=logits.argmax(1).numpy(), contribution_map=contrib.numpy(), **rec_np)
+                        prediction=logits.argmax(1).numpy(), contribution_map=contrib.numpy(), weights_01=wts.numpy(),
+                        **rec_np, **gate_np)
     with open(os.path.join(HERE, "resnet50_small.json"), "w") as f:
         json.dump(dict(arch=arch, weight_seed=0, image_seed=123, n_images=2, calib_images=4,
-                       calib_order=list(record.keys()), state_checksum=state_checksum(sd),
+                       calib_order=list(record.keys()), state_checksum=state_checksum(sd), gate_shapes=gate_shapes,
                        torch_version=torch.__version__), f, indent=1)
 
 

@@ -430,6 +430,14 @@ def test_resnet50_against_reference_golden(lib, golden_dir):
     pinned = eng.explain(x, gates=_oracle_gates(net, x, meta["arch"]))
     assert rel(pinned["contribution_map"], host["contribution_map"]) <= 1e-4
     assert rel(pinned["dynamic_linear_weights"], host["dynamic_linear_weights"]) <= 1e-4
+    # gates pinned to the REFERENCE's recorded decisions (fixture, both images): maps and W(x) of the 54-layer network
+    # hold the 1e-4 target against the reference-recorded outputs outright
+    gates = [torch.from_numpy(np.unpackbits(data[f"gate/{i:02d}"])[: int(np.prod(shp))].reshape(shp).astype(np.float32)).to(DEV)
+             for i, shp in enumerate(meta["gate_shapes"])]
+    pinned_ref = eng.explain(x, gates=gates)
+    assert rel(pinned_ref["logits"], data["logits"]) <= 1e-4
+    assert rel(pinned_ref["contribution_map"], data["contribution_map"]) <= 1e-4
+    assert rel(pinned_ref["dynamic_linear_weights"], data["weights_01"]) <= 1e-4
 
 
 
@@ -833,16 +841,70 @@ def test_tapconv_group_matches_separate_launches(lib):
         Ho2 = (H + 2 * p_ - k) // s_ + 1
         gl = torch.randn(N, Ho2, Ho2, Cout, generator=g).to(DEV)
         add = torch.randn(N, H, H, Cin, generator=g).to(DEV)
-        ops._NO_GROUP = False
-        a = plan.run(gl, H, H, addend=add)
-        ops._NO_GROUP = True
+        ops._NO_GROUP, no_d2s = False, ops._NO_D2S
+        ops._NO_D2S = True                      # (the depth-to-space launch would take these shapes first, see the next test)
         try:
+            a = plan.run(gl, H, H, addend=add)
+            ops._NO_GROUP = True
             b = plan.run(gl, H, H, addend=add)
         finally:
-            ops._NO_GROUP = False
+            ops._NO_GROUP, ops._NO_D2S = False, no_d2s
         assert rel(a, b) <= 1e-6, (Cin, k)        # same products; the channel-slice grouping of the sums may differ
         ref = torch.nn.grad.conv2d_input((N, Cin, H, H), w.cpu(), gl.permute(0, 3, 1, 2).cpu(), stride=s_, padding=p_)
         assert rel(a.permute(0, 3, 1, 2), ref + add.permute(0, 3, 1, 2).cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
+def test_depth_to_space_dgrad_matches_per_class_launches(lib, mode):
+    """bcos_tapconv_geom.out_cgroup: all parity classes of a narrow strided input gradient as ONE contraction whose columns
+    are (class, channel) over the union of the classes' taps (DgradPlan._depth_to_space) -- against the one-launch-per-class
+    path, against torch's conv2d_input, with the addend / multiplier epilogue, into a padded channel pitch, on both
+    epilogue implementations."""
+    from bcos_hip import ops
+    from bcos_hip import lib as blib
+    prev = blib.get_contraction_mode()
+    blib.set_contraction_mode(mode)
+    g = torch.Generator().manual_seed(29)
+    try:
+        for (N, Hh, Cout, Cin, pitch, k, s_, p_) in [(3, 40, 64, 6, 8, 7, 2, 3), (2, 18, 32, 6, 8, 3, 2, 1), (2, 24, 16, 4, 4, 3, 2, 1),
+                                                     (1, 12, 64, 8, 8, 4, 4, 0), (2, 30, 24, 3, 4, 5, 3, 2)]:
+            w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cout) ** 0.5).to(DEV)
+            plan = ops.DgradPlan(w, (s_, s_), (p_, p_), (1, 1))
+            if plan.has_empty:
+                continue
+            H = Hh - Hh % s_
+            Ho = (H + 2 * p_ - k) // s_ + 1
+            gl = ops.ensure_absmax(torch.randn(N, Ho, Ho, Cout, generator=g).to(DEV))
+            add = torch.randn(N, H, H, pitch, generator=g).to(DEV)
+            mul = torch.randn(N, H, H, pitch, generator=g).to(DEV)
+            ref = torch.nn.grad.conv2d_input((N, Cin, H, H), w.cpu(), gl.permute(0, 3, 1, 2).cpu(), stride=s_, padding=p_)
+            for kw in (dict(), dict(addend=add), dict(mul=mul), dict(addend=add, mul=mul)):
+                outs = {}
+                for name, no_d2s, generic in (("d2s", False, False), ("d2s_generic", False, True), ("classes", True, False)):
+                    out = torch.full((N, H, H, pitch), float("nan"), device=DEV)
+                    prev_flag = ops._NO_D2S
+                    ops._NO_D2S = no_d2s
+                    if generic:
+                        os.environ["BCOS_EPI_GENERIC"] = "1"
+                    try:
+                        plan.run(gl, H, H, out=out, **kw)
+                    finally:
+                        ops._NO_D2S = prev_flag
+                        os.environ.pop("BCOS_EPI_GENERIC", None)
+                    outs[name] = out
+                assert plan._d2s, "the depth-to-space launch was not taken"
+                assert torch.equal(outs["d2s"], outs["d2s_generic"])                       # NaN canaries gone, same bits
+                if pitch > Cin and "addend" not in kw:
+                    assert torch.all(outs["d2s"][..., Cin:] == 0)                           # padded channels: zero weights
+                assert rel(outs["d2s"][..., :Cin], outs["classes"][..., :Cin]) <= 2e-6, (mode, Cin, k, sorted(kw))
+                want = ref.permute(0, 2, 3, 1)
+                if "addend" in kw:
+                    want = want + add[..., :Cin].cpu()
+                if "mul" in kw:
+                    want = want * mul[..., :Cin].cpu()
+                assert rel(outs["d2s"][..., :Cin], want) <= 1e-5, (mode, Cin, k, sorted(kw))
+    finally:
+        blib.set_contraction_mode(prev)
 
 
 def test_operand_larger_than_2gib_is_split_by_images(lib):
