@@ -5,10 +5,12 @@ reference bcosconv2d.py:153-194 issues 9 ATen launches for the same thing).
 Backward:
   * explanation mode (`detach=True`): the dynamic scale is a constant, so d out / d x = conv_transpose(g * s, W) -- the
     "dynamic linear weights" W(x) of bcos/common.py:177-181 -- and d out / d W = wgrad(g * s, x);
-  * training mode (first slice: max_out == 1, groups == 1): the scale is differentiated too
-    (bcosconv2d.py:176-194 without .detach()):  gx = dgrad(g * dy/dlin, W) + x (.) PatchSum^T(dL/dnorm / norm),
-    gW = wgrad(g * dy/dlin, x), gbias = sum_pixels g * dy/dlin  (csrc/bcos_train.hip).
-MaxOut / grouped layers outside explanation mode still raise instead of silently producing explanation-mode gradients.
+  * training mode (groups == 1): the scale is differentiated too (bcosconv2d.py:176-194 without
+    .detach()):  gx = dgrad(g * dy/dlin, W) + x (.) PatchSum^T(dL/dnorm / norm), gW = wgrad(g * dy/dlin, x),
+    gbias = sum_pixels g * dy/dlin (csrc/bcos_train.hip); MaxOut routes g * dy/dlin to the winning filter of each unit
+    (bcos_maxout_scatter); a learnable exponent (`b` an nn.Parameter, trainer.py:451-463) receives
+    sum g y ln(|cos| + 1e-6) times d B_eff / d b; native layers differentiate through their unit-norm projection (UnitNormFn).
+Grouped layers outside explanation mode still raise instead of silently producing explanation-mode gradients.
 """
 import torch
 import torch.nn.functional as F
@@ -55,15 +57,33 @@ def _pad_last(t: torch.Tensor, mult: int = 4) -> torch.Tensor:
     return t if r == 0 else F.pad(t, (0, r))
 
 
-def refuse_unit_norm_training(module, w_eff, w_src):
-    """The unit-norm projection of NormedConv2d / NormedLinear runs as a HIP kernel outside autograd, so gradients cannot
-    reach the raw weight through it.  Explanation (eval, or explanation mode) never needs them; a training step does and
-    must not run silently without weight updates (SURVEY.md section 8(f) N4 covers the B-cosified, un-normalised layers)."""
-    if (w_eff is not w_src and module.training and not module.detach and torch.is_grad_enabled() and w_src.requires_grad):
-        raise NotImplementedError(
-            f"{type(module).__name__}: weight gradients through the unit-norm projection (native B-cos layers in training "
-            "mode) are not built for MI355X; train the B-cosified layers (BcosifyConv2d / BcosifyLinear), call .eval(), or "
-            "freeze the weight")
+class UnitNormFn(Function):
+    """w -> gain * w / ||w||_2 per filter (NormedConv2d / NormedLinear, bcosconv2d.py:26-35, bcoslinear.py:25-27) with its
+    backward (bcos_weight_rownorm_bwd): used in training mode, where the raw weight (and a trainable `scale`) need the
+    gradient that arrives at the projected weight.  Eval / explanation use the cached, detached projection instead."""
+
+    @staticmethod
+    def forward(ctx, w, scale):
+        require_hip(w, "NormedConv2d / NormedLinear")
+        w2 = w.detach().contiguous().view(w.shape[0], -1)
+        gain = scale.detach().reshape(-1).contiguous() if scale is not None else None
+        ctx.save_for_backward(w2, *([gain] if gain is not None else []))
+        ctx.has_gain = gain is not None
+        ctx.scale_shape = tuple(scale.shape) if scale is not None else None
+        return ops.weight_rownorm_scale(w2, gain).view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        w2 = ctx.saved_tensors[0]
+        gain = ctx.saved_tensors[1] if ctx.has_gain else None
+        need_w, need_s = ctx.needs_input_grad[0], ctx.has_gain and ctx.needs_input_grad[1]
+        gw, gg = ops.weight_rownorm_bwd(w2, g.contiguous().view(w2.shape[0], -1), gain, want_gw=need_w, want_ggain=need_s)
+        return (gw.view_as(g) if gw is not None else None), (gg.view(ctx.scale_shape) if gg is not None else None)
+
+
+def wants_projection_grad(module, *params) -> bool:
+    """training-mode call of a unit-norm layer whose raw weight (or scale) is being trained"""
+    return bool(module.training and torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params))
 
 
 class WeightCache:
@@ -108,12 +128,24 @@ class WeightCache:
         return self._dgrad[k]
 
 
+def _b_gradient_applies(cfg, b: float) -> bool:
+    """Does the output depend on the exponent at this value?  The reference's `self.b == 1` (plain linear output) and
+    `self.b == 2` (|lin| / norm) branches do not touch B (bcosifyconv2d.py:78-79,91-92); only the general pow form does."""
+    return b != 1.0 and (b != 2.0 or bool(cfg.get("force_pow")))
+
+
+def learnable_b(module):
+    """the module's exponent when it is a tensor that wants a gradient (trainer.py:451-463 turns `b` into an nn.Parameter)"""
+    b = getattr(module, "b", None)
+    return b if isinstance(b, torch.Tensor) and b.requires_grad and torch.is_grad_enabled() else None
+
+
 class BcosConv2dFn(Function):
     """y = bcos_conv(x): see module docstring.  cfg keys: stride, padding, dilation, groups, b, max_out,
     detach, cache (WeightCache), w_src (the parameter the cache is keyed on)."""
 
     @staticmethod
-    def forward(ctx, x, w_eff, bias, cfg):
+    def forward(ctx, x, w_eff, bias, cfg, b_param=None):
         require_hip(x, "BcosConv2d")
         stride, padding, dilation = cfg["stride"], cfg["padding"], cfg["dilation"]
         groups, b, max_out = cfg["groups"], float(cfg["b"]), cfg["max_out"]
@@ -131,21 +163,23 @@ class BcosConv2dFn(Function):
         elif cin_g % 4 != 0:
             raise BcosHipError(f"grouped B-cos conv needs in_channels/groups % 4 == 0 (got {cin_g})")
         need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
-        train = (need_grad or need_w or need_b) and not cfg["detach"] and b != 1.0     # the scale is differentiated
-        if (train or need_w or need_b) and (max_out != 1 or groups != 1):
+        need_bp = b_param is not None and ctx.needs_input_grad[4] and _b_gradient_applies(cfg, b)
+        train = (need_grad or need_w or need_b or need_bp) and not cfg["detach"] and b != 1.0     # the scale is differentiated
+        if (train or need_w or need_b) and groups != 1:
             raise NotImplementedError(
-                "BcosConv2d: weight gradients / training-mode gradients are built for max_out == 1, groups == 1 "
-                "(SURVEY.md section 8(f) N4); MaxOut and grouped layers support explanation-mode input gradients only")
-        want_scale = bool((need_grad or need_w or need_b) and b != 1.0)
+                "BcosConv2d: weight gradients / training-mode gradients are built for groups == 1 (SURVEY.md section 8(f) N4); "
+                "grouped layers support explanation-mode input gradients only")
+        want_scale = bool((need_grad or need_w or need_b or need_bp) and b != 1.0)
         # MaxOut over 2 or 4 filters is taken inside the contraction's epilogue (one launch, bcosconv2d.py:166-170); other
-        # unit sizes and grouped layers go through the general path (full-width lin + bcos_maxout_scale)
-        mo_fused = max_out in (2, 4) and groups == 1 and Cout_all % 4 == 0
+        # unit sizes, grouped layers and training-mode calls (which need the unit-wide y, s and the winner indices) go through
+        # the general path (full-width lin + bcos_maxout_scale)
+        mo_fused = max_out in (2, 4) and groups == 1 and Cout_all % 4 == 0 and not train
         if mo_fused:
             return BcosConv2dFn._forward_maxout(ctx, x, xh, wk, w_eff, bias, cfg, (N, Cin, H, W), (kh, kw, Ho, Wo), Cout_all, need_grad)
         fused = max_out == 1
         y_cl, y = empty_cl(N, Cout_all, Ho, Wo, x.device)
         scale = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if (want_scale and fused) else None
-        if train:
+        if train and fused:
             norm = torch.empty((N, Ho, Wo), device=x.device, dtype=torch.float32)
         else:
             norm = None if fused or b == 1.0 else torch.empty((N, Ho, Wo, groups), device=x.device, dtype=torch.float32)
@@ -171,13 +205,14 @@ class BcosConv2dFn(Function):
             y_cl, y2 = empty_cl(N, Cout, Ho, Wo, x.device)
             _, scale, argmax = ops.maxout_scale(y.reshape(-1, Cout_all), norm.view(-1, groups) if norm is not None else None,
                                                 Cout, max_out, b, groups=groups, want_scale=want_scale,
-                                                want_argmax=need_grad, out=y2.view(-1, Cout))
+                                                want_argmax=need_grad or need_w or need_b, out=y2.view(-1, Cout))
             if scale is not None:
                 scale = scale.view(N, Ho, Wo, Cout)
         ctx.cfg = cfg
         ctx.in_shape = (N, Cin, H, W)
         ctx.w_eff = w_eff
         ctx.train = bool(train)
+        ctx.need_bp = bool(need_bp and train)
         ctx.mo_fused = False
         ctx.geom = (kh, kw, Ho, Wo)
         keep_x = xh if (train or need_w) else None                  # the padded NHWC input: weight gradient / norm term
@@ -197,13 +232,15 @@ class BcosConv2dFn(Function):
         stride, padding, dilation = cfg["stride"], cfg["padding"], cfg["dilation"]
         Cout = Cout_all // M
         y_cl, y = empty_cl(N, Cout, Ho, Wo, x.device)
-        t_full = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if need_grad else None
+        need_wb = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+        t_full = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if (need_grad or need_wb) else None
         gm = ops.fwd_geom(N, H, W, wk.shape[3], Cout_all, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1])
         ops.tapconv(xh, wk, gm, out=y, scale_out=t_full, bias=bias, bcos_mode=BCOS_NONE if b == 1.0 else BCOS_CONV_EPS, b=b,
                     flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0, max_out=M)
-        ctx.cfg, ctx.in_shape, ctx.w_eff, ctx.train, ctx.geom = cfg, in_shape, w_eff, False, geom
-        ctx.save_for_backward(*(t for t in (t_full,) if t is not None))
-        ctx.has = (t_full is not None, False, False, False, False)
+        ctx.cfg, ctx.in_shape, ctx.w_eff, ctx.train, ctx.geom, ctx.need_bp = cfg, in_shape, w_eff, False, geom, False
+        keep_x = xh if need_wb else None                # explanation-mode weight gradient (scale held constant)
+        ctx.save_for_backward(*(t for t in (t_full, keep_x) if t is not None))
+        ctx.has = (t_full is not None, False, keep_x is not None, False, False)
         ctx.mo_fused = True
         return y_cl
 
@@ -222,13 +259,17 @@ class BcosConv2dFn(Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         g = to_nhwc(gy)
         addend = None
+        gbp = None
         if ctx.train:
             Cout = g.shape[3]
             if Cout % 4:
                 raise NotImplementedError("training-mode backward needs out_channels % 4 == 0")
-            glin, rnorm = ops.train_scale_bwd(g.view(-1, Cout), to_nhwc(y_cl).view(-1, Cout), scale.view(-1, Cout),
-                                              norm.view(-1), BCOS_CONV_EPS, float(cfg["b"]), bool(cfg.get("force_pow")))
+            glin, rnorm, bgrad = ops.train_scale_bwd(g.view(-1, Cout), to_nhwc(y_cl).view(-1, Cout), scale.view(-1, Cout),
+                                                     norm.view(-1), BCOS_CONV_EPS, float(cfg["b"]), bool(cfg.get("force_pow")),
+                                                     want_bgrad=ctx.need_bp)
             glin = glin.view(N, Ho, Wo, Cout)
+            if ctx.need_bp:
+                gbp = (bgrad * float(cfg.get("b_chain", 1.0))).view(())
             if need_x:      # gradient through calc_patch_norms: x * PatchSum^T(dL/dnorm / norm), added by the dgrad epilogue
                 addend = ops.patch_norm_bwd(xh, rnorm.view(N, Ho, Wo), Cin, (kh, kw), cfg["stride"], cfg["padding"], cfg["dilation"])
         elif ctx.mo_fused:      # the gradient goes to the winning filter of each unit, times its scale
@@ -236,6 +277,9 @@ class BcosConv2dFn(Function):
             glin = ops.maxout_expand(g.reshape(-1, Cn), scale.view(-1, Cn * max_out), max_out).view(N, Ho, Wo, Cn * max_out)
         else:
             glin = ops.mul(g, scale) if scale is not None else g
+        if argmax is not None:   # MaxOut (general path): route the gradient to the winning filter of each unit
+            Cn = glin.shape[3]
+            glin = ops.maxout_scatter(glin.reshape(-1, Cn), argmax.view(-1, Cn), max_out).view(N, Ho, Wo, Cn * max_out)
         gw = gb = None
         if need_w or need_b:
             gl4 = _pad_last(glin).contiguous()
@@ -245,12 +289,7 @@ class BcosConv2dFn(Function):
             if need_b:
                 gb = ops.colsum(gl4.view(-1, gl4.shape[3]))[:glin.shape[3]].contiguous()
         if not need_x:
-            return None, gw, gb, None
-        if argmax is not None:   # MaxOut: route the gradient to the winning filter of each unit
-            full = torch.zeros(glin.shape[:3] + (glin.shape[3] * max_out,), device=glin.device, dtype=torch.float32)
-            idx = (torch.arange(glin.shape[3], device=glin.device) * max_out) + argmax.view(glin.shape).long()
-            full.scatter_(3, idx, glin)
-            glin = full
+            return None, gw, gb, None, gbp
         plans = cfg["cache"].dgrad(ctx.w_eff, cfg["w_src"], cfg["stride"], cfg["padding"], cfg["dilation"], groups)
         cout_g = glin.shape[3] // groups
         cin_g = Cin // groups
@@ -262,14 +301,14 @@ class BcosConv2dFn(Function):
                 plan.run(gl, H, W, out=gx, addend=addend)
             else:
                 gx[..., gi * cin_g:(gi + 1) * cin_g] = plan.run(gl, H, W)
-        return gx_cl, gw, gb, None
+        return gx_cl, gw, gb, None, gbp
 
 
 class BcosLinearFn(Function):
     """y = bcos_linear(x) over the last dimension.  cfg keys: b, max_out, detach, cache, w_src."""
 
     @staticmethod
-    def forward(ctx, x, w_eff, bias, cfg):
+    def forward(ctx, x, w_eff, bias, cfg, b_param=None):
         require_hip(x, "BcosLinear")
         b, max_out = float(cfg["b"]), cfg["max_out"]
         need_grad = ctx.needs_input_grad[0]
@@ -278,20 +317,17 @@ class BcosLinearFn(Function):
         x2 = _pad_last(x2 if x2.is_contiguous() else x2.contiguous())
         wk = cfg["cache"].fwd(w_eff, cfg["w_src"]).view(w_eff.shape[0], -1)
         need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
-        train = (need_grad or need_w or need_b) and not cfg["detach"] and b != 1.0
-        if (train or need_w or need_b) and max_out != 1:
-            raise NotImplementedError(
-                "BcosLinear: weight gradients / training-mode gradients are built for max_out == 1 (SURVEY.md section 8(f) "
-                "N4); MaxOut layers support explanation-mode input gradients only")
-        want_scale = bool((need_grad or need_w or need_b) and b != 1.0)
+        need_bp = b_param is not None and ctx.needs_input_grad[4] and _b_gradient_applies(cfg, b)
+        train = (need_grad or need_w or need_b or need_bp) and not cfg["detach"] and b != 1.0
+        want_scale = bool((need_grad or need_w or need_b or need_bp) and b != 1.0)
         Cout_all = w_eff.shape[0]
         argmax = None
         norm = None
-        mo_fused = max_out in (2, 4) and Cout_all % 4 == 0
+        mo_fused = max_out in (2, 4) and Cout_all % 4 == 0 and not train
         if mo_fused:
             rows = x2.shape[0]
             y = torch.empty((rows, Cout_all // max_out), device=x.device, dtype=torch.float32)
-            scale = torch.empty((rows, Cout_all), device=x.device, dtype=torch.float32) if need_grad else None
+            scale = torch.empty((rows, Cout_all), device=x.device, dtype=torch.float32) if (need_grad or need_w or need_b) else None
             g = dict(N=1, H=1, W=rows, C=x2.shape[1], P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
                      TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout_all)
             ops.tapconv(x2, wk, g, out=y, scale_out=scale, bias=bias, bcos_mode=BCOS_NONE if b == 1.0 else BCOS_LINEAR_EPS, b=b,
@@ -308,11 +344,12 @@ class BcosLinearFn(Function):
             ops.tapconv(x2, wk, g, out=lin, norm_out=norm, bias=bias,
                         bcos_mode=BCOS_NONE if b == 1.0 else BCOS_LINEAR_EPS, b=b, flags=BCOS_EPI_NORM_ONLY)
             y, scale, argmax = ops.maxout_scale(lin, norm, Cout_all // max_out, max_out, b, want_scale=want_scale,
-                                                want_argmax=need_grad)
+                                                want_argmax=need_grad or need_w or need_b)
         ctx.cfg = cfg
         ctx.w_eff = w_eff
         ctx.in_shape = tuple(x.shape)
         ctx.train = bool(train)
+        ctx.need_bp = bool(need_bp and train)
         ctx.mo_fused = bool(mo_fused)
         keep_x = x2 if (train or need_w) else None
         keep_y = y if train else None
@@ -336,10 +373,14 @@ class BcosLinearFn(Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
         addend = None
+        gbp = None
         if ctx.train:
             if g2.shape[1] % 4:
                 raise NotImplementedError("training-mode backward needs out_features % 4 == 0")
-            glin, rnorm = ops.train_scale_bwd(g2, y, scale, norm, BCOS_LINEAR_EPS, float(cfg["b"]), bool(cfg.get("force_pow")))
+            glin, rnorm, bgrad = ops.train_scale_bwd(g2, y, scale, norm, BCOS_LINEAR_EPS, float(cfg["b"]),
+                                                     bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
+            if ctx.need_bp:
+                gbp = (bgrad * float(cfg.get("b_chain", 1.0))).view(())
             if need_x:      # gradient through ||x||: x * dL/dnorm / ||x||, added by the dgrad epilogue
                 rows = x2.shape[0]
                 addend = ops.patch_norm_bwd(x2.view(1, 1, rows, x2.shape[1]), rnorm.view(1, 1, rows), Cin, (1, 1), (1, 1), (0, 0), (1, 1))
@@ -347,6 +388,8 @@ class BcosLinearFn(Function):
             glin = ops.maxout_expand(g2, scale, max_out)
         else:
             glin = ops.mul(g2, scale) if scale is not None else g2
+        if argmax is not None:   # MaxOut (general path): route the gradient to the winning filter of each unit
+            glin = ops.maxout_scatter(glin.contiguous(), argmax.view(glin.shape), max_out)
         gw = gb = None
         if need_w or need_b:
             gl4 = _pad_last(glin).contiguous()
@@ -357,17 +400,12 @@ class BcosLinearFn(Function):
             if need_b:
                 gb = ops.colsum(gl4)[:glin.shape[1]].contiguous()
         if not need_x:
-            return None, gw, gb, None
-        if argmax is not None:
-            full = torch.zeros((glin.shape[0], glin.shape[1] * max_out), device=glin.device, dtype=torch.float32)
-            idx = (torch.arange(glin.shape[1], device=glin.device) * max_out) + argmax.long()
-            full.scatter_(1, idx, glin)
-            glin = full
+            return None, gw, gb, None, gbp
         plan = cfg["cache"].dgrad(ctx.w_eff, cfg["w_src"], (1, 1), (0, 0), (1, 1), 1)[0]
         rows = glin.shape[0]
         glin = _pad_last(glin).contiguous()
         gx = plan.run(glin.view(1, 1, rows, glin.shape[1]), 1, rows, addend=addend)      # [1,1,rows,Cin]
-        return gx.view(ctx.in_shape), gw, gb, None
+        return gx.view(ctx.in_shape), gw, gb, None, gbp
 
 
 def plain_conv2d(x, w_eff, bias, stride, padding, dilation, groups, cache, w_src):

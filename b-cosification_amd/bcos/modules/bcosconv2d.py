@@ -35,11 +35,14 @@ class NormedConv2d(nn.Conv2d):
         self._unit_cache = (None, None)
         self._wcache = _hipfn.WeightCache()
 
-    def effective_weight(self) -> Tensor:
+    def effective_weight(self, track_grad: bool = True) -> Tensor:
+        """`track_grad=False` (explanation mode of the enclosing B-cos layer): always the cached, detached projection."""
         w = self.weight
         if not self.use_weight_norm:
             return w
         _hipfn.require_hip(w, "NormedConv2d")
+        if track_grad and _hipfn.wants_projection_grad(self, w, self.scale):       # training step: the projection is part of the graph
+            return _hipfn.UnitNormFn.apply(w, self.scale)
         gain = self.scale.detach().reshape(-1).contiguous() if self.scale is not None else None
         key = (w.data_ptr(), w._version, None if gain is None else (gain.data_ptr(), self.scale._version))
         if self._unit_cache[0] != key:
@@ -124,7 +127,7 @@ class BcosConv2d(DetachableModule):
     def _effective_weight_and_bias(self):
         lin = self.linear
         if isinstance(lin, NormedConv2d):
-            return lin.effective_weight(), lin.bias
+            return lin.effective_weight(track_grad=not self.detach), lin.bias
         if isinstance(lin, nn.Conv2d):
             return lin.weight, lin.bias
         raise TypeError(f"BcosConv2d.linear must be a (Normed)Conv2d, got {type(lin).__name__}")
@@ -141,11 +144,10 @@ class BcosConv2d(DetachableModule):
         if lin.padding_mode != "zeros":
             raise NotImplementedError("only zero padding is implemented by the HIP kernels")
         w, bias = self._effective_weight_and_bias()
-        _hipfn.refuse_unit_norm_training(self, w, lin.weight)
         cfg = dict(stride=tuple(lin.stride), padding=tuple(lin.padding), dilation=tuple(lin.dilation),
                    groups=lin.groups, b=self._b_value(), max_out=self.max_out, detach=self.detach,
                    cache=self._wcache, w_src=lin.weight)
-        return _hipfn.BcosConv2dFn.apply(in_tensor, w, bias, cfg)
+        return _hipfn.BcosConv2dFn.apply(in_tensor, w, bias, cfg, _hipfn.learnable_b(self))
 
     def calc_patch_norms(self, in_tensor: Tensor) -> Tensor:
         """sqrt(sum over each patch of x^2 + 1e-6), [N,1|G,Ho,Wo]  (reference :196-231): the same kernel run

@@ -80,6 +80,13 @@ class BcosifyConv2d(BcosConv2d):
     def _b_value(self) -> float:
         return self._scaling()[0]
 
+    def _b_chain(self) -> float:
+        """d B_eff / d b for a learnable exponent: clamp(b, 1 + 1e-6) passes the gradient where b >= the bound (fp32 compare,
+        like torch.clamp's backward); b + 2 (b_loss) and the plain exponent pass it unchanged."""
+        if self.clamping and not self.b_loss:
+            return 1.0 if self._b_host() >= float(torch.tensor(1.0 + 1e-6, dtype=torch.float32)) else 0.0
+        return 1.0
+
     def forward(self, in_tensor: Tensor) -> Tensor:
         return self.forward_impl(in_tensor)
 
@@ -90,8 +97,8 @@ class BcosifyConv2d(BcosConv2d):
         b, force_pow = self._scaling()
         cfg = dict(stride=tuple(lin.stride), padding=tuple(lin.padding), dilation=tuple(lin.dilation),
                    groups=lin.groups, b=b, max_out=self.max_out, detach=self.detach, cache=self._wcache,
-                   w_src=lin.weight, force_pow=force_pow)
-        return _hipfn.BcosConv2dFn.apply(in_tensor, lin.weight, lin.bias, cfg)
+                   w_src=lin.weight, force_pow=force_pow, b_chain=self._b_chain())
+        return _hipfn.BcosConv2dFn.apply(in_tensor, lin.weight, lin.bias, cfg, _hipfn.learnable_b(self))
 
     @classmethod
     def _from(cls, model_config, weight, bias, **geometry):

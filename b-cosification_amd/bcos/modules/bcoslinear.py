@@ -27,9 +27,12 @@ class NormedLinear(nn.Linear):
         self._unit_cache = (None, None)
         self._wcache = _hipfn.WeightCache()
 
-    def effective_weight(self) -> Tensor:
+    def effective_weight(self, track_grad: bool = True) -> Tensor:
+        """`track_grad=False` (explanation mode of the enclosing B-cos layer): always the cached, detached projection."""
         w = self.weight
         _hipfn.require_hip(w, "NormedLinear")
+        if track_grad and _hipfn.wants_projection_grad(self, w):    # training step: the projection is part of the graph
+            return _hipfn.UnitNormFn.apply(w, None)
         key = (w.data_ptr(), w._version)
         if self._unit_cache[0] != key:
             self._unit_cache = (key, ops.weight_rownorm_scale(w.detach().contiguous(), None))
@@ -70,7 +73,7 @@ class BcosLinear(DetachableModule):
     def _effective_weight_and_bias(self):
         lin = self.linear
         if isinstance(lin, NormedLinear):
-            return lin.effective_weight(), lin.bias
+            return lin.effective_weight(track_grad=not self.detach), lin.bias
         if isinstance(lin, nn.Linear):
             return lin.weight, lin.bias
         raise TypeError(f"BcosLinear.linear must be a (Normed)Linear, got {type(lin).__name__}")
@@ -81,10 +84,9 @@ class BcosLinear(DetachableModule):
 
     def forward(self, in_tensor: Tensor) -> Tensor:
         w, bias = self._effective_weight_and_bias()
-        _hipfn.refuse_unit_norm_training(self, w, self.linear.weight)
         cfg = dict(b=self._b_value(), max_out=self.max_out, detach=self.detach, cache=self._wcache,
                    w_src=self.linear.weight)
-        return _hipfn.BcosLinearFn.apply(in_tensor, w, bias, cfg)
+        return _hipfn.BcosLinearFn.apply(in_tensor, w, bias, cfg, _hipfn.learnable_b(self))
 
     def extra_repr(self) -> str:
         s = f"B={self._b_value():g}"

@@ -77,7 +77,9 @@ SIGNATURES = {
     "bcos_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "bcos_conv2d_dgrad_s1": (C.c_int, [_P, _P, _P] + [_I] * 9 + [_P]),
     "bcos_linear_dgrad": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
-    "bcos_train_scale_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "bcos_train_scale_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "bcos_weight_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _P]),
+    "bcos_maxout_scatter": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "bcos_patch_norm_bwd": (C.c_int, [_P, _P, _P] + [_I] * 15 + [_P]),
     "bcos_conv2d_wgrad": (C.c_int, [_P, _P, _P] + [_I] * 18 + [_P]),
     "bcos_colsum": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),

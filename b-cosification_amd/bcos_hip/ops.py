@@ -131,7 +131,7 @@ class AbsmaxArena:
 
 _ARENA: Optional[AbsmaxArena] = None
 DEFAULT_TRACK_ABSMAX = True    # what tapconv(track_absmax=None) means while the f16x2 contraction is selected (see no_absmax)
-F16X2_MIN_K = 512     # csrc/bcos_tapconv.hip: below this K a launch is HBM-bound and keeps the bf16x3 loop (no operand maxima needed)
+F16X2_MIN_K = int(os.environ.get("BCOS_F16X2_MIN_K", "512"))     # csrc/bcos_tapconv.hip: below this K a launch is HBM-bound and keeps the bf16x3 loop (no operand maxima needed)
 
 
 class no_absmax:
@@ -635,17 +635,42 @@ def channel_affine(x, scale, shift=None, relu=False, out=None):
 
 
 # ---- training-mode backward (csrc/bcos_train.hip) --------------------------------------------
-def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False):
-    """(gy * dy/dlin [rows,C], dL/dnorm / norm-denominator [rows]) of y = s(lin, norm) * lin with s not detached
-    (include/bcos_hip.h: bcos_train_scale_bwd)."""
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False):
+    """(gy * dy/dlin [rows,C], dL/dnorm / norm-denominator [rows], dL/dB_eff [1] or None) of y = s(lin, norm) * lin with s not
+    detached (include/bcos_hip.h: bcos_train_scale_bwd)."""
     lib = _l.load()
     rows, Cc = gy2d.shape
     glin = torch.empty_like(gy2d)
     rnorm = torch.empty((rows,), device=gy2d.device, dtype=torch.float32)
+    bgrad = torch.zeros((1,), device=gy2d.device, dtype=torch.float32) if want_bgrad else None
     _l.check(lib.bcos_train_scale_bwd(_dev(gy2d, "gy"), _dev(y2d, "y"), _dev(s2d, "s"), _dev(norm, "norm"), _dev(glin, "glin"),
-                                      _dev(rnorm, "rnorm"), rows, Cc, int(mode), float(b), int(bool(force_pow)), _stream()),
+                                      _dev(rnorm, "rnorm"), _dev(bgrad, "bgrad"), rows, Cc, int(mode), float(b),
+                                      int(bool(force_pow)), _stream()),
              "bcos_train_scale_bwd")
-    return glin, rnorm
+    return glin, rnorm, bgrad
+
+
+def weight_rownorm_bwd(w2d, g2d, gain=None, want_gw=True, want_ggain=False):
+    """Backward of weight_rownorm_scale: (gw [rows, cols] or None, ggain [rows] or None), include/bcos_hip.h."""
+    lib = _l.load()
+    rows, cols = w2d.shape
+    gw = torch.empty_like(w2d) if want_gw else None
+    gg = torch.empty((rows,), device=w2d.device, dtype=torch.float32) if want_ggain else None
+    _l.check(lib.bcos_weight_rownorm_bwd(_dev(w2d, "w"), _dev(g2d, "g_eff"), _dev(gain, "gain"), _dev(gw, "gw"), _dev(gg, "ggain"),
+                                         rows, cols, _stream()), "bcos_weight_rownorm_bwd")
+    return gw, gg
+
+
+def maxout_scatter(g2d, argmax2d, max_out):
+    """[rows, Cout] gradient w.r.t. the MaxOut units -> [rows, Cout * M]: the value at each unit's winning filter, 0 elsewhere."""
+    lib = _l.load()
+    rows, Cout = g2d.shape
+    full = torch.empty((rows, Cout * max_out), device=g2d.device, dtype=torch.float32)
+    if argmax2d.dtype != torch.int32 or not argmax2d.is_cuda or not argmax2d.is_contiguous():
+        raise BcosHipError("maxout_scatter: argmax must be a contiguous int32 HIP tensor")
+    _l.check(lib.bcos_maxout_scatter(_dev(g2d, "g"), C.c_void_p(argmax2d.data_ptr()), _dev(full, "full"), rows, Cout, int(max_out),
+                                     _stream()), "bcos_maxout_scatter")
+    return full
 
 
 def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation):

@@ -27,45 +27,100 @@ inline int check_launch(const char* what) {
     return BCOS_OK;
 }
 
-// ---- dy/dlin and dL/dnorm of one output pixel: one wavefront per row ---------------------------------------------------
+// ---- dy/dlin and dL/dnorm of one output pixel: one wavefront per row (grid-stride) ---------------------------------------
+// General form: s = c^(B-1), c = q + 1e-6, q = |lin| / norm.  q is rebuilt from lin = y / s (s > 0 in this form) rather than
+// from s^(1/(B-1)): a learnable B starts at 1 + 1e-6 (bcos/training/trainer.py:463), where s is 1 to fp32 precision and
+// carries no information about q.  `bgrad` (optional): dL/dB_eff = sum gy * y * ln c, one atomic per workgroup.
 __global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                         const float* __restrict__ s, const float* __restrict__ norm,
-                                                        float* __restrict__ glin, float* __restrict__ rnorm, int64_t rows, int C,
-                                                        int linear_eps, float b, int pow_form) {
+                                                        float* __restrict__ glin, float* __restrict__ rnorm, float* __restrict__ bgrad,
+                                                        int64_t rows, int C, int linear_eps, float b, int pow_form) {
+    __shared__ float red[4];
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float nrm = norm[row];
+    const int wave = threadIdx.x >> 6;
     const float bm1 = b - 1.0f;
-    const float inv_e = bm1 != 0.f ? 1.0f / bm1 : 0.f;
-    float acc = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-        const int64_t i = row * C + c;
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gy + i);
-        const f32x4 y4 = *reinterpret_cast<const f32x4*>(y + i);
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(s + i);
-        f32x4 o;
+    float bacc = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float nrm = norm[row];
+        float acc = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const int64_t i = row * C + c;
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gy + i);
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(y + i);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(s + i);
+            f32x4 o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (!pow_form) {                       // s = |lin| / norm:  dy/dlin = 2 s,  dy/dnorm = -y / norm
-                o[q] = g4[q] * 2.0f * s4[q];
-                acc = fmaf(g4[q], -y4[q] / nrm, acc);
-            } else {                               // s = (|lin| / norm + 1e-6)^(b-1) = c^(b-1), q = c - 1e-6
-                const float cc = powf(s4[q], inv_e);
-                const float qq = fmaxf(cc - 1e-6f, 0.f);
-                const float ratio = qq / cc;       // (|lin| / norm) / c
-                o[q] = g4[q] * s4[q] * (1.0f + bm1 * ratio);
-                acc = fmaf(g4[q], -bm1 * y4[q] * ratio / nrm, acc);
+            for (int q = 0; q < 4; ++q) {
+                if (!pow_form) {                       // s = |lin| / norm:  dy/dlin = 2 s,  dy/dnorm = -y / norm
+                    o[q] = g4[q] * 2.0f * s4[q];
+                    acc = fmaf(g4[q], -y4[q] / nrm, acc);
+                } else {
+                    const float qq = fabsf(y4[q] / s4[q]) / nrm;       // |lin| / norm
+                    const float cc = qq + 1e-6f;
+                    const float ratio = qq / cc;
+                    o[q] = g4[q] * s4[q] * (1.0f + bm1 * ratio);
+                    acc = fmaf(g4[q], -bm1 * y4[q] * ratio / nrm, acc);
+                    if (bgrad) bacc = fmaf(g4[q] * y4[q], logf(cc), bacc);
+                }
             }
+            *reinterpret_cast<f32x4*>(glin + i) = o;
         }
-        *reinterpret_cast<f32x4*>(glin + i) = o;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            // d norm / d x_j = x_j / ||.||: sqrt(S + 1e-6) differentiates to x / norm, ||x|| + 1e-12 to x / (norm - 1e-12)
+            const float div = linear_eps ? fmaxf(nrm - 1e-12f, 1e-30f) : nrm;
+            rnorm[row] = acc / div;
+        }
+    }
+    if (bgrad) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bacc += __shfl_xor(bacc, o);
+        if (lane == 0) red[wave] = bacc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(bgrad, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// ---- backward of the unit-norm projection w_eff[r,:] = gain[r] * w[r,:] / ||w[r,:]||: one wavefront per row ------------------
+//      gw[r,:] = gain[r] / ||w[r]|| * (g[r,:] - w_hat[r,:] <w_hat[r], g[r]>),   ggain[r] = <w_hat[r], g[r]>
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g,
+                                                          const float* __restrict__ gain, float* __restrict__ gw,
+                                                          float* __restrict__ ggain, int rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* wr = w + (int64_t)row * cols;
+    const float* gr = g + (int64_t)row * cols;
+    float ss = 0.f, dot = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) {
+        ss = fmaf(wr[c], wr[c], ss);
+        dot = fmaf(wr[c], gr[c], dot);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) {
-        // d norm / d x_j = x_j / ||.||: sqrt(S + 1e-6) differentiates to x / norm, ||x|| + 1e-12 to x / (norm - 1e-12)
-        const float div = linear_eps ? fmaxf(nrm - 1e-12f, 1e-30f) : nrm;
-        rnorm[row] = acc / div;
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o);
+        dot += __shfl_xor(dot, o);
+    }
+    const float nrm = sqrtf(ss);
+    const float inv = 1.0f / nrm;
+    const float gn = gain ? gain[row] : 1.0f;
+    const float dh = dot * inv;                     // <w_hat, g>
+    if (gw) {
+        float* o = gw + (int64_t)row * cols;
+        for (int64_t c = lane; c < cols; c += 64) o[c] = gn * inv * (gr[c] - wr[c] * inv * dh);
+    }
+    if (ggain && lane == 0) ggain[row] = dh;
+}
+
+// ---- MaxOut routing by index: full[r, c * M + argmax[r, c]] = g[r, c], zero elsewhere ---------------------------------------
+__global__ __launch_bounds__(256) void maxout_scatter_kernel(const float* __restrict__ g, const int* __restrict__ argmax,
+                                                             float* __restrict__ full, int64_t n, int M) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = g[i];
+        const int a = argmax[i];
+        for (int m = 0; m < M; ++m) full[i * M + m] = m == a ? v : 0.f;
     }
 }
 
@@ -290,16 +345,42 @@ __global__ __launch_bounds__(256) void channel_axpby_kernel(const float* __restr
 }  // namespace
 
 extern "C" int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin,
-                                    float* rnorm, int64_t rows, int C, int bcos_mode, float b, int force_pow, void* stream) {
+                                    float* rnorm, float* bgrad, int64_t rows, int C, int bcos_mode, float b, int force_pow,
+                                    void* stream) {
     if (!gy || !y || !s || !norm || !glin || !rnorm || rows <= 0 || C <= 0 || C % 4 != 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: bad argument (C must be a multiple of 4)");
     if (bcos_mode != BCOS_CONV_EPS && bcos_mode != BCOS_LINEAR_EPS)
         return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: bcos_mode must be BCOS_CONV_EPS or BCOS_LINEAR_EPS");
     if (b == 1.0f) return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: B == 1 has no dynamic scale");
     const int pow_form = (b != 2.0f || force_pow) ? 1 : 0;
-    hipLaunchKernelGGL(scale_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       gy, y, s, norm, glin, rnorm, rows, C, bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b, pow_form);
+    if (bgrad && !pow_form)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: the |lin| / norm form (B == 2 without force_pow) does not depend on B");
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       gy, y, s, norm, glin, rnorm, bgrad, rows, C, bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b, pow_form);
     return check_launch("train_scale_bwd launch");
+}
+
+extern "C" int bcos_weight_rownorm_bwd(const float* w, const float* g_eff, const float* gain, float* gw, float* ggain, int rows,
+                                       int64_t cols, void* stream) {
+    if (!w || !g_eff || (!gw && !ggain) || rows <= 0 || cols <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_weight_rownorm_bwd: bad argument");
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w, g_eff, gain, gw, ggain, rows, cols);
+    return check_launch("weight_rownorm_bwd launch");
+}
+
+extern "C" int bcos_maxout_scatter(const float* g, const int32_t* argmax, float* full, int64_t rows, int Cout, int max_out,
+                                   void* stream) {
+    if (!g || !argmax || !full || rows <= 0 || Cout <= 0 || max_out <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_maxout_scatter: bad argument");
+    const int64_t n = rows * Cout;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxout_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, argmax,
+                       full, n, max_out);
+    return check_launch("maxout_scatter launch");
 }
 
 extern "C" int bcos_patch_norm_bwd(const float* x, const float* rnorm, float* out, int N, int H, int W, int C, int x_pitch,

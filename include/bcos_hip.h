@@ -365,9 +365,23 @@ int bcos_channel_affine(const float* x, const float* scale, const float* shift, 
  *     rnorm[m]  = sum_c gy[m,c] * dy/dnorm / (d norm / d x denominator)
  *                                              B == 2: dy/dnorm = -y / norm   else: -(B-1) y q / ((q + 1e-6) norm)
  *   with the denominator norm (BCOS_CONV_EPS: sqrt(S + 1e-6)) or norm - 1e-12 (BCOS_LINEAR_EPS: ||x|| + 1e-12).
- *   force_pow selects the general form at B == 2 (the b_loss variants, bcosifyconv2d.py:91-98). */
+ *   force_pow selects the general form at B == 2 (the b_loss variants, bcosifyconv2d.py:91-98).
+ *   bgrad (NULL = off; general form only): *bgrad += sum_{m,c} gy y ln(q + 1e-6) = dL/dB_eff, the gradient of a learnable
+ *   exponent (the reference makes `b` an nn.Parameter, bcos/training/trainer.py:451-463; bcosifyconv2d.py:60-65,91-98); the
+ *   caller zeroes it and applies d B_eff / d b (clamping: [b >= 1 + 1e-6]; b_loss: 1). */
 int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin, float* rnorm,
-                         int64_t rows, int C, int bcos_mode, float b, int force_pow, void* stream);
+                         float* bgrad, int64_t rows, int C, int bcos_mode, float b, int force_pow, void* stream);
+
+/* Backward of bcos_weight_rownorm_scale (NormedConv2d / NormedLinear in training mode, bcosconv2d.py:26-35,
+ * bcoslinear.py:25-27): with w_hat = w / ||w|| per row and w_eff = gain * w_hat,
+ *     gw[r,:] = gain[r] / ||w[r]|| * (g_eff[r,:] - w_hat[r,:] <w_hat[r], g_eff[r]>),   ggain[r] = <w_hat[r], g_eff[r]>.
+ * gain NULL = 1; gw or ggain may be NULL. */
+int bcos_weight_rownorm_bwd(const float* w, const float* g_eff, const float* gain, float* gw, float* ggain, int rows,
+                            int64_t cols, void* stream);
+
+/* MaxOut backward by index (training mode): full[r, c * M + argmax[r, c]] = g[r, c], zero at the other filters of the unit
+ * (g [rows, Cout], argmax from bcos_maxout_scale, full [rows, Cout * M]; bcosconv2d.py:166-170). */
+int bcos_maxout_scatter(const float* g, const int32_t* argmax, float* full, int64_t rows, int Cout, int max_out, void* stream);
 
 /* out[n,h,w,c] = x[n,h,w,c] * sum of rnorm[n,i,j] over the output pixels (i,j) whose patch (kernel kh x kw, stride,
  * padding, dilation) contains (h,w): the input gradient through calc_patch_norms (bcosconv2d.py:196-231).  x [N,H,W,x_pitch]

@@ -60,9 +60,14 @@ int main(void) {
     EXPECT(bcos_conv2d_fwd(buf, buf, NULL, buf, NULL, NULL, 1, 8, 4, 4, 8, 3, 3, 0, 1, 1, 1, 1, 1, 2.0f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_conv2d_fwd(NULL, buf, NULL, buf, NULL, NULL, 1, 8, 4, 4, 8, 3, 3, 1, 1, 1, 1, 1, 1, 2.0f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_linear_fwd(buf, NULL, NULL, buf, NULL, NULL, 4, 8, 8, 2.0f, NULL), BCOS_E_INVAL);
-    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, 4, 6, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);
-    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, 4, 8, BCOS_NONE, 2.0f, 0, NULL), BCOS_E_INVAL);
-    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, 4, 8, BCOS_CONV_EPS, 1.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, NULL, 4, 6, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, NULL, 4, 8, BCOS_NONE, 2.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, NULL, 4, 8, BCOS_CONV_EPS, 1.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd(buf, buf, buf, buf, buf, buf, buf, 4, 8, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);   /* bgrad without the pow form */
+    EXPECT(bcos_weight_rownorm_bwd(NULL, buf, NULL, buf, NULL, 4, 8, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_weight_rownorm_bwd(buf, buf, NULL, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);                                /* no output */
+    EXPECT(bcos_maxout_scatter(buf, NULL, buf, 4, 8, 2, NULL), BCOS_E_INVAL);
+    g.out_cgroup = 4; EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.out_cgroup = 0;                         /* Cout != out_sh*out_sw*G */
     EXPECT(bcos_patch_norm_bwd(buf, buf, NULL, 1, 4, 4, 8, 0, 4, 4, 1, 1, 1, 1, 0, 0, 1, 1, NULL), BCOS_E_INVAL);
     EXPECT(bcos_conv2d_wgrad(buf, buf, buf, 1, 4, 4, 8, 6, 4, 4, 8, 0, 1, 1, 1, 1, 0, 0, 1, 1, 0, NULL), BCOS_E_INVAL);
     EXPECT(bcos_colsum(buf, NULL, NULL, NULL, buf, 4, 6, NULL), BCOS_E_INVAL);

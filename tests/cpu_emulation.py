@@ -262,18 +262,38 @@ def maxout_expand(gy2d, t2d, max_out):
 
 
 # ---- training-mode backward (include/bcos_hip.h: bcos_train_scale_bwd ... bcos_channel_axpby) ----------------------------
-def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False):
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False):
     nrm = norm.view(-1, 1)
+    bgrad = None
     if b == 2 and not force_pow:
         glin = gy2d * 2 * s2d
         dnorm = (gy2d * (-y2d / nrm)).sum(1)
     else:
-        c = s2d.pow(1.0 / (b - 1))
-        ratio = (c - 1e-6).clamp(min=0) / c
+        q = (y2d / s2d).abs() / nrm           # |lin| / norm, lin = y / s
+        c = q + 1e-6
+        ratio = q / c
         glin = gy2d * s2d * (1 + (b - 1) * ratio)
         dnorm = (gy2d * (-(b - 1) * y2d * ratio / nrm)).sum(1)
+        if want_bgrad:
+            bgrad = (gy2d.double() * y2d.double() * c.double().log()).sum().float().view(1)
     div = (norm - 1e-12).clamp(min=1e-30) if mode == BCOS_LINEAR_EPS else norm
-    return glin, dnorm / div
+    return glin, dnorm / div, bgrad
+
+
+def weight_rownorm_bwd(w2d, g2d, gain=None, want_gw=True, want_ggain=False):
+    nrm = w2d.norm(dim=1, keepdim=True)
+    what = w2d / nrm
+    dot = (what * g2d).sum(1, keepdim=True)
+    gn = gain.view(-1, 1) if gain is not None else 1.0
+    gw = gn / nrm * (g2d - what * dot) if want_gw else None
+    return gw, (dot.view(-1) if want_ggain else None)
+
+
+def maxout_scatter(g2d, argmax2d, max_out):
+    rows, Cout = g2d.shape
+    full = torch.zeros(rows, Cout, max_out, dtype=g2d.dtype)
+    full.scatter_(2, argmax2d.long().view(rows, Cout, 1), g2d.view(rows, Cout, 1))
+    return full.view(rows, Cout * max_out)
 
 
 def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation):
@@ -324,7 +344,8 @@ def install(monkeypatch):
                  "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
-                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand"):
+                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand",
+                 "weight_rownorm_bwd", "maxout_scatter"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

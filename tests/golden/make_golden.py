@@ -278,6 +278,83 @@ def train_cases():
         json.dump(meta, f, indent=1)
 
 
+# N4, second slice: learnable exponent (b as nn.Parameter: plain / clamping / b_loss), MaxOut in training mode, native
+# unit-norm layers (gradient through the projection, trainable scale)
+TRAIN2_CASES = [
+    # name,            kind,      layer,    b,          clamping, b_loss, max_out, learn_b
+    ("u_lb_conv",      "bcosify", "conv",   1.5,        False,    False,  1,       True),
+    ("u_lb_start",     "bcosify", "conv",   1.0 + 1e-6, False,    False,  1,       True),      # trainer.py:463 start value
+    ("u_lb_clamp_hi",  "bcosify", "conv",   1.7,        True,     False,  1,       True),
+    ("u_lb_clamp_lo",  "bcosify", "conv",   0.6,        True,     False,  1,       True),      # clamped: zero gradient
+    ("u_lb_bloss",     "bcosify", "conv",   -0.3,       False,    True,   1,       True),
+    ("u_lb_bloss0",    "bcosify", "conv",   0.0,        False,    True,   1,       True),      # B_eff = 2 in the pow form
+    ("u_lb_two",       "bcosify", "conv",   2.0,        False,    False,  1,       True),      # |lin| / norm branch: no dependence on b
+    ("u_lb_lin",       "bcosify", "linear", 1.5,        False,    False,  1,       True),
+    ("u_lb_lin_clamp", "bcosify", "linear", 1.3,        True,     False,  1,       True),
+    ("u_lb_lin_bloss", "bcosify", "linear", -0.5,       False,    True,   1,       True),
+    ("u_mo_conv",      "bcosify", "conv",   2.0,        False,    False,  2,       False),
+    ("u_mo_conv_b",    "bcosify", "conv",   1.5,        False,    False,  2,       True),
+    ("u_mo_lin",       "bcosify", "linear", 2.0,        False,    False,  2,       False),
+    ("u_nat_conv",     "native",  "conv",   2.0,        False,    False,  1,       False),
+    ("u_nat_conv_mo",  "native",  "conv",   2.0,        False,    False,  2,       False),
+    ("u_nat_conv_b",   "native",  "conv",   1.5,        False,    False,  1,       True),
+    ("u_nat_lin",      "native",  "linear", 2.0,        False,    False,  1,       False),
+    ("u_nat_lin_mo",   "native",  "linear", 2.0,        False,    False,  2,       False),
+]
+
+
+def train_cases2():
+    out = {}
+    g = torch.Generator().manual_seed(5151)
+    for (name, kind, layer, b, clamping, b_loss, max_out, learn_b) in TRAIN2_CASES:
+        if layer == "conv":
+            cin, cout, k, s_, p_ = 12, 16, 3, 1, 1
+            if kind == "bcosify":
+                mod = R.bcosifyconv2d.BcosifyConv2d(cin, cout, k, s_, p_, b=2, max_out=max_out, clamping=clamping, b_loss=b_loss)
+            else:
+                mod = R.bcos_modules.BcosConv2d(cin, cout, k, s_, p_, b=2, max_out=max_out)
+            x = torch.randn(2, cin, 8, 7, generator=g)
+        else:
+            cin, cout = 40, 24
+            if kind == "bcosify":
+                mod = R.bcosifylinear.BcosifyLinear(cin, cout, b=2, max_out=max_out, clamping=clamping, b_loss=b_loss)
+            else:
+                mod = R.bcos_modules.BcosLinear(cin, cout, b=2, max_out=max_out)
+            x = torch.randn(3, 5, cin, generator=g)
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+        mod.b = nn.Parameter(torch.tensor(b, dtype=torch.float32)) if learn_b else b
+        mod.train()
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        params = [mod.linear.weight] + ([mod.b] if learn_b else [])
+        grads = torch.autograd.grad(y, [xr] + params, gy, allow_unused=True)
+        case = dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=grads[0], gw=grads[1])
+        if learn_b:
+            case["gb_param"] = grads[2] if grads[2] is not None else torch.zeros(())
+            case["gb_param_unused"] = torch.tensor(grads[2] is None)
+        for kk, vv in case.items():
+            out[f"{name}/{kk}"] = vv
+    # NormedConv2d with a trainable scale (set_scale(..., trainable=True), bcosconv2d.py:37-38) inside a native layer
+    mod = R.bcos_modules.BcosConv2d(12, 16, 3, 1, 1, b=2)
+    with torch.no_grad():
+        mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+    mod.linear.set_scale(torch.randn(16, 12, 3, 3, generator=g) * 0.5, trainable=True)
+    mod.train()
+    x = torch.randn(2, 12, 8, 7, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn(y.shape, generator=g)
+    gx, gw, gs = torch.autograd.grad(y, [xr, mod.linear.weight, mod.linear.scale], gy)
+    for kk, vv in dict(x=x, weight=mod.linear.weight.detach(), scale=mod.linear.scale.detach(), y=y.detach(), gy=gy, gx=gx, gw=gw,
+                       gscale=gs).items():
+        out[f"u_nat_scale/{kk}"] = vv
+    np.savez_compressed(os.path.join(HERE, "train_layers2.npz"), **t2n(out))
+    with open(os.path.join(HERE, "train_layers2.json"), "w") as f:
+        json.dump([dict(zip(("name", "kind", "layer", "b", "clamping", "b_loss", "max_out", "learn_b"), c)) for c in TRAIN2_CASES], f, indent=1)
+
+
 # --------------------------------------------------------------------------------------------------------
 # F2-F5: patch norms fast vs slow, BNU fold, add_channels, scale invariance
 # --------------------------------------------------------------------------------------------------------
@@ -665,7 +742,7 @@ def localisation_grid():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "variants", "train", "train_r18", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
+    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -675,6 +752,8 @@ if __name__ == "__main__":
         variant_cases()
     if "train" in which:
         train_cases()
+    if "train2" in which:
+        train_cases2()
     if "train_r18" in which:
         resnet18_training_step()
     if "inv" in which:

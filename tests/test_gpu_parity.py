@@ -97,8 +97,11 @@ def test_training_mode_gradients_against_reference_golden(lib, golden_dir):
     scale differentiated (bcosconv2d.py:176-194 without detach), BatchNormUncentered2d with batch statistics
     (batchnorm_uncentered.py:36-44) -- bcos_train_scale_bwd, bcos_patch_norm_bwd, bcos_conv2d_wgrad (fp32 MFMA),
     bcos_colsum, bcos_channel_axpby -- against gradients recorded from the reference in train mode."""
-    from test_host_cpu import run_training_goldens
+    from test_host_cpu import run_training_goldens, run_training_goldens2
     run_training_goldens(golden_dir, DEV, 1e-5)
+    # second slice: learnable exponent (bcos_train_scale_bwd's bgrad), MaxOut in training mode (bcos_maxout_scatter), native
+    # unit-norm layers (bcos_weight_rownorm_bwd)
+    run_training_goldens2(golden_dir, DEV, 1e-5)
 
 
 def test_resnet18_training_step_against_reference_golden(lib, golden_dir):

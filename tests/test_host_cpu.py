@@ -348,23 +348,67 @@ def run_training_goldens(golden_dir, dev, tol):
         assert int(bn.num_batches_tracked) == 1
 
 
+def run_training_goldens2(golden_dir, dev, tol):
+    """N4, second slice (tests/golden/train_layers2.npz, recorded from the reference in train mode): the gradient of a
+    learnable exponent (`b` an nn.Parameter: plain, clamping, b_loss; trainer.py:451-463), MaxOut layers in training mode,
+    native unit-norm layers (gradient through the projection w / ||w||, trainable NormedConv2d.scale)."""
+    from bcos.modules import BcosConv2d, BcosLinear
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.bcosifylinear import BcosifyLinear
+    data = np.load(os.path.join(golden_dir, "train_layers2.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "train_layers2.json")))
+    t = lambda k: torch.from_numpy(data[k]).to(dev)      # noqa: E731
+    for c in meta:
+        n = c["name"]
+        if c["layer"] == "conv":
+            m = (BcosifyConv2d(12, 16, 3, 1, 1, b=2, max_out=c["max_out"], clamping=c["clamping"], b_loss=c["b_loss"])
+                 if c["kind"] == "bcosify" else BcosConv2d(12, 16, 3, 1, 1, b=2, max_out=c["max_out"]))
+        else:
+            m = (BcosifyLinear(40, 24, b=2, max_out=c["max_out"], clamping=c["clamping"], b_loss=c["b_loss"])
+                 if c["kind"] == "bcosify" else BcosLinear(40, 24, b=2, max_out=c["max_out"]))
+        with torch.no_grad():
+            m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+        m = m.to(dev).train()
+        m.b = nn.Parameter(torch.tensor(c["b"], dtype=torch.float32, device=dev)) if c["learn_b"] else c["b"]
+        x = t(f"{n}/x").requires_grad_(True)
+        y = m(x)
+        params = [m.linear.weight] + ([m.b] if c["learn_b"] else [])
+        grads = torch.autograd.grad(y, [x] + params, t(f"{n}/gy"), allow_unused=True)
+        assert rel(y, data[f"{n}/y"]) <= tol, n
+        assert rel(grads[0], data[f"{n}/gx"]) <= tol, (n, "gx")
+        assert rel(grads[1], data[f"{n}/gw"]) <= tol, (n, "gw")
+        if c["learn_b"]:
+            want = float(data[f"{n}/gb_param"])
+            if bool(data[f"{n}/gb_param_unused"]) or want == 0.0:      # no dependence on b (b == 2 branch) / clamped away
+                assert grads[2] is None or float(grads[2]) == 0.0, (n, grads[2])
+            else:
+                assert abs(float(grads[2]) - want) <= 10 * tol * abs(want), (n, float(grads[2]), want)
+    n = "u_nat_scale"
+    m = BcosConv2d(12, 16, 3, 1, 1, b=2)
+    with torch.no_grad():
+        m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+    m.linear.scale = nn.Parameter(torch.from_numpy(data[f"{n}/scale"]).clone(), requires_grad=True)
+    m = m.to(dev).train()
+    x = t(f"{n}/x").requires_grad_(True)
+    y = m(x)
+    gx, gw, gs = torch.autograd.grad(y, [x, m.linear.weight, m.linear.scale], t(f"{n}/gy"))
+    assert rel(y, data[f"{n}/y"]) <= tol and rel(gx, data[f"{n}/gx"]) <= tol, n
+    assert rel(gw, data[f"{n}/gw"]) <= tol and rel(gs, data[f"{n}/gscale"]) <= tol, n
+
+
 def test_training_mode_gradients_match_reference_golden(monkeypatch, golden_dir):
     cpu_emulation.install(monkeypatch)
     run_training_goldens(golden_dir, "cpu", 2e-6)
+    run_training_goldens2(golden_dir, "cpu", 4e-6)
 
 
 def test_training_mode_refusals(monkeypatch):
-    """What the first slice of N4 does not cover raises instead of training silently without (correct) gradients."""
+    """What N4 does not cover raises instead of training silently without (correct) gradients."""
     cpu_emulation.install(monkeypatch)
-    from bcos.modules import BcosConv2d, BcosLinear
-    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules import BcosConv2d
     x = torch.rand(1, 8, 5, 5, requires_grad=True)
-    with pytest.raises(NotImplementedError, match="max_out == 1"):                   # MaxOut outside explanation mode
-        BcosifyConv2d(8, 4, 3, padding=1, b=2, max_out=2).train()(x)
-    with pytest.raises(NotImplementedError, match="unit-norm"):                      # native layers: weight gradient would
-        BcosConv2d(8, 4, 3, padding=1, b=2).train()(x)                               # have to pass the unit-norm projection
-    with pytest.raises(NotImplementedError, match="unit-norm"):
-        BcosLinear(8, 4).train()(torch.rand(3, 8))
+    with pytest.raises(NotImplementedError, match="groups == 1"):                    # grouped layers outside explanation mode
+        BcosConv2d(8, 4, 3, padding=1, b=2, groups=2).train()(x)
     m = BcosConv2d(8, 4, 3, padding=1, b=2).eval()                                   # eval / explanation mode are unaffected
     m.set_explanation_mode(True)
     (g,) = torch.autograd.grad(m(x).sum(), x)
