@@ -131,7 +131,7 @@ class AbsmaxArena:
 
 _ARENA: Optional[AbsmaxArena] = None
 DEFAULT_TRACK_ABSMAX = True    # what tapconv(track_absmax=None) means while the f16x2 contraction is selected (see no_absmax)
-F16X2_MIN_K = int(os.environ.get("BCOS_F16X2_MIN_K", "512"))     # csrc/bcos_tapconv.hip: below this K a launch is HBM-bound and keeps the bf16x3 loop (no operand maxima needed)
+F16X2_MIN_K = int(os.environ.get("BCOS_F16X2_MIN_K", "256"))     # below this K a launch keeps the bf16x3 loop (no operand maxima needed); same-node A/B on ResNet-50: 512 -> 256 = -0.4 ms per step (the K = 256 layers at 14^2 spend a third of their SIMD cycles on the 6 bf16 products), 128 and 64: no further gain
 
 
 class no_absmax:

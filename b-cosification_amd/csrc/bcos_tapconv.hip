@@ -2031,9 +2031,10 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         p.wt3 = (p.x3 && wt3 && w3b < lim && !(reinterpret_cast<uintptr_t>(wt3) & 15)) ? wt3 : nullptr;
         p.wt3_bytes = (unsigned)(w3b < lim ? w3b : 0);
         const int64_t w2b = h2_image_bytes(g.Cout, p.Ktot), pixb = (int64_t)g.N * g.H * g.W * 4;
-        // below K = 512 a launch is HBM-bound: the leaner bf16x3 loop is as fast there, unless the caller insists on f16x2
-        // (the stem's K is all taps over 8 channels: compute-bound at any K)
-        const bool h2_pays = p.Ktot >= 512 || (g.C <= 16 && p.Ktot >= 128) || ops->contraction == BCOS_CONTRACT_F16X2;
+        // below K = 256 a launch is HBM-bound and the bf16x3 loop (no operand maxima to produce) is as fast, unless the caller
+        // insists on f16x2; at K = 256 the six bf16 products still occupy a third of the SIMD cycles (14^2 layers of ResNet-50:
+        // -12 % per launch with three f16 products).  The stem's K is all taps over 8 channels: compute-bound at any K.
+        const bool h2_pays = p.Ktot >= 256 || (g.C <= 16 && p.Ktot >= 128) || ops->contraction == BCOS_CONTRACT_F16X2;
         if (mode == 2 && h2_pays && p.x3 && ops->a_absmax && ops->wt_f16x2 && w2b < lim && pixb < lim &&
             !(reinterpret_cast<uintptr_t>(ops->wt_f16x2) & 15)) {
             p.h2 = 1;

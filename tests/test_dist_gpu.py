@@ -30,6 +30,10 @@ def _launch(config, n_global, tmp_path, world=WORLD, timeout=1500):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "dist_gpu_worker.py"), config, str(n_global), str(out)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    if proc.returncode != 0 and ("address already in use" in (proc.stdout + proc.stderr).lower() or "EADDRINUSE" in proc.stderr):
+        # the probed rendezvous port was taken between the probe and torchrun's bind: once more on a fresh port
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     return json.load(open(out))
 
