@@ -62,3 +62,32 @@ def test_attn_unpool_outputs_gather_along_batch_dim(tmp_path):
     v = _launch("unpool", 19, tmp_path, world=4)                  # ragged: 5 + 5 + 5 + 4 images
     assert v["gathered_shape"][1] == 19 and v["shards"] == [[0, 5], [5, 10], [10, 15], [15, 19]]
     assert v["sharded_equals_unsharded"] and v["rel_vs_oracle"] <= 1e-5, v
+
+
+@pytest.mark.gpu
+def test_rccl_backend_calls_single_rank(tmp_path):
+    """The collectives the product issues for N > 1 -- asynchronous all_gather_into_tensor on a flat fp32 buffer
+    (OverlappedGather), asynchronous all_reduce SUM (allreduce_gradients), barrier, all_reduce MAX on a float64 scalar
+    (bench.py's max-over-ranks timing) -- run through the "nccl" (= RCCL) backend in a fresh child process.  A 1-GPU box
+    gives world size 1: this checks that RCCL initialises in this environment and accepts exactly these calls and dtypes,
+    not the xGMI transport."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[1])
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+send = torch.arange(1000, device="cuda", dtype=torch.float32)
+recv = torch.empty((1, 1000), device="cuda", dtype=torch.float32)
+w = dist.all_gather_into_tensor(recv.view(-1), send, async_op=True); w.wait()
+assert torch.equal(recv[0], send)
+g = torch.ones(1 << 20, device="cuda"); w = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True); w.wait()
+assert float(g.sum()) == float(1 << 20)
+t = torch.tensor([1.25], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier(); torch.cuda.synchronize()
+assert float(t) == 1.25
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-c", code, str(_free_port())], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "rccl ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]
