@@ -133,8 +133,17 @@ class BcosConv2d(DetachableModule):
         raise TypeError(f"BcosConv2d.linear must be a (Normed)Conv2d, got {type(lin).__name__}")
 
     def _b_value(self) -> float:
+        """self.b as a host float; a tensor / Parameter B (trainer.py:463) is read back once per in-place version instead of
+        forcing a device sync in every forward."""
         b = self.b
-        return float(b.detach().item()) if isinstance(b, torch.Tensor) else float(b)
+        if not isinstance(b, torch.Tensor):
+            return float(b)
+        key = (b.data_ptr(), b._version)
+        cached = getattr(self, "_b_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, float(b.detach().item()))
+            object.__setattr__(self, "_b_cache", cached)
+        return cached[1]
 
     def forward(self, in_tensor: Tensor) -> Tensor:
         return self.forward_impl(in_tensor)

@@ -49,7 +49,7 @@ DTYPES = {
     "f32": "f32",
     "bf16x3": "f32 (contraction: exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products, fp32 accumulate)",
     "f16x2": "f32 (contraction: row-scaled 2-way fp16 split of the fp32 operands, 3 f16 MFMA products, fp32 accumulate; "
-             "launches without operand maxima or with K < 512 use the exact 3-way bf16 split)",
+             "launches without operand maxima or with K < 256 use the exact 3-way bf16 split)",
 }
 
 
