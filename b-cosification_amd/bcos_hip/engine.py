@@ -293,7 +293,7 @@ class ResNetEngine:
         add_inverse = x.shape[1] == 3
         self._absmax_arena.reset(x.device)
         ops.set_absmax_arena(self._absmax_arena)
-        xn = ops.ensure_absmax(ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse))
+        xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse, want_absmax=True)
         gates = list(gates) if gates is not None else None
         st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3], stem_ts=[], stem_hws=[], blocks=[]) if keep else None
         a = xn
@@ -482,9 +482,8 @@ class ResNetEngine:
                     # the pool's input gradient times the scale of conv(ci-1)
                     gp = convs[ci].dgrad.run(gl, h, w, track_absmax=False)
                     ph, pw = rec["pre_pool_hw"]
-                    gl = ops.avgpool2d_bwd(gp, ph, pw, blk.pool, blk.pool, 0, mul=rec["ts"][ci - 1])
-                    if convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K:
-                        ops.ensure_absmax(gl)
+                    gl = ops.avgpool2d_bwd(gp, ph, pw, blk.pool, blk.pool, 0, mul=rec["ts"][ci - 1],
+                                           want_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K)
                 else:
                     gl = convs[ci].dgrad.run(gl, h, w, track_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K,
                                              **_mul_kwargs(rec["ts"][ci - 1]))
@@ -497,9 +496,7 @@ class ResNetEngine:
         k, s, p = self.pool
         a_h, a_w = st["a0_hw"]
         ts = st["stem_ts"]
-        gl = ops.avgpool2d_bwd(g_pool, a_h, a_w, k, s, p, mul=ts[-1])
-        if self.stem[-1][0].k_dgrad >= ops.F16X2_MIN_K:
-            ops.ensure_absmax(gl)
+        gl = ops.avgpool2d_bwd(g_pool, a_h, a_w, k, s, p, mul=ts[-1], want_absmax=self.stem[-1][0].k_dgrad >= ops.F16X2_MIN_K)
         if consume:
             ts[-1] = None
         for si in range(len(self.stem) - 1, 0, -1):

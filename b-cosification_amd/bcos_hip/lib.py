@@ -88,11 +88,11 @@ SIGNATURES = {
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_maxout_scale": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     "bcos_maxout_expand": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
-    "bcos_prep_input": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bcos_prep_input": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bcos_finalize_explanation": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bcos_contrib_map": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "bcos_avgpool2d_fwd": (C.c_int, [_P, _P] + [_I] * 9 + [_P]),
-    "bcos_avgpool2d_bwd": (C.c_int, [_P, _P, _P] + [_I] * 9 + [_P]),
+    "bcos_avgpool2d_bwd": (C.c_int, [_P, _P, _P, _P] + [_I] * 9 + [_P]),
     "bcos_global_avgpool_logits": (C.c_int, [_P, _P, _I, _I, _I, _F, _F, _P]),
     "bcos_head_onehot_grad": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "bcos_argmax_rows": (C.c_int, [_P, _P, _P, _I, _I, _P]),

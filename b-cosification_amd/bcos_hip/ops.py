@@ -543,11 +543,24 @@ def maxout_scale(lin2d, norm, Cout, max_out, b, groups=1, want_scale=False, want
     return y, scale, arg
 
 
-def prep_input(x_nchw, mean6, std6, cpad=8, add_inverse=False):
+def _fused_absmax(t: torch.Tensor, want: bool):
+    """side tensor for a kernel that can emit the per-pixel maxima of its output `t` itself (f16x2 contraction only)"""
+    if not want or _l.get_contraction_mode() != "f16x2":
+        return None
+    am = _new_absmax(t.numel() // t.shape[-1], t.device)
+    _attach_absmax(t, am)
+    return am
+
+
+def prep_input(x_nchw, mean6, std6, cpad=8, add_inverse=False, want_absmax=False):
+    """`want_absmax`: the kernel also emits the per-pixel maxima of its output (what ensure_absmax would compute in a second
+    pass) for the f16x2 contraction that reads it."""
     lib = _l.load()
     N, Cx, H, W = x_nchw.shape
     out = torch.empty((N, H, W, cpad), device=x_nchw.device, dtype=torch.float32)
-    _l.check(lib.bcos_prep_input(_dev(x_nchw, "x"), _dev(out, "out"), _dev(mean6, "mean"), _dev(std6, "std"), N, Cx, H, W,
+    am = _fused_absmax(out, want_absmax)
+    _l.check(lib.bcos_prep_input(_dev(x_nchw, "x"), _dev(out, "out"), _dev(mean6, "mean"), _dev(std6, "std"),
+                                 C.c_void_p(am.data_ptr()) if am is not None else None, N, Cx, H, W,
                                  cpad, int(add_inverse), _stream()), "bcos_prep_input")
     return out
 
@@ -582,13 +595,20 @@ def avgpool2d_fwd(x, k, s, p, out=None):
     return y
 
 
-def avgpool2d_bwd(gy, H, W, k, s, p, mul=None, out=None):
+def avgpool2d_bwd(gy, H, W, k, s, p, mul=None, out=None, want_absmax=False):
+    """`want_absmax`: also emit the per-pixel maxima of the result (channel counts whose C / 4 is a power of two <= 64; other
+    widths fall back to the separate pass of ensure_absmax)."""
     lib = _l.load()
     N, OH, OW, Cc = gy.shape
     if out is None:
         out = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
-    _l.check(lib.bcos_avgpool2d_bwd(_dev(gy, "gy"), _dev(mul, "mul"), _dev(out, "gx"), N, H, W, Cc, k, s, p, OH, OW, _stream()),
-             "bcos_avgpool2d_bwd")
+    c4 = Cc // 4
+    fused = want_absmax and Cc % 4 == 0 and c4 <= 64 and (c4 & (c4 - 1)) == 0
+    am = _fused_absmax(out, fused)
+    _l.check(lib.bcos_avgpool2d_bwd(_dev(gy, "gy"), _dev(mul, "mul"), _dev(out, "gx"), C.c_void_p(am.data_ptr()) if am is not None else None,
+                                    N, H, W, Cc, k, s, p, OH, OW, _stream()), "bcos_avgpool2d_bwd")
+    if want_absmax and am is None:
+        ensure_absmax(out)
     return out
 
 

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(TPB) void maxout_scale_kernel(const float* __restri
 // ---- network input: AddInverse + Normalize + NCHW -> NHWC (padded) -----------------------------
 __global__ __launch_bounds__(TPB) void prep_input_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                          const float* __restrict__ mean6,
-                                                         const float* __restrict__ std6, int N, int Cx, int HW,
-                                                         int Cpad, int add_inverse) {
+                                                         const float* __restrict__ std6, unsigned* __restrict__ absmax,
+                                                         int N, int Cx, int HW, int Cpad, int add_inverse) {
     const int64_t total = (int64_t)N * HW;
     const int64_t stride = (int64_t)gridDim.x * TPB;
     float mu[6], sd[6];
@@ -120,9 +120,15 @@ __global__ __launch_bounds__(TPB) void prep_input_kernel(const float* __restrict
             for (int c = 0; c < 6; ++c) v[c] = src[(int64_t)c * HW];
         }
         float* dst = out + i * Cpad;
+        unsigned m = 0u;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) dst[c] = (v[c] - mu[c]) / sd[c];
+        for (int c = 0; c < 6; ++c) {
+            const float o = (v[c] - mu[c]) / sd[c];
+            dst[c] = o;
+            m = max(m, __float_as_uint(o) & 0x7fffffffu);
+        }
         for (int c = 6; c < Cpad; ++c) dst[c] = 0.f;
+        if (absmax) absmax[i] = m;          // per-pixel max |value| bit pattern (operand scale source of the f16x2 contraction)
     }
 }
 
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(TPB) void avgpool_fwd_kernel(const float* __restric
 // One workgroup per input row (n, h): 32-bit index arithmetic only (the flat 64-bit div/mod version was ALU-bound at
 // 3.2 TB/s on the stem's 822 MB gradient).
 __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mul,
-                                                          float* __restrict__ gx, int N, int H, int W, int C4,
-                                                          int k, int s, int p, int OH, int OW) {
+                                                          float* __restrict__ gx, unsigned* __restrict__ absmax, int N, int H, int W,
+                                                          int C4, int k, int s, int p, int OH, int OW) {
     const int n = blockIdx.x / H, h = blockIdx.x - n * H;
     // windows oh with oh*s - p <= h < oh*s - p + k
     int oh_lo = (h + p - k + s) / s;      // ceil((h+p-k+1)/s) for non-negative numerator
@@ -206,24 +212,35 @@ __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restric
     const int oh_hi = min((h + p) / s, OH - 1);
     const int64_t row = ((int64_t)n * H + h) * W * C4;
     const f32x4* gy4 = reinterpret_cast<const f32x4*>(gy) + (int64_t)n * OH * OW * C4;
-    for (int i = threadIdx.x; i < W * C4; i += TPB) {
-        const int w = i / C4, c4 = i - w * C4;
+    // (every lane runs every trip: the per-pixel maxima below are reduced across the C4 lanes of a pixel by shuffles)
+    for (int i0 = 0; i0 < W * C4; i0 += TPB) {
+        const int i = i0 + threadIdx.x;
+        const bool live = i < W * C4;
+        const int w = live ? i / C4 : 0, c4 = live ? i - w * C4 : 0;
         int ow_lo = (w + p - k + s) / s;
         if (w + p - k + 1 <= 0) ow_lo = 0;
         const int ow_hi = min((w + p) / s, OW - 1);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-            const int hs = oh * s - p;
-            const int he = min(hs + k, H + p);
-            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                const int ws = ow * s - p;
-                const int we = min(ws + k, W + p);
-                const float pool = (float)((he - hs) * (we - ws));
-                acc += gy4[(oh * OW + ow) * C4 + c4] / pool;
+        if (live) {
+            for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+                const int hs = oh * s - p;
+                const int he = min(hs + k, H + p);
+                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                    const int ws = ow * s - p;
+                    const int we = min(ws + k, W + p);
+                    const float pool = (float)((he - hs) * (we - ws));
+                    acc += gy4[(oh * OW + ow) * C4 + c4] / pool;
+                }
             }
+            if (mul) acc *= reinterpret_cast<const f32x4*>(mul)[row + i];
+            reinterpret_cast<f32x4*>(gx)[row + i] = acc;
         }
-        if (mul) acc *= reinterpret_cast<const f32x4*>(mul)[row + i];
-        reinterpret_cast<f32x4*>(gx)[row + i] = acc;
+        if (absmax) {      // C4 is a power of two <= 64 (host): the C4 lanes of a pixel are an aligned lane group
+            unsigned m = max(max(__float_as_uint(acc[0]) & 0x7fffffffu, __float_as_uint(acc[1]) & 0x7fffffffu),
+                             max(__float_as_uint(acc[2]) & 0x7fffffffu, __float_as_uint(acc[3]) & 0x7fffffffu));
+            for (int o = C4 >> 1; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            if (live && c4 == 0) absmax[((int64_t)n * H + h) * W + w] = m;
+        }
     }
 }
 
@@ -356,13 +373,13 @@ extern "C" int bcos_maxout_scale(const float* lin, const float* norm, float* y, 
     return check_launch("maxout_scale_kernel");
 }
 
-extern "C" int bcos_prep_input(const float* x, float* out, const float* mean6, const float* std6, int N, int Cx,
-                               int H, int W, int Cpad, int add_inverse, void* stream) {
+extern "C" int bcos_prep_input(const float* x, float* out, const float* mean6, const float* std6, uint32_t* absmax_out, int N,
+                               int Cx, int H, int W, int Cpad, int add_inverse, void* stream) {
     if (!x || !out || !mean6 || !std6 || N <= 0 || H <= 0 || W <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: bad argument");
     if (Cx != (add_inverse ? 3 : 6)) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: Cx must be 3 (add_inverse) or 6");
     if (Cpad < 6) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: Cpad < 6");
     hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), x, out,
-                       mean6, std6, N, Cx, H * W, Cpad, add_inverse);
+                       mean6, std6, absmax_out, N, Cx, H * W, Cpad, add_inverse);
     return check_launch("prep_input_kernel");
 }
 
@@ -397,13 +414,15 @@ extern "C" int bcos_avgpool2d_fwd(const float* x, float* y, int N, int H, int W,
     return check_launch("avgpool_fwd_kernel");
 }
 
-extern "C" int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, int N, int H, int W, int C, int k,
-                                  int s, int p, int OH, int OW, void* stream) {
+extern "C" int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, uint32_t* absmax_out, int N, int H, int W, int C,
+                                  int k, int s, int p, int OH, int OW, void* stream) {
     if (!gy || !gx || !pool_args_ok(N, H, W, C, k, s, p, OH, OW)) return bcos_set_error(BCOS_E_INVAL, "bcos_avgpool2d_bwd: bad argument");
     if ((int64_t)N * H >= ((int64_t)1 << 31) || (int64_t)OH * OW * (C / 4) >= ((int64_t)1 << 31))
         return bcos_set_error(BCOS_E_NOSUP, "bcos_avgpool2d_bwd: tensor too large");
+    if (absmax_out && (C / 4 > 64 || ((C / 4) & (C / 4 - 1)) != 0))
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_avgpool2d_bwd: absmax_out needs C / 4 to be a power of two <= 64");
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)(N * H)), dim3(TPB), 0, STREAM(stream), gy,
-                       mul, gx, N, H, W, C / 4, k, s, p, OH, OW);
+                       mul, gx, absmax_out, N, H, W, C / 4, k, s, p, OH, OW);
     return check_launch("avgpool_bwd_kernel");
 }
 

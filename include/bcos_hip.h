@@ -308,8 +308,10 @@ int bcos_maxout_scale(const float* lin, const float* norm, float* y, float* scal
  * Network input: AddInverse (bcos/data/transforms.py:54-55, if add_inverse) + the 6-channel
  * Normalize of BcosifyNetwork (bcosify.py:38-43) + NCHW -> NHWC with channel padding.
  * x: [N,Cx,H,W] NCHW with Cx = 3 (add_inverse) or 6; out: [N,H,W,Cpad], channels >= 6 zero.
+ * absmax_out (NULL or [N*H*W]): per-pixel max |out| bit patterns, the operand-scale side tensor of the f16x2
+ * contraction (see bcos_operands.a_absmax) -- saves the separate bcos_rows_absmax pass over the tensor.
  */
-int bcos_prep_input(const float* x, float* out, const float* mean6, const float* std6,
+int bcos_prep_input(const float* x, float* out, const float* mean6, const float* std6, uint32_t* absmax_out,
                     int N, int Cx, int H, int W, int Cpad, int add_inverse, void* stream);
 
 /*
@@ -332,8 +334,9 @@ int bcos_contrib_map(const float* x, const float* gx, float* out,
  * nn.AvgPool2d(3,2,1): bcosification/experiment_parameters.py:99), NHWC. */
 int bcos_avgpool2d_fwd(const float* x, float* y, int N, int H, int W, int C,
                        int k, int s, int p, int OH, int OW, void* stream);
-/* ... its input gradient, optionally multiplied elementwise by `mul` ([N,H,W,C]). */
-int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, int N, int H, int W, int C,
+/* ... its input gradient, optionally multiplied elementwise by `mul` ([N,H,W,C]); absmax_out (NULL or [N*H*W], needs
+ * C / 4 a power of two <= 64): per-pixel max |gx| bit patterns for the f16x2 contraction that reads gx. */
+int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, uint32_t* absmax_out, int N, int H, int W, int C,
                        int k, int s, int p, int OH, int OW, void* stream);
 
 /* AdaptiveAvgPool2d(1) + flatten + LogitLayer (bcos/modules/logitlayer.py:22-27):

@@ -139,7 +139,7 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
         no[:, oh[:, None], ow[None, :], 0] = nrm.to(no.dtype)
 
 
-def prep_input(x, mean6, std6, cpad=8, add_inverse=False):
+def prep_input(x, mean6, std6, cpad=8, add_inverse=False, want_absmax=False):
     if add_inverse:
         x = torch.cat([x, 1 - x], 1)
     xn = (x - mean6.view(1, 6, 1, 1)) / std6.view(1, 6, 1, 1)
@@ -161,7 +161,7 @@ def avgpool2d_fwd(x, k, s, p, out=None):
     return y
 
 
-def avgpool2d_bwd(gy, H, W, k, s, p, mul=None, out=None):
+def avgpool2d_bwd(gy, H, W, k, s, p, mul=None, out=None, want_absmax=False):
     with torch.enable_grad():
         x = torch.zeros(gy.shape[0], gy.shape[3], H, W, requires_grad=True)
         y = F.avg_pool2d(x, k, s, p)

@@ -264,8 +264,11 @@ def test_streaming_kernels(lib):
     assert rel(xn[..., :6].permute(0, 3, 1, 2), O.normalize6(x, mean.tolist(), std.tolist())) <= 1e-7
     assert float(xn[..., 6:].abs().max()) == 0.0
     x3 = x[:, :3].contiguous()
-    xn3 = ops.prep_input(x3.to(DEV), mean.to(DEV), std.to(DEV), cpad=8, add_inverse=True)
+    xn3 = ops.prep_input(x3.to(DEV), mean.to(DEV), std.to(DEV), cpad=8, add_inverse=True, want_absmax=True)
     assert rel(xn3[..., :6].permute(0, 3, 1, 2), O.normalize6(O.add_inverse(x3), mean.tolist(), std.tolist())) <= 1e-7
+    from bcos_hip import lib as blib
+    if blib.get_contraction_mode() == "f16x2":          # the per-pixel maxima emitted alongside are exact
+        assert torch.equal(ops.absmax_of(xn3), xn3.abs().amax(dim=-1).reshape(-1).view(torch.int32))
     gxn = torch.randn(3, 20, 18, 8, generator=g)
     wts, contrib = ops.finalize_explanation(gxn.to(DEV), x.to(DEV), std.to(DEV))
     w_ref = gxn[..., :6].permute(0, 3, 1, 2) / std.view(1, 6, 1, 1)
@@ -280,8 +283,15 @@ def test_streaming_kernels(lib):
         y = ops.avgpool2d_fwd(a.permute(0, 2, 3, 1).contiguous().to(DEV), k, s, p)
         assert rel(y.permute(0, 3, 1, 2), pr) <= 1e-6
         m = torch.randn(2, 13, 12, 64, generator=g)
-        gx = ops.avgpool2d_bwd(gp.permute(0, 2, 3, 1).contiguous().to(DEV), 13, 12, k, s, p, mul=m.to(DEV))
+        gx = ops.avgpool2d_bwd(gp.permute(0, 2, 3, 1).contiguous().to(DEV), 13, 12, k, s, p, mul=m.to(DEV), want_absmax=True)
         assert rel(gx, ga.permute(0, 2, 3, 1) * m) <= 1e-6
+        if blib.get_contraction_mode() == "f16x2":
+            assert torch.equal(ops.absmax_of(gx), gx.abs().amax(dim=-1).reshape(-1).view(torch.int32))
+    for Cw in (8, 24):          # narrow / non-power-of-two widths: fused for 8 (2 lanes per pixel), separate pass for 24
+        gp = torch.randn(2, 7, 6, Cw, generator=g).to(DEV)
+        gx = ops.avgpool2d_bwd(gp, 13, 12, 3, 2, 1, want_absmax=True)
+        if blib.get_contraction_mode() == "f16x2":
+            assert torch.equal(ops.absmax_of(gx), gx.abs().amax(dim=-1).reshape(-1).view(torch.int32))
     f = torch.randn(4, 7, 7, 1000, generator=g)
     lg = ops.global_avgpool_logits(f.to(DEV), None, -math.log(999))
     assert rel(lg, f.mean((1, 2)) - math.log(999)) <= 1e-6
