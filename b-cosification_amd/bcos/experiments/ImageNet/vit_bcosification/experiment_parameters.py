@@ -12,10 +12,10 @@ __all__ = ["CONFIGS", "SIMPLE_VIT_ARCHS"]
 
 NUM_CLASSES = 1000
 SEEDS = (5, 420, 1337)
-# The reference table also lists the conv-stem ViTs (vitc_{ti,s,b,l}_patch1_14).  They need DetachableGroupNorm2d and
-# conv stems, which SURVEY.md section 2 places outside the hot path, so no experiment names are generated for them.
+# plain and conv-stem SimpleViTs, as in the reference table (the conv stems run on BcosifyConv2d + DetachableGroupNorm2d)
 SIMPLE_VIT_ARCHS = ["simple_vit_ti_patch16_224", "simple_vit_s_patch16_224", "simple_vit_b_patch16_224",
-                    "simple_vit_l_patch16_224"]
+                    "simple_vit_l_patch16_224", "vitc_ti_patch1_14", "vitc_s_patch1_14", "vitc_b_patch1_14",
+                    "vitc_l_patch1_14"]
 
 
 def _model(arch: str, weight: str, use_bias: bool, gelu: bool, gap_reorder: bool) -> dict:

@@ -13,7 +13,9 @@ __all__ = ["get_model"]
 def get_model(model_config):
     arch_name = model_config["name"]
     args = model_config["args"]
+    # (the conv-stem archs take nn.Conv2d + a one-group nn.GroupNorm, the standard counterpart of DetachableGNLayerNorm2d)
     model = getattr(vit, arch_name)(channels=3, linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
+                                    conv2d_layer=nn.Conv2d, norm2d_layer=lambda c: nn.GroupNorm(1, c),
                                     num_classes=args.get("num_classes", 1000))
     if model_config.get("state_dict") is not None:
         model.load_state_dict(model_config["state_dict"])

@@ -19,7 +19,8 @@ from bcos.modules.common import DetachableModule
 from bcos_hip import ops
 
 __all__ = ["SimpleViT", "Attention", "PosEmbSinCos2d", "simple_vit_ti_patch16_224", "simple_vit_s_patch16_224",
-           "simple_vit_b_patch16_224", "simple_vit_l_patch16_224"]
+           "simple_vit_b_patch16_224", "simple_vit_l_patch16_224", "vitc_ti_patch1_14", "vitc_s_patch1_14",
+           "vitc_b_patch1_14", "vitc_l_patch1_14", "make_conv_stem"]
 
 
 def pair(t: Any) -> Tuple[Any, Any]:
@@ -147,13 +148,16 @@ class SimpleViT(nn.Module):
         patch_height, patch_width = pair(patch_size)
         assert linear_layer is not None and norm_layer is not None and act_layer is not None
         if conv_stem:
-            raise NotImplementedError("conv-stem ViTs (vitc_*) are outside the MI355X hot path")
+            assert conv2d_layer is not None, "Provide a conv2d layer class when using conv_stem!"
+            assert norm2d_layer is not None, "Provide a norm2d layer class when using conv_stem!"
         assert image_height % patch_height == 0 and image_width % patch_width == 0, \
             "Image dimensions must be divisible by the patch size."
         self.image_size, self.patch_size = (image_height, image_width), (patch_height, patch_width)
         self.num_patches = (image_height // patch_height) * (image_width // patch_width)
-        self.patch_dim = channels * patch_height * patch_width
-        self.to_patch_embedding = nn.Sequential(OrderedDict(rearrage=PatchRearrange(patch_height, patch_width),
+        self.patch_dim = (channels if not conv_stem else conv_stem[-1]) * patch_height * patch_width
+        stem = OrderedDict(conv_stem=make_conv_stem(channels, conv_stem, conv2d_layer, norm2d_layer, act_layer)) if conv_stem \
+            else OrderedDict()
+        self.to_patch_embedding = nn.Sequential(OrderedDict(**stem, rearrage=PatchRearrange(patch_height, patch_width),
                                                             linear=linear_layer(self.patch_dim, dim)))
         self.positional_embedding = PosEmbSinCos2d()
         dim_head = dim // heads
@@ -171,6 +175,40 @@ class SimpleViT(nn.Module):
         if self.gap_reorder:
             return self.linear_head(self.to_latent(x)).mean(dim=1)
         return self.linear_head(self.to_latent(x.mean(dim=1)))
+
+
+def make_conv_stem(in_channels: int, out_channels: List[int], conv2d_layer=None, norm2d_layer=None, act_layer=None):
+    """conv 3x3 (stride 2 whenever the width grows) + 2-D norm + activation per entry ("Early convolutions help
+    transformers see better"; reference :342-365)."""
+    layers = []
+    for outc in out_channels:
+        layers += [conv2d_layer(in_channels, outc, kernel_size=3, stride=(2 if outc > in_channels else 1), padding=1),
+                   norm2d_layer(outc), act_layer()]
+        in_channels = outc
+    return nn.Sequential(*layers)
+
+
+def _vitc(dim, depth, heads, mlp_dim, conv_stem, **kwargs):
+    """conv-stem ViTs: the stem takes 224 x 224 images to a 14 x 14 map that is tokenised with patch size 1; depth is one
+    block less than the plain model's (reference :368-426)."""
+    kwargs.setdefault("num_classes", 1_000)
+    return SimpleViT(image_size=14, patch_size=1, dim=dim, depth=depth, heads=heads, mlp_dim=mlp_dim, conv_stem=conv_stem, **kwargs)
+
+
+def vitc_ti_patch1_14(**kwargs):
+    return _vitc(192, 11, 3, 768, [24, 48, 96, 192], **kwargs)
+
+
+def vitc_s_patch1_14(**kwargs):
+    return _vitc(384, 11, 6, 1536, [48, 96, 192, 384], **kwargs)
+
+
+def vitc_b_patch1_14(**kwargs):
+    return _vitc(768, 11, 12, 3072, [64, 128, 128, 256, 256, 512], **kwargs)
+
+
+def vitc_l_patch1_14(**kwargs):
+    return _vitc(1024, 13, 16, 4096, [64, 128, 128, 256, 256, 512], **kwargs)
 
 
 def _simple_vit(dim, depth, heads, mlp_dim, **kwargs):

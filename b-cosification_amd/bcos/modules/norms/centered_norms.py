@@ -4,8 +4,8 @@ Reference: bcos/modules/norms/centered_norms.py -- `DetachableLayerNorm` :187-24
 (SURVEY.md a10).  In explanation mode its variance is a constant while the mean stays differentiable, so
     y = w (x - mean(x)) / std (+ b),    d y / d x  applied to g:   h - mean(h),  h = g w / std.
 Forward and that input gradient are one-wavefront-per-row HIP kernels (bcos_layernorm_fwd / _bwd_detached).
-The 2-D group-norm variants (`DetachableGroupNorm2d`, ViT-C conv stems only) are not part of any benchmarked
-configuration and are declared but not implemented.
+The 2-D group-norm variants (`DetachableGroupNorm2d` :93-160 and its instance / layer-norm forms: the conv stems of the
+ViT-C models) follow the same rule per (image, group) on NHWC data (bcos_groupnorm_fwd / _bwd_detached).
 """
 import torch
 import torch.nn as nn
@@ -17,7 +17,7 @@ from bcos_hip import ops
 from bcos.modules import _hipfn
 from bcos.modules.common import DetachableModule
 
-__all__ = ["DetachableLayerNorm", "DetachableGroupNorm2d", "DetachableGNLayerNorm2d"]
+__all__ = ["DetachableLayerNorm", "DetachableGroupNorm2d", "DetachableGNInstanceNorm2d", "DetachableGNLayerNorm2d"]
 
 
 class _LayerNormFn(Function):
@@ -71,26 +71,64 @@ class DetachableLayerNorm(nn.LayerNorm, DetachableModule):
         return new
 
 
+class _GroupNormFn(Function):
+    """GroupNorm on the NHWC image of a logical [N,C,H,W] tensor: one workgroup per (image, group)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, detach):
+        _hipfn.require_hip(x, "DetachableGroupNorm2d")
+        xh = _hipfn.to_nhwc(x)
+        w = weight.detach().contiguous() if weight is not None else None
+        b = bias.detach().contiguous() if bias is not None else None
+        y, rstd = ops.groupnorm_fwd(xh, groups, w, b, eps, want_rstd=ctx.needs_input_grad[0])
+        ctx.detach_mode, ctx.groups, ctx.w = detach, groups, w
+        if rstd is not None:
+            ctx.save_for_backward(rstd)
+        return _hipfn.from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.detach_mode:
+            raise NotImplementedError("GroupNorm backward outside explanation mode is not implemented in the MI355X build "
+                                      "(SURVEY.md section 8(f) N4 covers the B-cos layers): use model.explanation_mode()")
+        (rstd,) = ctx.saved_tensors
+        gx = ops.groupnorm_bwd_detached(_hipfn.to_nhwc(gy), ctx.groups, ctx.w, rstd)
+        return _hipfn.from_nhwc(gx), None, None, None, None, None
+
+
 class DetachableGroupNorm2d(nn.GroupNorm, DetachableModule):
-    """ViT-C conv-stem norm (reference :93-160): declared for import compatibility, not implemented (no benchmarked
-    configuration uses the conv-stem ViTs)."""
+    """nn.GroupNorm over [N,C,H,W] whose variance is detached in explanation mode (reference :93-160; the norm of the
+    conv stems of the ViT-C models).  Forward and the explanation-mode input gradient are HIP kernels
+    (bcos_groupnorm_fwd / _bwd_detached)."""
 
     def __init__(self, *args, **kwargs):
         DetachableModule.__init__(self)
         super().__init__(*args, **kwargs)
 
-    def forward(self, input):
-        raise NotImplementedError("DetachableGroupNorm2d (ViT-C conv stems) is outside the MI355X hot path")
+    def forward(self, input: Tensor) -> Tensor:
+        assert input.dim() == 4, f"Expected 4D input got {input.dim()}D instead!"
+        assert input.shape[1] % self.num_groups == 0, (
+            "Number of channels in input should be divisible by num_groups, "
+            f"but got input of shape {input.shape} and num_groups={self.num_groups}")
+        return _GroupNormFn.apply(input, self.weight, self.bias, self.num_groups, self.eps, self.detach)
 
     @classmethod
     def from_standard_module(cls, mod: nn.GroupNorm, model_config: dict):
-        new = cls(mod.num_groups, mod.num_channels, eps=mod.eps, affine=mod.affine)
+        new = cls(num_groups=mod.num_groups, num_channels=mod.num_channels, eps=mod.eps, affine=mod.affine)
         if model_config.get("weights", None) is not None and mod.affine:
             new.weight.data = mod.weight.data
-            new.bias.data = mod.bias.data
+            if mod.bias is not None:
+                new.bias.data = mod.bias.data
         return new
 
 
+class DetachableGNInstanceNorm2d(DetachableGroupNorm2d):
+    def __init__(self, num_channels: int, *args, **kwargs):
+        super().__init__(num_channels, num_channels, *args, **kwargs)
+
+
 class DetachableGNLayerNorm2d(DetachableGroupNorm2d):
+    """A CNN detachable layer norm: one group (reference :175-186)."""
+
     def __init__(self, num_channels: int, *args, **kwargs):
         super().__init__(1, num_channels, *args, **kwargs)

@@ -762,6 +762,26 @@ def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=
     return o, o2
 
 
+def groupnorm_fwd(x_nhwc, groups, weight, bias, eps, want_rstd=False):
+    """GroupNorm of an NHWC tensor [N,H,W,C] (include/bcos_hip.h: bcos_groupnorm_fwd) -> (y, rstd [N*G] or None)."""
+    lib = _l.load()
+    N, H, W, Cc = x_nhwc.shape
+    y = torch.empty_like(x_nhwc)
+    rstd = torch.empty((N * groups,), device=x_nhwc.device, dtype=torch.float32) if want_rstd else None
+    _l.check(lib.bcos_groupnorm_fwd(_dev(x_nhwc, "x"), _dev(weight, "weight"), _dev(bias, "bias"), _dev(y, "y"), _dev(rstd, "rstd"),
+                                    N, H * W, Cc, int(groups), float(eps), _stream()), "bcos_groupnorm_fwd")
+    return y, rstd
+
+
+def groupnorm_bwd_detached(gy_nhwc, groups, weight, rstd):
+    lib = _l.load()
+    N, H, W, Cc = gy_nhwc.shape
+    gx = torch.empty_like(gy_nhwc)
+    _l.check(lib.bcos_groupnorm_bwd_detached(_dev(gy_nhwc, "gy"), _dev(weight, "weight"), _dev(rstd, "rstd"), _dev(gx, "gx"),
+                                             N, H * W, Cc, int(groups), _stream()), "bcos_groupnorm_bwd_detached")
+    return gx
+
+
 def gelu_gate(x, want_gate=False, out=None):
     lib = _l.load()
     y = out if out is not None else torch.empty_like(x)

@@ -187,7 +187,8 @@ def standard_vit(arch: str, seed: int = 0, vit_module=None):
     if vit_module is None:
         from bcos.models import vit as vit_module
     torch.manual_seed(seed)
-    return getattr(vit_module, arch)(channels=3, linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU)
+    return getattr(vit_module, arch)(channels=3, linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
+                                     conv2d_layer=nn.Conv2d, norm2d_layer=lambda c: nn.GroupNorm(1, c))
 
 
 def finish_vit_conversion(model: nn.Module, model_config: dict):

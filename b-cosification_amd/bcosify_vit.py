@@ -25,18 +25,22 @@ class _GeluFn(Function):
     @staticmethod
     def forward(ctx, x, detach):
         _hipfn.require_hip(x, "MyGELU")
-        xc = x if x.is_contiguous() else x.contiguous()
+        # a channels_last [N,C,H,W] activation (conv stems of the ViT-C models) is processed as its dense NHWC image
+        ctx.cl = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+        xc = x.permute(0, 2, 3, 1) if ctx.cl else (x if x.is_contiguous() else x.contiguous())
         y, gate = ops.gelu_gate(xc, want_gate=ctx.needs_input_grad[0])
         ctx.detach_mode = detach
         if gate is not None:
             ctx.save_for_backward(gate)
-        return y
+        return y.permute(0, 3, 1, 2) if ctx.cl else y
 
     @staticmethod
     def backward(ctx, gy):
         if not ctx.detach_mode:
             raise NotImplementedError("GELU backward outside explanation mode is not implemented in the MI355X build")
         (gate,) = ctx.saved_tensors
+        if ctx.cl:
+            return ops.mul(gy.permute(0, 2, 3, 1).contiguous(), gate).permute(0, 3, 1, 2), None
         return ops.mul(gy if gy.is_contiguous() else gy.contiguous(), gate), None
 
 

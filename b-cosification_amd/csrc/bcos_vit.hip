@@ -311,6 +311,68 @@ inline unsigned grid_elems(int64_t n) {
     return (unsigned)b;
 }
 
+// ---- GroupNorm over NHWC tensors (DetachableGroupNorm2d, centered_norms.py:93-160): one workgroup per (image, group) ------
+// Group g owns the channels [g cg, (g + 1) cg) of every pixel.  Three passes over the group's HW x cg values (mean, centred
+// sum of squares, normalise): the group of one image is at most a few MB and stays in L2 between the passes.
+__device__ inline float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();                                   // red may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < TPB / 64; ++k) t += red[k];
+    return t;
+}
+
+__global__ __launch_bounds__(TPB) void groupnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ rstd_out, int HW, int C, int G, float eps) {
+    __shared__ float red[TPB / 64];
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+    const int cg = C / G;
+    const int64_t base = (int64_t)n * HW * C + g * cg;
+    const int64_t m = (int64_t)HW * cg;
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < m; e += TPB) s += x[base + (e / cg) * C + e % cg];
+    const float mean = block_sum(s, red) / (float)m;
+    float v = 0.f;
+    for (int64_t e = threadIdx.x; e < m; e += TPB) { const float d = x[base + (e / cg) * C + e % cg] - mean; v = fmaf(d, d, v); }
+    const float var = block_sum(v, red) / (float)m;
+    const float sd = sqrtf(var + eps);
+    for (int64_t e = threadIdx.x; e < m; e += TPB) {
+        const int c = (int)(e % cg);
+        const int64_t i = base + (e / cg) * C + c;
+        float o = (x[i] - mean) / sd;
+        if (w) o *= w[g * cg + c];
+        if (b) o += b[g * cg + c];
+        y[i] = o;
+    }
+    if (rstd_out && threadIdx.x == 0) rstd_out[blockIdx.x] = 1.0f / sd;
+}
+
+// explanation mode (variance constant, mean differentiable):  gx = h - mean_group(h),  h = gy * w / std
+__global__ __launch_bounds__(TPB) void groupnorm_bwd_detached_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                     const float* __restrict__ rstd, float* __restrict__ gx,
+                                                                     int HW, int C, int G) {
+    __shared__ float red[TPB / 64];
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+    const int cg = C / G;
+    const int64_t base = (int64_t)n * HW * C + g * cg;
+    const int64_t m = (int64_t)HW * cg;
+    const float rs = rstd[blockIdx.x];
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < m; e += TPB) {
+        const int c = (int)(e % cg);
+        s += gy[base + (e / cg) * C + c] * (w ? w[g * cg + c] : 1.0f) * rs;
+    }
+    const float mh = block_sum(s, red) / (float)m;
+    for (int64_t e = threadIdx.x; e < m; e += TPB) {
+        const int c = (int)(e % cg);
+        const int64_t i = base + (e / cg) * C + c;
+        gx[i] = gy[i] * (w ? w[g * cg + c] : 1.0f) * rs - mh;
+    }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -391,4 +453,24 @@ extern "C" int bcos_finalize_explanation_patches(const float* gp, const float* x
     hipLaunchKernelGGL(finalize_patches_kernel, dim3(grid_elems((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), gp, x,
                        std6, weights_out, contrib_out, N, Cx, H, W, patch, Cpad, add_inverse);
     return check_launch("finalize_patches_kernel");
+}
+
+extern "C" int bcos_groupnorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_out, int N, int HW,
+                                  int C, int G, float eps, void* stream) {
+    if (!x || !y || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_groupnorm_fwd: bad argument (C must be divisible by the group count)");
+    if ((int64_t)N * G >= ((int64_t)1 << 31)) return bcos_set_error(BCOS_E_NOSUP, "bcos_groupnorm_fwd: too many groups");
+    hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3((unsigned)(N * G)), dim3(TPB), 0, STREAM(stream), x, weight, bias, y, rstd_out, HW,
+                       C, G, eps);
+    return check_launch("groupnorm_fwd_kernel");
+}
+
+extern "C" int bcos_groupnorm_bwd_detached(const float* gy, const float* weight, const float* rstd, float* gx, int N, int HW, int C,
+                                           int G, void* stream) {
+    if (!gy || !rstd || !gx || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_groupnorm_bwd_detached: bad argument");
+    if ((int64_t)N * G >= ((int64_t)1 << 31)) return bcos_set_error(BCOS_E_NOSUP, "bcos_groupnorm_bwd_detached: too many groups");
+    hipLaunchKernelGGL(groupnorm_bwd_detached_kernel, dim3((unsigned)(N * G)), dim3(TPB), 0, STREAM(stream), gy, weight, rstd, gx, HW,
+                       C, G);
+    return check_launch("groupnorm_bwd_detached_kernel");
 }

@@ -426,6 +426,17 @@ int bcos_layernorm_fwd(const float* x, const float* weight, const float* bias, f
 int bcos_layernorm_bwd_detached(const float* gy, const float* weight, const float* rstd, const float* addend,
                                 const float* mul2, float* out, float* out2, int64_t rows, int D, void* stream);
 
+/* DetachableGroupNorm2d (bcos/modules/norms/centered_norms.py:93-160; the conv stems of the ViT-C models) on NHWC tensors
+ * x [N, HW, C]: group g owns channels [g C/G, (g+1) C/G) of every pixel; per (image, group): biased variance, eps inside the
+ * square root, then the per-channel affine (weight / bias may be NULL).  rstd_out (NULL or [N*G]): 1 / std per (image, group)
+ * for the gradient. */
+int bcos_groupnorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_out,
+                       int N, int HW, int C, int G, float eps, void* stream);
+/* ... its explanation-mode input gradient (variance detached, mean not: centered_norms.py:118-124):
+ * gx = h - mean_group(h), h = gy * weight / std. */
+int bcos_groupnorm_bwd_detached(const float* gy, const float* weight, const float* rstd, float* gx,
+                                int N, int HW, int C, int G, void* stream);
+
 /* MyGELU (bcosify_vit.py:27-32): y = gate * x with gate = 0.5 (1 + erf(x / sqrt 2)); gate_out may be NULL. */
 int bcos_gelu_gate(const float* x, float* y, float* gate_out, int64_t n, void* stream);
 

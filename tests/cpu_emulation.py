@@ -289,6 +289,27 @@ def weight_rownorm_bwd(w2d, g2d, gain=None, want_gw=True, want_ggain=False):
     return gw, (dot.view(-1) if want_ggain else None)
 
 
+def groupnorm_fwd(x_nhwc, groups, weight, bias, eps, want_rstd=False):
+    N, H, W, Cc = x_nhwc.shape
+    xg = x_nhwc.reshape(N, H * W, groups, Cc // groups).double()
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=(1, 3), keepdim=True)
+    rstd = 1.0 / (var + eps).sqrt()
+    y = ((xg - mean) * rstd).reshape(N, H, W, Cc)
+    if weight is not None:
+        y = y * weight.double()
+    if bias is not None:
+        y = y + bias.double()
+    return y.float(), (rstd.reshape(-1).float() if want_rstd else None)
+
+
+def groupnorm_bwd_detached(gy_nhwc, groups, weight, rstd):
+    N, H, W, Cc = gy_nhwc.shape
+    h = gy_nhwc.double() * (weight.double() if weight is not None else 1.0)
+    h = h.reshape(N, H * W, groups, Cc // groups) * rstd.double().view(N, 1, groups, 1)
+    return (h - h.mean(dim=(1, 3), keepdim=True)).reshape(N, H, W, Cc).float()
+
+
 def maxout_scatter(g2d, argmax2d, max_out):
     rows, Cout = g2d.shape
     full = torch.zeros(rows, Cout, max_out, dtype=g2d.dtype)
@@ -345,7 +366,7 @@ def install(monkeypatch):
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
                  "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand",
-                 "weight_rownorm_bwd", "maxout_scatter"):
+                 "weight_rownorm_bwd", "maxout_scatter", "groupnorm_fwd", "groupnorm_bwd_detached"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

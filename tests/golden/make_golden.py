@@ -596,6 +596,68 @@ def vit_ti_end_to_end():
                        torch_version=torch.__version__), f, indent=1)
 
 
+def vitc_and_groupnorm():
+    """The conv-stem ViT (vitc_ti_patch1_14: four BcosifyConv2d 3x3 / 2 + one-group DetachableGroupNorm2d + MyGELU stem, 11
+    encoder blocks) on 2 images, and DetachableGroupNorm2d alone (groups 1 / 4 / C, explanation-mode gradient)."""
+    import importlib
+    import warnings
+    warnings.simplefilter("ignore")
+    ref_vit = importlib.import_module("bcos.models.vit")
+    ref_bvit = importlib.import_module("bcosify_vit")
+    RefGN = importlib.import_module("bcos.modules.norms.centered_norms").DetachableGroupNorm2d
+    assert "/root/reference" in sys.modules[RefGN.__module__].__file__
+    out = {}
+    g = torch.Generator().manual_seed(808)
+    for name, groups, C, bias in (("gn_layer", 1, 24, True), ("gn_groups", 4, 32, False), ("gn_instance", 16, 16, True)):
+        m = RefGN(groups, C)
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            m.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        if not bias:
+            m.bias = None
+        x = torch.randn(3, C, 9, 7, generator=g) * 1.7 + 0.4
+        gy = torch.randn(3, C, 9, 7, generator=g)
+        with torch.no_grad():
+            y_plain = m(x)                                   # F.group_norm branch
+        m.set_explanation_mode(True)
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        (gx,) = torch.autograd.grad(y, xr, gy)
+        REPORT[f"{name}/plain_vs_detached_forward"] = rel(y_plain, y.detach())
+        for kk, vv in dict(x=x, weight=m.weight.detach(), y=y.detach(), gy=gy, gx=gx).items():
+            out[f"{name}/{kk}"] = vv
+        if bias:
+            out[f"{name}/bias"] = m.bias.detach()
+    arch = "vitc_ti_patch1_14"
+    cfg = synth.vit_model_config(arch)
+    std = synth.standard_vit(arch, 0, vit_module=ref_vit)
+    net = ref_bvit.BcosifyNetwork(std, cfg, add_channels=True, logit_layer=cfg["logit_layer"])
+    synth.finish_vit_conversion(net, cfg)
+    net.eval()
+    x = synth.synthetic_images(2)
+    record = synth.calibrate(net, x)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    logits, wts, contribs, preds = [], [], [], []
+    for i in range(2):
+        xi = x[i:i + 1].clone().requires_grad_(True)
+        res = net.explain(xi)
+        with torch.no_grad():
+            logits.append(net(x[i:i + 1]))
+        wts.append(res["dynamic_linear_weights"].detach())
+        contribs.append(res["contribution_map"].detach())
+        preds.append(res["prediction"])
+    logits = torch.cat(logits); wts = torch.cat(wts); contribs = torch.cat(contribs)
+    rec_np = {f"calib/{k}": v.numpy() for k, v in record.items()}
+    np.savez_compressed(os.path.join(HERE, "vitc_ti_e2e.npz"), logits=logits.numpy(), prediction=np.array(preds),
+                        contribution_map=contribs.numpy(), weights_0=wts[:1].numpy(), **rec_np, **t2n(out))
+    with open(os.path.join(HERE, "vitc_ti_e2e.json"), "w") as f:
+        json.dump(dict(arch=arch, weight_seed=0, image_seed=123, n_images=2, calib_images=2,
+                       calib_order=list(record.keys()), state_checksum=state_checksum(sd),
+                       gn_cases=[dict(name="gn_layer", groups=1, C=24, bias=True), dict(name="gn_groups", groups=4, C=32, bias=False),
+                                 dict(name="gn_instance", groups=16, C=16, bias=True)],
+                       torch_version=torch.__version__), f, indent=1)
+
+
 def clip_rn50_embeddings():
     """BASELINE.json configs[3] topology: B-cosified CLIP RN50 image encoder (clip_kd conversion, attention-pool head):
     embeddings of 4 images + the zero-shot head of clip_evaluate on a seeded text matrix."""
@@ -742,7 +804,7 @@ def localisation_grid():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "clip", "unpool", "loc"]
+    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "vitc", "clip", "unpool", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -754,6 +816,8 @@ if __name__ == "__main__":
         train_cases()
     if "train2" in which:
         train_cases2()
+    if "vitc" in which:
+        vitc_and_groupnorm()
     if "train_r18" in which:
         resnet18_training_step()
     if "inv" in which:

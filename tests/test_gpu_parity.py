@@ -575,6 +575,14 @@ def test_vit_ti_against_reference_golden(lib, golden_dir):
     assert torch.equal(again["dynamic_linear_weights"], out["dynamic_linear_weights"])     # deterministic
 
 
+def test_vitc_ti_and_groupnorm_against_reference_golden(lib, golden_dir):
+    """The conv-stem ViT (vitc_ti_patch1_14) and DetachableGroupNorm2d on the device: bcos_groupnorm_fwd /
+    bcos_groupnorm_bwd_detached, MyGELU on channels_last activations, the stem convolutions on the fused B-cos kernel --
+    logits, class indices, W(x) and contribution maps against the reference's recorded outputs."""
+    from test_host_cpu import run_vitc_goldens
+    run_vitc_goldens(golden_dir, DEV, 1e-5)
+
+
 def test_vit_ti_batch512_properties(lib):
     """BASELINE.json configs[2] at full size: batch 512 on one GPU; a sub-batch reproduces bit-identically and agrees
     with the CPU oracle."""

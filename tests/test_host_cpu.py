@@ -396,6 +396,54 @@ def run_training_goldens2(golden_dir, dev, tol):
     assert rel(gw, data[f"{n}/gw"]) <= tol and rel(gs, data[f"{n}/gscale"]) <= tol, n
 
 
+def run_vitc_goldens(golden_dir, dev, tol):
+    """DetachableGroupNorm2d (1 / 4 / C groups; forward and explanation-mode input gradient) and the B-cosified conv-stem
+    ViT vitc_ti_patch1_14 (nn.Module path: BcosifyConv2d + DetachableGroupNorm2d + MyGELU stem on 4-D tensors, then the
+    token path of the plain ViT) against outputs recorded from the reference (tests/golden/vitc_ti_e2e.npz)."""
+    from bcos.modules.norms import DetachableGroupNorm2d
+    from bcos_hip import synth
+    meta = json.load(open(os.path.join(golden_dir, "vitc_ti_e2e.json")))
+    data = np.load(os.path.join(golden_dir, "vitc_ti_e2e.npz"))
+    t = lambda k: torch.from_numpy(data[k]).to(dev)      # noqa: E731
+    for c in meta["gn_cases"]:
+        n = c["name"]
+        m = DetachableGroupNorm2d(c["groups"], c["C"])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+            if c["bias"]:
+                m.bias.copy_(torch.from_numpy(data[f"{n}/bias"]))
+        if not c["bias"]:
+            m.bias = None
+        m = m.to(dev)
+        with torch.no_grad():
+            assert rel(m(t(f"{n}/x")), data[f"{n}/y"]) <= tol, n           # plain mode: same forward
+        m.set_explanation_mode(True)
+        x = t(f"{n}/x").requires_grad_(True)
+        y = m(x)
+        (gx,) = torch.autograd.grad(y, x, t(f"{n}/gy"))
+        assert rel(y, data[f"{n}/y"]) <= tol and rel(gx, data[f"{n}/gx"]) <= tol, n
+        m.set_explanation_mode(False)
+        with pytest.raises(NotImplementedError):                            # training-mode norm gradients are not built
+            torch.autograd.grad(m(t(f"{n}/x").requires_grad_(True)).sum(), m.weight)
+    net = synth.build_bcosified_vit(meta["arch"], seed=meta["weight_seed"])
+    synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
+    sd = net.state_dict()
+    for k, (s1, s2) in meta["state_checksum"].items():
+        assert abs(float(sd[k].double().sum()) - s1) <= 1e-6 * max(1.0, s2), k
+    net = net.to(dev)
+    x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(dev)
+    out = net.explain_batch(x)
+    assert rel(out["logits"], data["logits"]) <= 1e-4
+    assert np.array_equal(out["prediction"].cpu().numpy(), data["prediction"])
+    assert rel(out["contribution_map"], data["contribution_map"]) <= 1e-4
+    assert rel(out["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
+
+
+def test_vitc_and_groupnorm_match_reference_golden(monkeypatch, golden_dir):
+    cpu_emulation.install(monkeypatch)
+    run_vitc_goldens(golden_dir, "cpu", 4e-6)
+
+
 def test_training_mode_gradients_match_reference_golden(monkeypatch, golden_dir):
     cpu_emulation.install(monkeypatch)
     run_training_goldens(golden_dir, "cpu", 2e-6)
