@@ -566,7 +566,8 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     constexpr int RPP = NT / CPR;
     constexpr int PASSES = SBM / RPP;
     constexpr int NIN = (ADDEND ? 1 : 0) + (MUL ? 1 : 0) + (MUL2 ? 1 : 0);
-    constexpr int G = (NIN <= 1 && PASSES % 8 == 0 && NT <= 256 && PM * PN == 1) ? 8 : (PASSES % 4 == 0 ? 4 : 2);
+    // (the narrow split-f16 forward kernels are compiled for three workgroups per CU -- 168 registers: 4 chunks there)
+    constexpr int G = (NIN <= 1 && PASSES % 8 == 0 && NT <= 256 && PM * PN == 1 && !(SCALED && NORM && BN <= 64)) ? 8 : (PASSES % 4 == 0 ? 4 : 2);
     static_assert(PASSES % G == 0, "epilogue grouping");
     const int cq = tid % CPR;
     const int rbase = tid / CPR;
@@ -1545,6 +1546,17 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n);
 }
 
+// Narrow split-f16 tiles (128 x 64, 128 x 32: the stem, the 56^2 3x3 layers) hold 16-32 accumulator registers per wave and run
+// 6-12 matrix instructions per 16-k step: their steps wait on load latency, not on a pipe.  The FORWARD kernels of these
+// tiles are compiled for three resident workgroups per CU (168 registers): same-node A/B on ResNet-50, stem forward
+// 1.36 -> 1.07 ms, 3x3 @56^2 forward 1.10 -> 0.92 ms; the gradient kernels (no norm) measured no gain (128 x 64) or a small
+// loss (128 x 32, the depth-to-space stem gradient) and stay at two; four workgroups (128 registers) spill.
+#ifndef H2_NARROW_WGS
+#define H2_NARROW_WGS 3           // resident workgroups per CU the narrow forward kernels are compiled for
+#endif
+#ifndef H2_NARROW_BN
+#define H2_NARROW_BN 64
+#endif
 // XCD-aware id remap: the 8 XCDs (private L2s) each get a contiguous range of `nt` work items (bijective for any nt)
 __device__ __forceinline__ int xcd_remap(int bid, int nt) {
     const int xcd = bid % NXCD, idx = bid / NXCD;
@@ -1558,7 +1570,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 // tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
 // = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights, 3 split-f16
-__global__ __launch_bounds__(NTHREADS, 2) void tapconv_kernel(const KArgs p) {
+__global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN) ? H2_NARROW_WGS : 2) void tapconv_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     if (bid < p.n_big) {
