@@ -222,12 +222,12 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
     }
     const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
     const bool vec = p.vec_ok && (col + 3 < Cout);     // whole chunk inside the tensor and 16-byte addressable
-    // depth-to-space launches (bcos_tapconv_geom.out_cgroup): the column chunk is channel colc of the pixel colpix further on
-    int colpix = 0, colc = col;
+    // element offset of the column chunk inside its output row: the column itself, or -- depth-to-space launches
+    // (bcos_tapconv_geom.out_cgroup) -- channel col % G of the pixel (dh * OW + dw) further on
+    int coladd = col;
     if (g.out_cgroup > 0) {
         const int cls = col / g.out_cgroup;
-        colc = col - cls * g.out_cgroup;
-        colpix = (cls / g.out_sw) * g.OW + cls % g.out_sw;
+        coladd = ((cls / g.out_sw) * g.OW + cls % g.out_sw) * g.out_pitch + (col - cls * g.out_cgroup);
     }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
@@ -262,7 +262,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
         for (int u = 0; u < EPI_G; ++u) {
             const int lrow = rbase + (p0 + u) * RPP;
             const int64_t pix = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
-            const int64_t idx = ((pix >= 0 ? pix : 0) + colpix) * g.out_pitch + colc;
+            const int64_t idx = (pix >= 0 ? pix : 0) * g.out_pitch + coladd;
             in.ad[u] = (vec && e.addend) ? *reinterpret_cast<const f32x4*>(e.addend + idx) : zero4;
             in.m1[u] = (vec && e.mul) ? *reinterpret_cast<const f32x4*>(e.mul + idx) : zero4;
         }
@@ -315,7 +315,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                 const int row = (lrow / HM) * WM + pm * HM + lrow % HM;
                 const int64_t pix = pixs[u];
                 ok[u] = pix >= 0;
-                idx[u] = ((ok[u] ? pix : 0) + colpix) * g.out_pitch + colc;
+                idx[u] = (ok[u] ? pix : 0) * g.out_pitch + coladd;
                 v[u] = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
                 if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
                 rinv[u] = NORM ? sRinv[row] : 1.f;
