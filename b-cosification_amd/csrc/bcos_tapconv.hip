@@ -464,11 +464,14 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
 //     loads, so the loop body has no predicates,
 //   * keeps the per-row values (output offset, 1 / norm, inverse operand scale, pixel index) as one 16-byte LDS record.
 // Anything else (MaxOut, B != 2, GELU, replayed gates, ragged Cout, tensors >= 2 GiB, ...) takes the general epilogue.
-enum : int { EF_ADDEND = 1, EF_RELU = 2, EF_SCALE_OUT = 4, EF_MUL = 8, EF_OUT2 = 16, EF_MUL2 = 32 };
+enum : int { EF_ADDEND = 1, EF_RELU = 2, EF_SCALE_OUT = 4, EF_MUL = 8, EF_OUT2 = 16, EF_MUL2 = 32, EF_GELU = 64, EF_NONE = -1 };
 // forward kinds (NORM kernels): B = 2 scale, optional bias / channel affine;  backward kinds (no norm): gradient multipliers
-constexpr int EPI_KINDS_FWD[] = {EF_RELU | EF_SCALE_OUT, EF_RELU | EF_SCALE_OUT | EF_ADDEND, EF_SCALE_OUT, EF_RELU, EF_RELU | EF_ADDEND, 0};
-constexpr int EPI_KINDS_BWD[] = {EF_MUL, EF_MUL | EF_ADDEND | EF_OUT2, EF_MUL | EF_ADDEND | EF_OUT2 | EF_MUL2, 0, EF_ADDEND, EF_MUL | EF_OUT2};
-constexpr int N_EPI_KINDS = 6;
+// (the GELU kinds are the linear1 layers of the B-cosified ViTs: MyGELU with its gate folded into the stored multiplier)
+constexpr int EPI_KINDS_FWD[] = {EF_RELU | EF_SCALE_OUT, EF_RELU | EF_SCALE_OUT | EF_ADDEND, EF_SCALE_OUT, EF_RELU, EF_RELU | EF_ADDEND, 0,
+                                 EF_GELU | EF_SCALE_OUT, EF_GELU};
+constexpr int EPI_KINDS_BWD[] = {EF_MUL, EF_MUL | EF_ADDEND | EF_OUT2, EF_MUL | EF_ADDEND | EF_OUT2 | EF_MUL2, 0, EF_ADDEND, EF_MUL | EF_OUT2,
+                                 EF_NONE, EF_NONE};
+constexpr int N_EPI_KINDS = 8;
 
 struct __attribute__((aligned(16))) EpiRow { unsigned off; float rinv; float ainv; int pix; };
 
@@ -536,8 +539,9 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     BCOS_EPI_KARGS
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool ADDEND = (EF & EF_ADDEND) != 0, RELU = (EF & EF_RELU) != 0, SCALE_OUT = (EF & EF_SCALE_OUT) != 0;
-    constexpr bool MUL = (EF & EF_MUL) != 0, OUT2 = (EF & EF_OUT2) != 0, MUL2 = (EF & EF_MUL2) != 0;
-    static_assert(NORM ? !(MUL || OUT2 || MUL2) : !(RELU || SCALE_OUT), "forward kinds scale, backward kinds multiply");
+    constexpr bool MUL = (EF & EF_MUL) != 0, OUT2 = (EF & EF_OUT2) != 0, MUL2 = (EF & EF_MUL2) != 0, GELU = (EF & EF_GELU) != 0;
+    static_assert(NORM ? !(MUL || OUT2 || MUL2) : !(RELU || SCALE_OUT || GELU), "forward kinds scale, backward kinds multiply");
+    static_assert(!(RELU && GELU), "one activation");
     float* sC = smem;
     EpiRow* sRow = reinterpret_cast<EpiRow*>(smem + SBM * LDC);    // [BM]
     float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
@@ -633,6 +637,14 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
                     val[q] = open_gate ? val[q] : 0.f;
                 }
             }
+            if (GELU) {           // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
+                    s[q] *= gate;
+                    val[q] *= gate;
+                }
+            }
             const f32x4 o1 = MUL ? val * m1[u] : val;
             stq(r_out, voff[u], o1);
             mx1[u] = want_max1 ? absmax4(o1) : 0u;
@@ -701,11 +713,18 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
         epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, (NORM ? EPI_KINDS_FWD[I] : EPI_KINDS_BWD[I])>(smem, pm, pn, part, \
                                                                                                                 n0, tile_n); \
         break;
+#define BCOS_EPI_CASE_FWD(I)                                                                                                 \
+    case I + 1:                                                                                                              \
+        if constexpr (NORM)                                                                                                  \
+            epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, EPI_KINDS_FWD[I]>(smem, pm, pn, part, n0, tile_n);     \
+        break;
         switch (kind) {
             BCOS_EPI_CASE(0) BCOS_EPI_CASE(1) BCOS_EPI_CASE(2) BCOS_EPI_CASE(3) BCOS_EPI_CASE(4) BCOS_EPI_CASE(5)
+            BCOS_EPI_CASE_FWD(6) BCOS_EPI_CASE_FWD(7)
             default: epi_part_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, pm, pn, part, n0, tile_n);
         }
 #undef BCOS_EPI_CASE
+#undef BCOS_EPI_CASE_FWD
     };
     static_assert(PM * PN <= 4, "parts");
     drain(std::integral_constant<int, 0>{});
@@ -2077,8 +2096,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                   ((reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.ch_scale) | reinterpret_cast<uintptr_t>(e.ch_shift)) & 15) == 0;
         int ef = 0;
         if (norm_l) {
-            ok = ok && e.b == 2.0f && (e.relu == 0 || e.relu == 1) && !e.mul && !e.mul2 && !e.out2 && !e.out2_absmax;
-            ef = (e.addend ? EF_ADDEND : 0) | (e.relu == 1 ? EF_RELU : 0) | (e.scale_out ? EF_SCALE_OUT : 0);
+            ok = ok && e.b == 2.0f && e.relu >= 0 && e.relu <= 2 && !e.mul && !e.mul2 && !e.out2 && !e.out2_absmax;
+            ef = (e.addend ? EF_ADDEND : 0) | (e.relu == 1 ? EF_RELU : 0) | (e.relu == 2 ? EF_GELU : 0) | (e.scale_out ? EF_SCALE_OUT : 0);
         } else {
             ok = ok && e.relu == 0 && !e.bias && !e.ch_scale && !e.ch_shift && !e.scale_out && (!e.mul2 || e.out2) &&
                  (!e.out2 || e.mul) && (!e.out2_absmax || e.out2);

@@ -255,6 +255,10 @@ def main():
     hbm_gbps = sum(nb for _, _, nb in hbm) / hbm_ms / 1e6 if hbm_ms > 0 else 0.0
     mfma_tf = sum(fl for _, fl, _ in mfma) / mfma_ms / 1e9 if mfma_ms > 0 else 0.0
     prod = PRODUCTS[contraction]
+    # per-launch roofline time: the larger of (executed matrix work / the pipe's dense peak) and (algorithmic bytes / HBM peak);
+    # their sum over the launches against the measured kernel time is the fraction of the two-sided roofline the path reaches
+    pipe_peak = PEAK_16BIT_MFMA_TFLOPS if prod > 1 else PEAK_FP32_MFMA_TFLOPS
+    ideal_ms = sum(max(prod * fl / (pipe_peak * 1e9), nb / (PEAK_HBM_GBPS * 1e6)) for _, fl, nb in per_launch)
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                     kernel="tapconv_kernel (all instantiations) + skinny_kernel", launches_per_step=launches // n_ev,
@@ -262,6 +266,9 @@ def main():
                     kernel_ms_per_step=round(kernel_ms / n_ev, 3), steps_with_events=len(event_steps),
                     algorithmic_gflop_per_step=round(gflop_step, 1),
                     frac_of_executing_pipe=round(prod * achieved / (PEAK_16BIT_MFMA_TFLOPS if prod > 1 else PEAK_FP32_MFMA_TFLOPS), 4),
+                    two_sided=dict(roofline_ms_per_step=round(ideal_ms / n_ev, 3), frac=round(ideal_ms / kernel_ms, 4) if kernel_ms > 0 else None,
+                                   note="sum over launches of max(matrix instructions on the executing pipe at its dense peak, algorithmic "
+                                        "bytes at 8 TB/s) / measured kernel time"),
                     by_bound=dict(
                         mfma=dict(launches_per_step=len(mfma) // n_ev, ms_per_step=round(mfma_ms / n_ev, 3),
                                   achieved_tflops=round(mfma_tf, 1), frac_of_fp32_peak=round(mfma_tf / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -1026,7 +1026,7 @@ def test_fast_epilogue_bit_identical(lib, golden_dir, monkeypatch):
                 csh = torch.randn(Cout, generator=g).to(DEV) * 0.1
                 Ho = ops.conv_out_size(H, k, st, pd)
                 add = torch.randn(N, Ho, Ho, Cout, generator=g).to(DEV)
-                for relu in (False, True):
+                for relu in (False, True, 2):          # 2 = GELU with the gate held constant (MyGELU)
                     for addend in (None, add):
                         for want_scale in (False, True):
                             for flags in ((0, 4) if (relu and want_scale) else (0,)):
