@@ -28,12 +28,13 @@ from .lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM_MUL, BC
                   BCOS_NONE, BcosHipError)
 
 _GATE_TENSOR = bool(os.environ.get("BCOS_GATE_TENSOR"))   # development switch: ReLU gates as tensors, not as the bit in t
-# Rebuilding a layer's multiplier t from its kept activation (BCOS_EPI_MUL_FROM_ACT) instead of storing it saves one
-# output-sized write in the forward launches of conv1 / conv2 of every block (-0.57 ms of HBM-bound launch time per step at
-# ResNet-50 batch 256), but the input-gradient launches that rebuild it are instruction-issue bound in their epilogue and lose
-# +0.76 ms (measured on one node, interleaved runs: 6 963 vs 6 992 images/s).  Stored t stays the default; BCOS_REBUILD_T=1
-# selects the rebuild (same results: tests run both).
-_STORE_T = not bool(os.environ.get("BCOS_REBUILD_T"))
+# The multiplier t of conv1 / conv2 of every block (B = 2, own ReLU, no residual) is REBUILT from the kept activation, the patch
+# norms and the BN scale / shift (BCOS_EPI_MUL_FROM_ACT) instead of being stored: one output-sized write less per such forward
+# launch (2.8 GB per ResNet-50 step at batch 256) and 32 output-sized tensors less to keep.  With the general epilogue the
+# rebuild cost +0.76 ms in the issue-bound gradient epilogues against -0.57 ms in the forward; with the specialised kinds
+# (csrc/bcos_tapconv.hip: EF_MULACT) the step time is the same or slightly lower (same-node A/B: 29.60 vs 29.60, 29.48 vs 29.58
+# ms).  BCOS_STORE_T=1 keeps the stored multipliers (same results to 1e-5: tests run both).
+_STORE_T = bool(os.environ.get("BCOS_STORE_T"))
 
 
 def _pair(v):

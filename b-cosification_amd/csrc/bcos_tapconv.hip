@@ -464,13 +464,13 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
 //     loads, so the loop body has no predicates,
 //   * keeps the per-row values (output offset, 1 / norm, inverse operand scale, pixel index) as one 16-byte LDS record.
 // Anything else (MaxOut, B != 2, GELU, replayed gates, ragged Cout, tensors >= 2 GiB, ...) takes the general epilogue.
-enum : int { EF_ADDEND = 1, EF_RELU = 2, EF_SCALE_OUT = 4, EF_MUL = 8, EF_OUT2 = 16, EF_MUL2 = 32, EF_GELU = 64, EF_NONE = -1 };
+enum : int { EF_ADDEND = 1, EF_RELU = 2, EF_SCALE_OUT = 4, EF_MUL = 8, EF_OUT2 = 16, EF_MUL2 = 32, EF_GELU = 64, EF_MULACT = 128, EF_NONE = -1 };
 // forward kinds (NORM kernels): B = 2 scale, optional bias / channel affine;  backward kinds (no norm): gradient multipliers
 // (the GELU kinds are the linear1 layers of the B-cosified ViTs: MyGELU with its gate folded into the stored multiplier)
 constexpr int EPI_KINDS_FWD[] = {EF_RELU | EF_SCALE_OUT, EF_RELU | EF_SCALE_OUT | EF_ADDEND, EF_SCALE_OUT, EF_RELU, EF_RELU | EF_ADDEND, 0,
                                  EF_GELU | EF_SCALE_OUT, EF_GELU};
 constexpr int EPI_KINDS_BWD[] = {EF_MUL, EF_MUL | EF_ADDEND | EF_OUT2, EF_MUL | EF_ADDEND | EF_OUT2 | EF_MUL2, 0, EF_ADDEND, EF_MUL | EF_OUT2,
-                                 EF_NONE, EF_NONE};
+                                 EF_MUL | EF_MULACT, EF_NONE};       // MULACT: the multiplier is rebuilt from the kept activation (BCOS_EPI_MUL_FROM_ACT)
 constexpr int N_EPI_KINDS = 8;
 
 struct __attribute__((aligned(16))) EpiRow { unsigned off; float rinv; float ainv; int pix; };
@@ -542,6 +542,8 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     constexpr bool MUL = (EF & EF_MUL) != 0, OUT2 = (EF & EF_OUT2) != 0, MUL2 = (EF & EF_MUL2) != 0, GELU = (EF & EF_GELU) != 0;
     static_assert(NORM ? !(MUL || OUT2 || MUL2) : !(RELU || SCALE_OUT || GELU), "forward kinds scale, backward kinds multiply");
     static_assert(!(RELU && GELU), "one activation");
+    constexpr bool MULACT = (EF & EF_MULACT) != 0;
+    static_assert(!MULACT || (MUL && !OUT2), "rebuilt multipliers: plain gradient launches");
     float* sC = smem;
     EpiRow* sRow = reinterpret_cast<EpiRow*>(smem + SBM * LDC);    // [BM]
     float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
@@ -599,6 +601,11 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
 #pragma unroll
         for (int q = 0; q < 4; ++q) cinv4[q] = p.wt2_cinv[col_ok ? col + q : 0];
     }
+    f32x4 mcsc4 = {1.f, 1.f, 1.f, 1.f}, mcsh4 = {0.f, 0.f, 0.f, 0.f};
+    if (MULACT && col_ok) {
+        if (e.mul_csc) mcsc4 = *reinterpret_cast<const f32x4*>(e.mul_csc + col);
+        if (e.mul_csh) mcsh4 = *reinterpret_cast<const f32x4*>(e.mul_csh + col);
+    }
 #pragma unroll 1
     for (int p0 = 0; p0 < PASSES; p0 += G) {
         EpiRow rw[G];
@@ -643,6 +650,15 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
                     const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
                     s[q] *= gate;
                     val[q] *= gate;
+                }
+            }
+            if (MULACT) {          // t = csc sqrt(|a - csh| / (|csc| norm)) where the kept activation a is positive (B = 2, no residual)
+                const float mn = e.mul_norm[rw[u].pix >= 0 ? rw[u].pix : 0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a = m1[u][q];
+                    const float den = fabsf(mcsc4[q]) * mn;
+                    m1[u][q] = (a > 0.f && den > 0.f) ? mcsc4[q] * __builtin_amdgcn_sqrtf(fabsf(a - mcsh4[q]) * __builtin_amdgcn_rcpf(den)) : 0.f;
                 }
             }
             const f32x4 o1 = MUL ? val * m1[u] : val;
@@ -720,7 +736,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
         break;
         switch (kind) {
             BCOS_EPI_CASE(0) BCOS_EPI_CASE(1) BCOS_EPI_CASE(2) BCOS_EPI_CASE(3) BCOS_EPI_CASE(4) BCOS_EPI_CASE(5)
-            BCOS_EPI_CASE_FWD(6) BCOS_EPI_CASE_FWD(7)
+            BCOS_EPI_CASE(6) BCOS_EPI_CASE_FWD(7)
             default: epi_part_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, pm, pn, part, n0, tile_n);
         }
 #undef BCOS_EPI_CASE
@@ -2092,17 +2108,21 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         const bool norm_l = e.bcos_mode != BCOS_NONE;
         const bool off = getenv("BCOS_EPI_GENERIC") != nullptr;                 // development / test switch (read per call)
         bool ok = !off && p.vec_ok && g.Cout % 4 == 0 && obytes < ((int64_t)1 << 31) && e.max_out <= 1 && e.out != nullptr &&
-                  !e.gate2 && !e.relu_gate && !(e.flags & (BCOS_EPI_NORM_ONLY | BCOS_EPI_FORCE_POW | BCOS_EPI_MUL_FROM_ACT)) &&
+                  !e.gate2 && !e.relu_gate && !(e.flags & (BCOS_EPI_NORM_ONLY | BCOS_EPI_FORCE_POW)) &&
                   ((reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.ch_scale) | reinterpret_cast<uintptr_t>(e.ch_shift)) & 15) == 0;
         int ef = 0;
         if (norm_l) {
-            ok = ok && e.b == 2.0f && e.relu >= 0 && e.relu <= 2 && !e.mul && !e.mul2 && !e.out2 && !e.out2_absmax;
+            ok = ok && e.b == 2.0f && e.relu >= 0 && e.relu <= 2 && !e.mul && !e.mul2 && !e.out2 && !e.out2_absmax &&
+                 !(e.flags & BCOS_EPI_MUL_FROM_ACT);
             ef = (e.addend ? EF_ADDEND : 0) | (e.relu == 1 ? EF_RELU : 0) | (e.relu == 2 ? EF_GELU : 0) | (e.scale_out ? EF_SCALE_OUT : 0);
         } else {
             ok = ok && e.relu == 0 && !e.bias && !e.ch_scale && !e.ch_shift && !e.scale_out && (!e.mul2 || e.out2) &&
                  (!e.out2 || e.mul) && (!e.out2_absmax || e.out2);
             // out2 is either ungated or gated by the low bit of mul (BCOS_EPI_GATE2_FROM_MUL): both are what the kinds compute
-            ef = (e.addend ? EF_ADDEND : 0) | (e.mul ? EF_MUL : 0) | (e.out2 ? EF_OUT2 : 0) | (e.mul2 ? EF_MUL2 : 0);
+            ef = (e.addend ? EF_ADDEND : 0) | (e.mul ? EF_MUL : 0) | (e.out2 ? EF_OUT2 : 0) | (e.mul2 ? EF_MUL2 : 0) |
+                 ((e.flags & BCOS_EPI_MUL_FROM_ACT) ? EF_MULACT : 0);
+            if (e.flags & BCOS_EPI_MUL_FROM_ACT)
+                ok = ok && ((reinterpret_cast<uintptr_t>(e.mul_csc) | reinterpret_cast<uintptr_t>(e.mul_csh)) & 15) == 0;
         }
         if (ok) {
             const int* kinds = norm_l ? EPI_KINDS_FWD : EPI_KINDS_BWD;

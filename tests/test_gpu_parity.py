@@ -477,8 +477,9 @@ def test_rebuilt_multipliers_match_stored_ones(lib, golden_dir, monkeypatch):
     net, meta, data = _golden_net(golden_dir, "resnet18_e2e")
     x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
     eng = engine.attach(net)
+    monkeypatch.setattr(engine, "_STORE_T", True)
     stored = eng.explain(x)
-    monkeypatch.setattr(engine, "_STORE_T", False)
+    monkeypatch.setattr(engine, "_STORE_T", False)          # the default
     rebuilt = eng.explain(x)
     _, st = eng._run_forward(x[:2], keep=True)
     assert any(isinstance(t, engine._ActScale) for rec in st["blocks"] for t in rec["ts"])      # the rebuild path is taken
@@ -1042,8 +1043,13 @@ def test_fast_epilogue_bit_identical(lib, golden_dir, monkeypatch):
                 mul = torch.randn(N, H, H, Cin, generator=g).to(DEV)
                 mul2 = torch.randn(N, H, H, Cin, generator=g).to(DEV)
                 add_in = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+                act_in = torch.randn(N, H, H, Cin, generator=g).clamp_min(0).to(DEV)          # a kept ReLU activation and its layer's
+                nrm_in = (torch.rand(N, H, H, generator=g) + 0.5).to(DEV)                     # patch norms / BN scale / shift
+                csc_in = (torch.rand(Cin, generator=g) + 0.5).to(DEV) * torch.where(torch.rand(Cin, generator=g) < 0.2, -1.0, 1.0).to(DEV)
+                csh_in = (torch.randn(Cin, generator=g) * 0.1).to(DEV)
                 for kw in (dict(), dict(addend=add_in), dict(mul=mul), dict(mul=mul, addend=add_in, want2=True, flags=8),
-                           dict(mul=mul, addend=add_in, mul2=mul2, want2=True, flags=8), dict(mul=mul, want2=True), dict(mul=mul, want2=True, flags=8)):
+                           dict(mul=mul, addend=add_in, mul2=mul2, want2=True, flags=8), dict(mul=mul, want2=True), dict(mul=mul, want2=True, flags=8),
+                           dict(mul=act_in, mul_norm=nrm_in, mul_csc=csc_in, mul_csh=csh_in, flags=16)):       # BCOS_EPI_MUL_FROM_ACT
                     def run():
                         kw2 = dict(kw)
                         out2 = torch.full((N, H, H, Cin), float("nan"), device=DEV) if kw2.pop("want2", False) else None
