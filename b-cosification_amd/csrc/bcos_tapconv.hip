@@ -1208,8 +1208,16 @@ constexpr int H2_MAX_TAPS = 16;    // channel-chunk-major K walk for up to this 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// pipeline of a split-f16 tile: 1 for the 8-accumulator tiles, H2_PIPE_SMALL otherwise -- except the 32-column gradient tiles
+// (the depth-to-space stem gradient: 3 matrix instructions per 16-k step and wave), which take two sub-steps per barrier
+// (same-node A/B of that launch: 1.38 -> 1.26 ms; the 64- and 128-column tiles lose with it)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
+constexpr int h2_pipe() {
+    return (BM / WAVES_M) * (BN / WAVES_N) > 64 * 64 ? 1 : ((BN == 32 && !NORM) ? 3 : H2_PIPE_SMALL);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NT = NTHREADS,
-          int PIPE = ((BM / WAVES_M) * (BN / WAVES_N) <= 64 * 64 ? H2_PIPE_SMALL : 1)>
+          int PIPE = h2_pipe<BM, BN, WAVES_M, WAVES_N, NORM>()>
 __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -1701,8 +1709,8 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-constexpr size_t h2_staging_lds() {
-    constexpr int nbuf = ((BM / WAVES_M) * (BN / WAVES_N) <= 64 * 64 && H2_PIPE_SMALL == 3) ? 4 : 2;
+constexpr size_t h2_staging_lds() {      // (sized for the deeper of the norm / no-norm pipelines of the tile)
+    constexpr int nbuf = (h2_pipe<BM, BN, WAVES_M, WAVES_N, false>() == 3 || h2_pipe<BM, BN, WAVES_M, WAVES_N, true>() == 3) ? 4 : 2;
     return nbuf * ((size_t)2 * BM * X3_ROW + (size_t)(BN / 32) * 2048) + (size_t)H2_MAX_TAPS * BM * 4;
 }
 
