@@ -6,7 +6,7 @@ import torch
 from bcos_hip import ops
 from bcos_hip.lib import BCOS_EPI_SCALE_GATE_LSB
 N, H, Cin, Cout = 256, int(os.environ.get("HH", "56")), int(os.environ.get("CIN", "64")), int(os.environ.get("COUT", "256"))
-x = torch.randn(N, H, H, Cin, device="cuda"); w = ops.mark_static(torch.randn(Cout, 1, 1, Cin, device="cuda") / Cin ** 0.5)
+x = ops.ensure_absmax(torch.randn(N, H, H, Cin, device="cuda")); w = ops.mark_static(torch.randn(Cout, 1, 1, Cin, device="cuda") / Cin ** 0.5)
 res = torch.randn(N, H, H, Cout, device="cuda"); out = torch.empty_like(res); sc = torch.empty_like(res)
 csc = torch.rand(Cout, device="cuda") + 0.5
 for _ in range(3):
