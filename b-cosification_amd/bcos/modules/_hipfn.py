@@ -185,20 +185,15 @@ class BcosConv2dFn(Function):
             norm = None if fused or b == 1.0 else torch.empty((N, Ho, Wo, groups), device=x.device, dtype=torch.float32)
         mode = BCOS_NONE if b == 1.0 else BCOS_CONV_EPS
         cout_g = Cout_all // groups
-        for g in range(groups):
-            geom = ops.fwd_geom(N, H, W, wk.shape[3], cout_g, kh, kw, stride[0], stride[1], padding[0], padding[1],
-                                dilation[0], dilation[1])
-            a = xh
-            if groups > 1:
-                geom.update(a_pitch=Cin, out_pitch=Cout_all, norm_pitch=groups)
-                a = xh[..., g * cin_g:]
-            ops.tapconv(a, wk[g * cout_g:(g + 1) * cout_g], geom,
-                        out=y[..., g * cout_g:] if groups > 1 else y,
-                        scale_out=(scale[..., g * cout_g:] if groups > 1 else scale) if scale is not None else None,
-                        norm_out=(norm[..., g:] if norm is not None else None),
-                        bias=(bias[g * cout_g:(g + 1) * cout_g] if bias is not None else None),
-                        bcos_mode=mode, b=b,
-                        flags=(0 if fused else BCOS_EPI_NORM_ONLY) | (BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0))
+        # one launch for all groups (bcos_tapconv_geom.groups): group g contracts its channel slice with its filters and writes
+        # its output columns / its patch norm
+        geom = ops.fwd_geom(N, H, W, wk.shape[3], cout_g, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                            dilation[0], dilation[1])
+        if groups > 1:
+            geom.update(groups=groups, a_pitch=Cin, out_pitch=Cout_all, norm_pitch=groups)
+        ops.tapconv(xh, wk, geom, out=y, scale_out=scale, norm_out=norm, bias=bias, bcos_mode=mode, b=b,
+                    flags=(0 if fused else BCOS_EPI_NORM_ONLY) | (BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0),
+                    **({"track_absmax": False} if groups > 1 else {}))
         argmax = None
         if not fused:
             Cout = Cout_all // max_out

@@ -176,13 +176,12 @@ class BcosConv2d(DetachableModule):
                             lin.dilation[0], lin.dilation[1])
         norm = torch.empty((N, geom["P"], geom["Q"], G), device=x.device, dtype=torch.float32)
         dummy = torch.empty((N, geom["P"], geom["Q"], 4), device=x.device, dtype=torch.float32)
-        for g in range(G):
-            a = x
-            if G > 1:
-                geom.update(a_pitch=Cin, norm_pitch=G)
-                a = x[..., g * cin_g:]
-            ops.tapconv(a, zero_w, geom, out=dummy, norm_out=norm[..., g:], bcos_mode=_hipfn.BCOS_CONV_EPS,
-                        flags=_hipfn.BCOS_EPI_NORM_ONLY)
+        if G > 1:
+            geom.update(groups=G, a_pitch=Cin, out_pitch=4 * G, norm_pitch=G)
+            dummy = torch.empty((N, geom["P"], geom["Q"], 4 * G), device=x.device, dtype=torch.float32)
+            zero_w = torch.zeros((4 * G, kh, kw, cpad), device=x.device, dtype=torch.float32)
+        ops.tapconv(x, zero_w, geom, out=dummy, norm_out=norm, bcos_mode=_hipfn.BCOS_CONV_EPS, flags=_hipfn.BCOS_EPI_NORM_ONLY,
+                    track_absmax=False)
         norm = norm.permute(0, 3, 1, 2)
         if G > 1:
             norm = torch.repeat_interleave(norm, repeats=self.out_channels // G, dim=1)

@@ -39,7 +39,7 @@ class TapconvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "C", "P", "Q", "in_sh", "in_sw", "dh0", "dw0", "dstep_h", "dstep_w",
         "TH", "TW", "OH", "OW", "out_sh", "out_sw", "out_h0", "out_w0", "Cout",
-        "a_pitch", "out_pitch", "norm_pitch", "out_cgroup")]
+        "a_pitch", "out_pitch", "norm_pitch", "out_cgroup", "groups")]
 
 
 class Epilogue(C.Structure):

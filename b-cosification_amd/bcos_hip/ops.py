@@ -213,7 +213,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     selected; a caller that knows the reader of a tensor will not use them -- K < F16X2_MIN_K -- passes False)."""
     lib = _l.load()
     g = TapconvGeom()
-    for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup"):
+    for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup", "groups"):
         setattr(g, k, 0)
     for k, v in geom.items():
         setattr(g, k, int(v))
@@ -282,7 +282,7 @@ def tapconv_group(a: torch.Tensor, wts, geoms, *, out, addend=None, mul=None):
     earr = (Epilogue * n)()
     warr = (C.c_void_p * n)()
     for i, (w, geom) in enumerate(zip(wts, geoms)):
-        for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup"):
+        for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup", "groups"):
             setattr(garr[i], k, 0)
         for k, v in geom.items():
             setattr(garr[i], k, int(v))

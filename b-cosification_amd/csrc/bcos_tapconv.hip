@@ -204,7 +204,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
     const bool mul_from_act = (e.flags & BCOS_EPI_MUL_FROM_ACT) != 0 && e.mul != nullptr && e.mul_norm != nullptr;
     const bool want_max = e.out_absmax != nullptr || e.out2_absmax != nullptr;
     const float bm1 = e.b - 1.0f;
-    const int Cout = g.Cout;
+    const int Cout = ((int)blockIdx.y + 1) * g.Cout;      // end of this launch's (group's) column range; blockIdx.y = group
     constexpr int CPR = SBN / 4;             // 16-byte chunks per part row
     constexpr int RPP = NT / CPR;            // rows per pass
     constexpr int PASSES = SBM / RPP;
@@ -217,7 +217,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
     if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
         for (int r = tid; r < BM; r += NT) {
             const int64_t pix = sPix[r];
-            if (pix >= 0) e.norm_out[pix * g.norm_pitch] = sNorm[r];
+            if (pix >= 0) e.norm_out[pix * g.norm_pitch + blockIdx.y] = sNorm[r];
         }
     }
     const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
@@ -549,7 +549,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
     const unsigned lsb = (RELU && SCALE_OUT && (e.flags & BCOS_EPI_SCALE_GATE_LSB)) ? 1u : 0u;
     const bool want_max1 = e.out_absmax != nullptr, want_max2 = OUT2 && e.out2_absmax != nullptr;
-    const int Cout = g.Cout;
+    const int Cout = ((int)blockIdx.y + 1) * g.Cout;      // end of this launch's (group's) column range; blockIdx.y = group
     const unsigned tbytes = p.out_bytes;
     auto rsrc = [&](const void* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q), 0, tbytes, 0x00020000); };
     const __amdgpu_buffer_rsrc_t r_out = rsrc(e.out);
@@ -581,7 +581,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
         for (int r = tid; r < BM; r += NT) {
             const int pix = sRow[r].pix;
-            if (pix >= 0) e.norm_out[(int64_t)pix * g.norm_pitch] = sNorm[r];
+            if (pix >= 0) e.norm_out[(int64_t)pix * g.norm_pitch + blockIdx.y] = sNorm[r];
         }
     }
     const int col = n0 + ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
@@ -796,7 +796,7 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int co = n0 + r0 + 32 * j;
-        b_ok[j] = co < g.Cout;
+        b_ok[j] = co < ((int)blockIdx.y + 1) * g.Cout;          // (grouped launches: blockIdx.y = group, n0 counts global columns)
         b_off[j] = (int64_t)(b_ok[j] ? co : 0) * p.Ktot;
     }
 
@@ -834,7 +834,7 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
             const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
             const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.a + (int)blockIdx.y * g.C + a_nbase[j] + ((int64_t)ih * W + iw) * a_pitch + cc * 4);
             ra[j] = v;
         }
 #pragma unroll
@@ -958,7 +958,10 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     // zeros -- no exec-mask branches, no zero-filling moves, 32-bit offsets.  Inside a tap the K walk advances through
     // the scalar offset operand, so a steady-state step issues its loads with no vector ALU work at all.
     constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    // (grouped launches: blockIdx.y = group; it reads its channel slice of A, n0 counts global output columns)
+    const unsigned a_goff = (unsigned)blockIdx.y * (unsigned)g.C * 4u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.a) + a_goff), 0, p.a_bytes - a_goff, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
     unsigned a_nbase[A_LD];          // byte offset of the row's image (+ this lane's 16-byte chunk)
     int a_ih0[A_LD], a_iw0[A_LD];
@@ -983,7 +986,7 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int co = n0 + r0 + 64 * j;
-        const bool ok = co < g.Cout && (!B_HALF || r0 < BN);
+        const bool ok = co < ((int)blockIdx.y + 1) * g.Cout && (!B_HALF || r0 < BN);
         b_off[j] = ok ? ((unsigned)co * p.Ktot + chunk * 4) * 4u : OOB;
     }
 
@@ -1620,10 +1623,11 @@ __global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN) ?
         const int tile = xcd_remap(bid, p.n_big);
         const int tile_m = tile / p.tiles_n;
         const int tile_n = tile - tile_m * p.tiles_n;
+        const int gcol = (int)blockIdx.y * p.g.Cout;        // first global column of this group (0 unless a grouped launch)
         if constexpr (X3 == 3) tile_body_h2<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
-        else if constexpr (X3 == 2) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, tile_m * BM, tile_n * BN, tile_n);
-        else if constexpr (X3 == 1) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, tile_m * BM, tile_n * BN, tile_n);
-        else tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        else if constexpr (X3 == 2) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, tile_m * BM, gcol + tile_n * BN, tile_n);
+        else if constexpr (X3 == 1) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, tile_m * BM, gcol + tile_n * BN, tile_n);
+        else tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, gcol + tile_n * BN, tile_n);
     } else {
         constexpr int BMS = BM / 2;
         constexpr int WMS = (BMS / 32 >= WAVES_M) ? WAVES_M : BMS / 32;    // waves along M of the small tile
@@ -1632,10 +1636,11 @@ __global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN) ?
             const int tile = xcd_remap(bid - p.n_big, p.n_small);
             const int tile_m = tile / p.tiles_n;
             const int tile_n = tile - tile_m * p.tiles_n;
+            const int gcol = (int)blockIdx.y * p.g.Cout;
             if constexpr (X3 == 3) tile_body_h2<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
-            else if constexpr (X3 == 2) tile_body_x3<BMS, BN, WMS, WNS, NORM, true>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
-            else if constexpr (X3 == 1) tile_body_x3<BMS, BN, WMS, WNS, NORM, false>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
-            else tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            else if constexpr (X3 == 2) tile_body_x3<BMS, BN, WMS, WNS, NORM, true>(p, smem, p.rows_big + tile_m * BMS, gcol + tile_n * BN, tile_n);
+            else if constexpr (X3 == 1) tile_body_x3<BMS, BN, WMS, WNS, NORM, false>(p, smem, p.rows_big + tile_m * BMS, gcol + tile_n * BN, tile_n);
+            else tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, gcol + tile_n * BN, tile_n);
         }
     }
 }
@@ -1684,7 +1689,7 @@ int launch_cfg(const KArgs& base, bool norm, hipStream_t stream) {
     size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
     if (lds_epi > lds) lds = lds_epi;
-    const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
+    const dim3 grid((unsigned)(p.n_big + p.n_small), (unsigned)(p.g.groups > 1 ? p.g.groups : 1)), block(NTHREADS);     // y = group
     hipError_t err;
     const size_t lds_x3 = 2 * 3 * (size_t)(BM + BN) * X3_ROW;
     if (p.x3 && lds_x3 > lds_epi) lds = lds_x3;
@@ -2012,6 +2017,10 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     if ((g.P - 1) * g.out_sh + g.out_h0 >= g.OH || (g.Q - 1) * g.out_sw + g.out_w0 >= g.OW || g.out_h0 < 0 ||
         g.out_w0 < 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: output mapping outside [OH,OW]");
+    const int G = g.groups > 1 ? g.groups : 1;
+    if (g.groups < 0 || g.groups > 65535) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad group count");
+    if (G > 1 && (g.out_cgroup != 0 || epi->max_out > 1 || epi->out_absmax || epi->out2_absmax))
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: grouped launches exclude out_cgroup, fused MaxOut and *_absmax");
     if (g.out_cgroup != 0) {     // depth to space: columns = (output parity class, channel)
         if (g.out_cgroup < 0 || g.out_cgroup % 4 != 0 || g.out_sh <= 0 || g.out_sw <= 0 || g.out_h0 != 0 || g.out_w0 != 0 ||
             g.Cout != g.out_sh * g.out_sw * g.out_cgroup || g.P * g.out_sh > g.OH || g.Q * g.out_sw > g.OW ||
@@ -2028,13 +2037,14 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     p.a = a;
     p.wt = wt;
     p.g = g;
-    if (p.g.a_pitch == 0) p.g.a_pitch = g.C;
-    if (p.g.out_pitch == 0) p.g.out_pitch = g.out_cgroup > 0 ? g.out_cgroup : g.Cout;
-    if (p.g.norm_pitch == 0) p.g.norm_pitch = 1;
-    if (p.g.a_pitch % 4 != 0 || p.g.a_pitch < g.C) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad a_pitch");
+    if (p.g.a_pitch == 0) p.g.a_pitch = G * g.C;
+    if (p.g.out_pitch == 0) p.g.out_pitch = g.out_cgroup > 0 ? g.out_cgroup : G * g.Cout;
+    if (p.g.norm_pitch == 0) p.g.norm_pitch = G;
+    if (p.g.a_pitch % 4 != 0 || p.g.a_pitch < G * g.C) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad a_pitch");
     if (epi->max_out > 1 && g.out_pitch == 0) p.g.out_pitch = g.Cout / epi->max_out;
-    if (g.out_cgroup == 0 && p.g.out_pitch < g.Cout / (epi->max_out > 1 ? epi->max_out : 1))
+    if (g.out_cgroup == 0 && p.g.out_pitch < G * g.Cout / (epi->max_out > 1 ? epi->max_out : 1))
         return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: bad out_pitch");
+    if (p.g.norm_pitch < G) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: norm_pitch smaller than the group count");
     p.e = *epi;
     p.M = (int)M64;
     p.PQ = g.P * g.Q;
@@ -2054,7 +2064,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     {   // the split-bf16 path addresses its operands through 32-bit buffer offsets: keep each launch below 2 GiB of A
         // by splitting the batch (every tensor of the call is per-image separable); fall back to fp32 MFMA otherwise
         const int64_t img_bytes = (int64_t)g.H * g.W * p.g.a_pitch * 4;
-        const int64_t a_bytes = img_bytes * g.N, wt_bytes = (int64_t)g.Cout * p.Ktot * 4;
+        const int64_t a_bytes = img_bytes * g.N, wt_bytes = (int64_t)G * g.Cout * p.Ktot * 4;
         const int64_t lim = (int64_t)1 << 31;
         if (p.x3 && a_bytes >= lim && g.N > 1 && img_bytes < lim && wt_bytes < lim) {
             const int per = (int)((lim - 1) / img_bytes);
@@ -2082,15 +2092,16 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         if (a_bytes >= lim || wt_bytes >= lim) p.x3 = 0;
         p.a_bytes = (unsigned)(a_bytes < lim ? a_bytes : 0);
         p.wt_bytes = (unsigned)(wt_bytes < lim ? wt_bytes : 0);
-        const int64_t w3b = split_bytes(g.Cout, p.Ktot);
-        p.wt3 = (p.x3 && wt3 && w3b < lim && !(reinterpret_cast<uintptr_t>(wt3) & 15)) ? wt3 : nullptr;
+        const int64_t w3b = split_bytes(G * g.Cout, p.Ktot);
+        // (grouped launches index the image by global weight row: a group's rows must start on a 32-row fragment tile)
+        p.wt3 = (p.x3 && wt3 && w3b < lim && !(reinterpret_cast<uintptr_t>(wt3) & 15) && (G == 1 || g.Cout % 32 == 0)) ? wt3 : nullptr;
         p.wt3_bytes = (unsigned)(w3b < lim ? w3b : 0);
         const int64_t w2b = h2_image_bytes(g.Cout, p.Ktot), pixb = (int64_t)g.N * g.H * g.W * 4;
         // below K = 256 a launch is HBM-bound and the bf16x3 loop (no operand maxima to produce) is as fast, unless the caller
         // insists on f16x2; at K = 256 the six bf16 products still occupy a third of the SIMD cycles (14^2 layers of ResNet-50:
         // -12 % per launch with three f16 products).  The stem's K is all taps over 8 channels: compute-bound at any K.
         const bool h2_pays = p.Ktot >= 256 || (g.C <= 16 && p.Ktot >= 128) || ops->contraction == BCOS_CONTRACT_F16X2;
-        if (mode == 2 && h2_pays && p.x3 && ops->a_absmax && ops->wt_f16x2 && w2b < lim && pixb < lim &&
+        if (mode == 2 && G == 1 && h2_pays && p.x3 && ops->a_absmax && ops->wt_f16x2 && w2b < lim && pixb < lim &&
             !(reinterpret_cast<uintptr_t>(ops->wt_f16x2) & 15)) {
             p.h2 = 1;
             p.a_absmax = ops->a_absmax;
@@ -2140,7 +2151,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g.Cout <= 8 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1) {
+    if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1) {
         const int handled = bcos_try_skinny(a, wt, p.g, p.e, p.M, s);
         if (handled != 0) return handled < 0 ? handled : BCOS_OK;
     }

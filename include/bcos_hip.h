@@ -84,6 +84,14 @@ typedef struct bcos_tapconv_geom {
                                     gradient in one launch over the union of their taps (weights of taps a class
                                     does not use are zero; bcos_hip/ops.py: DgradPlan).  Needs G % 4 == 0,
                                     out_h0 == out_w0 == 0, 16-byte addressable tensors, no max_out, no *_absmax */
+    int32_t groups;              /* 0 / 1: off.  G > 1 (grouped convolution, bcosconv2d.py:84-140 `groups`): one launch for all
+                                    groups.  C and Cout are PER GROUP: group g reads channels [g C, (g+1) C) of every pixel of A
+                                    (a_pitch 0 = G C), contracts them with weight rows [g Cout, (g+1) Cout) of wt [G Cout][taps][C]
+                                    and writes output columns g Cout + co (out_pitch 0 = G Cout; bias / ch_scale / ch_shift are
+                                    indexed by that global column); norm_out holds one patch norm per pixel AND group
+                                    ([pixels][norm_pitch], norm_pitch 0 = G).  Runs on the fp32 / bf16x3 loops (no f16x2, no
+                                    *_absmax, no out_cgroup, no fused MaxOut); the pre-split bf16x3 image is used when
+                                    Cout % 32 == 0. */
 } bcos_tapconv_geom;
 
 /*

@@ -18,8 +18,23 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
             mul_norm=None, mul_csc=None, mul_csh=None):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
-    g = dict(a_pitch=0, out_pitch=0, norm_pitch=0, out_cgroup=0)
+    g = dict(a_pitch=0, out_pitch=0, norm_pitch=0, out_cgroup=0, groups=0)
     g.update(geom)
+    if g["groups"] > 1:       # grouped launch (include/bcos_hip.h: bcos_tapconv_geom.groups): the documented result = one launch per group
+        G, C, Cout = g["groups"], g["C"], g["Cout"]
+        sub = dict(g, groups=0, a_pitch=g["a_pitch"] or G * C, out_pitch=g["out_pitch"] or G * Cout, norm_pitch=g["norm_pitch"] or G)
+        a4 = a if a.dim() == 4 else a.view(g["N"], g["H"], g["W"], -1)
+
+        def cols(t, k):
+            return None if t is None else (t if t.dim() == 4 else t.view(g["N"], g["OH"], g["OW"], -1))[..., k * Cout:]
+        for k in range(G):
+            tapconv(a4[..., k * C:], wt.reshape(G * Cout, -1)[k * Cout:(k + 1) * Cout], sub, out=cols(out, k), out2=cols(out2, k),
+                    scale_out=cols(scale_out, k), norm_out=None if norm_out is None else norm_out.view(g["N"], g["OH"], g["OW"], -1)[..., k:],
+                    bias=None if bias is None else bias[k * Cout:(k + 1) * Cout],
+                    ch_scale=None if ch_scale is None else ch_scale[k * Cout:(k + 1) * Cout],
+                    ch_shift=None if ch_shift is None else ch_shift[k * Cout:(k + 1) * Cout], addend=cols(addend, k), mul=cols(mul, k),
+                    mul2=cols(mul2, k), gate2=cols(gate2, k), relu_gate=cols(relu_gate, k), bcos_mode=bcos_mode, b=b, relu=relu, flags=flags)
+        return
     N, H, W, C = g["N"], g["H"], g["W"], g["C"]
     P, Q, TH, TW, Cout = g["P"], g["Q"], g["TH"], g["TW"], g["Cout"]
     a4 = (a if a.dim() == 4 else a.view(N, H, W, -1))[..., :C]

@@ -929,6 +929,61 @@ def test_depth_to_space_dgrad_matches_per_class_launches(lib, mode):
         blib.set_contraction_mode(prev)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32", "f16x2"])
+def test_grouped_launch_matches_one_launch_per_group(lib, mode):
+    """bcos_tapconv_geom.groups: all groups of a grouped B-cos convolution in ONE launch (blockIdx.y = group: its channel slice
+    of A, its filter rows, its output columns, its patch norm) gives the bits of one launch per group -- forward with bias,
+    BN affine, residual, ReLU, stored multiplier, norms; pre-split weights when Cout % 32 == 0, in-kernel split otherwise;
+    against torch's grouped convolution with the B-cos scaling applied per group."""
+    from bcos_hip import ops
+    from bcos_hip import lib as blib
+    prev = blib.get_contraction_mode()
+    blib.set_contraction_mode(mode)
+    g = torch.Generator().manual_seed(41)
+    try:
+        for (N, H, G, cin_g, cout_g, k, st, pd) in [(2, 12, 2, 8, 12, 3, 1, 1), (3, 9, 4, 16, 32, 1, 1, 0), (2, 11, 3, 4, 40, 3, 2, 1),
+                                                    (1, 7, 8, 32, 64, 3, 1, 1)]:
+            Cin, Cout = G * cin_g, G * cout_g
+            x = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+            w = ops.mark_static((torch.randn(Cout, k, k, cin_g, generator=g) / (k * k * cin_g) ** 0.5).to(DEV))
+            bias = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+            csc = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+            csh = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+            geom = ops.fwd_geom(N, H, H, cin_g, cout_g, k, k, st, st, pd, pd)
+            P = geom["P"]
+            add = torch.randn(N, P, P, Cout, generator=g).to(DEV)
+
+            def run(grouped):
+                y = torch.full((N, P, P, Cout), float("nan"), device=DEV)
+                t = torch.full_like(y, float("nan"))
+                nrm = torch.full((N, P, P, G), float("nan"), device=DEV)
+                kw = dict(bias=bias, ch_scale=csc, ch_shift=csh, bcos_mode=1, b=2.0, relu=True, track_absmax=False)
+                if grouped:
+                    ops.tapconv(x, w, dict(geom, groups=G, a_pitch=Cin, out_pitch=Cout, norm_pitch=G), out=y, scale_out=t, norm_out=nrm,
+                                addend=add, **kw)
+                else:
+                    for i in range(G):
+                        kwi = dict(kw, bias=bias[i * cout_g:(i + 1) * cout_g], ch_scale=csc[i * cout_g:(i + 1) * cout_g],
+                                   ch_shift=csh[i * cout_g:(i + 1) * cout_g])
+                        ops.tapconv(x[..., i * cin_g:], ops.mark_static(w[i * cout_g:(i + 1) * cout_g].contiguous()),
+                                    dict(geom, a_pitch=Cin, out_pitch=Cout, norm_pitch=G), out=y[..., i * cout_g:], scale_out=t[..., i * cout_g:],
+                                    norm_out=nrm[..., i:], addend=add[..., i * cout_g:], **kwi)
+                return y, t, nrm
+            one, per = run(True), run(False)
+            for a, b_ in zip(one, per):
+                assert torch.equal(a.view(torch.int32), b_.view(torch.int32)), (mode, G, cin_g, cout_g, k)
+            # against torch: grouped convolution, per-group patch norms, B = 2 scale, affine, residual, ReLU
+            xn, wn = x.permute(0, 3, 1, 2).cpu(), w.permute(0, 3, 1, 2).cpu()
+            lin = F.conv2d(xn, wn, bias.cpu(), st, pd, 1, G)
+            ss = F.conv2d(xn.pow(2).reshape(N * G, cin_g, H, H), torch.ones(1, cin_g, k, k), None, st, pd).reshape(N, G, P, P)
+            norm = (ss + 1e-6).sqrt()
+            ref = lin * lin.abs() / norm.repeat_interleave(cout_g, dim=1)
+            ref = (ref * csc.cpu().view(1, -1, 1, 1) + csh.cpu().view(1, -1, 1, 1) + add.permute(0, 3, 1, 2).cpu()).clamp_min(0)
+            assert rel(one[0].permute(0, 3, 1, 2), ref) <= 1e-5 and rel(one[2].permute(0, 3, 1, 2), norm) <= 1e-6, (mode, G, k)
+    finally:
+        blib.set_contraction_mode(prev)
+
+
 def test_operand_larger_than_2gib_is_split_by_images(lib):
     """The split-bf16 path addresses its operands through 32-bit buffer offsets; a call whose input exceeds 2 GiB is
     split by images inside bcos_tapconv.  2 x 1024 x 1024 x 272 fp32 = 2.28 GB in, 1x1 conv to 16 channels."""
