@@ -5,12 +5,12 @@ reference bcosconv2d.py:153-194 issues 9 ATen launches for the same thing).
 Backward:
   * explanation mode (`detach=True`): the dynamic scale is a constant, so d out / d x = conv_transpose(g * s, W) -- the
     "dynamic linear weights" W(x) of bcos/common.py:177-181 -- and d out / d W = wgrad(g * s, x);
-  * training mode (groups == 1): the scale is differentiated too (bcosconv2d.py:176-194 without
+  * training mode (grouped layers per group): the scale is differentiated too (bcosconv2d.py:176-194 without
     .detach()):  gx = dgrad(g * dy/dlin, W) + x (.) PatchSum^T(dL/dnorm / norm), gW = wgrad(g * dy/dlin, x),
     gbias = sum_pixels g * dy/dlin (csrc/bcos_train.hip); MaxOut routes g * dy/dlin to the winning filter of each unit
     (bcos_maxout_scatter); a learnable exponent (`b` an nn.Parameter, trainer.py:451-463) receives
     sum g y ln(|cos| + 1e-6) times d B_eff / d b; native layers differentiate through their unit-norm projection (UnitNormFn).
-Grouped layers outside explanation mode still raise instead of silently producing explanation-mode gradients.
+Layers that are grouped AND MaxOut still raise outside explanation mode instead of silently producing explanation-mode gradients.
 """
 import torch
 import torch.nn.functional as F
@@ -165,10 +165,10 @@ class BcosConv2dFn(Function):
         need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
         need_bp = b_param is not None and ctx.needs_input_grad[4] and _b_gradient_applies(cfg, b)
         train = (need_grad or need_w or need_b or need_bp) and not cfg["detach"] and b != 1.0     # the scale is differentiated
-        if (train or need_w or need_b) and groups != 1:
+        if (train or need_w or need_b) and groups != 1 and max_out != 1:
             raise NotImplementedError(
-                "BcosConv2d: weight gradients / training-mode gradients are built for groups == 1 (SURVEY.md section 8(f) N4); "
-                "grouped layers support explanation-mode input gradients only")
+                "BcosConv2d: weight gradients / training-mode gradients of layers that are grouped AND MaxOut are not built "
+                "(SURVEY.md section 8(f) N4); such layers support explanation-mode input gradients only")
         want_scale = bool((need_grad or need_w or need_b or need_bp) and b != 1.0)
         # MaxOut over 2 or 4 filters is taken inside the contraction's epilogue (one launch, bcosconv2d.py:166-170); other
         # unit sizes, grouped layers and training-mode calls (which need the unit-wide y, s and the winner indices) go through
@@ -180,7 +180,7 @@ class BcosConv2dFn(Function):
         y_cl, y = empty_cl(N, Cout_all, Ho, Wo, x.device)
         scale = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if (want_scale and fused) else None
         if train and fused:
-            norm = torch.empty((N, Ho, Wo), device=x.device, dtype=torch.float32)
+            norm = torch.empty((N, Ho, Wo, groups), device=x.device, dtype=torch.float32)
         else:
             norm = None if fused or b == 1.0 else torch.empty((N, Ho, Wo, groups), device=x.device, dtype=torch.float32)
         mode = BCOS_NONE if b == 1.0 else BCOS_CONV_EPS
@@ -255,7 +255,32 @@ class BcosConv2dFn(Function):
         g = to_nhwc(gy)
         addend = None
         gbp = None
-        if ctx.train:
+        if ctx.train and groups > 1:
+            # grouped layer: every group has its own patch norms, so the scale derivative and the norm term run per group on
+            # dense copies of the group's slices (a rarely used path: clarity over launch count)
+            Cout = g.shape[3]
+            cout_g, cin_g = Cout // groups, Cin // groups
+            if cout_g % 4:
+                raise NotImplementedError("training-mode backward needs out_channels / groups % 4 == 0")
+            yh = to_nhwc(y_cl)
+            glin = torch.empty((N, Ho, Wo, Cout), device=g.device, dtype=torch.float32)
+            addend_g = [None] * groups
+            btot = None
+            for gi in range(groups):
+                sl = slice(gi * cout_g, (gi + 1) * cout_g)
+                gl_g, rn_g, bg = ops.train_scale_bwd(g[..., sl].reshape(-1, cout_g).contiguous(), yh[..., sl].reshape(-1, cout_g).contiguous(),
+                                                     scale[..., sl].reshape(-1, cout_g).contiguous(), norm[..., gi].reshape(-1).contiguous(),
+                                                     BCOS_CONV_EPS, float(cfg["b"]), bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
+                glin[..., sl] = gl_g.view(N, Ho, Wo, cout_g)
+                if bg is not None:
+                    btot = bg if btot is None else btot + bg
+                if need_x:
+                    addend_g[gi] = ops.patch_norm_bwd(xh[..., gi * cin_g:(gi + 1) * cin_g].contiguous(), rn_g.view(N, Ho, Wo), cin_g,
+                                                      (kh, kw), cfg["stride"], cfg["padding"], cfg["dilation"])
+            if ctx.need_bp:
+                gbp = (btot * float(cfg.get("b_chain", 1.0))).view(())
+            addend = addend_g
+        elif ctx.train:
             Cout = g.shape[3]
             if Cout % 4:
                 raise NotImplementedError("training-mode backward needs out_channels % 4 == 0")
@@ -278,7 +303,13 @@ class BcosConv2dFn(Function):
         gw = gb = None
         if need_w or need_b:
             gl4 = _pad_last(glin).contiguous()
-            if need_w:
+            if need_w and groups > 1:      # per group: its output-gradient columns against its input channels
+                cout_g, cin_g = glin.shape[3] // groups, Cin // groups
+                parts = [ops.conv2d_wgrad(_pad_last(glin[..., gi * cout_g:(gi + 1) * cout_g]).contiguous(),
+                                          xh[..., gi * cin_g:(gi + 1) * cin_g].contiguous(), cin_g, cout_g, (kh, kw), cfg["stride"],
+                                          cfg["padding"], cfg["dilation"]) for gi in range(groups)]
+                gw = torch.cat(parts, 0).permute(0, 3, 1, 2).contiguous()     # [Cout,kh,kw,Cin/G] -> OIHW
+            elif need_w:
                 gwk = ops.conv2d_wgrad(gl4, xh, Cin, glin.shape[3], (kh, kw), cfg["stride"], cfg["padding"], cfg["dilation"])
                 gw = gwk.permute(0, 3, 1, 2).contiguous()                     # [Cout,kh,kw,Cin] -> OIHW
             if need_b:
@@ -295,7 +326,7 @@ class BcosConv2dFn(Function):
             if groups == 1:
                 plan.run(gl, H, W, out=gx, addend=addend)
             else:
-                gx[..., gi * cin_g:(gi + 1) * cin_g] = plan.run(gl, H, W)
+                gx[..., gi * cin_g:(gi + 1) * cin_g] = plan.run(gl, H, W, addend=addend[gi] if isinstance(addend, list) else None)
         return gx_cl, gw, gb, None, gbp
 
 

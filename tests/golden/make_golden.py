@@ -350,6 +350,26 @@ def train_cases2():
     for kk, vv in dict(x=x, weight=mod.linear.weight.detach(), scale=mod.linear.scale.detach(), y=y.detach(), gy=gy, gx=gx, gw=gw,
                        gscale=gs).items():
         out[f"u_nat_scale/{kk}"] = vv
+    # grouped layers in training mode (per-group patch norms, bcosconv2d.py:200-221): B-cosified, native, learnable exponent
+    for name, kind, b, learn_b in (("u_grp_conv", "bcosify", 2.0, False), ("u_grp_nat", "native", 2.0, False), ("u_grp_b", "bcosify", 1.5, True)):
+        if kind == "bcosify":
+            mod = R.bcosifyconv2d.BcosifyConv2d(8, 16, 3, 1, 1, 1, 2, b=2, max_out=1)
+        else:
+            mod = R.bcos_modules.BcosConv2d(8, 16, 3, 1, 1, 1, 2, b=2, max_out=1)
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+        mod.b = nn.Parameter(torch.tensor(b, dtype=torch.float32)) if learn_b else b
+        mod.train()
+        x = torch.randn(2, 8, 7, 6, generator=g)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad(y, [xr, mod.linear.weight] + ([mod.b] if learn_b else []), gy)
+        case = dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=grads[0], gw=grads[1])
+        if learn_b:
+            case["gb_param"] = grads[2]
+        for kk, vv in case.items():
+            out[f"{name}/{kk}"] = vv
     np.savez_compressed(os.path.join(HERE, "train_layers2.npz"), **t2n(out))
     with open(os.path.join(HERE, "train_layers2.json"), "w") as f:
         json.dump([dict(zip(("name", "kind", "layer", "b", "clamping", "b_loss", "max_out", "learn_b"), c)) for c in TRAIN2_CASES], f, indent=1)

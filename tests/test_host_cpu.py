@@ -383,6 +383,19 @@ def run_training_goldens2(golden_dir, dev, tol):
                 assert grads[2] is None or float(grads[2]) == 0.0, (n, grads[2])
             else:
                 assert abs(float(grads[2]) - want) <= 10 * tol * abs(want), (n, float(grads[2]), want)
+    for n, kind, b, learn_b in (("u_grp_conv", "bcosify", 2.0, False), ("u_grp_nat", "native", 2.0, False), ("u_grp_b", "bcosify", 1.5, True)):
+        m = (BcosifyConv2d if kind == "bcosify" else BcosConv2d)(8, 16, 3, 1, 1, 1, 2, b=2, max_out=1)      # groups = 2
+        with torch.no_grad():
+            m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+        m = m.to(dev).train()
+        m.b = nn.Parameter(torch.tensor(b, dtype=torch.float32, device=dev)) if learn_b else b
+        x = t(f"{n}/x").requires_grad_(True)
+        y = m(x)
+        grads = torch.autograd.grad(y, [x, m.linear.weight] + ([m.b] if learn_b else []), t(f"{n}/gy"))
+        assert rel(y, data[f"{n}/y"]) <= tol and rel(grads[0], data[f"{n}/gx"]) <= tol and rel(grads[1], data[f"{n}/gw"]) <= tol, n
+        if learn_b:
+            want = float(data[f"{n}/gb_param"])
+            assert abs(float(grads[2]) - want) <= 10 * tol * abs(want), (n, float(grads[2]), want)
     n = "u_nat_scale"
     m = BcosConv2d(12, 16, 3, 1, 1, b=2)
     with torch.no_grad():
@@ -455,8 +468,8 @@ def test_training_mode_refusals(monkeypatch):
     cpu_emulation.install(monkeypatch)
     from bcos.modules import BcosConv2d
     x = torch.rand(1, 8, 5, 5, requires_grad=True)
-    with pytest.raises(NotImplementedError, match="groups == 1"):                    # grouped layers outside explanation mode
-        BcosConv2d(8, 4, 3, padding=1, b=2, groups=2).train()(x)
+    with pytest.raises(NotImplementedError, match="grouped AND MaxOut"):             # grouped MaxOut layers outside explanation mode
+        BcosConv2d(8, 4, 3, padding=1, b=2, groups=2, max_out=2).train()(x)
     m = BcosConv2d(8, 4, 3, padding=1, b=2).eval()                                   # eval / explanation mode are unaffected
     m.set_explanation_mode(True)
     (g,) = torch.autograd.grad(m(x).sum(), x)
