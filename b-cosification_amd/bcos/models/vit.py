@@ -80,14 +80,16 @@ class _AttentionCoreFn(Function):
         out, stats = ops.attention_fwd(qkv, heads, scale, want_stats=need)
         ctx.cfg = (heads, scale, detach)
         if need:
-            ctx.save_for_backward(qkv, stats)
+            ctx.save_for_backward(qkv, stats, *([] if detach else [out]))
         return out
 
     @staticmethod
     def backward(ctx, gout):
         heads, scale, detach = ctx.cfg
-        if not detach:
-            raise NotImplementedError("attention backward outside explanation mode is not implemented in the MI355X build")
+        gout = gout if gout.is_contiguous() else gout.contiguous()
+        if not detach:          # training mode: q, k and v all receive gradients (csrc/bcos_vit.hip: attention_bwd_full_kernel)
+            qkv, stats, out = ctx.saved_tensors
+            return ops.attention_bwd(qkv, stats, out, gout, heads, scale), None, None, None
         qkv, stats = ctx.saved_tensors
         gv = ops.attention_bwd_v(qkv, stats, gout if gout.is_contiguous() else gout.contiguous(), heads, scale)
         gqkv = torch.zeros_like(qkv)

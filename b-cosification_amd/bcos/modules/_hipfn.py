@@ -401,10 +401,15 @@ class BcosLinearFn(Function):
         addend = None
         gbp = None
         if ctx.train:
-            if g2.shape[1] % 4:
-                raise NotImplementedError("training-mode backward needs out_features % 4 == 0")
-            glin, rnorm, bgrad = ops.train_scale_bwd(g2, y, scale, norm, BCOS_LINEAR_EPS, float(cfg["b"]),
-                                                     bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
+            co = g2.shape[1]
+            if co % 4:      # the scale-derivative kernel moves float4: pad the columns (g = y = 0, s = 1 contribute nothing)
+                pad = (-co) % 4
+                glin, rnorm, bgrad = ops.train_scale_bwd(F.pad(g2, (0, pad)), F.pad(y, (0, pad)), F.pad(scale, (0, pad), value=1.0), norm,
+                                                         BCOS_LINEAR_EPS, float(cfg["b"]), bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
+                glin = glin[:, :co].contiguous()
+            else:
+                glin, rnorm, bgrad = ops.train_scale_bwd(g2, y, scale, norm, BCOS_LINEAR_EPS, float(cfg["b"]),
+                                                         bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
             if ctx.need_bp:
                 gbp = (bgrad * float(cfg.get("b_chain", 1.0))).view(())
             if need_x:      # gradient through ||x||: x * dL/dnorm / ||x||, added by the dgrad epilogue

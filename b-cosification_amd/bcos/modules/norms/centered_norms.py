@@ -29,21 +29,34 @@ class _LayerNormFn(Function):
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         w = weight.detach().contiguous() if weight is not None else None
         b = bias.detach().contiguous() if bias is not None else None
-        y, rstd = ops.layernorm_fwd(x2, w, b, eps, want_rstd=ctx.needs_input_grad[0])
+        need_x = ctx.needs_input_grad[0]
+        need_wb = (weight is not None and ctx.needs_input_grad[1]) or (bias is not None and ctx.needs_input_grad[2])
+        y, rstd = ops.layernorm_fwd(x2, w, b, eps, want_rstd=need_x or need_wb)
         ctx.detach_mode = detach
         ctx.w = w
+        ctx.has_bias = bias is not None
         if rstd is not None:
-            ctx.save_for_backward(rstd)
+            ctx.save_for_backward(rstd, *([x2] if not detach else []))
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, gy):
-        if not ctx.detach_mode:
-            raise NotImplementedError("LayerNorm backward outside explanation mode is not implemented in the MI355X "
-                                      "build (SURVEY.md section 8(f) N4): use model.explanation_mode()")
-        (rstd,) = ctx.saved_tensors
+        rstd = ctx.saved_tensors[0]
         g2 = gy.reshape(-1, gy.shape[-1])
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        need_w = ctx.w is not None and ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gw = gb = None
+        if not ctx.detach_mode:
+            # training mode (= F.layer_norm's gradient, centered_norms.py:200-202): nothing detached
+            x2 = ctx.saved_tensors[1]
+            gx, xhat = ops.layernorm_bwd(g2, x2, ctx.w, rstd, want_xhat=need_w)
+            if need_w:
+                gw = ops.colsum(g2, xhat) if g2.shape[1] % 4 == 0 else (g2 * xhat).sum(0)
+            if need_b:
+                gb = ops.colsum(g2) if g2.shape[1] % 4 == 0 else g2.sum(0)
+            return gx.view(gy.shape), gw, gb, None, None
+        # explanation mode: the input gradient only (the affine parameters receive gradients in training mode)
         gx, _ = ops.layernorm_bwd_detached(g2, ctx.w, rstd)
         return gx.view(gy.shape), None, None, None, None
 

@@ -762,6 +762,34 @@ def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=
     return o, o2
 
 
+def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False):
+    """Full LayerNorm input gradient (+ x_hat for the weight gradient), include/bcos_hip.h: bcos_layernorm_bwd."""
+    lib = _l.load()
+    rows, D = gy2d.shape
+    gx = torch.empty_like(gy2d)
+    xhat = torch.empty_like(gy2d) if want_xhat else None
+    _l.check(lib.bcos_layernorm_bwd(_dev(gy2d, "gy"), _dev(x2d, "x"), _dev(weight, "weight"), _dev(rstd, "rstd"), _dev(gx, "gx"),
+                                    _dev(xhat, "xhat"), rows, D, _stream()), "bcos_layernorm_bwd")
+    return gx, xhat
+
+
+def gelu_bwd(gy, x):
+    lib = _l.load()
+    gx = torch.empty_like(gy)
+    _l.check(lib.bcos_gelu_bwd(_dev(gy, "gy"), _dev(x, "x"), _dev(gx, "gx"), gy.numel(), _stream()), "bcos_gelu_bwd")
+    return gx
+
+
+def attention_bwd(qkv, stats, out, gout, heads, scale):
+    """gradient w.r.t. the packed qkv [B,T,3*inner] with q, k and v all differentiated (include/bcos_hip.h: bcos_attention_bwd)"""
+    lib = _l.load()
+    B, T, three_inner = qkv.shape
+    gqkv = torch.empty_like(qkv)
+    _l.check(lib.bcos_attention_bwd(_dev(qkv, "qkv"), _dev(stats, "stats"), _dev(out, "out"), _dev(gout, "gout"), _dev(gqkv, "gqkv"),
+                                    B, T, heads, three_inner // (3 * heads), float(scale), _stream()), "bcos_attention_bwd")
+    return gqkv
+
+
 def groupnorm_fwd(x_nhwc, groups, weight, bias, eps, want_rstd=False):
     """GroupNorm of an NHWC tensor [N,H,W,C] (include/bcos_hip.h: bcos_groupnorm_fwd) -> (y, rstd [N*G] or None)."""
     lib = _l.load()

@@ -28,16 +28,19 @@ class _GeluFn(Function):
         # a channels_last [N,C,H,W] activation (conv stems of the ViT-C models) is processed as its dense NHWC image
         ctx.cl = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
         xc = x.permute(0, 2, 3, 1) if ctx.cl else (x if x.is_contiguous() else x.contiguous())
-        y, gate = ops.gelu_gate(xc, want_gate=ctx.needs_input_grad[0])
+        y, gate = ops.gelu_gate(xc, want_gate=ctx.needs_input_grad[0] and detach)
         ctx.detach_mode = detach
-        if gate is not None:
-            ctx.save_for_backward(gate)
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(gate if detach else xc)
         return y.permute(0, 3, 1, 2) if ctx.cl else y
 
     @staticmethod
     def backward(ctx, gy):
-        if not ctx.detach_mode:
-            raise NotImplementedError("GELU backward outside explanation mode is not implemented in the MI355X build")
+        if not ctx.detach_mode:         # training mode: the gate is differentiated too, d/dx [x Phi(x)] = Phi(x) + x phi(x)
+            (xc,) = ctx.saved_tensors
+            if ctx.cl:
+                return ops.gelu_bwd(gy.permute(0, 2, 3, 1).contiguous(), xc).permute(0, 3, 1, 2), None
+            return ops.gelu_bwd(gy if gy.is_contiguous() else gy.contiguous(), xc), None
         (gate,) = ctx.saved_tensors
         if ctx.cl:
             return ops.mul(gy.permute(0, 2, 3, 1).contiguous(), gate).permute(0, 3, 1, 2), None

@@ -373,6 +373,141 @@ __global__ __launch_bounds__(TPB) void groupnorm_bwd_detached_kernel(const float
     }
 }
 
+// ---- training-mode backward of the token path (SURVEY.md section 8(f) N4 for the ViT family) ---------------------------------
+// LayerNorm, nothing detached: x_hat = (x - mean) rstd, h = gy w:  gx = rstd (h - mean(h) - x_hat mean(h x_hat)); x_hat is also
+// written out for the weight gradient (sum_rows gy x_hat, a column reduction).  One wavefront per row.
+__global__ __launch_bounds__(TPB) void layernorm_bwd_full_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                 const float* __restrict__ w, const float* __restrict__ rstd,
+                                                                 float* __restrict__ gx, float* __restrict__ xhat, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float* xs = x + r * D;
+        const float* gs = gy + r * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += xs[c];
+        const float mean = wave_sum(s) / (float)D;
+        const float rs = rstd[r];
+        float sh = 0.f, shx = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float xh = (xs[c] - mean) * rs;
+            const float h = gs[c] * (w ? w[c] : 1.0f);
+            sh += h;
+            shx = fmaf(h, xh, shx);
+        }
+        const float mh = wave_sum(sh) / (float)D, mhx = wave_sum(shx) / (float)D;
+        for (int c = lane; c < D; c += 64) {
+            const float xh = (xs[c] - mean) * rs;
+            const float h = gs[c] * (w ? w[c] : 1.0f);
+            gx[r * D + c] = rs * (h - mh - xh * mhx);
+            if (xhat) xhat[r * D + c] = xh;
+        }
+    }
+}
+
+// GELU, gate not detached: d/dx [x Phi(x)] = Phi(x) + x phi(x)
+__global__ __launch_bounds__(TPB) void gelu_bwd_full_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                            float* __restrict__ gx, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+        const float v = x[i];
+        const float Phi = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        const float phi = 0.3989422804014327f * expf(-0.5f * v * v);
+        gx[i] = gy[i] * (Phi + v * phi);
+    }
+}
+
+// Softmax attention, nothing detached: per (image, head) one workgroup; K and V of the head stay in LDS, the query rows are walked
+// in chunks of ARB; thread j owns key j (dK_j, dV_j accumulate in its registers), then threads (r, d) finish dQ of the chunk.
+//   P = softmax(scale Q K^T) (from the stored statistics), dP = dO V^T, D_i = dO_i . O_i, dS = scale P (dP - D)
+//   dQ = dS K,  dK = dS^T Q,  dV = P^T dO.   Plain FMA loops: training throughput of the ViTs is not a benchmarked quantity.
+constexpr int ARB = 16;
+constexpr int AKLD = DH + 1;      // padded K / V rows in LDS: lanes = keys read the same d without bank conflicts
+
+__global__ __launch_bounds__(256) void attention_bwd_full_kernel(const float* __restrict__ qkv, const float* __restrict__ stats,
+                                                                 const float* __restrict__ out, const float* __restrict__ gout,
+                                                                 float* __restrict__ gqkv, int B, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int inner = H * DH;
+    const int tid = threadIdx.x;
+    // (one key per thread: the host guarantees T <= 256)
+    float* sK = sm;                         // [T][AKLD]
+    float* sV = sK + T * AKLD;              // [T][AKLD]
+    float* sQ = sV + T * AKLD;              // [ARB][DH]
+    float* sdO = sQ + ARB * DH;             // [ARB][DH]
+    float* sD = sdO + ARB * DH;             // [ARB]
+    float* sSt = sD + ARB;                  // [ARB][2]
+    float* sdS = sSt + 2 * ARB;             // [ARB][T]
+    const float* base = qkv + (int64_t)b * T * 3 * inner + h * DH;
+    for (int i = tid; i < T * DH; i += 256) {
+        const int t = i / DH, d = i - t * DH;
+        sK[t * AKLD + d] = base[(int64_t)t * 3 * inner + inner + d];
+        sV[t * AKLD + d] = base[(int64_t)t * 3 * inner + 2 * inner + d];
+    }
+    float dk[DH], dv[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    const bool key = tid < T;
+    for (int i0 = 0; i0 < T; i0 += ARB) {
+        __syncthreads();                                     // previous chunk consumed (first trip: K / V staged)
+        for (int i = tid; i < ARB * DH; i += 256) {
+            const int r = i / DH, d = i - r * DH;
+            const int t = i0 + r;
+            sQ[i] = t < T ? base[(int64_t)t * 3 * inner + d] : 0.f;
+            sdO[i] = t < T ? gout[((int64_t)b * T + t) * inner + h * DH + d] : 0.f;
+        }
+        if (tid < ARB) {
+            const int t = i0 + tid;
+            float dd = 0.f;
+            if (t < T) {
+                const float* go = gout + ((int64_t)b * T + t) * inner + h * DH;
+                const float* oo = out + ((int64_t)b * T + t) * inner + h * DH;
+                for (int d = 0; d < DH; ++d) dd = fmaf(go[d], oo[d], dd);
+                sSt[2 * tid] = stats[(((int64_t)b * H + h) * T + t) * 2];
+                sSt[2 * tid + 1] = stats[(((int64_t)b * H + h) * T + t) * 2 + 1];
+            } else {
+                sSt[2 * tid] = INFINITY;                     // padded query rows: p = exp(-inf) * 0 = 0
+                sSt[2 * tid + 1] = 0.f;
+            }
+            sD[tid] = dd;
+        }
+        __syncthreads();
+        if (key) {
+            const float* kj = sK + tid * AKLD;
+            const float* vj = sV + tid * AKLD;
+            for (int r = 0; r < ARB; ++r) {
+                const float* q = sQ + r * DH;
+                const float* go = sdO + r * DH;
+                float sc = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) { sc = fmaf(q[d], kj[d], sc); dp = fmaf(go[d], vj[d], dp); }
+                const float pr = expf(sc * scale - sSt[2 * r]) * sSt[2 * r + 1];
+                const float ds = pr * (dp - sD[r]) * scale;
+                sdS[r * T + tid] = ds;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) { dk[d] = fmaf(ds, q[d], dk[d]); dv[d] = fmaf(pr, go[d], dv[d]); }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < ARB * DH; i += 256) {          // dQ of the chunk: thread (r, d)
+            const int r = i / DH, d = i - r * DH;
+            const int t = i0 + r;
+            if (t >= T) continue;
+            float acc = 0.f;
+            for (int j = 0; j < T; ++j) acc = fmaf(sdS[r * T + j], sK[j * AKLD + d], acc);
+            gqkv[((int64_t)b * T + t) * 3 * inner + h * DH + d] = acc;
+        }
+    }
+    if (key) {
+        float* gk = gqkv + ((int64_t)b * T + tid) * 3 * inner + inner + h * DH;
+        float* gv = gk + inner;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) { gk[d] = dk[d]; gv[d] = dv[d]; }
+    }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -473,4 +608,35 @@ extern "C" int bcos_groupnorm_bwd_detached(const float* gy, const float* weight,
     hipLaunchKernelGGL(groupnorm_bwd_detached_kernel, dim3((unsigned)(N * G)), dim3(TPB), 0, STREAM(stream), gy, weight, rstd, gx, HW,
                        C, G);
     return check_launch("groupnorm_bwd_detached_kernel");
+}
+
+extern "C" int bcos_layernorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,
+                                  int64_t rows, int D, void* stream) {
+    if (!gy || !x || !rstd || !gx || rows <= 0 || D <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_layernorm_bwd: bad argument");
+    hipLaunchKernelGGL(layernorm_bwd_full_kernel, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), gy, x, weight, rstd, gx, xhat_out,
+                       rows, D);
+    return check_launch("layernorm_bwd_full_kernel");
+}
+
+extern "C" int bcos_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream) {
+    if (!gy || !x || !gx || n <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_gelu_bwd: bad argument");
+    int64_t blocks = (n + TPB - 1) / TPB;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gelu_bwd_full_kernel, dim3((unsigned)blocks), dim3(TPB), 0, STREAM(stream), gy, x, gx, n);
+    return check_launch("gelu_bwd_full_kernel");
+}
+
+extern "C" int bcos_attention_bwd(const float* qkv, const float* stats, const float* out, const float* gout, float* gqkv, int B, int T,
+                                  int H, int Dh, float scale, void* stream) {
+    if (!qkv || !stats || !out || !gout || !gqkv || B <= 0 || T <= 0 || H <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_attention_bwd: bad argument");
+    if (Dh != DH) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_bwd: head dim must be 64");
+    if (T > 256) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_bwd: at most 256 tokens");
+    const size_t bytes = ((size_t)2 * T * AKLD + 2 * ARB * DH + 3 * ARB + (size_t)ARB * T) * sizeof(float);
+    static std::atomic<size_t> lds_hw;
+    hipError_t err = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_bwd_full_kernel), bytes, lds_hw);
+    if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
+    hipLaunchKernelGGL(attention_bwd_full_kernel, dim3((unsigned)(B * H)), dim3(256), bytes, STREAM(stream), qkv, stats, out, gout, gqkv,
+                       B, T, H, scale);
+    return check_launch("attention_bwd_full_kernel");
 }

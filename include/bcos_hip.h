@@ -460,6 +460,19 @@ int bcos_attention_fwd(const float* qkv, float* out, float* stats, int B, int T,
 int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout, float* gv, int B, int T, int H, int Dh,
                          float scale, void* stream);
 
+/* -- training-mode backward of the token path (nothing detached; SURVEY.md section 8(f) N4 for the ViT family) ---------- */
+/* LayerNorm over the last dimension (centered_norms.py:187-245 outside explanation mode = F.layer_norm's gradient):
+ * gx = rstd (h - mean(h) - x_hat mean(h x_hat)), h = gy * weight, x_hat = (x - mean) rstd; xhat_out (NULL or [rows, D])
+ * receives x_hat for the weight gradient sum_rows gy x_hat (bcos_colsum). */
+int bcos_layernorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,
+                       int64_t rows, int D, void* stream);
+/* MyGELU with the gate differentiated (bcosify_vit.py:27-32 with detach off): gx = gy (Phi(x) + x phi(x)). */
+int bcos_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream);
+/* Softmax attention with q, k, v all differentiated (vit.py:143-158 outside explanation mode): gqkv [B, T, 3*H*64] from qkv,
+ * the forward's stats and output, and gout [B, T, H*64].  T <= 256. */
+int bcos_attention_bwd(const float* qkv, const float* stats, const float* out, const float* gout, float* gqkv,
+                       int B, int T, int H, int Dh, float scale, void* stream);
+
 /* End of the ViT explanation pass: gp [N, H/p, W/p, p, p, Cpad] (input gradient of the patch embedding, one row per
  * patch in the "(p1 p2 c)" order of vit.py:291) -> W(x) [N,6,H,W] (/ std) and contribution map [N,H,W]. */
 int bcos_finalize_explanation_patches(const float* gp, const float* x, const float* std6, float* weights_out,

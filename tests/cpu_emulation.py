@@ -304,6 +304,36 @@ def weight_rownorm_bwd(w2d, g2d, gain=None, want_gw=True, want_ggain=False):
     return gw, (dot.view(-1) if want_ggain else None)
 
 
+def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False):
+    x = x2d.double()
+    xhat = (x - x.mean(1, keepdim=True)) * rstd.double().view(-1, 1)
+    h = gy2d.double() * (weight.double() if weight is not None else 1.0)
+    gx = rstd.double().view(-1, 1) * (h - h.mean(1, keepdim=True) - xhat * (h * xhat).mean(1, keepdim=True))
+    return gx.float(), (xhat.float() if want_xhat else None)
+
+
+def gelu_bwd(gy, x):
+    v = x.double()
+    Phi = 0.5 * (1 + torch.erf(v / 2 ** 0.5))
+    phi = torch.exp(-0.5 * v * v) / (2 * torch.pi) ** 0.5
+    return (gy.double() * (Phi + v * phi)).float()
+
+
+def attention_bwd(qkv, stats, out, gout, heads, scale):
+    B, T, three_inner = qkv.shape
+    inner = three_inner // 3
+    d = inner // heads
+    q, k, v = (t.reshape(B, T, heads, d).permute(0, 2, 1, 3).double() for t in qkv.split(inner, dim=-1))
+    go = gout.reshape(B, T, heads, d).permute(0, 2, 1, 3).double()
+    P = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    dP = go @ v.transpose(-1, -2)
+    D = (P * dP).sum(-1, keepdim=True)
+    dS = P * (dP - D) * scale
+    gq, gk, gv = dS @ k, dS.transpose(-1, -2) @ q, P.transpose(-1, -2) @ go
+    pack = lambda t: t.permute(0, 2, 1, 3).reshape(B, T, inner)        # noqa: E731
+    return torch.cat([pack(gq), pack(gk), pack(gv)], dim=-1).float()
+
+
 def groupnorm_fwd(x_nhwc, groups, weight, bias, eps, want_rstd=False):
     N, H, W, Cc = x_nhwc.shape
     xg = x_nhwc.reshape(N, H * W, groups, Cc // groups).double()
@@ -381,7 +411,8 @@ def install(monkeypatch):
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
                  "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand",
-                 "weight_rownorm_bwd", "maxout_scatter", "groupnorm_fwd", "groupnorm_bwd_detached"):
+                 "weight_rownorm_bwd", "maxout_scatter", "groupnorm_fwd", "groupnorm_bwd_detached",
+                 "layernorm_bwd", "gelu_bwd", "attention_bwd"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

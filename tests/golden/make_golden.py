@@ -678,6 +678,82 @@ def vitc_and_groupnorm():
                        torch_version=torch.__version__), f, indent=1)
 
 
+def vit_training_cases():
+    """N4 for the token path: DetachableLayerNorm, MyGELU and Attention in TRAINING mode (nothing detached) and one training
+    step of a small B-cosified SimpleViT (dim 128, 2 heads, 2 blocks, 64 x 64 images, patch 16): loss, input gradient, every
+    parameter-gradient norm and three full gradients."""
+    import importlib
+    import warnings
+    warnings.simplefilter("ignore")
+    ref_vit = importlib.import_module("bcos.models.vit")
+    ref_bvit = importlib.import_module("bcosify_vit")
+    RefLN = importlib.import_module("bcos.modules.norms.centered_norms").DetachableLayerNorm
+    out = {}
+    g = torch.Generator().manual_seed(919)
+    ln = RefLN(48)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(48, generator=g) + 0.5); ln.bias.copy_(torch.randn(48, generator=g) * 0.2)
+    ln.train()
+    x = torch.randn(3, 7, 48, generator=g) * 1.5 + 0.3
+    xr = x.clone().requires_grad_(True)
+    y = ln(xr)
+    gy = torch.randn(y.shape, generator=g)
+    gx, gw, gb = torch.autograd.grad(y, [xr, ln.weight, ln.bias], gy)
+    for kk, vv in dict(x=x, weight=ln.weight.detach(), bias=ln.bias.detach(), y=y.detach(), gy=gy, gx=gx, gw=gw, gb=gb).items():
+        out[f"ln/{kk}"] = vv
+    gelu = ref_bvit.MyGELU().train()
+    x = torch.randn(4, 9, 40, generator=g) * 2
+    xr = x.clone().requires_grad_(True)
+    y = gelu(xr)
+    gy = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, xr, gy)
+    for kk, vv in dict(x=x, y=y.detach(), gy=gy, gx=gx).items():
+        out[f"gelu/{kk}"] = vv
+    # Attention block (pre-norm, to_qkv plain, to_out B-cosified) in training mode
+    cfg = synth.vit_model_config("simple_vit_ti_patch16_224")
+    torch.manual_seed(7)
+    att = ref_vit.Attention(128, heads=2, dim_head=64, linear_layer=nn.Linear, norm_layer=nn.LayerNorm)
+    holder = nn.Sequential(att)
+    ref_bvit.BcosifyNetwork.bcosify(holder, cfg)
+    att = holder[0].train()
+    x = torch.randn(2, 10, 128, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = att(xr)
+    gy = torch.randn(y.shape, generator=g)
+    names = [n for n, _ in att.named_parameters()]
+    grads = torch.autograd.grad(y, [xr] + [p_ for _, p_ in att.named_parameters()], gy)
+    out.update({"attn/x": x, "attn/y": y.detach(), "attn/gy": gy, "attn/gx": grads[0]})
+    for n, p_, gr in zip(names, [p_ for _, p_ in att.named_parameters()], grads[1:]):
+        out[f"attn/param/{n}"] = p_.detach()
+        out[f"attn/grad/{n}"] = gr
+    # one training step of a small B-cosified SimpleViT
+    torch.manual_seed(11)
+    std = ref_vit.SimpleViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, channels=3,
+                            linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU)
+    cfg = synth.vit_model_config("simple_vit_ti_patch16_224")
+    net = ref_bvit.BcosifyNetwork(std, cfg, add_channels=True, logit_layer=cfg["logit_layer"])
+    synth.finish_vit_conversion(net, cfg)
+    net.train()
+    xs = synth.synthetic_images(3, seed=77, size=64)
+    target = torch.nn.functional.one_hot(torch.tensor([1, 7, 4]), 10).float()
+    xr = xs.clone().requires_grad_(True)
+    logits = net(xr)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, target)
+    params = [(n, p_) for n, p_ in net.named_parameters() if p_.requires_grad]
+    grads = torch.autograd.grad(loss, [xr] + [p_ for _, p_ in params])
+    out.update({"vit/logits": logits.detach(), "vit/loss": loss.detach(), "vit/gx": grads[0]})
+    gnorm = {}
+    for (n, p_), gr in zip(params, grads[1:]):
+        out[f"vit/param/{n}"] = p_.detach()
+        gnorm[n] = float(gr.double().norm())
+    for n in ("model.to_patch_embedding.linear.linear.weight", "model.transformer.encoder_0.attn.to_qkv.weight",
+              "model.transformer.encoder_1.ff.net.norm.weight"):
+        out[f"vit/grad/{n}"] = dict(zip([n_ for n_, _ in params], grads[1:]))[n]
+    np.savez_compressed(os.path.join(HERE, "vit_train.npz"), **t2n(out))
+    with open(os.path.join(HERE, "vit_train.json"), "w") as f:
+        json.dump(dict(attn_params=names, vit_params=[n for n, _ in params], grad_norms=gnorm, torch_version=torch.__version__), f, indent=1)
+
+
 def clip_rn50_embeddings():
     """BASELINE.json configs[3] topology: B-cosified CLIP RN50 image encoder (clip_kd conversion, attention-pool head):
     embeddings of 4 images + the zero-shot head of clip_evaluate on a seeded text matrix."""
@@ -824,7 +900,7 @@ def localisation_grid():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "vitc", "clip", "unpool", "loc"]
+    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "vitc", "vit_train", "clip", "unpool", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -838,6 +914,8 @@ if __name__ == "__main__":
         train_cases2()
     if "vitc" in which:
         vitc_and_groupnorm()
+    if "vit_train" in which:
+        vit_training_cases()
     if "train_r18" in which:
         resnet18_training_step()
     if "inv" in which:

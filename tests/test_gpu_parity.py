@@ -576,6 +576,13 @@ def test_vit_ti_against_reference_golden(lib, golden_dir):
     assert torch.equal(again["dynamic_linear_weights"], out["dynamic_linear_weights"])     # deterministic
 
 
+def test_vit_training_mode_against_reference_golden(lib, golden_dir):
+    """Training mode of the token path on the device: full LayerNorm / GELU / softmax-attention gradients and a BCE training
+    step of a small B-cosified SimpleViT against the reference's recorded gradients."""
+    from test_host_cpu import run_vit_training_goldens
+    run_vit_training_goldens(golden_dir, DEV, 1e-5)
+
+
 def test_vitc_ti_and_groupnorm_against_reference_golden(lib, golden_dir):
     """The conv-stem ViT (vitc_ti_patch1_14) and DetachableGroupNorm2d on the device: bcos_groupnorm_fwd /
     bcos_groupnorm_bwd_detached, MyGELU on channels_last activations, the stem convolutions on the fused B-cos kernel --

@@ -452,6 +452,76 @@ def run_vitc_goldens(golden_dir, dev, tol):
     assert rel(out["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
 
 
+def run_vit_training_goldens(golden_dir, dev, tol):
+    """N4 on the token path: DetachableLayerNorm, MyGELU and Attention in TRAINING mode (bcos_layernorm_bwd, bcos_gelu_bwd,
+    bcos_attention_bwd) and one BCE training step of a small B-cosified SimpleViT against gradients recorded from the reference
+    (tests/golden/vit_train.npz)."""
+    import bcos.models.vit as vit
+    from bcos.modules.norms import DetachableLayerNorm
+    from bcos_hip import synth
+    from bcosify_vit import BcosifyNetwork, MyGELU
+    data = np.load(os.path.join(golden_dir, "vit_train.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "vit_train.json")))
+    t = lambda k: torch.from_numpy(data[k]).to(dev)      # noqa: E731
+    ln = DetachableLayerNorm(48)
+    with torch.no_grad():
+        ln.weight.copy_(torch.from_numpy(data["ln/weight"])); ln.bias.copy_(torch.from_numpy(data["ln/bias"]))
+    ln = ln.to(dev).train()
+    x = t("ln/x").requires_grad_(True)
+    y = ln(x)
+    gx, gw, gb = torch.autograd.grad(y, [x, ln.weight, ln.bias], t("ln/gy"))
+    assert rel(y, data["ln/y"]) <= tol and rel(gx, data["ln/gx"]) <= tol and rel(gw, data["ln/gw"]) <= tol and rel(gb, data["ln/gb"]) <= tol
+    gelu = MyGELU().train()
+    x = t("gelu/x").requires_grad_(True)
+    y = gelu(x)
+    (gx,) = torch.autograd.grad(y, x, t("gelu/gy"))
+    assert rel(y, data["gelu/y"]) <= tol and rel(gx, data["gelu/gx"]) <= tol
+    cfg = synth.vit_model_config("simple_vit_ti_patch16_224")
+    att = vit.Attention(128, heads=2, dim_head=64, linear_layer=nn.Linear, norm_layer=nn.LayerNorm)
+    holder = nn.Sequential(att)
+    BcosifyNetwork.bcosify(holder, cfg)
+    att = holder[0]
+    with torch.no_grad():
+        for n, p_ in att.named_parameters():
+            p_.copy_(torch.from_numpy(data[f"attn/param/{n}"]))
+    att = att.to(dev).train()
+    assert [n for n, _ in att.named_parameters()] == meta["attn_params"]
+    x = t("attn/x").requires_grad_(True)
+    y = att(x)
+    grads = torch.autograd.grad(y, [x] + [p_ for _, p_ in att.named_parameters()], t("attn/gy"))
+    assert rel(y, data["attn/y"]) <= tol and rel(grads[0], data["attn/gx"]) <= 2 * tol, (rel(y, data["attn/y"]), rel(grads[0], data["attn/gx"]))
+    for n, gr in zip(meta["attn_params"], grads[1:]):
+        assert rel(gr, data[f"attn/grad/{n}"]) <= 2 * tol, (n, rel(gr, data[f"attn/grad/{n}"]))
+    std = vit.SimpleViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, channels=3,
+                        linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU)
+    net = BcosifyNetwork(std, cfg, add_channels=True, logit_layer=cfg["logit_layer"])
+    synth.finish_vit_conversion(net, cfg)
+    params = [(n, p_) for n, p_ in net.named_parameters() if p_.requires_grad]
+    assert [n for n, _ in params] == meta["vit_params"]
+    with torch.no_grad():
+        for n, p_ in params:
+            p_.copy_(torch.from_numpy(data[f"vit/param/{n}"]))
+    net = net.to(dev).train()
+    params = [(n, p_) for n, p_ in net.named_parameters() if p_.requires_grad]
+    xs = synth.synthetic_images(3, seed=77, size=64).to(dev).requires_grad_(True)
+    target = F.one_hot(torch.tensor([1, 7, 4]), 10).float().to(dev)
+    logits = net(xs)
+    loss = F.binary_cross_entropy_with_logits(logits, target)
+    grads = torch.autograd.grad(loss, [xs] + [p_ for _, p_ in params])
+    assert rel(logits, data["vit/logits"]) <= 10 * tol and abs(float(loss) - float(data["vit/loss"])) <= 10 * tol * abs(float(data["vit/loss"]))
+    assert rel(grads[0], data["vit/gx"]) <= 1e-4, rel(grads[0], data["vit/gx"])
+    for (n, _), gr in zip(params, grads[1:]):
+        want = meta["grad_norms"][n]
+        assert abs(float(gr.double().norm()) - want) <= 1e-4 * want, (n, float(gr.double().norm()), want)
+        if f"vit/grad/{n}" in data.files:
+            assert rel(gr, data[f"vit/grad/{n}"]) <= 1e-4, (n, rel(gr, data[f"vit/grad/{n}"]))
+
+
+def test_vit_training_mode_matches_reference_golden(monkeypatch, golden_dir):
+    cpu_emulation.install(monkeypatch)
+    run_vit_training_goldens(golden_dir, "cpu", 4e-6)
+
+
 def test_vitc_and_groupnorm_match_reference_golden(monkeypatch, golden_dir):
     cpu_emulation.install(monkeypatch)
     run_vitc_goldens(golden_dir, "cpu", 4e-6)
