@@ -93,20 +93,31 @@ class _GroupNormFn(Function):
         xh = _hipfn.to_nhwc(x)
         w = weight.detach().contiguous() if weight is not None else None
         b = bias.detach().contiguous() if bias is not None else None
-        y, rstd = ops.groupnorm_fwd(xh, groups, w, b, eps, want_rstd=ctx.needs_input_grad[0])
-        ctx.detach_mode, ctx.groups, ctx.w = detach, groups, w
+        need = ctx.needs_input_grad[0] or (weight is not None and ctx.needs_input_grad[1]) or (bias is not None and ctx.needs_input_grad[2])
+        y, rstd = ops.groupnorm_fwd(xh, groups, w, b, eps, want_rstd=need)
+        ctx.detach_mode, ctx.groups, ctx.w, ctx.has_bias = detach, groups, w, bias is not None
         if rstd is not None:
-            ctx.save_for_backward(rstd)
+            ctx.save_for_backward(rstd, *([xh] if not detach else []))
         return _hipfn.from_nhwc(y)
 
     @staticmethod
     def backward(ctx, gy):
-        if not ctx.detach_mode:
-            raise NotImplementedError("GroupNorm backward outside explanation mode is not implemented in the MI355X build "
-                                      "(SURVEY.md section 8(f) N4 covers the B-cos layers): use model.explanation_mode()")
-        (rstd,) = ctx.saved_tensors
-        gx = ops.groupnorm_bwd_detached(_hipfn.to_nhwc(gy), ctx.groups, ctx.w, rstd)
-        return _hipfn.from_nhwc(gx), None, None, None, None, None
+        rstd = ctx.saved_tensors[0]
+        gh = _hipfn.to_nhwc(gy)
+        if ctx.detach_mode:         # explanation mode: variance constant, the input gradient only
+            return _hipfn.from_nhwc(ops.groupnorm_bwd_detached(gh, ctx.groups, ctx.w, rstd)), None, None, None, None, None
+        xh = ctx.saved_tensors[1]   # training mode (= F.group_norm's gradient, reference :109-113)
+        need_w = ctx.w is not None and ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gx, xhat = ops.groupnorm_bwd(gh, xh, ctx.groups, ctx.w, rstd, want_xhat=need_w)
+        Cc = gh.shape[-1]
+        g2 = gh.reshape(-1, Cc)
+        gw = gb = None
+        if need_w:
+            gw = ops.colsum(g2, xhat.reshape(-1, Cc)) if Cc % 4 == 0 else (g2 * xhat.reshape(-1, Cc)).sum(0)
+        if need_b:
+            gb = ops.colsum(g2) if Cc % 4 == 0 else g2.sum(0)
+        return _hipfn.from_nhwc(gx), gw, gb, None, None, None
 
 
 class DetachableGroupNorm2d(nn.GroupNorm, DetachableModule):

@@ -773,6 +773,17 @@ def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False):
     return gx, xhat
 
 
+def groupnorm_bwd(gy_nhwc, x_nhwc, groups, weight, rstd, want_xhat=False):
+    """Full GroupNorm input gradient (+ x_hat for the affine gradients), include/bcos_hip.h: bcos_groupnorm_bwd."""
+    lib = _l.load()
+    N, H, W, Cc = gy_nhwc.shape
+    gx = torch.empty_like(gy_nhwc)
+    xhat = torch.empty_like(gy_nhwc) if want_xhat else None
+    _l.check(lib.bcos_groupnorm_bwd(_dev(gy_nhwc, "gy"), _dev(x_nhwc, "x"), _dev(weight, "weight"), _dev(rstd, "rstd"), _dev(gx, "gx"),
+                                    _dev(xhat, "xhat"), N, H * W, Cc, int(groups), _stream()), "bcos_groupnorm_bwd")
+    return gx, xhat
+
+
 def gelu_bwd(gy, x):
     lib = _l.load()
     gx = torch.empty_like(gy)

@@ -373,6 +373,41 @@ __global__ __launch_bounds__(TPB) void groupnorm_bwd_detached_kernel(const float
     }
 }
 
+// GroupNorm, nothing detached (F.group_norm's gradient): per (image, group) with m values,  x_hat = (x - mean) rstd, h = gy w:
+//   gx = rstd (h - mean(h) - x_hat mean(h x_hat));  x_hat is written out for the weight gradient (a column reduction)
+__global__ __launch_bounds__(TPB) void groupnorm_bwd_full_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                 const float* __restrict__ w, const float* __restrict__ rstd,
+                                                                 float* __restrict__ gx, float* __restrict__ xhat, int HW, int C, int G) {
+    __shared__ float red[TPB / 64];
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+    const int cg = C / G;
+    const int64_t base = (int64_t)n * HW * C + g * cg;
+    const int64_t m = (int64_t)HW * cg;
+    const float rs = rstd[blockIdx.x];
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < m; e += TPB) s += x[base + (e / cg) * C + e % cg];
+    const float mean = block_sum(s, red) / (float)m;
+    float sh = 0.f, shx = 0.f;
+    for (int64_t e = threadIdx.x; e < m; e += TPB) {
+        const int c = (int)(e % cg);
+        const int64_t i = base + (e / cg) * C + c;
+        const float xh = (x[i] - mean) * rs;
+        const float h = gy[i] * (w ? w[g * cg + c] : 1.0f);
+        sh += h;
+        shx = fmaf(h, xh, shx);
+    }
+    const float mh = block_sum(sh, red) / (float)m;
+    const float mhx = block_sum(shx, red) / (float)m;
+    for (int64_t e = threadIdx.x; e < m; e += TPB) {
+        const int c = (int)(e % cg);
+        const int64_t i = base + (e / cg) * C + c;
+        const float xh = (x[i] - mean) * rs;
+        const float h = gy[i] * (w ? w[g * cg + c] : 1.0f);
+        gx[i] = rs * (h - mh - xh * mhx);
+        if (xhat) xhat[i] = xh;
+    }
+}
+
 // ---- training-mode backward of the token path (SURVEY.md section 8(f) N4 for the ViT family) ---------------------------------
 // LayerNorm, nothing detached: x_hat = (x - mean) rstd, h = gy w:  gx = rstd (h - mean(h) - x_hat mean(h x_hat)); x_hat is also
 // written out for the weight gradient (sum_rows gy x_hat, a column reduction).  One wavefront per row.
@@ -639,4 +674,14 @@ extern "C" int bcos_attention_bwd(const float* qkv, const float* stats, const fl
     hipLaunchKernelGGL(attention_bwd_full_kernel, dim3((unsigned)(B * H)), dim3(256), bytes, STREAM(stream), qkv, stats, out, gout, gqkv,
                        B, T, H, scale);
     return check_launch("attention_bwd_full_kernel");
+}
+
+extern "C" int bcos_groupnorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,
+                                  int N, int HW, int C, int G, void* stream) {
+    if (!gy || !x || !rstd || !gx || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_groupnorm_bwd: bad argument");
+    if ((int64_t)N * G >= ((int64_t)1 << 31)) return bcos_set_error(BCOS_E_NOSUP, "bcos_groupnorm_bwd: too many groups");
+    hipLaunchKernelGGL(groupnorm_bwd_full_kernel, dim3((unsigned)(N * G)), dim3(TPB), 0, STREAM(stream), gy, x, weight, rstd, gx, xhat_out,
+                       HW, C, G);
+    return check_launch("groupnorm_bwd_full_kernel");
 }

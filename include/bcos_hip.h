@@ -466,6 +466,10 @@ int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout
  * receives x_hat for the weight gradient sum_rows gy x_hat (bcos_colsum). */
 int bcos_layernorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,
                        int64_t rows, int D, void* stream);
+/* DetachableGroupNorm2d outside explanation mode (= F.group_norm's gradient, centered_norms.py:109-113): per (image, group)
+ * gx = rstd (h - mean(h) - x_hat mean(h x_hat)), h = gy * weight; xhat_out (NULL or like x) for the affine gradients. */
+int bcos_groupnorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,
+                       int N, int HW, int C, int G, void* stream);
 /* MyGELU with the gate differentiated (bcosify_vit.py:27-32 with detach off): gx = gy (Phi(x) + x phi(x)). */
 int bcos_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream);
 /* Softmax attention with q, k, v all differentiated (vit.py:143-158 outside explanation mode): gqkv [B, T, 3*H*64] from qkv,

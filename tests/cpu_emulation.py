@@ -312,6 +312,16 @@ def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False):
     return gx.float(), (xhat.float() if want_xhat else None)
 
 
+def groupnorm_bwd(gy_nhwc, x_nhwc, groups, weight, rstd, want_xhat=False):
+    N, H, W, Cc = gy_nhwc.shape
+    xg = x_nhwc.reshape(N, H * W, groups, Cc // groups).double()
+    rs = rstd.double().view(N, 1, groups, 1)
+    xhat = (xg - xg.mean(dim=(1, 3), keepdim=True)) * rs
+    h = (gy_nhwc.double() * (weight.double() if weight is not None else 1.0)).reshape(N, H * W, groups, Cc // groups)
+    gx = rs * (h - h.mean(dim=(1, 3), keepdim=True) - xhat * (h * xhat).mean(dim=(1, 3), keepdim=True))
+    return gx.reshape(N, H, W, Cc).float(), (xhat.reshape(N, H, W, Cc).float() if want_xhat else None)
+
+
 def gelu_bwd(gy, x):
     v = x.double()
     Phi = 0.5 * (1 + torch.erf(v / 2 ** 0.5))
@@ -412,7 +422,7 @@ def install(monkeypatch):
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
                  "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand",
                  "weight_rownorm_bwd", "maxout_scatter", "groupnorm_fwd", "groupnorm_bwd_detached",
-                 "layernorm_bwd", "gelu_bwd", "attention_bwd"):
+                 "layernorm_bwd", "gelu_bwd", "attention_bwd", "groupnorm_bwd"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_device", lambda t, who="": None)
     from bcos.modules import _hipfn

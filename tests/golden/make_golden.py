@@ -646,6 +646,12 @@ def vitc_and_groupnorm():
         REPORT[f"{name}/plain_vs_detached_forward"] = rel(y_plain, y.detach())
         for kk, vv in dict(x=x, weight=m.weight.detach(), y=y.detach(), gy=gy, gx=gx).items():
             out[f"{name}/{kk}"] = vv
+        m.set_explanation_mode(False)                        # training mode: F.group_norm's full gradient
+        xt = x.clone().requires_grad_(True)
+        tg = torch.autograd.grad(m(xt), [xt, m.weight] + ([m.bias] if bias else []), gy)
+        out[f"{name}/gx_train"], out[f"{name}/gw_train"] = tg[0], tg[1]
+        if bias:
+            out[f"{name}/gb_train"] = tg[2]
         if bias:
             out[f"{name}/bias"] = m.bias.detach()
     arch = "vitc_ti_patch1_14"

@@ -435,9 +435,12 @@ def run_vitc_goldens(golden_dir, dev, tol):
         y = m(x)
         (gx,) = torch.autograd.grad(y, x, t(f"{n}/gy"))
         assert rel(y, data[f"{n}/y"]) <= tol and rel(gx, data[f"{n}/gx"]) <= tol, n
-        m.set_explanation_mode(False)
-        with pytest.raises(NotImplementedError):                            # training-mode norm gradients are not built
-            torch.autograd.grad(m(t(f"{n}/x").requires_grad_(True)).sum(), m.weight)
+        m.set_explanation_mode(False)                                       # training mode: the full gradient (bcos_groupnorm_bwd)
+        xt = t(f"{n}/x").requires_grad_(True)
+        tg = torch.autograd.grad(m(xt), [xt, m.weight] + ([m.bias] if c["bias"] else []), t(f"{n}/gy"))
+        assert rel(tg[0], data[f"{n}/gx_train"]) <= tol and rel(tg[1], data[f"{n}/gw_train"]) <= tol, n
+        if c["bias"]:
+            assert rel(tg[2], data[f"{n}/gb_train"]) <= tol, n
     net = synth.build_bcosified_vit(meta["arch"], seed=meta["weight_seed"])
     synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
     sd = net.state_dict()
