@@ -1213,7 +1213,7 @@ constexpr int H2_MAX_TAPS = 16;    // channel-chunk-major K walk for up to this 
 #define H2_KO 0                   // development knock-outs (timing only, wrong results): 1 no MFMA, 2 no split VALU, 4 no global loads in the loop, 8 no fragment reads
 #endif
 #ifndef H2_MFMA_ORDER
-#define H2_MFMA_ORDER 0           // 0 = product-major (consecutive MFMAs on different accumulators), 1 = accumulator-major
+#define H2_MFMA_ORDER 0           // 0 = chosen by tile shape (see mma_step), 1 = accumulator-major, 2 = product-major
 #endif
 #ifndef H2_PIPE_SMALL
 #define H2_PIPE_SMALL 2           // pipeline of the <= 4-accumulator tiles: 2 = one 16-k step per barrier, 3 = two
@@ -1481,32 +1481,36 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
                 bf[sp][j] = *reinterpret_cast<const f16x8*>(base + b_frag + j * 2048 + sp * 1024);
 #endif
         }
-        // smallest terms first; product-major order, so that consecutive matrix instructions write DIFFERENT accumulators
-        // (a dependent v_mfma on the same accumulator waits for the previous one to retire)
-#if H2_MFMA_ORDER == 0
+        // smallest terms first.  Product-major order (consecutive matrix instructions write DIFFERENT accumulators: a dependent
+        // v_mfma on the same accumulator waits for the previous one to retire) for the 2- and 4-accumulator wave tiles; the
+        // 8-accumulator tiles (128 x 256) measured 3-5 % faster accumulator-major (same-node A/B; the 4-accumulator tiles 3-6 %
+        // slower).  Per accumulator the three products arrive in the same order either way: identical bits.
+        // H2_MFMA_ORDER 0 = by tile shape, 1 = accumulator-major everywhere, 2 = product-major everywhere
+        constexpr bool ACC_MAJOR = H2_MFMA_ORDER == 1 || (H2_MFMA_ORDER == 0 && TM * TN >= 8);
+        if constexpr (!ACC_MAJOR) {
 #pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                    {
+#if H2_KO & 1
+                        asm volatile("" :: "v"(af[pr == 0 ? 1 : 0][i]), "v"(bf[pr == 1 ? 1 : 0][j]));
+#else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[pr == 0 ? 1 : 0][i], bf[pr == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+#endif
+                    }
+        } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                {
-#if H2_KO & 1
-                    asm volatile("" :: "v"(af[pr == 0 ? 1 : 0][i]), "v"(bf[pr == 1 ? 1 : 0][j]));
-#else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[pr == 0 ? 1 : 0][i], bf[pr == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
-#endif
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
                 }
-#else
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
-            }
-#endif
+        }
     };
 
     if (kmajor) __syncthreads();        // the (tap, row) offset table is complete
