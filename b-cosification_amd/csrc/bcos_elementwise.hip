@@ -213,13 +213,19 @@ __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restric
     const int64_t row = ((int64_t)n * H + h) * W * C4;
     const f32x4* gy4 = reinterpret_cast<const f32x4*>(gy) + (int64_t)n * OH * OW * C4;
     // (every lane runs every trip: the per-pixel maxima below are reduced across the C4 lanes of a pixel by shuffles)
+    // The (pixel, channel-chunk) decode and the window bounds are integer divisions by run-time values; with the usual powers of
+    // two (C4 = 16, stride 2) they become shifts -- the generic form spent more instructions on them than on the 6 memory
+    // operations of an element.
+    const int c4_shift = (C4 & (C4 - 1)) == 0 ? __builtin_ctz(C4) : -1;
+    const int s_shift = (s & (s - 1)) == 0 ? __builtin_ctz(s) : -1;
     for (int i0 = 0; i0 < W * C4; i0 += TPB) {
         const int i = i0 + threadIdx.x;
         const bool live = i < W * C4;
-        const int w = live ? i / C4 : 0, c4 = live ? i - w * C4 : 0;
-        int ow_lo = (w + p - k + s) / s;
+        const int w = live ? (c4_shift >= 0 ? i >> c4_shift : i / C4) : 0, c4 = live ? i - w * C4 : 0;
+        const int lo_num = w + p - k + s;                   // ceil((w + p - k + 1) / s) for a non-negative numerator
+        int ow_lo = s_shift >= 0 ? lo_num >> s_shift : lo_num / s;
         if (w + p - k + 1 <= 0) ow_lo = 0;
-        const int ow_hi = min((w + p) / s, OW - 1);
+        const int ow_hi = min(s_shift >= 0 ? (w + p) >> s_shift : (w + p) / s, OW - 1);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (live) {
             for (int oh = oh_lo; oh <= oh_hi; ++oh) {
@@ -228,8 +234,8 @@ __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restric
                 for (int ow = ow_lo; ow <= ow_hi; ++ow) {
                     const int ws = ow * s - p;
                     const int we = min(ws + k, W + p);
-                    const float pool = (float)((he - hs) * (we - ws));
-                    acc += gy4[(oh * OW + ow) * C4 + c4] / pool;
+                    const float rpool = 1.0f / (float)((he - hs) * (we - ws));      // one division per window, not four per chunk
+                    acc += gy4[(oh * OW + ow) * C4 + c4] * rpool;
                 }
             }
             if (mul) acc *= reinterpret_cast<const f32x4*>(mul)[row + i];
