@@ -233,7 +233,8 @@ class ResNetEngine:
     def _refresh_attnpool(self):
         ap = self.attnpool
         self._ap_fp = tuple((p.weight.data_ptr(), p.weight._version) for p in (ap.q_proj, ap.k_proj, ap.v_proj, ap.c_proj))
-        w = lambda lin: lin.weight.detach().contiguous()   # noqa: E731  (c_proj may be a BcosifyLinear: .weight property)
+        # (c_proj may be a BcosifyLinear: .weight property); inference-constant copies: pre-split images, f16x2 contraction
+        w = lambda lin: ops.mark_static(lin.weight.detach().clone().contiguous())   # noqa: E731
         self.ap_w = dict(q=w(ap.q_proj), k=w(ap.k_proj), v=w(ap.v_proj), c=w(ap.c_proj))
         self.ap_heads = ap.num_heads
         # explanation mode detaches q and k (bcosattnpool.py:37-39): the gradient reaches the feature map through v only,

@@ -149,8 +149,8 @@ class ViTEngine:
         if w.shape[1] != p * p * 6:
             raise BcosHipError("vit engine: patch embedding must take 6-channel patches")
         w4 = torch.nn.functional.pad(w.detach().view(dim, p, p, 6), (0, 2))           # [dim, p, p, 8]
-        self.embed_w = w4.contiguous()
-        self.embed_wt = w4.reshape(dim, p * p * 8).t().contiguous()                   # [p*p*8, dim]
+        self.embed_w = ops.mark_static(w4.contiguous())                               # inference constants: pre-split images are kept
+        self.embed_wt = ops.mark_static(w4.reshape(dim, p * p * 8).t().contiguous())  # [p*p*8, dim]
         self.embed_bias = bias.detach().contiguous() if bias is not None else None
         self.embed_b = e._b_value()
         self.dim = dim
@@ -159,8 +159,8 @@ class ViTEngine:
                 blk[k].refresh()
             wq = blk["qkv"].weight.detach()
             inner = wq.shape[0] // 3
-            blk["wqkv"] = wq.contiguous()                                            # [3*inner, dim]
-            blk["wv_t"] = wq[2 * inner:].t().contiguous()                            # [dim, inner]: gx = gv @ Wv
+            blk["wqkv"] = ops.mark_static(wq.clone().contiguous())                   # [3*inner, dim]
+            blk["wv_t"] = ops.mark_static(wq[2 * inner:].t().contiguous())           # [dim, inner]: gx = gv @ Wv
             blk["inner"] = inner
         self.head_ln.refresh()
         self.head.refresh()
