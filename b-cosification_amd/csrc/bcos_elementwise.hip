@@ -121,13 +121,20 @@ __global__ __launch_bounds__(TPB) void prep_input_kernel(const float* __restrict
         }
         float* dst = out + i * Cpad;
         unsigned m = 0u;
+        float o[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const float o = (v[c] - mu[c]) / sd[c];
-            dst[c] = o;
-            m = max(m, __float_as_uint(o) & 0x7fffffffu);
+            o[c] = (v[c] - mu[c]) / sd[c];
+            m = max(m, __float_as_uint(o[c]) & 0x7fffffffu);
         }
-        for (int c = 6; c < Cpad; ++c) dst[c] = 0.f;
+        if (Cpad == 8 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {        // the usual padded pixel: two 16-byte stores
+            reinterpret_cast<f32x4*>(dst)[0] = f32x4{o[0], o[1], o[2], o[3]};
+            reinterpret_cast<f32x4*>(dst)[1] = f32x4{o[4], o[5], 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) dst[c] = o[c];
+            for (int c = 6; c < Cpad; ++c) dst[c] = 0.f;
+        }
         if (absmax) absmax[i] = m;          // per-pixel max |value| bit pattern (operand scale source of the f16x2 contraction)
     }
 }
@@ -148,10 +155,18 @@ __global__ __launch_bounds__(TPB) void finalize_expl_kernel(const float* __restr
         const int64_t hw = i - n * HW;
         const float* g = gxn + i * Cpad;
         const float* src = x + n * (int64_t)Cx * HW + hw;
+        float gv[6];
+        if (Cpad == 8 && (reinterpret_cast<uintptr_t>(gxn) & 15) == 0) {        // the usual padded pixel: two 16-byte loads
+            const f32x4 a = reinterpret_cast<const f32x4*>(g)[0], b = reinterpret_cast<const f32x4*>(g)[1];
+            gv[0] = a[0]; gv[1] = a[1]; gv[2] = a[2]; gv[3] = a[3]; gv[4] = b[0]; gv[5] = b[1];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) gv[c] = g[c];
+        }
         float contrib = 0.f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const float wv = g[c] / sd[c];
+            const float wv = gv[c] / sd[c];
             float xv;
             if (add_inverse) xv = c < 3 ? src[(int64_t)c * HW] : 1.0f - src[(int64_t)(c - 3) * HW];
             else xv = src[(int64_t)c * HW];
