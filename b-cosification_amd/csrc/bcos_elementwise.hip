@@ -253,7 +253,7 @@ __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restric
                     acc += gy4[(oh * OW + ow) * C4 + c4] * rpool;
                 }
             }
-            if (mul) acc *= reinterpret_cast<const f32x4*>(mul)[row + i];
+            if (mul) acc *= __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mul) + row + i);     // read exactly once
             reinterpret_cast<f32x4*>(gx)[row + i] = acc;
         }
         if (absmax) {      // C4 is a power of two <= 64 (host): the C4 lanes of a pixel are an aligned lane group
