@@ -10,7 +10,7 @@ Backward:
     gbias = sum_pixels g * dy/dlin (csrc/bcos_train.hip); MaxOut routes g * dy/dlin to the winning filter of each unit
     (bcos_maxout_scatter); a learnable exponent (`b` an nn.Parameter, trainer.py:451-463) receives
     sum g y ln(|cos| + 1e-6) times d B_eff / d b; native layers differentiate through their unit-norm projection (UnitNormFn).
-Layers that are grouped AND MaxOut still raise outside explanation mode instead of silently producing explanation-mode gradients.
+Grouped MaxOut layers train per group too; only units that would straddle two groups (out_channels % groups != 0) raise.
 """
 import torch
 import torch.nn.functional as F
@@ -165,10 +165,10 @@ class BcosConv2dFn(Function):
         need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
         need_bp = b_param is not None and ctx.needs_input_grad[4] and _b_gradient_applies(cfg, b)
         train = (need_grad or need_w or need_b or need_bp) and not cfg["detach"] and b != 1.0     # the scale is differentiated
-        if (train or need_w or need_b) and groups != 1 and max_out != 1:
+        if (train or need_w or need_b) and groups != 1 and max_out != 1 and (Cout_all // max_out) % groups:
             raise NotImplementedError(
-                "BcosConv2d: weight gradients / training-mode gradients of layers that are grouped AND MaxOut are not built "
-                "(SURVEY.md section 8(f) N4); such layers support explanation-mode input gradients only")
+                "BcosConv2d: weight gradients / training-mode gradients of grouped MaxOut layers need out_channels % groups == 0 "
+                "(a unit's filters must not straddle two groups); such layers support explanation-mode input gradients only")
         want_scale = bool((need_grad or need_w or need_b or need_bp) and b != 1.0)
         # MaxOut over 2 or 4 filters is taken inside the contraction's epilogue (one launch, bcosconv2d.py:166-170); other
         # unit sizes, grouped layers and training-mode calls (which need the unit-wide y, s and the winner indices) go through

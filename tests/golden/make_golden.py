@@ -370,6 +370,22 @@ def train_cases2():
             case["gb_param"] = grads[2]
         for kk, vv in case.items():
             out[f"{name}/{kk}"] = vv
+    # grouped AND MaxOut in training mode (units never straddle a group: bcosconv2d.py:166-170 after the grouped NormedConv2d)
+    for name, kind, b, mo in (("u_grp_mo", "bcosify", 2.0, 2), ("u_grp_mo_nat", "native", 2.0, 2), ("u_grp_mo_b15", "bcosify", 1.5, 4)):
+        if kind == "bcosify":
+            mod = R.bcosifyconv2d.BcosifyConv2d(8, 8, 3, 1, 1, 1, 2, b=b, max_out=mo)
+        else:
+            mod = R.bcos_modules.BcosConv2d(8, 8, 3, 1, 1, 1, 2, b=b, max_out=mo)
+        with torch.no_grad():
+            mod.linear.weight.copy_(torch.randn(mod.linear.weight.shape, generator=g) * 0.3)
+        mod.train()
+        x = torch.randn(2, 8, 7, 6, generator=g)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        gy = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad(y, [xr, mod.linear.weight], gy)
+        for kk, vv in dict(x=x, weight=mod.linear.weight.detach(), y=y.detach(), gy=gy, gx=grads[0], gw=grads[1]).items():
+            out[f"{name}/{kk}"] = vv
     np.savez_compressed(os.path.join(HERE, "train_layers2.npz"), **t2n(out))
     with open(os.path.join(HERE, "train_layers2.json"), "w") as f:
         json.dump([dict(zip(("name", "kind", "layer", "b", "clamping", "b_loss", "max_out", "learn_b"), c)) for c in TRAIN2_CASES], f, indent=1)

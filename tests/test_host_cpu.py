@@ -396,6 +396,15 @@ def run_training_goldens2(golden_dir, dev, tol):
         if learn_b:
             want = float(data[f"{n}/gb_param"])
             assert abs(float(grads[2]) - want) <= 10 * tol * abs(want), (n, float(grads[2]), want)
+    for n, kind, b, mo in (("u_grp_mo", "bcosify", 2.0, 2), ("u_grp_mo_nat", "native", 2.0, 2), ("u_grp_mo_b15", "bcosify", 1.5, 4)):
+        m = (BcosifyConv2d if kind == "bcosify" else BcosConv2d)(8, 8, 3, 1, 1, 1, 2, b=b, max_out=mo)      # groups = 2 AND MaxOut
+        with torch.no_grad():
+            m.linear.weight.copy_(torch.from_numpy(data[f"{n}/weight"]))
+        m = m.to(dev).train()
+        x = t(f"{n}/x").requires_grad_(True)
+        y = m(x)
+        gx, gw = torch.autograd.grad(y, [x, m.linear.weight], t(f"{n}/gy"))
+        assert rel(y, data[f"{n}/y"]) <= tol and rel(gx, data[f"{n}/gx"]) <= tol and rel(gw, data[f"{n}/gw"]) <= tol, n
     n = "u_nat_scale"
     m = BcosConv2d(12, 16, 3, 1, 1, b=2)
     with torch.no_grad():
@@ -541,8 +550,8 @@ def test_training_mode_refusals(monkeypatch):
     cpu_emulation.install(monkeypatch)
     from bcos.modules import BcosConv2d
     x = torch.rand(1, 8, 5, 5, requires_grad=True)
-    with pytest.raises(NotImplementedError, match="grouped AND MaxOut"):             # grouped MaxOut layers outside explanation mode
-        BcosConv2d(8, 4, 3, padding=1, b=2, groups=2, max_out=2).train()(x)
+    with pytest.raises(NotImplementedError, match="straddle"):              # grouped MaxOut whose units straddle two groups
+        BcosConv2d(8, 3, 3, padding=1, b=2, groups=2, max_out=2).train()(x)
     m = BcosConv2d(8, 4, 3, padding=1, b=2).eval()                                   # eval / explanation mode are unaffected
     m.set_explanation_mode(True)
     (g,) = torch.autograd.grad(m(x).sum(), x)
