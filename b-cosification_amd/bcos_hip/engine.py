@@ -34,6 +34,7 @@ _GATE_TENSOR = bool(os.environ.get("BCOS_GATE_TENSOR"))   # development switch: 
 # rebuild cost +0.76 ms in the issue-bound gradient epilogues against -0.57 ms in the forward; with the specialised kinds
 # (csrc/bcos_tapconv.hip: EF_MULACT) the step time is the same or slightly lower (same-node A/B: 29.60 vs 29.60, 29.48 vs 29.58
 # ms).  BCOS_STORE_T=1 keeps the stored multipliers (same results to 1e-5: tests run both).
+_SUB_ADDEND = not os.environ.get("BCOS_NO_SUB_ADDEND")     # development switch: scatter shortcut gradients into full-size tensors
 _STORE_T = bool(os.environ.get("BCOS_STORE_T"))
 
 
@@ -543,6 +544,12 @@ class _Consumer:
             if self.sc_pool:
                 pooled = self.shortcut_conv.dgrad.run(self.g_sc, H // self.sc_pool, W // self.sc_pool, track_absmax=False)
                 addend = ops.avgpool2d_bwd(pooled, H, W, self.sc_pool, self.sc_pool, 0)
+            elif _SUB_ADDEND and self.shortcut_conv.dgrad.subsampled and not self.conv.dgrad.has_empty:
+                # 1x1 / stride-s shortcut: its input gradient is zero off the s-grid -- hand the grid pixels alone to the main
+                # branch's launch (bcos_epilogue.addend_sub) instead of scattering them into a zero-filled full-size tensor
+                # (ResNet-50: 1.44 GB of zero fill per step and as much again read back as an addend)
+                addend = self.shortcut_conv.dgrad.run_compact(self.g_sc, track_absmax=False)
+                kw["addend_sub"] = self.shortcut_conv.dgrad.subsampled
             else:
                 addend = self.shortcut_conv.dgrad.run(self.g_sc, H, W, track_absmax=False)
         else:

@@ -206,8 +206,9 @@ def _out_absmax(t: Optional[torch.Tensor], pixels: int):
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
             gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0, contraction=None,
-            track_absmax=None, track_absmax2=None, max_out=1, mul_norm=None, mul_csc=None, mul_csh=None):
+            track_absmax=None, track_absmax2=None, max_out=1, mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0):
     """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv_ops).
+    `addend_sub` = s > 1: `addend` is the dense [N, ceil(OH/s), ceil(OW/s), pitch] tensor of the output pixels on the s-grid.
     `contraction`: None = the library default, or 'f32' / 'bf16x3' / 'f16x2' for this call.
     `track_absmax` / `track_absmax2`: emit the per-pixel maxima of out / out2 (default: whenever the f16x2 contraction is
     selected; a caller that knows the reader of a tensor will not use them -- K < F16X2_MIN_K -- passes False)."""
@@ -229,6 +230,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     e.b = float(b)
     e.flags = int(flags)
     e.max_out = int(max_out)
+    e.addend_sub = int(addend_sub)
     if e.max_out > 1:                    # fused MaxOut: plain forward epilogue, no operand maxima of the (narrow) output
         track_absmax = track_absmax2 = False
     mode = contraction if contraction is not None else _l.get_contraction_mode()
@@ -267,8 +269,10 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         # algorithmic work of the launch: 2 M K N flops; bytes = A once + weights once + every output-sized epilogue tensor
         m_rows = int(g.N) * int(g.P) * int(g.Q)
         ktot = int(g.TH) * int(g.TW) * int(g.C)
-        epi_tensors = sum(1 for t in (out, out2, scale_out, addend, mul, mul2, gate2, relu_gate) if t is not None)
-        nbytes = 4 * (int(g.N) * int(g.H) * int(g.W) * int(g.C) + ktot * int(g.Cout) + m_rows * int(g.Cout) * epi_tensors)
+        epi_tensors = sum(1 for t in (out, out2, scale_out, mul, mul2, gate2, relu_gate) if t is not None)
+        if addend is not None:
+            epi_tensors += 1.0 / max(int(addend_sub), 1) ** 2          # a subsampled addend holds 1 / s^2 of the pixels
+        nbytes = int(4 * (int(g.N) * int(g.H) * int(g.W) * int(g.C) + ktot * int(g.Cout) + m_rows * int(g.Cout) * epi_tensors))
         timing.append((ev0, ev1, 2.0 * m_rows * ktot * int(g.Cout), nbytes))
     _l.check(code, "bcos_tapconv")
 
@@ -431,6 +435,25 @@ class DgradPlan:
             return [], 0, 1
         e = (rho + p - r0) // s
         return rs[::-1], e - U + 1, 1
+
+    @property
+    def subsampled(self) -> int:
+        """s when this is the gradient of a 1x1 / stride-s / unpadded convolution (a ResNet shortcut): gx is zero off the
+        s-grid and `run_compact` returns the grid pixels alone; 0 otherwise."""
+        sh, sw = self.stride
+        return sh if (self.k == (1, 1) and sh == sw and sh > 1 and self.padding == (0, 0)) else 0
+
+    def run_compact(self, glin, **track):
+        """glin [N,Ho,Wo,Cout] -> the non-zero pixels of gx as a dense [N,Ho,Wo,Cin] tensor (gx[:, ::s, ::s] of `run`), for
+        a reader that takes it as a subsampled addend (bcos_epilogue.addend_sub) instead of a zero-filled full-size tensor."""
+        assert self.subsampled
+        N, Ho, Wo, Cout = glin.shape
+        wt = self.classes[0][8]
+        out = torch.empty((N, Ho, Wo, self.Cin), device=glin.device, dtype=torch.float32)
+        g = dict(N=N, H=Ho, W=Wo, C=Cout, P=Ho, Q=Wo, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1, TH=1, TW=1,
+                 OH=Ho, OW=Wo, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=self.Cin)
+        tapconv(glin, wt, g, out=out, **track)
+        return out
 
     def run(self, glin, H, W, *, out=None, **epi):
         """glin [N,Ho,Wo,Cout] -> gx [N,H,W,Cin]; **epi are tapconv epilogue tensors indexed like gx.

@@ -142,15 +142,21 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
     float* sAinv = sRinv + BM;                                     // [BM] inverse operand scale of the row (SCALED)
     for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
-        int64_t pix = -1;
+        int64_t pix = -1, apix = -1;
         if (m < p.M) {
             const int n = m / p.PQ;
             const int rem = m - n * p.PQ;
             const int i = rem / g.Q;
             const int jj = rem - i * g.Q;
             pix = ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+            if (!NORM && e.addend_sub > 1) {     // subsampled addend: this row's pixel in [N, ceil(OH / s), ceil(OW / s)] or -1
+                const int s = e.addend_sub;
+                const int h = i * g.out_sh + g.out_h0, w = jj * g.out_sw + g.out_w0;
+                apix = (h % s == 0 && w % s == 0) ? ((int64_t)n * ((g.OH + s - 1) / s) + h / s) * ((g.OW + s - 1) / s) + w / s : -1;
+            }
         }
         sPix[r] = pix;
+        if (!NORM && e.addend_sub > 1) reinterpret_cast<int64_t*>(sNorm)[r] = apix;
     }
     if (NORM && ROWSS == nullptr) {
         // row sums of squares in MFMA fragment layout (fp32 kernel): lane (row, k-half), two halves per row
@@ -256,6 +262,11 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
         // element in an epilogue that is issue-bound, and t enters a product whose other factor carries fp32 rounding anyway
         return (a > 0.f && den > 0.f) ? csc * __builtin_amdgcn_sqrtf(z * __builtin_amdgcn_rcpf(den)) : 0.f;
     };
+    // subsampled addend (bcos_epilogue.addend_sub = s > 1, gradient launches only): the addend tensor holds the pixels
+    // (h % s == 0, w % s == 0) alone; epi_rows_generic left each row's pixel index in it (or -1) where forward launches keep
+    // their patch norms
+    const int64_t* sApix = reinterpret_cast<const int64_t*>(sNorm);
+    const bool asub = !NORM && e.addend != nullptr && e.addend_sub > 1;
     struct EpiIn { f32x4 ad[EPI_G], m1[EPI_G]; };
     auto issue = [&](int p0, EpiIn& in) {
 #pragma unroll
@@ -263,7 +274,16 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
             const int lrow = rbase + (p0 + u) * RPP;
             const int64_t pix = sPix[(lrow / HM) * WM + pm * HM + lrow % HM];
             const int64_t idx = (pix >= 0 ? pix : 0) * g.out_pitch + coladd;
-            in.ad[u] = (vec && e.addend) ? *reinterpret_cast<const f32x4*>(e.addend + idx) : zero4;
+            int64_t aidx = idx;
+            bool a_ok = true;
+            if constexpr (!NORM) {
+                if (asub) {
+                    const int64_t ap = sApix[(lrow / HM) * WM + pm * HM + lrow % HM];
+                    a_ok = ap >= 0;
+                    aidx = (a_ok ? ap : 0) * g.out_pitch + coladd;
+                }
+            }
+            in.ad[u] = (vec && e.addend && a_ok) ? *reinterpret_cast<const f32x4*>(e.addend + aidx) : zero4;
             in.m1[u] = (vec && e.mul) ? *reinterpret_cast<const f32x4*>(e.mul + idx) : zero4;
         }
     };
@@ -402,7 +422,8 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                     }
                     v = v * csc4[q] + csh4[q];
                     s *= csc4[q];
-                    if (e.addend) v += e.addend[idx];
+                    if (!NORM && asub) v += sApix[row] >= 0 ? e.addend[sApix[row] * g.out_pitch + col + q] : 0.f;
+                    else if (e.addend) v += e.addend[idx];
                     if (e.relu == 1) {
                         const bool open_gate = e.relu_gate ? e.relu_gate[idx] > 0.f : v > 0.f;
                         s = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s) | 1u) : s) : 0.f;
@@ -498,6 +519,21 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
         }
         sRow[r].pix = pix;
         sRow[r].off = pix >= 0 ? (unsigned)pix * (unsigned)out_pitch * 4u : OOB;
+        if (!NORM && e.addend_sub > 1) {
+            // subsampled addend (gradient kinds, whose rows carry no 1 / norm): byte offset of this row in the
+            // [N, ceil(OH / s), ceil(OW / s), out_pitch] addend, out of range where the pixel is off the s-grid
+            const int s = e.addend_sub;
+            unsigned aoff = OOB;
+            if (pix >= 0) {
+                const int n = m / p.PQ;
+                const int rem = m - n * p.PQ;
+                const int i = rem / g.Q;
+                const int h = i * g.out_sh + g.out_h0, w = (rem - i * g.Q) * g.out_sw + g.out_w0;
+                if (h % s == 0 && w % s == 0)
+                    aoff = (unsigned)((n * ((g.OH + s - 1) / s) + h / s) * ((g.OW + s - 1) / s) + w / s) * (unsigned)out_pitch * 4u;
+            }
+            sRow[r].rinv = __uint_as_float(aoff);
+        }
     }
     if (NORM && ROWSS == nullptr) {
 #pragma unroll
@@ -587,6 +623,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     static_assert(PASSES % G == 0, "epilogue grouping");
     const int cq = tid % CPR;
     const int rbase = tid / CPR;
+    const bool asub = ADDEND && !NORM && e.addend_sub > 1;      // subsampled addend: its row offsets are in EpiRow.rinv
 
     if (NORM && e.norm_out != nullptr && tile_n == 0 && part == 0) {
         for (int r = tid; r < BM; r += NT) {
@@ -626,7 +663,10 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
             const int lrow = rbase + (p0 + u) * RPP;
             rw[u] = sRow[(lrow / HM) * WM + pm * HM + lrow % HM];
             voff[u] = (rw[u].off + coloff) | ((rw[u].off | coloff) & OOB);
-            if (ADDEND) ad[u] = ldq(r_ad, voff[u]);
+            if (ADDEND && !NORM && asub) {
+                const unsigned aoff = __float_as_uint(rw[u].rinv);
+                ad[u] = ldq(r_ad, (aoff + coloff) | ((aoff | coloff) & OOB));
+            } else if (ADDEND) ad[u] = ldq(r_ad, voff[u]);
             if (MUL) m1[u] = ldq(r_mul, voff[u]);
             if (MUL2) m2[u] = ldq(r_mul2, voff[u]);
         }
@@ -2027,6 +2067,9 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         if ((reinterpret_cast<uintptr_t>(epi->scale_out) & 15))
             return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: scale_out must be 16-byte aligned");
     }
+    if (epi->addend_sub < 0 || (epi->addend_sub > 1 && (!epi->addend || g.out_cgroup != 0 || g.groups > 1 || epi->bcos_mode != BCOS_NONE)))
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: addend_sub > 1 needs an addend and a plain gradient launch (bcos_mode BCOS_NONE, "
+                                            "no out_cgroup, no groups)");
     // the last row/col written must be inside the output tensor
     if ((g.P - 1) * g.out_sh + g.out_h0 >= g.OH || (g.Q - 1) * g.out_sw + g.out_w0 >= g.OW || g.out_h0 < 0 ||
         g.out_w0 < 0)
@@ -2089,6 +2132,10 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 const int64_t opix = (int64_t)n0 * g.OH * g.OW;
                 const float** cin[] = {&e2.addend, &e2.mul, &e2.mul2, &e2.gate2, &e2.relu_gate};
                 for (const float** q : cin) if (*q) *q += opix * p.g.out_pitch;
+                if (e2.addend && e2.addend_sub > 1) {      // subsampled addend: its own image size
+                    const int sb = e2.addend_sub;
+                    e2.addend = epi->addend + (int64_t)n0 * ((g.OH + sb - 1) / sb) * ((g.OW + sb - 1) / sb) * p.g.out_pitch;
+                }
                 float** cout[] = {&e2.out, &e2.out2, &e2.scale_out};
                 for (float** q : cout) if (*q) *q += opix * p.g.out_pitch;
                 if (e2.norm_out) e2.norm_out += opix * p.g.norm_pitch;
@@ -2165,7 +2212,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1) {
+    if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1 && epi->addend_sub <= 1) {
         const int handled = bcos_try_skinny(a, wt, p.g, p.e, p.M, s);
         if (handled != 0) return handled < 0 ? handled : BCOS_OK;
     }

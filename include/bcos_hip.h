@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 3
+#define BCOS_ABI_VERSION 4
 
 enum {
     BCOS_OK = 0,
@@ -145,6 +145,11 @@ typedef struct bcos_epilogue {
                                scale; out is [pixels, Cout / M] (out_pitch 0 = Cout / M); scale_out keeps width Cout and holds s at
                                the winning filter (first maximum) and 0 elsewhere, i.e. d out / d lin.  Only with bias, the scale,
                                out, scale_out, norm_out.                                                          */
+    int32_t addend_sub;     /* 0 / 1: `addend` is indexed like `out`.  s > 1 (ABI v4): `addend` is the dense tensor
+                               [N, ceil(OH / s), ceil(OW / s), out_pitch] of the output pixels (h % s == 0, w % s == 0); nothing is
+                               added at the other pixels.  This is the input gradient of a 1x1 / stride-s shortcut convolution
+                               (zero off its s-grid) handed to the main branch's gradient launch without being scattered into a
+                               zero-filled full-size tensor first.  Gradient launches only (bcos_mode BCOS_NONE, no out_cgroup, no groups). */
 } bcos_epilogue;
 
 /* compute the patch norms (norm_out) but leave v unscaled: used by the MaxOut / grouped

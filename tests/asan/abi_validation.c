@@ -42,6 +42,8 @@ int main(void) {
     g.out_h0 = 9;      EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.out_h0 = 0; /* mapping outside [OH,OW] */
     g.a_pitch = 6;     EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.a_pitch = 0;
     g.out_pitch = 4;   EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.out_pitch = 0;
+    e.addend_sub = 2;  EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); e.addend_sub = 0;   /* subsampled addend without addend */
+    e.addend_sub = -1; EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); e.addend_sub = 0;
     EXPECT(bcos_tapconv(NULL, buf, &g, &e, NULL), BCOS_E_INVAL);
     EXPECT(bcos_tapconv_presplit(buf, NULL, NULL, &g, &e, NULL), BCOS_E_INVAL);
     EXPECT(bcos_tapconv_group(buf, NULL, &g, &e, 1, NULL), BCOS_E_INVAL);

@@ -15,7 +15,7 @@ from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
             ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
             b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None, max_out=1,
-            mul_norm=None, mul_csc=None, mul_csh=None):
+            mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
     g = dict(a_pitch=0, out_pitch=0, norm_pitch=0, out_cgroup=0, groups=0)
@@ -114,7 +114,15 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
         def wr(t, val):
             v4(t)[:, oh[:, None], ow[None, :], :Cout] = val.to(t.dtype)
 
-    if addend is not None:
+    if addend is not None and addend_sub > 1:
+        # include/bcos_hip.h: bcos_epilogue.addend_sub -- the addend holds the output pixels on the s-grid, zero elsewhere
+        sb = int(addend_sub)
+        assert not cg and g["groups"] <= 1 and max_out <= 1
+        sub = addend if addend.dim() == 4 else addend.view(N, -(-g["OH"] // sb), -(-g["OW"] // sb), -1)
+        full = torch.zeros((N, g["OH"], g["OW"], sub.shape[-1]), dtype=sub.dtype)
+        full[:, ::sb, ::sb] = sub
+        v = v + rd(full)
+    elif addend is not None:
         v = v + rd(addend)
     if relu == 2:
         gate = 0.5 * (1 + torch.erf(v / 2 ** 0.5))

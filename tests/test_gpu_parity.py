@@ -1090,6 +1090,72 @@ def test_presplit_weights_bit_identical(lib):
         assert torch.equal(y2, y3)
 
 
+def test_subsampled_addend_bit_identical(lib, golden_dir, monkeypatch):
+    """bcos_epilogue.addend_sub (ABI v4): a gradient launch that takes the s-grid pixels of its addend as a dense tensor writes
+    exactly what it writes with the same values scattered into a zero-filled full-size addend -- every gradient epilogue kind,
+    general and specialised epilogue, every contraction mode, odd image sizes, strided output mappings (the parity classes of a
+    3x3 / 2 gradient) -- and a whole ResNet-50 / ResNet-18 explanation pass is bit-identical with and without it."""
+    from bcos_hip import engine, ops, synth
+    from bcos_hip import lib as blib
+    g = torch.Generator().manual_seed(31)
+    prev = blib.get_contraction_mode()
+    try:
+        for mode in ("f16x2", "bf16x3", "f32"):
+            blib.set_contraction_mode(mode)
+            for (N, H, Cin, Cout, k, st, pd, sb) in [(3, 14, 64, 256, 1, 1, 0, 2), (2, 15, 32, 52, 3, 2, 1, 2), (2, 13, 256, 24, 1, 1, 0, 2),
+                                                      (1, 28, 128, 512, 1, 1, 0, 2), (2, 10, 48, 40, 1, 1, 0, 3)]:
+                # the launch: input gradient of conv(Cin -> Cout, k, st, pd) on H x H images; its output has Cin channels
+                w = ops.mark_static((torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV))
+                plan = ops.DgradPlan(w.permute(0, 3, 1, 2).contiguous(), (st, st), (pd, pd))
+                Ho = ops.conv_out_size(H, k, st, pd)
+                gl = ops.ensure_absmax(torch.randn(N, Ho, Ho, Cout, generator=g).to(DEV))
+                Hs = -(-H // sb)
+                sub = torch.randn(N, Hs, Hs, Cin, generator=g).to(DEV)
+                full = torch.zeros(N, H, H, Cin, device=DEV)
+                full[:, ::sb, ::sb] = sub
+                mul = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+                mul2 = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+                for kw in (dict(), dict(mul=mul, want2=True, flags=8), dict(mul=mul, mul2=mul2, want2=True, flags=8), dict(mul=mul)):
+                    res = {}
+                    for generic in (False, True):
+                        if generic:
+                            monkeypatch.setenv("BCOS_EPI_GENERIC", "1")
+                        else:
+                            monkeypatch.delenv("BCOS_EPI_GENERIC", raising=False)
+                        for name, extra in (("full", dict(addend=full)), ("sub", dict(addend=sub, addend_sub=sb))):
+                            kw2 = dict(kw)
+                            out2 = torch.full((N, H, H, Cin), float("nan"), device=DEV) if kw2.pop("want2", False) else None
+                            if out2 is not None:
+                                kw2["out2"] = out2
+                            out = plan.run(gl, H, H, track_absmax=True, track_absmax2=out2 is not None, **kw2, **extra)
+                            res[(generic, name)] = (out, out2, ops.absmax_of(out), ops.absmax_of(out2) if out2 is not None else None)
+                    monkeypatch.delenv("BCOS_EPI_GENERIC", raising=False)
+                    ref = res[(True, "full")]
+                    assert not torch.isnan(ref[0]).any()
+                    for key, got in res.items():
+                        for i, (a, b) in enumerate(zip(got, ref)):
+                            assert (a is None and b is None) or torch.equal(a.view(torch.int32), b.view(torch.int32)), (mode, key, i, N, H, Cin, Cout, k, sorted(kw))
+        blib.set_contraction_mode(prev)
+        # refused where it is not defined: forward (B-cos) launches
+        x = torch.randn(1, 4, 4, 8, device=DEV)
+        wf = torch.randn(8, 1, 1, 8, device=DEV)
+        with pytest.raises(blib.BcosHipError):
+            ops.tapconv(x, wf, ops.fwd_geom(1, 4, 4, 8, 8, 1, 1, 1, 1, 0, 0, 1, 1), out=torch.empty(1, 4, 4, 8, device=DEV),
+                        addend=torch.zeros(1, 2, 2, 8, device=DEV), addend_sub=2, bcos_mode=blib.BCOS_CONV_EPS)
+        for fixture in ("resnet18_e2e", "resnet50_small"):
+            net, meta, data = _golden_net(golden_dir, fixture)
+            x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+            monkeypatch.setattr(engine, "_SUB_ADDEND", True)
+            a = engine.attach(net).explain(x)
+            monkeypatch.setattr(engine, "_SUB_ADDEND", False)
+            b = engine.attach(net).explain(x)
+            for key in ("logits", "dynamic_linear_weights", "contribution_map"):
+                assert torch.equal(a[key], b[key]), (fixture, key)
+    finally:
+        blib.set_contraction_mode(prev)
+        monkeypatch.delenv("BCOS_EPI_GENERIC", raising=False)
+
+
 def test_fast_epilogue_bit_identical(lib, golden_dir, monkeypatch):
     """The specialised epilogues (csrc/bcos_tapconv.hip: tile_epilogue_fast, selected per launch from the feature set)
     evaluate the same expressions in the same order as the general one: every tensor they write is identical bit for bit
