@@ -28,7 +28,7 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 ABI_VERSION = 4
-TAPCONV_PARTS = 4
+TAPCONV_PARTS = 5
 
 
 class BcosHipError(RuntimeError):

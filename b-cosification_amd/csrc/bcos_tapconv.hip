@@ -1266,7 +1266,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // (same-node A/B of that launch: 1.38 -> 1.26 ms; the 64- and 128-column tiles lose with it)
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM>
 constexpr int h2_pipe() {
-    return (BM / WAVES_M) * (BN / WAVES_N) > 64 * 64 ? 1 : ((BN == 32 && !NORM) ? 3 : H2_PIPE_SMALL);
+    return (BM / WAVES_M) * (BN / WAVES_N) > 64 * 64 ? 1 : ((BN == 32 && !NORM && BM <= 128) ? 3 : H2_PIPE_SMALL);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NT = NTHREADS,
@@ -1670,7 +1670,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 // tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
 // = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights, 3 split-f16
-__global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN) ? H2_NARROW_WGS : 2) void tapconv_kernel(const KArgs p) {
+__global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN && BM <= 128) ? H2_NARROW_WGS : 2) void tapconv_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     if (bid < p.n_big) {
@@ -1817,6 +1817,8 @@ BCOS_TC_LAUNCHER(bcos_tc_h2_128x256);
 BCOS_TC_LAUNCHER(bcos_tc_h2_128x128);
 BCOS_TC_LAUNCHER(bcos_tc_h2_128x64);
 BCOS_TC_LAUNCHER(bcos_tc_h2_128x32);
+BCOS_TC_LAUNCHER(bcos_tc_h2_256x64);
+BCOS_TC_LAUNCHER(bcos_tc_h2_256x32);
 #define BCOS_TC_DEFINE(name, call) BCOS_TC_LAUNCHER(name) { return call(*static_cast<const KArgs*>(kargs), norm != 0, s); }
 #if BCOS_TC_IN(1)
 BCOS_TC_DEFINE(bcos_tc_cfg_128x128, (launch_cfg<128, 128, 2, 2>))
@@ -1828,6 +1830,10 @@ BCOS_TC_DEFINE(bcos_tc_cfg_128x32, (launch_cfg<128, 32, 4, 1>))
 #if BCOS_TC_IN(3)
 BCOS_TC_DEFINE(bcos_tc_h2_128x256, (launch_h2<128, 256, 2, 2>))
 BCOS_TC_DEFINE(bcos_tc_h2_128x128, (launch_h2<128, 128, 2, 2>))
+#endif
+#if BCOS_TC_IN(4)
+BCOS_TC_DEFINE(bcos_tc_h2_256x64, (launch_h2<256, 64, 4, 1>))
+BCOS_TC_DEFINE(bcos_tc_h2_256x32, (launch_h2<256, 32, 4, 1>))
 #endif
 #if BCOS_TC_IN(0)
 BCOS_TC_DEFINE(bcos_tc_h2_128x64, (launch_h2<128, 64, 2, 2>))
@@ -2229,7 +2235,20 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             if (wide) return bcos_tc_h2_128x256(&p, norm, s);
             return bcos_tc_h2_128x128(&p, norm, s);
         }
-        if (g.Cout > 32) return bcos_tc_h2_128x64(&p, norm, s);
+        if (g.Cout > 32) {
+            // 256 x 64 tiles (four waves of 64 x 64: the A operand's split, its LDS image and the per-tile prologue / epilogue
+            // latencies are shared by twice the matrix instructions of a 128 x 64 tile) from four rounds of tiles on.  Same-node
+            // A/B on the ResNet-50 step at batch 256 (M = 802 816): 3x3 64 -> 64 gradient 1.03 -> 0.90 ms, 256 -> 64 gradient
+            // 1.21 -> 1.13 ms, stem forward 1.05 -> 1.01 ms, the forward launches -1 %.  Results are identical bit for bit (same
+            // K walk, same product order per accumulator).
+            const char* tall = getenv("BCOS_H2_TALL");       // development switch: "0" keeps the 128-row tiles
+            if (M64 >= 4 * 256 * SLOTS && !(tall && tall[0] == '0')) return bcos_tc_h2_256x64(&p, norm, s);
+            return bcos_tc_h2_128x64(&p, norm, s);
+        }
+        {   // 256 x 32 tiles likewise (the depth-to-space stem gradient, M = 3.2 M: 1.29-1.38 -> 1.17-1.20 ms in a same-node A/B)
+            const char* tall = getenv("BCOS_H2_TALL");
+            if (M64 >= 4 * 256 * SLOTS && !(tall && tall[0] == '0')) return bcos_tc_h2_256x32(&p, norm, s);
+        }
         return bcos_tc_h2_128x32(&p, norm, s);
     }
     if (g.Cout > 64) return bcos_tc_cfg_128x128(&p, norm, s);
