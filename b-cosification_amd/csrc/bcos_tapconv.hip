@@ -2229,6 +2229,9 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             const char* force = getenv("BCOS_H2_TILE");      // development switch: "128x128" | "128x256"
             const int64_t tm = (M64 + 127) / 128;
             const int64_t t1 = tm * ((g.Cout + 127) / 128), t2 = tm * ((g.Cout + 255) / 256);
+            // (a finer cost model -- a wide tile = 1.75 narrow ones, which moves M = 200 704 with N = 256 / 512 and M = 50 176 with
+            // N = 1024, K = 512 to wide tiles -- wins 11-18 % on those launches timed one by one and loses 0.1 ms on the step, where
+            // consecutive launches overlap their tails: not adopted)
             const int64_t c1 = (t1 + SLOTS - 1) / SLOTS, c2 = 2 * ((t2 + SLOTS - 1) / SLOTS);
             bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && p.Ktot >= 1024));
             if (force) wide = g.Cout > 128 && force[4] == '2';
@@ -2237,12 +2240,14 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         }
         if (g.Cout > 32) {
             // 256 x 64 tiles (four waves of 64 x 64: the A operand's split, its LDS image and the per-tile prologue / epilogue
-            // latencies are shared by twice the matrix instructions of a 128 x 64 tile) from four rounds of tiles on.  Same-node
+            // latencies are shared by twice the matrix instructions of a 128 x 64 tile) from two rounds of tiles on.  Same-node
             // A/B on the ResNet-50 step at batch 256 (M = 802 816): 3x3 64 -> 64 gradient 1.03 -> 0.90 ms, 256 -> 64 gradient
             // 1.21 -> 1.13 ms, stem forward 1.05 -> 1.01 ms, the forward launches -1 %.  Results are identical bit for bit (same
             // K walk, same product order per accumulator).
             const char* tall = getenv("BCOS_H2_TALL");       // development switch: "0" keeps the 128-row tiles
-            if (M64 >= 4 * 256 * SLOTS && !(tall && tall[0] == '0')) return bcos_tc_h2_256x64(&p, norm, s);
+            const char* tmin = getenv("BCOS_H2_TALL_MIN");
+            const int64_t tall_min = tmin ? atoll(tmin) : 2 * 256 * SLOTS;     // (batch 128, M = 401 408: +0.4 % per step; M = 200 704: neutral)
+            if (M64 >= tall_min && !(tall && tall[0] == '0')) return bcos_tc_h2_256x64(&p, norm, s);
             return bcos_tc_h2_128x64(&p, norm, s);
         }
         {   // 256 x 32 tiles likewise (the depth-to-space stem gradient, M = 3.2 M: 1.29-1.38 -> 1.17-1.20 ms in a same-node A/B)
