@@ -2252,7 +2252,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         }
         {   // 256 x 32 tiles likewise (the depth-to-space stem gradient, M = 3.2 M: 1.29-1.38 -> 1.17-1.20 ms in a same-node A/B)
             const char* tall = getenv("BCOS_H2_TALL");
-            if (M64 >= 4 * 256 * SLOTS && !(tall && tall[0] == '0')) return bcos_tc_h2_256x32(&p, norm, s);
+            if (M64 >= 2 * 256 * SLOTS && !(tall && tall[0] == '0')) return bcos_tc_h2_256x32(&p, norm, s);
         }
         return bcos_tc_h2_128x32(&p, norm, s);
     }

@@ -1090,6 +1090,43 @@ def test_presplit_weights_bit_identical(lib):
         assert torch.equal(y2, y3)
 
 
+def test_tall_tiles_bit_identical(lib, monkeypatch):
+    """Launches with <= 64 output columns and two or more rounds of tiles run on 256-row tiles (csrc/bcos_tapconv.hip:
+    bcos_tc_h2_256x64 / 256x32); an output element's K walk and product order do not depend on the tile, so every tensor is
+    identical bit for bit to the 128-row tiles (BCOS_H2_TALL=0) -- ragged row counts (M not a multiple of 32), 1x1 and 3x3
+    forward launches with the B-cos epilogue and their input gradients, 64- and 24-column outputs."""
+    from bcos_hip import ops
+    from bcos_hip import lib as blib
+    if blib.get_contraction_mode() != "f16x2":
+        pytest.skip("the 256-row tiles belong to the split-f16 loop")
+    g = torch.Generator().manual_seed(41)
+    for (N, H, Cin, Cout, k, pd) in [(2, 363, 256, 64, 1, 0), (3, 301, 64, 64, 3, 1), (2, 365, 64, 24, 3, 1)]:
+        x = ops.ensure_absmax(torch.randn(N, H, H, Cin, generator=g).to(DEV))
+        w = ops.mark_static((torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV))
+        csc = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+        plan = ops.DgradPlan(w.permute(0, 3, 1, 2).contiguous(), (1, 1), (pd, pd))
+        gl = ops.ensure_absmax(torch.randn(N, H, H, Cout, generator=g).to(DEV))
+        mul = torch.randn(N, H, H, Cin, generator=g).to(DEV) if Cin <= 64 else None
+        res = {}
+        for tall in ("1", "0"):
+            monkeypatch.setenv("BCOS_H2_TALL", tall)
+            y, sc, nrm = ops.conv2d_fwd(x, w, padding=(pd, pd), ch_scale=csc, relu=True, want_scale=True, want_norm=True, track_absmax=True)
+            gx = plan.run(gl, H, H, track_absmax=True, **({"mul": mul} if mul is not None else {}))
+            res[tall] = (y, sc, nrm, ops.absmax_of(y), gx, ops.absmax_of(gx))
+        monkeypatch.delenv("BCOS_H2_TALL", raising=False)
+        assert not torch.isnan(res["1"][0]).any() and not torch.isnan(res["1"][4]).any()
+        for i, (a, b) in enumerate(zip(res["1"], res["0"])):
+            assert (a is None and b is None) or torch.equal(a.view(torch.int32), b.view(torch.int32)), (N, H, Cin, Cout, k, i)
+        # and against a float64 reference of the forward contraction on a slice of rows
+        xs = x[0, :2].double().cpu()
+        if k == 1:
+            lin = xs.reshape(-1, Cin) @ w.view(Cout, Cin).double().cpu().t()
+            nr = xs.reshape(-1, Cin).pow(2).sum(1).add(1e-6).sqrt()
+            want = (lin * lin.abs() / nr[:, None] * csc.double().cpu()).clamp_min(0)
+            assert rel(res["1"][0][0, :2].reshape(-1, Cout), want) <= 2e-6
+        del x, w, gl, res
+
+
 def test_subsampled_addend_bit_identical(lib, golden_dir, monkeypatch):
     """bcos_epilogue.addend_sub (ABI v4): a gradient launch that takes the s-grid pixels of its addend as a dense tensor writes
     exactly what it writes with the same values scattered into a zero-filled full-size addend -- every gradient epilogue kind,
