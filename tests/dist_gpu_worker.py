@@ -37,12 +37,28 @@ def free_others(rank):
     dist.barrier()
 
 
+def replicate(net, world):
+    """Data-parallel replicas carry rank 0's parameters (what loading one checkpoint / a broadcast gives in deployment); the
+    ranks then prove it: a digest of every state-dict entry is exchanged and compared.
+    Eight processes time-slicing ONE device are not the deployment mode, and independent per-rank calibrations were seen to
+    diverge under it about once in a hundred processes (scripts/probe/calibrate_stress*.py)."""
+    for v in net.state_dict().values():
+        t = v.detach().cpu()
+        dist.broadcast(t, src=0)
+        v.copy_(t.to(v.device))
+    digest = {k: float(v.double().abs().sum()) for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    all_d = [None] * world
+    dist.all_gather_object(all_d, digest)
+    return [f"rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]
+
+
 def run_resnet50(rank, world, n_global):
     """BASELINE configs[4]: ResNet-50 explanation maps, global batch 1024 = 8 x 128, logits + maps gathered."""
     from oracle import bcos_oracle as O
     net = synth.build_bcosified_resnet("resnet50").to(DEV)
     with torch.no_grad():
         synth.calibrate(net, synth.synthetic_images(8).to(DEV))
+        replica_diff = replicate(net, world)
     eng = engine.attach(net)
     x = synth.synthetic_images(n_global, seed=4321).to(DEV)
     res = bdist.explain_sharded(eng, x, gather=("logits", "contribution_map", "prediction"), num_outputs=1000)
@@ -52,7 +68,7 @@ def run_resnet50(rank, world, n_global):
     mine = eng.explain(x[lo:hi], want_weights=False)
     pipe.submit({"logits": mine["logits"], "contribution_map": mine["contribution_map"]})
     packed = pipe.flush()[0]
-    verdict = dict(config="resnet50", world=world, n_global=n_global, shard=[lo, hi],
+    verdict = dict(config="resnet50", world=world, n_global=n_global, shard=[lo, hi], replicas_identical=not replica_diff,
                    gathered_shape=list(res["contribution_map"].shape),
                    overlapped_equals_gather=bool(torch.equal(packed["logits"], res["logits"])
                                                  and torch.equal(packed["contribution_map"], res["contribution_map"])))
@@ -82,6 +98,8 @@ def run_clip(rank, world, n_global):
     net = synth.build_bcosified_clip_rn50().to(DEV)
     with torch.no_grad():
         synth.calibrate(net, synth.synthetic_images(8).to(DEV))
+    with torch.no_grad():
+        replica_diff = replicate(net, world)
     eng = engine.attach(net)
     x = synth.synthetic_images(n_global, seed=99).to(DEV)
     lo, hi = bdist.shard_bounds(n_global, rank, world)
@@ -94,13 +112,29 @@ def run_clip(rank, world, n_global):
     expl = eng.explain(x[lo:hi], targets=tg, want_weights=False)
     maps = bdist.all_gather_batch(expl["contribution_map"], dim=0)
     verdict = dict(config="clip_rn50", world=world, n_global=n_global, shard=[lo, hi], gathered_shape=list(gathered.shape),
-                   maps_shape=list(maps.shape), finite=bool(torch.isfinite(gathered).all() and torch.isfinite(maps).all()))
+                   maps_shape=list(maps.shape), finite=bool(torch.isfinite(gathered).all() and torch.isfinite(maps).all()),
+                   replicas_identical=not replica_diff, replica_diff=replica_diff[:6])
     del expl
     free_others(rank)
+    # every rank: is its first forward (the one that built the lazily created weight images) what a repeat gives?
+    again1 = eng.forward(x[lo:hi])
+    again2 = eng.forward(x[lo:hi])
+    verdict.update(first_forward_repeatable=bool(torch.equal(again1, emb)), later_forwards_repeatable=bool(torch.equal(again1, again2)),
+                   first_forward_max_abs=float((again1 - emb).abs().max()))
+    del again1, again2
+    dist.barrier()
     if rank == 0:
         half = n_global // 2
         full = torch.cat([eng.forward(x[:half]), eng.forward(x[half:])])   # a different split of the same batch
         verdict.update(sharded_equals_unsharded=bool(torch.equal(full, gathered)), rel_vs_unsharded=rel(gathered, full))
+        if not verdict["sharded_equals_unsharded"]:          # diagnostics: which images differ, and is a repeat of either side stable?
+            bad = (full != gathered).any(1).nonzero().flatten().tolist()
+            again = torch.cat([eng.forward(x[:half]), eng.forward(x[half:])])
+            mine = eng.forward(x[lo:hi])
+            verdict.update(mismatch_rows=len(bad), mismatch_first=bad[:8], unsharded_repeatable=bool(torch.equal(again, full)),
+                           own_shard_repeatable=bool(torch.equal(mine, gathered[lo:hi])),
+                           own_shard_equals_unsharded=bool(torch.equal(mine, full[lo:hi])),
+                           max_abs=float((full - gathered).abs().max()))
         one = eng.explain(x[3 * (n_global // world) + 1: 3 * (n_global // world) + 3], targets=torch.tensor([7, 7]), want_weights=False)
         verdict.update(maps_equal_small_batch=bool(torch.equal(one["contribution_map"], maps[3 * (n_global // world) + 1: 3 * (n_global // world) + 3])))
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
@@ -140,6 +174,8 @@ def main():
     dist.all_gather_object(all_v, verdict)
     if rank == 0:
         verdict["shards"] = [v["shard"] for v in all_v]
+        verdict["per_rank"] = [{k: v[k] for k in ("first_forward_repeatable", "later_forwards_repeatable", "first_forward_max_abs") if k in v}
+                               for v in all_v]
         with open(out_path, "w") as f:
             json.dump(verdict, f, indent=1)
     dist.barrier()
