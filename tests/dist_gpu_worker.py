@@ -41,7 +41,8 @@ def replicate(net, world):
     """Data-parallel replicas carry rank 0's parameters (what loading one checkpoint / a broadcast gives in deployment); the
     ranks then prove it: a digest of every state-dict entry is exchanged and compared.
     Eight processes time-slicing ONE device are not the deployment mode, and independent per-rank calibrations were seen to
-    diverge under it about once in a hundred processes (scripts/probe/calibrate_stress*.py)."""
+    diverge under it about once in a hundred processes: torch's multi-block `var` reduction returns wrong values for a few
+    channels of an identical input (scripts/probe/layer3_stress2.py)."""
     for v in net.state_dict().values():
         t = v.detach().cpu()
         dist.broadcast(t, src=0)
