@@ -55,8 +55,10 @@ class Bottleneck(nn.Module):
 
 
 class AttentionPool2d(nn.Module):
-    """Parameter container of CLIP's QKV attention pool (positional embedding + q/k/v/c projections with biases).
-    `bcosify.BcosifyNetwork` turns it into `bcos.modules.BcosAttentionPool2d`, which owns the forward pass."""
+    """CLIP's QKV attention pool (positional embedding + q/k/v/c projections with biases).  `bcosify.BcosifyNetwork` turns it
+    into `bcos.modules.BcosAttentionPool2d` (the hot-path form) when `bcosify_args['clip_kd']` is set; the plain pool stays
+    usable for every other CLIP configuration and for the un-converted image encoder (the distillation teacher)
+    -- reference CLIP/clip/model.py:58-92, bcosify.py:80 -- as a handful of torch ops: it is outside the B-cos hot path."""
 
     def __init__(self, spacial_dim: int, embed_dim: int, num_heads: int, output_dim: int = None):
         super().__init__()
@@ -66,8 +68,15 @@ class AttentionPool2d(nn.Module):
         self.num_heads = num_heads
 
     def forward(self, x):
-        raise NotImplementedError("the un-converted CLIP attention pool is not part of the MI355X hot path: convert the "
-                                  "model with bcosify.BcosifyNetwork (bcosify_args['clip_kd']) first")
+        n, c, h, w = x.shape
+        heads, dh = self.num_heads, c // self.num_heads
+        tok = x.reshape(n, c, h * w).transpose(1, 2)                                   # [N, HW, C]
+        tok = torch.cat((tok.mean(1, keepdim=True), tok), 1) + self.positional_embedding.to(x.dtype)
+        q = self.q_proj(tok[:, :1]).reshape(n, 1, heads, dh) * dh ** -0.5             # the mean token is the only query
+        k = self.k_proj(tok).reshape(n, -1, heads, dh)
+        v = self.v_proj(tok).reshape(n, -1, heads, dh)
+        att = torch.einsum("nqhd,nkhd->nhqk", q, k).softmax(-1)
+        return self.c_proj(torch.einsum("nhqk,nkhd->nqhd", att, v).reshape(n, c))
 
 
 class ModifiedResNet(nn.Module):

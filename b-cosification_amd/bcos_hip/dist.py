@@ -31,6 +31,30 @@ def init(backend: Optional[str] = None):
     return rank, local_rank, world
 
 
+def replicate_parameters(module) -> list:
+    """Give every rank rank 0's parameters and buffers (one broadcast per state-dict entry -- what loading one checkpoint
+    on every rank gives in deployment), then prove the replicas identical: each rank's digest of every entry is exchanged
+    and compared.  Returns the list of differing entries ("rank r: key"); empty = identical.  No-op for world 1."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return []
+    world = dist.get_world_size()
+    on_cpu = dist.get_backend() == "gloo"
+    for v in module.state_dict().values():
+        t = v.detach()
+        if on_cpu:
+            t = t.cpu()
+        elif not t.is_contiguous():
+            t = t.contiguous()
+        dist.broadcast(t, src=0)
+        if t.device != v.device or t.data_ptr() != v.data_ptr():
+            v.copy_(t.to(v.device))
+    digest = {k: (float(v.double().abs().sum()), float(v.double().sum())) for k, v in module.state_dict().items()
+              if v.dtype.is_floating_point}
+    all_d = [None] * world
+    dist.all_gather_object(all_d, digest)
+    return [f"rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]
+
+
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous shard [lo, hi) of `n` items for `rank`; the first n % world ranks get one extra item."""
     base, extra = divmod(n, world)
@@ -86,17 +110,28 @@ def explain_sharded(engine, images: torch.Tensor, targets: Optional[torch.Tensor
     n = images.shape[0]
     lo, hi = shard_bounds(n, rank, world)
     counts = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
+    # Everything that decides WHICH collectives are issued is derived from arguments every rank holds alike -- never from
+    # what this rank's engine happened to return -- and is validated BEFORE any rank enters a collective: a rank that raised
+    # alone (or skipped a key the others gather) would leave the rest hanging in all_gather_into_tensor.
+    unknown = [k for k in gather if k not in _OUT_TAILS]
+    if unknown:
+        raise KeyError(f"explain_sharded: cannot gather {unknown}; known outputs: {sorted(_OUT_TAILS)}")
+    if "dynamic_linear_weights" in gather and not want_weights:
+        raise ValueError("explain_sharded: gathering 'dynamic_linear_weights' needs want_weights=True")
+    if min(counts) == 0 and "logits" in gather and num_outputs is None:
+        raise ValueError("explain_sharded: fewer images than ranks: a rank without images needs num_outputs to shape its "
+                         "empty logits (raised on every rank)")
     if hi > lo:
         out = engine.explain(images[lo:hi], None if targets is None else targets[lo:hi], want_weights=want_weights)
+        missing = [k for k in gather if out.get(k) is None]
+        if missing:         # an engine that does not produce a requested output: a bug on every non-empty rank alike
+            raise KeyError(f"explain_sharded: engine.explain returned no {missing}")
     else:
-        if "logits" in gather and num_outputs is None:
-            raise ValueError("explain_sharded: rank without images needs num_outputs to shape its empty logits")
         out = {k: torch.empty((0,) + _OUT_TAILS[k](images, num_outputs), device=images.device, dtype=_OUT_DTYPES.get(k, torch.float32))
                for k in gather}
     res = dict(out)
     for k in gather:
-        if out.get(k) is not None:
-            res[k] = all_gather_rows(out[k], counts)
+        res[k] = all_gather_rows(out[k], counts)
     res["shard"] = (lo, hi)
     return res
 

@@ -62,6 +62,7 @@ if tr:
     res["rocprof_kernel_trace"] = {"launches": len(steps), "avg_launch_us": sum(steps) / len(steps) / 1e3,
                                    "kernel_ms_per_step": sum(steps) / 1e6 / STEPS_PROFILED}
 json.dump(res, open(os.path.join(summ, f"{tag}_hbm_traffic.json"), "w"), indent=1)
-json.dump({"hbm_bytes_per_launch": int(res.get("hbm_bytes_per_launch", 0)) or None, "round": tag,
+json.dump({"hbm_bytes_per_launch": int(res.get("hbm_bytes_per_launch", 0)) or None,
+           "hbm_bytes_per_step": int(res.get("hbm_bytes_per_step", 0)) or None, "round": tag,
            "source": f"profiles/{tag}_hbm_traffic.json"}, open(os.path.join(summ, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -39,18 +39,12 @@ def free_others(rank):
 
 def replicate(net, world):
     """Data-parallel replicas carry rank 0's parameters (what loading one checkpoint / a broadcast gives in deployment); the
-    ranks then prove it: a digest of every state-dict entry is exchanged and compared.
+    ranks then prove it: a digest of every state-dict entry is exchanged and compared (bcos_hip.dist.replicate_parameters,
+    the call bench.py makes for N > 1).
     Eight processes time-slicing ONE device are not the deployment mode, and independent per-rank calibrations were seen to
     diverge under it about once in a hundred processes: torch's multi-block `var` reduction returns wrong values for a few
     channels of an identical input (scripts/probe/layer3_stress2.py)."""
-    for v in net.state_dict().values():
-        t = v.detach().cpu()
-        dist.broadcast(t, src=0)
-        v.copy_(t.to(v.device))
-    digest = {k: float(v.double().abs().sum()) for k, v in net.state_dict().items() if v.dtype.is_floating_point}
-    all_d = [None] * world
-    dist.all_gather_object(all_d, digest)
-    return [f"rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]
+    return bdist.replicate_parameters(net)
 
 
 def run_resnet50(rank, world, n_global):

@@ -51,6 +51,28 @@ def _worker(rank, world, port, n_images, q):
     t = torch.arange(5 * n_images * 3, dtype=torch.float32).view(5, n_images, 3)
     counts = [bdist.shard_bounds(n_images, r, world)[1] - bdist.shard_bounds(n_images, r, world)[0] for r in range(world)]
     ok = ok and torch.equal(bdist.all_gather_batch(t[:, lo:hi].contiguous(), dim=1, counts=counts), t)
+    # the collectives issued depend on the arguments only, and bad requests are refused on EVERY rank before any collective
+    # (a rank raising alone would leave the others hanging in all_gather_into_tensor) -- the empty-shard rank included
+    w = bdist.explain_sharded(eng, x, gather=("dynamic_linear_weights", "contribution_map"), want_weights=True)
+    ok = ok and torch.allclose(w["dynamic_linear_weights"], full["dynamic_linear_weights"], rtol=1e-4, atol=1e-7)
+    ok = ok and w["dynamic_linear_weights"].shape[0] == n_images
+    refused = 0
+    for kw, exc in ((dict(gather=("dynamic_linear_weights",), want_weights=False), ValueError),
+                    (dict(gather=("no_such_output",)), KeyError)) + (
+                   ((dict(gather=("logits",)), ValueError),) if n_images < world else ()):
+        try:
+            bdist.explain_sharded(eng, x, **kw)
+        except exc:
+            refused += 1
+    ok = ok and refused == (3 if n_images < world else 2)
+    # replicas: rank 1 perturbs its parameters, replicate_parameters() restores rank 0's and the digests agree
+    if rank == 1:
+        with torch.no_grad():
+            next(net.parameters()).add_(1.0)
+    ok = ok and bdist.replicate_parameters(net) == []
+    ref = [torch.zeros_like(next(net.parameters())) for _ in range(world)]
+    dist.all_gather(ref, next(net.parameters()).detach())
+    ok = ok and torch.equal(ref[0], ref[1])
     q.put((rank, bool(ok), lo, hi))
     dist.barrier()
     dist.destroy_process_group()
@@ -159,3 +181,17 @@ def test_gradient_allreduce_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+def test_bench_self_launches_ranks_as_children():
+    """`python bench.py --gpus 2` without a torchrun environment starts the ranks itself as a child process group and relays
+    their exit code; on this GPU-less box the ranks stop at "needs a HIP device" -- loudly, in the children, while the parent
+    (which never touches the GPU and never execs) reports the failure."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_dist_gpu.py::test_bench_two_ranks_self_launched")
+    proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                           "--batch", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode != 0
+    assert "needs a HIP device" in proc.stderr and "torch.distributed" in proc.stderr, proc.stderr[-2000:]

@@ -66,6 +66,24 @@ def test_attn_unpool_outputs_gather_along_batch_dim(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_self_launched():
+    """`python bench.py --gpus 2 ...` as the driver types it for N = 1 (no torchrun around it): the parent starts the two ranks
+    as a child process group before touching the GPU, the ranks exchange rank 0's parameters + digests, run the step with
+    the packed all-gather and rank 0's JSON line comes back through the parent.  Both ranks share the one device of the
+    test box (BCOS_SINGLE_DEVICE, gloo transport)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BCOS_SINGLE_DEVICE="1", BCOS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                           "--batch", "32"], env=env, capture_output=True, text=True, timeout=1200)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["config"]["backend"] == "gloo"
+    assert res["config"]["replicas_identical"] is True and res["config"]["global_batch"] == 64
+    assert res["value"] > 0 and res["steps"] == 2 and res["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
 def test_rccl_backend_calls_single_rank(tmp_path):
     """The collectives the product issues for N > 1 -- asynchronous all_gather_into_tensor on a flat fp32 buffer
     (OverlappedGather), asynchronous all_reduce SUM (allreduce_gradients), barrier, all_reduce MAX on a float64 scalar

@@ -894,3 +894,21 @@ def test_explainer_registry_and_ixg_semantics(monkeypatch):
     assert multi.shape == (4, 6, 32, 32) and rel(multi[0], ixg_ref[0]) <= 1e-4 and rel(multi[2], ixg_ref[1]) <= 1e-4
     with pytest.raises(KeyError, match="out of scope"):
         get_explainer(net, "RISE", "default")
+
+
+def test_plain_clip_attention_pool_stays_usable():
+    """The un-converted CLIP pool (any CLIP configuration without `clip_kd`, and the distillation teacher) keeps a working
+    forward: reference CLIP/clip/model.py:58-92 calls F.multi_head_attention_forward with separate projection weights,
+    the mean token as the only query; checked against that torch function."""
+    from CLIP.clip.model import AttentionPool2d
+    torch.manual_seed(0)
+    m = AttentionPool2d(7, 64, 4, 32)
+    x = torch.randn(3, 64, 7, 7)
+    t = x.flatten(2).permute(2, 0, 1)
+    t = torch.cat([t.mean(0, keepdim=True), t], 0) + m.positional_embedding[:, None, :]
+    ref, _ = F.multi_head_attention_forward(
+        query=t[:1], key=t, value=t, embed_dim_to_check=64, num_heads=4, q_proj_weight=m.q_proj.weight, k_proj_weight=m.k_proj.weight,
+        v_proj_weight=m.v_proj.weight, in_proj_weight=None, in_proj_bias=torch.cat([m.q_proj.bias, m.k_proj.bias, m.v_proj.bias]),
+        bias_k=None, bias_v=None, add_zero_attn=False, dropout_p=0, out_proj_weight=m.c_proj.weight, out_proj_bias=m.c_proj.bias,
+        use_separate_proj_weight=True, training=False, need_weights=False)
+    assert torch.allclose(m(x), ref.squeeze(0), rtol=1e-5, atol=1e-6)
