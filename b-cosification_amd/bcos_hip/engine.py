@@ -294,8 +294,6 @@ class ResNetEngine:
         x = x if x.is_contiguous() else x.contiguous()
         mean, std = self._consts(x.device)
         add_inverse = x.shape[1] == 3
-        self._absmax_arena.reset(x.device)
-        ops.set_absmax_arena(self._absmax_arena)
         xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse, want_absmax=True)
         gates = list(gates) if gates is not None else None
         st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3], stem_ts=[], stem_hws=[], blocks=[]) if keep else None
@@ -412,7 +410,8 @@ class ResNetEngine:
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self._run_forward(x, keep=False)[0]
+        with ops.absmax_arena(self._absmax_arena, x.device):
+            return self._run_forward(x, keep=False)[0]
 
     @torch.no_grad()
     def explain(self, x: torch.Tensor, targets: Optional[torch.Tensor] = None, want_weights: bool = True,
@@ -421,10 +420,11 @@ class ResNetEngine:
         (batched bcos/common.py:163-181).  `targets` [N] int64 selects the logits (default: arg-max).
         `gates`: optional list of NHWC 0/1 tensors, one per ReLU in execution order, that REPLACE the v > 0
         decisions (replay of gates recorded elsewhere; used by the gate-pinned parity test)."""
-        logits, st = self._run_forward(x, keep=True, gates=gates)
-        pred, _ = ops.argmax_rows(logits)
-        cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
-        wts, contrib = self._backward(x, st, cls, want_weights, consume=True)
+        with ops.absmax_arena(self._absmax_arena, x.device):
+            logits, st = self._run_forward(x, keep=True, gates=gates)
+            pred, _ = ops.argmax_rows(logits)
+            cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
+            wts, contrib = self._backward(x, st, cls, want_weights, consume=True)
         return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
                     contribution_map=contrib)
 
@@ -435,18 +435,19 @@ class ResNetEngine:
         bcos/common.py:319-344) re-runs the forward for every target; the dynamic weights of the forward do not depend on
         the explained logit, so they are kept and only the backward is repeated.
         Returns logits [N,K], contribution_maps [N,T,H,W] and, if requested, dynamic_linear_weights [N,T,6,H,W]."""
-        logits, st = self._run_forward(x, keep=True)
-        tg = targets.to(device=logits.device, dtype=torch.int64)
-        if tg.dim() == 1:
-            tg = tg.view(1, -1).expand(x.shape[0], -1)
-        T = tg.shape[1]
-        maps = torch.empty((x.shape[0], T, st["H"], st["W"]), device=x.device, dtype=torch.float32)
-        wall = torch.empty((x.shape[0], T, 6, st["H"], st["W"]), device=x.device, dtype=torch.float32) if want_weights else None
-        for k in range(T):
-            wts, contrib = self._backward(x, st, tg[:, k].contiguous(), want_weights, consume=(k == T - 1))
-            maps[:, k] = contrib
-            if want_weights:
-                wall[:, k] = wts
+        with ops.absmax_arena(self._absmax_arena, x.device):
+            logits, st = self._run_forward(x, keep=True)
+            tg = targets.to(device=logits.device, dtype=torch.int64)
+            if tg.dim() == 1:
+                tg = tg.view(1, -1).expand(x.shape[0], -1)
+            T = tg.shape[1]
+            maps = torch.empty((x.shape[0], T, st["H"], st["W"]), device=x.device, dtype=torch.float32)
+            wall = torch.empty((x.shape[0], T, 6, st["H"], st["W"]), device=x.device, dtype=torch.float32) if want_weights else None
+            for k in range(T):
+                wts, contrib = self._backward(x, st, tg[:, k].contiguous(), want_weights, consume=(k == T - 1))
+                maps[:, k] = contrib
+                if want_weights:
+                    wall[:, k] = wts
         out = dict(logits=logits, contribution_maps=maps)
         if want_weights:
             out["dynamic_linear_weights"] = wall

@@ -122,11 +122,17 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/*.hip for gfx950 into lib/libbcos_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [CSRC / s for s in SOURCES]
     deps = srcs + [CSRC / "bcos_internal.h", INCLUDE / "bcos_hip.h"]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # the compiler flags are part of the build's identity: objects (and the library) built with other BCOS_HIPCC_FLAGS are
+    # never reused -- the flags are recorded in a stamp file next to the objects and a change forces a full rebuild
+    stamp = LIB_PATH.parent / "obj" / "flags.stamp"
+    flag_id = " ".join([hipcc] + os.environ.get("BCOS_HIPCC_FLAGS", "").split())
+    if stamp.exists() and stamp.read_text() != flag_id:
+        force = True
     if LIB_PATH.exists() and not force:
         if all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
             return LIB_PATH
     LIB_PATH.parent.mkdir(parents=True, exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # one object per (source, part) compiled in parallel, then one link: bcos_tapconv.hip is compiled in TAPCONV_PARTS slices
     # (-DBCOS_TAPCONV_PART=k selects which kernel instantiations a slice carries) because its ~30 kernels dominate the build
     objdir = LIB_PATH.parent / "obj"
@@ -153,6 +159,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(run, jobs))
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [str(o) for o in objs] + ["-o", str(LIB_PATH)], check=True)
+    stamp.write_text(flag_id)
     return LIB_PATH
 
 

@@ -110,8 +110,10 @@ class AbsmaxArena:
         self.buf = None
         self.used = 0
         self.want = 0
+        self.gen = 0        # generation: slices handed out before the latest reset() are stale (absmax_of refuses them)
 
     def reset(self, device):
+        self.gen += 1
         need = max(self.want, self.used)
         if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < need:
             self.buf = torch.zeros(max(need, 1 << 20), device=device, dtype=torch.int32)
@@ -125,6 +127,7 @@ class AbsmaxArena:
         if self.buf is None or self.buf.device != torch.device(device) or self.used + n_al > self.buf.numel():
             return torch.zeros(n, device=device, dtype=torch.int32)
         out = self.buf[self.used:self.used + n]
+        out._bcos_arena = (self, self.gen)
         self.used += n_al
         return out
 
@@ -155,6 +158,25 @@ def set_absmax_arena(arena: Optional[AbsmaxArena]):
     _ARENA = arena
 
 
+class absmax_arena:
+    """Context: the launches inside draw their per-pixel maxima from `arena` (reset on entry); the previous arena -- normally
+    none: the module / autograd path allocates per tensor -- is restored on exit, so an engine's arena never serves launches
+    outside its own pass.  Slices still attached to tensors that outlive the pass go stale at the arena's next reset."""
+
+    def __init__(self, arena: AbsmaxArena, device):
+        self.arena, self.device = arena, device
+
+    def __enter__(self):
+        self._prev = _ARENA
+        self.arena.reset(self.device)
+        set_absmax_arena(self.arena)
+        return self.arena
+
+    def __exit__(self, *exc):
+        set_absmax_arena(self._prev)
+        return False
+
+
 def _new_absmax(n: int, device) -> torch.Tensor:
     return _ARENA.take(n, device) if _ARENA is not None else torch.zeros(n, device=device, dtype=torch.int32)
 
@@ -167,6 +189,9 @@ def absmax_of(t: torch.Tensor) -> Optional[torch.Tensor]:
     """The valid per-pixel max |t| side tensor of `t`, or None (never produced, or `t` was modified in place since)."""
     rec = getattr(t, "_bcos_absmax", None)
     if rec is None or rec[1] != t._version:
+        return None
+    src = getattr(rec[0], "_bcos_arena", None)
+    if src is not None and src[0].gen != src[1]:      # a slice of an arena that has been reset (and re-issued) since
         return None
     return rec[0]
 

@@ -912,3 +912,27 @@ def test_plain_clip_attention_pool_stays_usable():
         bias_k=None, bias_v=None, add_zero_attn=False, dropout_p=0, out_proj_weight=m.c_proj.weight, out_proj_bias=m.c_proj.bias,
         use_separate_proj_weight=True, training=False, need_weights=False)
     assert torch.allclose(m(x), ref.squeeze(0), rtol=1e-5, atol=1e-6)
+
+
+def test_absmax_arena_is_scoped_to_a_pass_and_stale_slices_are_refused():
+    """The per-pass arena of operand maxima serves launches of its own pass only: the previous arena (none, for the module
+    path) is restored on exit, and a slice still attached to a tensor that outlived the pass is refused once the arena
+    has been reset and re-issued (it would hold another tensor's maxima, or zeros)."""
+    from bcos_hip import ops
+    arena = ops.AbsmaxArena()
+    assert ops._ARENA is None
+    with ops.absmax_arena(arena, "cpu"):
+        assert ops._ARENA is arena
+        t = torch.ones(4, 8)
+        am = ops._new_absmax(4, t.device)
+        ops._attach_absmax(t, am)
+        assert ops.absmax_of(t) is am
+    assert ops._ARENA is None and ops.absmax_of(t) is am          # valid until the arena is reset
+    with ops.absmax_arena(arena, "cpu"):
+        assert ops.absmax_of(t) is None                           # the slice has been re-issued: stale
+        u = torch.ones(4, 8)
+        ops._attach_absmax(u, ops._new_absmax(4, u.device))
+        assert ops.absmax_of(u) is not None
+    own = torch.zeros(4, dtype=torch.int32)
+    ops._attach_absmax(t, own)
+    assert ops.absmax_of(t) is own                                # per-tensor buffers never go stale this way
