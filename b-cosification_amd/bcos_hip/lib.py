@@ -28,7 +28,7 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 ABI_VERSION = 4
-TAPCONV_PARTS = 5
+TAPCONV_PARTS = 8
 
 
 class BcosHipError(RuntimeError):
@@ -137,7 +137,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     # (-DBCOS_TAPCONV_PART=k selects which kernel instantiations a slice carries) because its ~30 kernels dominate the build
     objdir = LIB_PATH.parent / "obj"
     objdir.mkdir(parents=True, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
     flags += os.environ.get("BCOS_HIPCC_FLAGS", "").split()
     jobs = []
     for s in srcs:

@@ -1646,6 +1646,434 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n);
 }
 
+// ---- split-f16 contraction, ASYNCHRONOUS staging (round 3) ---------------------------------------------------------------------
+// Same arithmetic as tile_body_h2 -- the same split of every operand element, the same three products per accumulator in the
+// same order over the same K walk, the same partial sums of the patch norm: results are bit-identical -- with the operands moved
+// by the LDS-DMA path instead of through registers:
+//   * A stays fp32 on its way into LDS: `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 bytes straight into the slot (lanes
+//     whose tap is out of the image fail the buffer bounds check and land as zeros: scripts/probe/lds_dma_probe.hip); the slot
+//     is [BM rows][16 k] fp32 = 64 B rows whose four 16-byte pieces are permuted by (row >> 2) & 3 ON THE SOURCE SIDE (the DMA
+//     writes lane-linear), which makes the fragment reads (two ds_read_b128 per 32 x 16 fragment) bank-conflict free;
+//   * the fp32 -> (h, l) f16 split happens on the fragment, in the wave that feeds it to the matrix pipe.  Waves are laid out
+//     WAVES_M x 1 wherever the tile allows, so every A element is still converted exactly once per tile and the conversion
+//     (~3 VALU per element with the packed f32 / cvt_pk forms) sits in the shadow of that wave's own matrix instructions;
+//   * B (pre-split weights in fragment order) is DMA'd verbatim, one 1-KB block per wave instruction;
+//   * no staging registers, no ds_write, no VALU on the load path: a ring of D_NSLOT slots, the loads of step ks + 2 are issued
+//     at the top of step ks and have two steps of matrix work to land; ONE raw s_barrier per step, counted s_waitcnt vmcnt
+//     (never 0 inside the loop).  The compiler keeps ds_reads clear of the DMA queue as long as all LDS is one array.
+#ifndef D_NSLOT
+#define D_NSLOT 3
+#endif
+#ifndef D_SCHED
+#define D_SCHED 1                 // 1 = pin the issue order of a step's fragment reads / matrix / vector instructions (sched_group_barrier)
+#endif
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define BCOS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int BM, int BN>
+constexpr int d_slot_bytes() { return BM * 64 + (BN / 32) * 2048; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NT = NTHREADS>
+__device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NW = NT / 64;
+    constexpr int RP = NT / 4;                      // rows covered by one DMA pass of the workgroup (16 per wave)
+    static_assert(WAVES_M * WAVES_N == NW && BM % RP == 0, "wave layout");
+    constexpr int A_LD = BM / RP;                   // A DMA instructions per wave per 16-k step (1 KB = 16 rows each)
+    static_assert(WM == 16 * WAVES_N * A_LD, "a wave row-group's rows are loaded by its own waves");
+    constexpr int NBLK = (BN / 32) * 2;             // 1-KB fragment blocks of B per step: (32-column tile, plane)
+    constexpr int B_LD = (NBLK + NW - 1) / NW;      // B DMA instructions per wave per step (waves without a block issue a dummy: equal counts)
+    constexpr int A_BYTES = BM * 64;
+    constexpr int SLOT = d_slot_bytes<BM, BN>();
+    constexpr bool PRIV = WAVES_N == 1;             // a wave's fragment rows are loaded by that wave alone: it converts them a step ahead
+    char* lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    // DMA instruction j of wave (wave_m, wave_n) fills rows wave_m WM + 16 (wave_n A_LD + j) + [0, 16) of the slot: lane l
+    // writes byte 16 l of that 1-KB piece = physical position l & 3 of row l >> 2, which holds LOGICAL chunk
+    // (l & 3) ^ ((row >> 2) & 3) (4 k of the 16-k step; the permutation makes the fragment reads bank-conflict free)
+    const int r0 = wave_m * WM + 16 * wave_n * A_LD + (lane >> 2);     // row of pass 0 (+16 per pass)
+    const int chunk = (lane & 3) ^ ((lane >> 4) & 3);                  // (row >> 2) & 3 == (lane >> 4) & 3: the row bases are multiples of 16
+    const bcos_tapconv_geom& g = p.g;
+    const int H = g.H, W = g.W;
+    const int a_pitch = g.a_pitch;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt2), 0, p.wt2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.a_absmax), 0, p.absmax_bytes, 0x00020000);
+    unsigned a_nbase[A_LD];          // byte offset of the row's image (+ this lane's 16-byte chunk)
+    int a_ih0[A_LD], a_iw0[A_LD];
+    float* s_scale = reinterpret_cast<float*>(lds + D_NSLOT * SLOT);                          // [BM] row scales
+    char* s_dummy = lds + D_NSLOT * SLOT + BM * 4;                                           // 1 KB: target of the dummy B DMAs
+    unsigned* s_tapoff = reinterpret_cast<unsigned*>(lds + D_NSLOT * SLOT + BM * 4 + 1024);    // [tap][BM] byte offsets (without the lane's chunk)
+    {
+        // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 lanes of a row share the taps
+        unsigned rmax[A_LD];
+        int pix0[A_LD];
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int m = m0 + r0 + 16 * j;
+            rmax[j] = 0u;
+            if (m < p.M) {
+                const int n = m / p.PQ;
+                const int rem = m - n * p.PQ;
+                const int i = rem / g.Q;
+                const int jj = rem - i * g.Q;
+                a_nbase[j] = ((unsigned)n * H * W * a_pitch + chunk * 4) * 4u;
+                pix0[j] = n * H * W;
+                a_ih0[j] = i * g.in_sh + g.dh0;
+                a_iw0[j] = jj * g.in_sw + g.dw0;
+            } else {
+                a_nbase[j] = 0;
+                pix0[j] = 0;
+                a_ih0[j] = -(1 << 28);
+                a_iw0[j] = -(1 << 28);
+            }
+        }
+        const int ntaps = g.TH * g.TW;
+        for (int t = chunk; t < ntaps; t += 4) {
+            const int th = t / g.TW, tw = t - th * g.TW;
+            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)(pix0[j] + ih * W + iw) * 4u : OOB, 0, 0);
+                rmax[j] = max(rmax[j], v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            unsigned v = rmax[j];
+            v = max(v, (unsigned)__shfl_xor((int)v, 1));
+            v = max(v, (unsigned)__shfl_xor((int)v, 2));
+            unsigned E = v >> 23;                  // biased exponent of the row max (the bit patterns carry no sign)
+            E = E < 15u ? 15u : E;
+            if ((lane & 3) == 0) s_scale[r0 + 16 * j] = __uint_as_float((268u - E) << 23);     // max * scale in [2^14, 2^15)
+        }
+    }
+
+    const int nk = (p.nchunks + 3) / 4;
+    const bool uniform = (g.C % X3_BK) == 0;
+    const bool small_c = g.C == 4 || g.C == 8;      // see tile_body_h2
+    const int tps = small_c ? 16 / g.C : 1;
+    const int l_cc = small_c ? (g.C == 8 ? (chunk & 1) : 0) : 0;
+    int l_th = 0, l_tw = 0;
+    if (small_c) {
+        const int sub = g.C == 8 ? (chunk >> 1) : chunk;
+        l_th = sub / g.TW;
+        l_tw = sub - l_th * g.TW;
+    }
+    const int ntaps = g.TH * g.TW;
+    const bool kmajor = ntaps > 1 && ntaps <= H2_MAX_TAPS && uniform;      // channel-chunk-major K walk (see tile_body_h2)
+    if (kmajor) {
+        for (int t = chunk; t < ntaps; t += 4) {
+            const int th = t / g.TW, tw = t - th * g.TW;
+            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                s_tapoff[t * BM + r0 + 16 * j] = ok ? a_nbase[j] - chunk * 16u + (unsigned)((ih * W + iw) * a_pitch) * 4u : OOB;
+            }
+        }
+    }
+    int s_tap = 0;
+    int s_cc = 0, s_th = 0, s_tw = 0;
+    unsigned a_cur[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) a_cur[j] = OOB;
+    const int b_tile0 = n0 >> 5;
+    const int a_dst0 = (wave_m * WM + 16 * wave_n * A_LD) * 64;           // this wave's first 1-KB piece inside the A slot
+    // issue the DMA of 16-k step ks into ring slot `slot`: the wave's A pieces first, then its B blocks (calls come in
+    // increasing ks: the walk state advances with them)
+    // K walk of the launch, fixed outside the loop: 0 channel-chunk-major taps (3x3 ...), 1 one tap per step (C % 16 == 0), 2 C = 4 / 8
+    // (16 / C taps per step, every lane walks its own tap), 3 general
+    const int walk = kmajor ? 0 : uniform ? 1 : small_c ? 2 : 3;
+    // (calls come in increasing ks: the walk state advances with them)
+    auto issue_a = [&](auto walk_c, int ks, int slot_off) {
+        constexpr int WALK = decltype(walk_c)::value;
+        char* sa = lds + slot_off + a_dst0;
+        auto dma_a = [&](int j, unsigned voff, int soff) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, BCOS_LDS_PTR(sa + j * 1024), 16, (int)voff, soff, 0, 0);
+        };
+        if constexpr (WALK == 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) dma_a(j, s_tapoff[s_tap * BM + r0 + 16 * j] + chunk * 16u, s_cc * 16);
+            if (++s_tap == ntaps) { s_tap = 0; s_cc += 4; }
+        } else if constexpr (WALK == 1) {
+            if (s_cc == 0) {
+                const int dh = s_th * g.dstep_h, dw = s_tw * g.dstep_w;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) {
+                    const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    a_cur[j] = ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch) * 4u : OOB;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) dma_a(j, a_cur[j], s_cc * 16);
+            s_cc += 4;
+            if (s_cc == p.cpt) {
+                s_cc = 0;
+                if (++s_tw == g.TW) { s_tw = 0; ++s_th; }
+            }
+        } else if constexpr (WALK == 2) {
+            const bool kvalid = l_th < g.TH;
+            const int dh = l_th * g.dstep_h, dw = l_tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                dma_a(j, ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch + (l_cc - chunk) * 4) * 4u : OOB, 0);
+            }
+            l_tw += tps;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (l_tw >= g.TW) { l_tw -= g.TW; ++l_th; }
+        } else {
+            const int q = ks * 4 + chunk;
+            const bool kvalid = q < p.nchunks;
+            const int tap = q / p.cpt;
+            const int cc = q - tap * p.cpt;
+            const int th = tap / g.TW;
+            const int tw = tap - th * g.TW;
+            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                dma_a(j, ok ? a_nbase[j] + (unsigned)((ih * W + iw) * a_pitch + (cc - chunk) * 4) * 4u : OOB, 0);
+            }
+        }
+    };
+    // B: wave w copies blocks w, w + NW, ... of the step (block = (32-column tile c, plane sp) = 1 KB, lane-linear)
+    auto issue_b = [&](int ks, int slot_off) {
+        char* sbb = lds + slot_off + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int blk = wave + NW * j;
+            if (NBLK % NW == 0 || blk < NBLK) {
+                const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(sbb + blk * 1024), 16, lane * 16, soff, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(s_dummy), 16, (int)OOB, 0, 0, 0);   // keeps every wave's DMA count equal
+            }
+        }
+    };
+    constexpr int LA = A_LD, LB = B_LD;      // DMA instructions per wave and step: A pieces, then B blocks
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float pa[TM], pb[TM];            // patch-norm partial sums of the lane's two chunks: the chains of tile_body_h2's chunk lanes
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
+
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    int a_frag[TM];                  // byte offset of the fragment row's first piece (chunk 2 * half) inside the A slot
+    float f_scale[TM];
+    const int b_frag = A_BYTES + (wave_n * TN) * 2048 + lane * 16;
+
+    __syncthreads();                 // scales and the (tap, row) offset table are complete
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int R = wave_m * WM + i * 32 + frag_row;
+        a_frag[i] = R * 64 + (((2 * frag_half) ^ ((R >> 2) & 3)) << 4);
+        f_scale[i] = s_scale[R];
+    }
+    float a_inv[BM / (NT / 4)];      // inverse row scales in staging layout (what tile_epilogue takes): 2^-e from the row's 2^e
+#pragma unroll
+    for (int j = 0; j < BM / (NT / 4); ++j)
+        a_inv[j] = __uint_as_float((254u - (__float_as_uint(s_scale[(tid >> 2) + (NT / 4) * j]) >> 23)) << 23);
+
+    f16x8 af[2][TM];                 // the A fragments of the step about to be multiplied: [h | l][row tile]
+    // fp32 fragment rows of the slot at byte offset `off` -> registers (two 16-byte pieces per 32 x 16 fragment) ...
+    auto read_a = [&](int off, f32x4 (&x0)[TM], f32x4 (&x1)[TM]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            x0[i] = *reinterpret_cast<const f32x4*>(lds + off + a_frag[i]);            // k = 8 half .. + 3
+            x1[i] = *reinterpret_cast<const f32x4*>(lds + off + (a_frag[i] ^ 16));     // k = 8 half + 4 .. + 7
+        }
+    };
+    // ... -> patch-norm partial sums and the (h, l) f16 fragments, in 4 TM slices of two elements each (slice = (row tile i,
+    // piece x0 | x1, element pair)) so that the vector instructions can be dealt out between matrix instructions
+    constexpr int NSLICE = 4 * TM;
+    auto split_slice = [&](auto slice_c, const f32x4 (&x0)[TM], const f32x4 (&x1)[TM]) {
+        constexpr int SL = decltype(slice_c)::value;
+        constexpr int i = SL / 4, piece = (SL / 2) & 1, q0 = (SL & 1) * 2;
+        const f32x4 x = piece ? x1[i] : x0[i];
+#pragma unroll
+        for (int q = q0; q < q0 + 2; ++q) {
+            if (NORM) {
+                if (piece) pb[i] = fmaf(x[q], x[q], pb[i]);
+                else pa[i] = fmaf(x[q], x[q], pa[i]);
+            }
+            const float xs = x[q] * f_scale[i];
+            const _Float16 h = (_Float16)xs;
+            af[0][i][piece * 4 + q] = h;
+            af[1][i][piece * 4 + q] = (_Float16)(xs - (float)h);
+        }
+    };
+    auto split_a = [&](const f32x4 (&x0)[TM], const f32x4 (&x1)[TM]) {
+        split_slice(std::integral_constant<int, 0>{}, x0, x1); split_slice(std::integral_constant<int, 1>{}, x0, x1);
+        split_slice(std::integral_constant<int, 2>{}, x0, x1); split_slice(std::integral_constant<int, 3>{}, x0, x1);
+        if constexpr (TM > 1) {
+            split_slice(std::integral_constant<int, 4>{}, x0, x1); split_slice(std::integral_constant<int, 5>{}, x0, x1);
+            split_slice(std::integral_constant<int, 6>{}, x0, x1); split_slice(std::integral_constant<int, 7>{}, x0, x1);
+        }
+        static_assert(TM <= 2, "slices");
+    };
+    // The matrix instructions of one step on slot `off`, af = this step's A fragments.  `NEXT` (wave-private A rows only): the
+    // next step's A rows (slot `off_nx`, already landed) are read up front and split slice by slice BETWEEN this step's matrix
+    // instructions, whose shadow hides the vector work.  The issue order is pinned (sched_barrier between the chunks): left
+    // to itself the scheduler sinks every fragment read to just before its first use and the whole split behind the last
+    // matrix instruction.  Product order per accumulator as in tile_body_h2 (smallest terms first): l_a h_b, h_a l_b, h_a h_b.
+    auto mma_step = [&](int off, auto next_c, int off_nx) {
+        constexpr bool NEXT = decltype(next_c)::value;
+        const char* bb = lds + off + b_frag;
+        f32x4 x0[TM], x1[TM];
+        f16x8 a1[TM], a0[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { a0[i] = af[0][i]; a1[i] = af[1][i]; }
+        constexpr int G = 3 * TM * TN;                              // matrix instructions of the step
+        constexpr int D = G >= 12 ? G / 4 : 1;                      // ... issued before the first slice (the A reads need ~2 of them to return)
+        constexpr int PER = (NSLICE + (G - D) - 1) / (G - D);        // slices dealt out behind each later one
+        auto deal = [&](auto m_c) {                                  // the slices that follow matrix instruction m
+            constexpr int m = decltype(m_c)::value;
+            if constexpr (NEXT && m >= D) {
+                constexpr int s0 = (m - D) * PER;
+                if constexpr (s0 < NSLICE) split_slice(std::integral_constant<int, s0>{}, x0, x1);
+                if constexpr (PER > 1 && s0 + 1 < NSLICE) split_slice(std::integral_constant<int, s0 + 1>{}, x0, x1);
+                static_assert(PER <= 2, "slices per matrix instruction");
+            }
+        };
+        constexpr bool ACC_MAJOR = H2_MFMA_ORDER == 1 || (H2_MFMA_ORDER == 0 && TM * TN >= 8);
+        if constexpr (!ACC_MAJOR) {
+            f16x8 bf[2][TN];
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[sp][j] = *reinterpret_cast<const f16x8*>(bb + j * 2048 + sp * 1024);
+            if constexpr (NEXT) read_a(off_nx, x0, x1);
+            __builtin_amdgcn_sched_barrier(0);
+            auto mm = [&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                constexpr int pr = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? a1[i] : a0[i], bf[pr == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                deal(m_c);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (mm(std::integral_constant<int, Ms>{}), ...); }(std::make_integer_sequence<int, G>{});
+        } else {
+            // (TM = 1) column tiles in PAIRS: the six matrix instructions of tiles (2p, 2p + 1) alternate between the two accumulators
+            // (a dependent v_mfma directly behind its producer waits for it, and any instruction placed between the two costs ~40
+            // cycles more: the pair's chains hide each other, and the reads / split slices go between independent instructions);
+            // the B fragments of pair p + 1 are read behind the first two instructions of pair p
+            static_assert(TM == 1 && TN % 2 == 0, "pair order");
+            f16x8 bq[TN][2];
+            auto read_b = [&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                bq[j][0] = *reinterpret_cast<const f16x8*>(bb + j * 2048);
+                bq[j][1] = *reinterpret_cast<const f16x8*>(bb + j * 2048 + 1024);
+            };
+            read_b(std::integral_constant<int, 0>{});
+            read_b(std::integral_constant<int, 1>{});
+            if constexpr (NEXT) read_a(off_nx, x0, x1);
+            __builtin_amdgcn_sched_barrier(0);
+            auto mm = [&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                constexpr int pp = m / 6, pr = (m % 6) / 2, j = 2 * pp + (m & 1);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? a1[0] : a0[0], bq[j][pr == 1 ? 1 : 0], acc[0][j], 0, 0, 0);
+                if constexpr (m % 6 < 2 && 2 * pp + 2 + (m & 1) < TN) read_b(std::integral_constant<int, (2 * pp + 2 + (m & 1) < TN ? 2 * pp + 2 + (m & 1) : 0)>{});
+                deal(m_c);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (mm(std::integral_constant<int, Ms>{}), ...); }(std::make_integer_sequence<int, G>{});
+        }
+        if constexpr (NEXT) {         // (whatever the deal above did not reach: none for the compiled tiles)
+            constexpr int done = (G - D) * PER;
+            static_assert(done >= NSLICE, "every slice is dealt out");
+        }
+    };
+
+    // Ring: step s lives in slot s % D_NSLOT (A rows and B blocks).  The loops are peeled so that the steady state has no branch.
+    auto rot = [](int o) { return o + SLOT == D_NSLOT * SLOT ? 0 : o + SLOT; };
+    auto barrier = []() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");         // (the raw barrier does not order the compiler's memory operations)
+    };
+    auto run = [&](auto walk_c) {
+        if constexpr (PRIV) {
+            // A wave converts its OWN A rows one step ahead of the matrix instructions that use them, so A runs one step ahead
+            // of B in the DMA queue: at the top of step ks the queue of a wave holds, oldest first,
+            //   A(ks+1) B(ks) | A(ks+2) B(ks+1)            (A(ks+3) B(ks+2) are issued behind the barrier)
+            // and ONE counted wait (everything but the last pair) covers what step ks needs: B(ks) for its matrix instructions,
+            // A(ks+1) for the split that runs in their shadow.  Every piece has two steps to land.
+            issue_a(walk_c, 0, 0);
+            if (nk > 1) issue_a(walk_c, 1, SLOT);
+            issue_b(0, 0);
+            if (nk > 2) issue_a(walk_c, 2, 2 * SLOT);
+            if (nk > 1) issue_b(1, SLOT);
+            if (nk > 2) wait_vmcnt<2 * LA + 2 * LB>(); else if (nk > 1) wait_vmcnt<LA + 2 * LB>(); else wait_vmcnt<LB>();
+            {
+                f32x4 x0[TM], x1[TM];
+                read_a(0, x0, x1);
+                split_a(x0, x1);
+            }
+            int off = 0, off_nx = SLOT, off_in = 2 * SLOT;      // slots of step ks, ks + 1, ks + 2 (= ks + 3 for A: that slot's rows were split in step ks - 1)
+            auto step = [&](auto ia_c, auto ib_c, auto wait_c, auto next_c, int ks) {
+                wait_vmcnt<decltype(wait_c)::value>();
+                barrier();                         // every wave's B blocks of step ks have landed; the B slot of step ks + 2 (read in step ks - 1) is free
+                if constexpr (decltype(ia_c)::value) issue_a(walk_c, ks + 3, off);
+                if constexpr (decltype(ib_c)::value) issue_b(ks + 2, off_in);
+                mma_step(off, next_c, off_nx);
+                off = off_nx; off_nx = off_in; off_in = rot(off_in);
+            };
+            using T = std::true_type; using F = std::false_type;
+            int ks = 0;
+            for (; ks + 3 < nk; ++ks) step(T{}, T{}, std::integral_constant<int, LA + LB>{}, T{}, ks);
+            if (ks + 2 < nk) { step(F{}, T{}, std::integral_constant<int, LA + LB>{}, T{}, ks); ++ks; }
+            if (ks + 1 < nk) { step(F{}, F{}, std::integral_constant<int, LB>{}, T{}, ks); ++ks; }
+            step(F{}, F{}, std::integral_constant<int, 0>{}, F{}, ks);
+        } else {
+            // A rows shared by the waves of a row group (half-height tiles): A and B of step ks + 2 are issued together at the top of
+            // step ks, the split happens at the top of the step behind the barrier
+            issue_a(walk_c, 0, 0); issue_b(0, 0);
+            if (nk > 1) { issue_a(walk_c, 1, SLOT); issue_b(1, SLOT); }
+            int off = 0, off_in = (2 * SLOT) % (D_NSLOT * SLOT);
+            for (int ks = 0; ks < nk; ++ks) {
+                if (ks + 1 < nk) wait_vmcnt<LA + LB>(); else wait_vmcnt<0>();
+                barrier();
+                if (ks + 2 < nk) { issue_a(walk_c, ks + 2, off_in); issue_b(ks + 2, off_in); }
+                f32x4 x0[TM], x1[TM];
+                read_a(off, x0, x1);
+                split_a(x0, x1);
+                mma_step(off, std::false_type{}, 0);
+                off = rot(off); off_in = rot(off_in);
+            }
+        }
+    };
+    if (walk == 0) run(std::integral_constant<int, 0>{});
+    else if (walk == 1) run(std::integral_constant<int, 1>{});
+    else if (walk == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+    __syncthreads();                           // the ring is free: the epilogue reuses it
+    float ss[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ss[i] = pa[i] + pb[i];
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, NORM ? ss : nullptr, nullptr, a_inv, m0, n0, tile_n);
+}
+
 // Narrow split-f16 tiles (128 x 64, 128 x 32: the stem, the 56^2 3x3 layers) hold 16-32 accumulator registers per wave and run
 // 6-12 matrix instructions per 16-k step: their steps wait on load latency, not on a pipe.  The FORWARD kernels of these
 // tiles are compiled for three resident workgroups per CU (168 registers): same-node A/B on ResNet-50, stem forward
@@ -1669,8 +2097,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 // dispatched in blockIdx order, so the half-height tiles fill the tail of the launch: with a few hundred equal
 // tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
 // = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights, 3 split-f16
-__global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN && BM <= 128) ? H2_NARROW_WGS : 2) void tapconv_kernel(const KArgs p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights, 3 split-f16 (register staging), 4 split-f16 (LDS-DMA staging)
+__global__ __launch_bounds__(NTHREADS, (X3 >= 3 && NORM && BN <= H2_NARROW_BN && BM <= 128) ? H2_NARROW_WGS : 2) void tapconv_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     if (bid < p.n_big) {
@@ -1678,7 +2106,8 @@ __global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN &&
         const int tile_m = tile / p.tiles_n;
         const int tile_n = tile - tile_m * p.tiles_n;
         const int gcol = (int)blockIdx.y * p.g.Cout;        // first global column of this group (0 unless a grouped launch)
-        if constexpr (X3 == 3) tile_body_h2<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        if constexpr (X3 == 4) tile_body_d<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+        else if constexpr (X3 == 3) tile_body_h2<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, tile_n * BN, tile_n);
         else if constexpr (X3 == 2) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, true>(p, smem, tile_m * BM, gcol + tile_n * BN, tile_n);
         else if constexpr (X3 == 1) tile_body_x3<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, tile_m * BM, gcol + tile_n * BN, tile_n);
         else tile_body<BM, BN, WAVES_M, WAVES_N, NORM>(p, smem, tile_m * BM, gcol + tile_n * BN, tile_n);
@@ -1691,7 +2120,8 @@ __global__ __launch_bounds__(NTHREADS, (X3 == 3 && NORM && BN <= H2_NARROW_BN &&
             const int tile_m = tile / p.tiles_n;
             const int tile_n = tile - tile_m * p.tiles_n;
             const int gcol = (int)blockIdx.y * p.g.Cout;
-            if constexpr (X3 == 3) tile_body_h2<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            if constexpr (X3 == 4) tile_body_d<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
+            else if constexpr (X3 == 3) tile_body_h2<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, tile_n * BN, tile_n);
             else if constexpr (X3 == 2) tile_body_x3<BMS, BN, WMS, WNS, NORM, true>(p, smem, p.rows_big + tile_m * BMS, gcol + tile_n * BN, tile_n);
             else if constexpr (X3 == 1) tile_body_x3<BMS, BN, WMS, WNS, NORM, false>(p, smem, p.rows_big + tile_m * BMS, gcol + tile_n * BN, tile_n);
             else tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, gcol + tile_n * BN, tile_n);
@@ -1800,6 +2230,32 @@ int launch_h2(const KArgs& base, bool norm, hipStream_t stream) {
     return BCOS_OK;
 }
 
+// split-f16 launches with LDS-DMA staging (tile_body_d): ring + row scales + (channel-chunk-major launches) the tap table
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_d(const KArgs& base, bool norm, hipStream_t stream) {
+    KArgs p = base;
+    plan_tiles<BM, BN, WAVES_M>(p);
+    const int ntaps = p.g.TH * p.g.TW;
+    const bool kmajor = ntaps > 1 && ntaps <= H2_MAX_TAPS && p.g.C % X3_BK == 0;
+    size_t lds = (size_t)D_NSLOT * d_slot_bytes<BM, BN>() + (size_t)BM * 4 + 1024 + (kmajor ? (size_t)ntaps * BM * 4 : 0);    // (the half-height body needs less)
+    const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
+    if (lds_epi > lds) lds = lds_epi;
+    const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
+    static std::atomic<size_t> lds_hw[2];
+    auto launch = [&](auto k, int which) -> hipError_t {
+        hipError_t e2 = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_hw[which]);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+        return hipSuccess;
+    };
+    hipError_t err = norm ? launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, true, 4>, 0)
+                          : launch(tapconv_kernel<BM, BN, WAVES_M, WAVES_N, false, 4>, 1);
+    if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
+    err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);
+    return BCOS_OK;
+}
+
 }  // namespace
 
 // The file is compiled either whole or in slices (-DBCOS_TAPCONV_PART=k, bcos_hip/lib.py: build): slice 0 carries the C ABI
@@ -1819,6 +2275,12 @@ BCOS_TC_LAUNCHER(bcos_tc_h2_128x64);
 BCOS_TC_LAUNCHER(bcos_tc_h2_128x32);
 BCOS_TC_LAUNCHER(bcos_tc_h2_256x64);
 BCOS_TC_LAUNCHER(bcos_tc_h2_256x32);
+BCOS_TC_LAUNCHER(bcos_tc_d_128x256);
+BCOS_TC_LAUNCHER(bcos_tc_d_128x128);
+BCOS_TC_LAUNCHER(bcos_tc_d_128x64);
+BCOS_TC_LAUNCHER(bcos_tc_d_128x32);
+BCOS_TC_LAUNCHER(bcos_tc_d_256x64);
+BCOS_TC_LAUNCHER(bcos_tc_d_256x32);
 #define BCOS_TC_DEFINE(name, call) BCOS_TC_LAUNCHER(name) { return call(*static_cast<const KArgs*>(kargs), norm != 0, s); }
 #if BCOS_TC_IN(1)
 BCOS_TC_DEFINE(bcos_tc_cfg_128x128, (launch_cfg<128, 128, 2, 2>))
@@ -1834,6 +2296,18 @@ BCOS_TC_DEFINE(bcos_tc_h2_128x128, (launch_h2<128, 128, 2, 2>))
 #if BCOS_TC_IN(4)
 BCOS_TC_DEFINE(bcos_tc_h2_256x64, (launch_h2<256, 64, 4, 1>))
 BCOS_TC_DEFINE(bcos_tc_h2_256x32, (launch_h2<256, 32, 4, 1>))
+#endif
+#if BCOS_TC_IN(5)
+BCOS_TC_DEFINE(bcos_tc_d_128x256, (launch_d<128, 256, 4, 1>))
+#endif
+#if BCOS_TC_IN(6)
+BCOS_TC_DEFINE(bcos_tc_d_128x128, (launch_d<128, 128, 4, 1>))
+BCOS_TC_DEFINE(bcos_tc_d_128x64, (launch_d<128, 64, 4, 1>))
+#endif
+#if BCOS_TC_IN(7)
+BCOS_TC_DEFINE(bcos_tc_d_256x64, (launch_d<256, 64, 4, 1>))
+BCOS_TC_DEFINE(bcos_tc_d_256x32, (launch_d<256, 32, 4, 1>))
+BCOS_TC_DEFINE(bcos_tc_d_128x32, (launch_d<128, 32, 4, 1>))
 #endif
 #if BCOS_TC_IN(0)
 BCOS_TC_DEFINE(bcos_tc_h2_128x64, (launch_h2<128, 64, 2, 2>))
@@ -2223,6 +2697,9 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         if (handled != 0) return handled < 0 ? handled : BCOS_OK;
     }
     if (p.h2) {
+        // staging of the split-f16 loop: LDS-DMA (tile_body_d, default) or registers (tile_body_h2: BCOS_H2_LOOP=regs); same bits
+        const char* loop = getenv("BCOS_H2_LOOP");
+        const bool dma = !(loop && loop[0] == 'r');
         if (g.Cout > 64) {
             // 128 x 256 tiles stage half the A bytes per MFMA; they pay when they do not cost an extra round of tiles
             // (measured on the ResNet-50 shapes: M = 50176, N = 256: -3 %; M = 12544, N = 512: +17 % -> stays 128 x 128)
@@ -2235,8 +2712,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             const int64_t c1 = (t1 + SLOTS - 1) / SLOTS, c2 = 2 * ((t2 + SLOTS - 1) / SLOTS);
             bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && p.Ktot >= 1024));
             if (force) wide = g.Cout > 128 && force[4] == '2';
-            if (wide) return bcos_tc_h2_128x256(&p, norm, s);
-            return bcos_tc_h2_128x128(&p, norm, s);
+            if (wide) return dma ? bcos_tc_d_128x256(&p, norm, s) : bcos_tc_h2_128x256(&p, norm, s);
+            return dma ? bcos_tc_d_128x128(&p, norm, s) : bcos_tc_h2_128x128(&p, norm, s);
         }
         if (g.Cout > 32) {
             // 256 x 64 tiles (four waves of 64 x 64: the A operand's split, its LDS image and the per-tile prologue / epilogue
@@ -2247,14 +2724,14 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             const char* tall = getenv("BCOS_H2_TALL");       // development switch: "0" keeps the 128-row tiles
             const char* tmin = getenv("BCOS_H2_TALL_MIN");
             const int64_t tall_min = tmin ? atoll(tmin) : 2 * 256 * SLOTS;     // (batch 128, M = 401 408: +0.4 % per step; M = 200 704: neutral)
-            if (M64 >= tall_min && !(tall && tall[0] == '0')) return bcos_tc_h2_256x64(&p, norm, s);
-            return bcos_tc_h2_128x64(&p, norm, s);
+            if (M64 >= tall_min && !(tall && tall[0] == '0')) return dma ? bcos_tc_d_256x64(&p, norm, s) : bcos_tc_h2_256x64(&p, norm, s);
+            return dma ? bcos_tc_d_128x64(&p, norm, s) : bcos_tc_h2_128x64(&p, norm, s);
         }
         {   // 256 x 32 tiles likewise (the depth-to-space stem gradient, M = 3.2 M: 1.29-1.38 -> 1.17-1.20 ms in a same-node A/B)
             const char* tall = getenv("BCOS_H2_TALL");
-            if (M64 >= 2 * 256 * SLOTS && !(tall && tall[0] == '0')) return bcos_tc_h2_256x32(&p, norm, s);
+            if (M64 >= 2 * 256 * SLOTS && !(tall && tall[0] == '0')) return dma ? bcos_tc_d_256x32(&p, norm, s) : bcos_tc_h2_256x32(&p, norm, s);
         }
-        return bcos_tc_h2_128x32(&p, norm, s);
+        return dma ? bcos_tc_d_128x32(&p, norm, s) : bcos_tc_h2_128x32(&p, norm, s);
     }
     if (g.Cout > 64) return bcos_tc_cfg_128x128(&p, norm, s);
     if (g.Cout > 32) return bcos_tc_cfg_128x64(&p, norm, s);

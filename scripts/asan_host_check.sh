@@ -10,7 +10,7 @@ SRC="$ROOT/b-cosification_amd/csrc"
 LIB="$OUT/libbcos_hip_asan.so"
 newest=$(ls -t "$SRC"/*.hip "$SRC"/*.h "$ROOT/include/bcos_hip.h" | head -1)
 if [ ! -f "$LIB" ] || [ "$newest" -nt "$LIB" ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address -fno-gpu-sanitize \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++20 -fPIC -shared -fsanitize=address -fno-gpu-sanitize \
      -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" "$SRC"/bcos_*.hip -o "$LIB"
 fi
 /opt/rocm/lib/llvm/bin/clang -O1 -g -fsanitize=address -fno-omit-frame-pointer -I"$ROOT/include" \

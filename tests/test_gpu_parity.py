@@ -1346,3 +1346,61 @@ def test_contraction_modes_parity(lib, golden_dir, mode):
     finally:
         blib.set_contraction_mode(prev)
         ops.F16X2_MIN_K = prev_min_k
+
+
+def test_dma_loop_bit_identical_to_register_loop(lib, golden_dir, monkeypatch):
+    """Round 3: the split-f16 contraction stages its operands through the LDS-DMA path (csrc/bcos_tapconv.hip: tile_body_d --
+    fp32 A straight into LDS, split on the fragment, ring of three slots).  It performs the same arithmetic as the register-
+    staged loop of round 2 (BCOS_H2_LOOP=regs: tile_body_h2) in the same order: every tensor a launch writes -- output, kept
+    scale, patch norms, per-pixel maxima -- is identical bit for bit.  Shapes cover every K walk (1x1, channel-chunk-major
+    3x3, 7x7 over 8 channels, ragged channel counts), every tile configuration (32 ... 256 columns, 128- and 256-row tiles,
+    half-height tail tiles, ragged rows / columns) and the gradient forms (stride-2 parity classes, depth to space), then
+    whole ResNet-18 / ResNet-50 passes."""
+    from bcos_hip import engine, ops, synth
+    g = torch.Generator().manual_seed(31)
+
+    def both(fn):
+        monkeypatch.delenv("BCOS_H2_LOOP", raising=False)
+        dma = fn()
+        monkeypatch.setenv("BCOS_H2_LOOP", "regs")
+        regs = fn()
+        monkeypatch.delenv("BCOS_H2_LOOP", raising=False)
+        return dma, regs
+
+    def same(a_list, b_list, what):
+        for i, (a, b) in enumerate(zip(a_list, b_list)):
+            if a is None:
+                assert b is None
+                continue
+            assert torch.isfinite(a).all() or a.dtype != torch.float32, (what, i)
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (what, i, rel(a.float(), b.float()))
+
+    cases = [(3, 13, 64, 200, 1, 1, 0), (2, 15, 32, 52, 3, 2, 1), (1, 9, 256, 24, 1, 1, 0), (2, 28, 128, 512, 1, 1, 0),
+             (5, 7, 512, 384, 3, 1, 1), (2, 14, 256, 256, 3, 1, 1), (6, 14, 1024, 256, 1, 1, 0), (2, 33, 8, 64, 7, 2, 3),
+             (40, 30, 64, 64, 3, 1, 1), (40, 30, 256, 64, 1, 1, 0), (3, 12, 20, 40, 3, 1, 1), (2, 20, 16, 128, 5, 1, 2),
+             (9, 28, 128, 128, 3, 1, 1), (1, 5, 2048, 1000, 1, 1, 0)]
+    for (N, H, Cin, Cout, k, st, pd) in cases:
+        x = ops.ensure_absmax(torch.randn(N, H, H, Cin, generator=g).to(DEV))
+        w = ops.mark_static((torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV))
+        Ho = ops.conv_out_size(H, k, st, pd)
+
+        def run():
+            y, sc, nrm = ops.conv2d_fwd(x, w, stride=(st, st), padding=(pd, pd), relu=True, want_scale=True, want_norm=True,
+                                        track_absmax=True)
+            return y, sc, nrm, ops.absmax_of(y)
+        same(*both(run), ("fwd", N, H, Cin, Cout, k, st))
+        plan = ops.DgradPlan(w.permute(0, 3, 1, 2).contiguous(), (st, st), (pd, pd))
+        gl = ops.ensure_absmax(torch.randn(N, Ho, Ho, Cout, generator=g).to(DEV))
+        mul = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+
+        def run_b():
+            out = plan.run(gl, H, H, mul=mul, track_absmax=True)
+            return out, ops.absmax_of(out)
+        same(*both(run_b), ("bwd", N, H, Cin, Cout, k, st))
+    for name in ("resnet18_e2e", "resnet50_small"):
+        net, meta, data = _golden_net(golden_dir, name)
+        x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+        eng = engine.attach(net)
+        dma, regs = both(lambda: eng.explain(x))
+        for key in ("logits", "dynamic_linear_weights", "contribution_map"):
+            assert torch.equal(dma[key], regs[key]), (name, key)
