@@ -134,7 +134,7 @@ class AbsmaxArena:
 
 _ARENA: Optional[AbsmaxArena] = None
 DEFAULT_TRACK_ABSMAX = True    # what tapconv(track_absmax=None) means while the f16x2 contraction is selected (see no_absmax)
-F16X2_MIN_K = int(os.environ.get("BCOS_F16X2_MIN_K", "256"))     # below this K a launch keeps the bf16x3 loop (no operand maxima needed); same-node A/B on ResNet-50: 512 -> 256 = -0.4 ms per step (the K = 256 layers at 14^2 spend a third of their SIMD cycles on the 6 bf16 products), 128 and 64: no further gain
+F16X2_MIN_K = int(os.environ.get("BCOS_F16X2_MIN_K", "64"))     # below this K a launch keeps the bf16x3 loop (no operand maxima needed); same-node A/B on ResNet-50: 512 -> 256 = -0.4 ms per step (the K = 256 layers at 14^2 spend a third of their SIMD cycles on the 6 bf16 products); with the LDS-DMA loop of round 3 the K = 64 / 128 layers gain too (256 -> 128: -0.33 ms, -> 64: -0.39 ms per step)
 
 
 class no_absmax:

@@ -1664,6 +1664,12 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
 #ifndef D_NSLOT
 #define D_NSLOT 3
 #endif
+#ifndef D_KO
+#define D_KO 0                    // development knock-outs (timing only, wrong results): 1 no DMA issue in the steady loop, 2 no split of the next A rows
+#endif
+#ifndef D_DEAL_DMA
+#define D_DEAL_DMA 0              // 1 = issue the DMA pieces one by one behind the step's matrix instructions instead of together behind the barrier
+#endif
 #ifndef D_SCHED
 #define D_SCHED 1                 // 1 = pin the issue order of a step's fragment reads / matrix / vector instructions (sched_group_barrier)
 #endif
@@ -1796,12 +1802,9 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     // (16 / C taps per step, every lane walks its own tap), 3 general
     const int walk = kmajor ? 0 : uniform ? 1 : small_c ? 2 : 3;
     // (calls come in increasing ks: the walk state advances with them)
-    auto issue_a = [&](auto walk_c, int ks, int slot_off) {
+    // walk_a: the source offsets of the wave's A pieces of the next step of the walk, handed to dma_a(j, voffset, soffset)
+    auto walk_a = [&](auto walk_c, int ks, auto dma_a) {
         constexpr int WALK = decltype(walk_c)::value;
-        char* sa = lds + slot_off + a_dst0;
-        auto dma_a = [&](int j, unsigned voff, int soff) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, BCOS_LDS_PTR(sa + j * 1024), 16, (int)voff, soff, 0, 0);
-        };
         if constexpr (WALK == 0) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) dma_a(j, s_tapoff[s_tap * BM + r0 + 16 * j] + chunk * 16u, s_cc * 16);
@@ -1852,19 +1855,25 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             }
         }
     };
+    auto piece_a = [&](int j, int slot_off, unsigned voff, int soff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, BCOS_LDS_PTR(lds + slot_off + a_dst0 + j * 1024), 16, (int)voff, soff, 0, 0);
+    };
+    auto issue_a = [&](auto walk_c, int ks, int slot_off) {
+        walk_a(walk_c, ks, [&](int j, unsigned voff, int soff) { piece_a(j, slot_off, voff, soff); });
+    };
     // B: wave w copies blocks w, w + NW, ... of the step (block = (32-column tile c, plane sp) = 1 KB, lane-linear)
-    auto issue_b = [&](int ks, int slot_off) {
-        char* sbb = lds + slot_off + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const int blk = wave + NW * j;
-            if (NBLK % NW == 0 || blk < NBLK) {
-                const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(sbb + blk * 1024), 16, lane * 16, soff, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(s_dummy), 16, (int)OOB, 0, 0, 0);   // keeps every wave's DMA count equal
-            }
+    auto piece_b = [&](int j, int ks, int slot_off) {
+        const int blk = wave + NW * j;
+        if (NBLK % NW == 0 || blk < NBLK) {
+            const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(lds + slot_off + A_BYTES + blk * 1024), 16, lane * 16, soff, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(s_dummy), 16, (int)OOB, 0, 0, 0);   // keeps every wave's DMA count equal
         }
+    };
+    auto issue_b = [&](int ks, int slot_off) {
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) piece_b(j, ks, slot_off);
     };
     constexpr int LA = A_LD, LB = B_LD;      // DMA instructions per wave and step: A pieces, then B blocks
 
@@ -1938,23 +1947,32 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     // instructions, whose shadow hides the vector work.  The issue order is pinned (sched_barrier between the chunks): left
     // to itself the scheduler sinks every fragment read to just before its first use and the whole split behind the last
     // matrix instruction.  Product order per accumulator as in tile_body_h2 (smallest terms first): l_a h_b, h_a l_b, h_a h_b.
-    auto mma_step = [&](int off, auto next_c, int off_nx) {
+    auto mma_step = [&](int off, auto next_c, int off_nx, auto npiece_c, auto piece) {
         constexpr bool NEXT = decltype(next_c)::value;
+        constexpr int NPIECE = decltype(npiece_c)::value;           // DMA pieces of later steps to issue behind this step's matrix instructions
         const char* bb = lds + off + b_frag;
         f32x4 x0[TM], x1[TM];
         f16x8 a1[TM], a0[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) { a0[i] = af[0][i]; a1[i] = af[1][i]; }
         constexpr int G = 3 * TM * TN;                              // matrix instructions of the step
-        constexpr int D = G >= 12 ? G / 4 : 1;                      // ... issued before the first slice (the A reads need ~2 of them to return)
-        constexpr int PER = (NSLICE + (G - D) - 1) / (G - D);        // slices dealt out behind each later one
-        auto deal = [&](auto m_c) {                                  // the slices that follow matrix instruction m
+        // "actions" dealt out behind the matrix instructions, one group per instruction from the second one on: first the DMA
+        // pieces (a piece issued right behind a matrix instruction hides ~half of its issue time in that instruction's shadow;
+        // issued at the top of the step, behind the barrier, all of it is exposed), then the slices of the split (the A
+        // reads have returned by then)
+        constexpr int NACT = NPIECE + ((NEXT && !(D_KO & 2)) ? NSLICE : 0);
+        constexpr int D0 = (NPIECE == 0 && G >= 12) ? G / 4 : (G > 1 ? 1 : 0);     // matrix instructions ahead of the first action (slices: the A reads need a few of them to return)
+        constexpr int PER = (NACT + (G - D0) - 1) / (G - D0);
+        auto act = [&](auto a_c) {
+            constexpr int a = decltype(a_c)::value;
+            if constexpr (a < NPIECE) piece(a_c);
+            else if constexpr (a < NACT) split_slice(std::integral_constant<int, (a < NACT ? a - NPIECE : 0)>{}, x0, x1);
+        };
+        auto deal = [&](auto m_c) {
             constexpr int m = decltype(m_c)::value;
-            if constexpr (NEXT && m >= D) {
-                constexpr int s0 = (m - D) * PER;
-                if constexpr (s0 < NSLICE) split_slice(std::integral_constant<int, s0>{}, x0, x1);
-                if constexpr (PER > 1 && s0 + 1 < NSLICE) split_slice(std::integral_constant<int, s0 + 1>{}, x0, x1);
-                static_assert(PER <= 2, "slices per matrix instruction");
+            if constexpr (m >= D0) {
+                constexpr int a0 = (m - D0) * PER;
+                [&]<int... As>(std::integer_sequence<int, As...>) { (act(std::integral_constant<int, a0 + As>{}), ...); }(std::make_integer_sequence<int, PER>{});
             }
         };
         constexpr bool ACC_MAJOR = H2_MFMA_ORDER == 1 || (H2_MFMA_ORDER == 0 && TM * TN >= 8);
@@ -2000,10 +2018,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             };
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (mm(std::integral_constant<int, Ms>{}), ...); }(std::make_integer_sequence<int, G>{});
         }
-        if constexpr (NEXT) {         // (whatever the deal above did not reach: none for the compiled tiles)
-            constexpr int done = (G - D) * PER;
-            static_assert(done >= NSLICE, "every slice is dealt out");
-        }
+        static_assert((G - D0) * PER >= NACT, "every action is dealt out");
     };
 
     // Ring: step s lives in slot s % D_NSLOT (A rows and B blocks).  The loops are peeled so that the steady state has no branch.
@@ -2034,9 +2049,26 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             auto step = [&](auto ia_c, auto ib_c, auto wait_c, auto next_c, int ks) {
                 wait_vmcnt<decltype(wait_c)::value>();
                 barrier();                         // every wave's B blocks of step ks have landed; the B slot of step ks + 2 (read in step ks - 1) is free
-                if constexpr (decltype(ia_c)::value) issue_a(walk_c, ks + 3, off);
-                if constexpr (decltype(ib_c)::value) issue_b(ks + 2, off_in);
-                mma_step(off, next_c, off_nx);
+                constexpr bool IA = decltype(ia_c)::value && !(D_KO & 1), IB = decltype(ib_c)::value && !(D_KO & 1);
+#if D_DEAL_DMA
+                // the DMA pieces dealt out one by one behind the step's matrix instructions.  Measured AGAINST issuing them
+                // together behind the barrier (same node, batch 256): 3x3 @14^2 190 vs 181 us, 3x3 @28^2 226 vs 211 us,
+                // 1024 -> 256 @14^2 93.5 vs 87.5 us -- a piece between two matrix instructions delays the second one by more than
+                // the piece's issue time saved at the top; not the default
+                unsigned va[A_LD];
+                int sa = 0;
+                if constexpr (IA) walk_a(walk_c, ks + 3, [&](int j, unsigned voff, int soff) { va[j] = voff; sa = soff; });
+                const int o_a = off, o_b = off_in;
+                mma_step(off, next_c, off_nx, std::integral_constant<int, (IA ? LA : 0) + (IB ? LB : 0)>{}, [&](auto q_c) {
+                    constexpr int q = decltype(q_c)::value;
+                    if constexpr (IA && q < LA) piece_a(q, o_a, va[q < LA ? q : 0], sa);
+                    else piece_b(q - (IA ? LA : 0), ks + 2, o_b);
+                });
+#else
+                if constexpr (IA) issue_a(walk_c, ks + 3, off);
+                if constexpr (IB) issue_b(ks + 2, off_in);
+                mma_step(off, next_c, off_nx, std::integral_constant<int, 0>{}, [](auto) {});
+#endif
                 off = off_nx; off_nx = off_in; off_in = rot(off_in);
             };
             using T = std::true_type; using F = std::false_type;
@@ -2058,7 +2090,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
                 f32x4 x0[TM], x1[TM];
                 read_a(off, x0, x1);
                 split_a(x0, x1);
-                mma_step(off, std::false_type{}, 0);
+                mma_step(off, std::false_type{}, 0, std::integral_constant<int, 0>{}, [](auto) {});
                 off = rot(off); off_in = rot(off_in);
             }
         }
@@ -2152,6 +2184,9 @@ void plan_tiles(KArgs& p) {
         const int64_t rem = total - full;
         if (rem > 0 && rem < (SLOTS * 9) / 10) m_big = (int)(full / p.tiles_n);
     }
+    // (Between half a round and one round -- 392 tiles on 512 slots: 136 CUs carry two tiles, 120 one -- keeping one full-height
+    // tile per CU and cutting the rest into half-height tiles was measured with the LDS-DMA loop too: 243 against 181 us at
+    // M = 50 176, N = 256, K = 2304; the 64-row bodies convert every A row twice and cannot run the split a step ahead.)
     p.rows_big = m_big * BM;
     if (p.rows_big > p.M) p.rows_big = p.M;
     p.n_big = m_big * p.tiles_n;
@@ -2240,6 +2275,10 @@ int launch_d(const KArgs& base, bool norm, hipStream_t stream) {
     size_t lds = (size_t)D_NSLOT * d_slot_bytes<BM, BN>() + (size_t)BM * 4 + 1024 + (kmajor ? (size_t)ntaps * BM * 4 : 0);    // (the half-height body needs less)
     const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
     if (lds_epi > lds) lds = lds_epi;
+    if (const char* one = getenv("BCOS_D_ONE_WG")) {      // development switch: LDS request that leaves room for `one` workgroups per CU only
+        const size_t want = (size_t)160 * 1024 / (atoi(one) > 0 ? atoi(one) : 1) - 512;
+        if (want > lds) lds = want;
+    }
     const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
     static std::atomic<size_t> lds_hw[2];
     auto launch = [&](auto k, int which) -> hipError_t {

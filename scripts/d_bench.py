@@ -24,8 +24,12 @@ for (H, Cin, Cout, k, st) in SHAPES:
     res = {}
     for rnd in range(3):
         for mode in ("dma", "regs"):
-            if mode == "regs": os.environ["BCOS_H2_LOOP"] = "regs"
+            if mode == "regs" and not os.environ.get("AB_ENV"): os.environ["BCOS_H2_LOOP"] = "regs"
             else: os.environ.pop("BCOS_H2_LOOP", None)
+            if os.environ.get("AB_ENV"):         # AB_ENV="NAME=value": the second arm sets that variable instead of the register loop
+                k_, v_ = os.environ["AB_ENV"].split("=")
+                if mode == "regs": os.environ[k_] = v_
+                else: os.environ.pop(k_, None)
             f(); f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
