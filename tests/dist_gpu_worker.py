@@ -47,6 +47,14 @@ def replicate(net, world):
     return bdist.replicate_parameters(net)
 
 
+def _oracle_pre_activations(sd, x_cpu):
+    from oracle import bcos_oracle as O
+    log = []
+    with torch.no_grad():
+        O.resnet_logits(sd, x_cpu, "resnet50", detach=True, gate_log=log)
+    return log
+
+
 def run_resnet50(rank, world, n_global):
     """BASELINE configs[4]: ResNet-50 explanation maps, global batch 1024 = 8 x 128, logits + maps gathered."""
     from oracle import bcos_oracle as O
@@ -77,11 +85,19 @@ def run_resnet50(rank, world, n_global):
                        rel_logits_vs_unsharded=rel(res["logits"], full["logits"]),
                        rel_maps_vs_unsharded=rel(res["contribution_map"], full["contribution_map"]))
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-        idx = [0, n_global // 2 + 3]                                        # one image of rank 0's shard, one of rank 4's
+        idx = [0, n_global // 2 + 3, n_global // 2 + 3 + n_global // world, n_global - 1]     # images of four different ranks' shards
         ref = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, "resnet50", detach=detach), x[idx].cpu())
         verdict.update(rel_logits_vs_oracle=rel(res["logits"][idx], ref["logits"]),
                        classes_equal_oracle=bool(torch.equal(res["prediction"][idx].cpu(), ref["prediction"])),
                        rel_maps_vs_oracle=rel(res["contribution_map"][idx], ref["contribution_map"]))
+        # the same images with the oracle's ReLU decisions replayed: W(x) and maps hold 1e-4; and a sub-batch
+        # reproduces its rows of the gathered maps bit for bit
+        gates = [(p > 0).float().permute(0, 2, 3, 1).contiguous().to(DEV) for p in _oracle_pre_activations(sd, x[idx].cpu())]
+        pinned = eng.explain(x[idx], gates=gates)
+        sub = eng.explain(x[idx[1]:idx[1] + 2], want_weights=False)
+        verdict.update(rel_weights_pinned_vs_oracle=rel(pinned["dynamic_linear_weights"], ref["dynamic_linear_weights"]),
+                       rel_maps_pinned_vs_oracle=rel(pinned["contribution_map"], ref["contribution_map"]),
+                       sub_batch_maps_equal=bool(torch.equal(sub["contribution_map"], res["contribution_map"][idx[1]:idx[1] + 2])))
     return verdict
 
 

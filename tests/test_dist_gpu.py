@@ -46,6 +46,8 @@ def test_config5_resnet50_global1024_sharded_over_8_ranks(tmp_path):
     assert v["sharded_equals_unsharded"], json.dumps(v)                       # same bits as one pass over all 1024 images
     assert v["rel_logits_vs_oracle"] <= 1e-4 and v["classes_equal_oracle"], v
     assert v["rel_maps_vs_oracle"] <= 3e-3, v                     # free ReLU gates: the ResNet-50 map floor (H1)
+    assert v["rel_weights_pinned_vs_oracle"] <= 1e-4 and v["rel_maps_pinned_vs_oracle"] <= 1e-4, v     # the oracle's gates replayed
+    assert v["sub_batch_maps_equal"], v
 
 
 @pytest.mark.gpu

@@ -155,6 +155,8 @@ CONV_GEOMS = [  # N, Cin, H, W, Cout, k, s, p   (the distinct R18/R50 geometry c
     (2, 64, 14, 14, 64, 3, 1, 1), (2, 128, 14, 14, 128, 3, 2, 1), (2, 256, 14, 14, 512, 1, 2, 0),
     (2, 8, 32, 32, 64, 7, 2, 3), (3, 512, 7, 7, 1000, 1, 1, 0), (1, 32, 5, 3, 36, 3, 1, 1),
     (1, 4, 1, 1, 4, 1, 1, 0), (5, 12, 9, 11, 20, 3, 2, 1), (2, 2048, 7, 7, 512, 1, 1, 0),
+    # ResNet-50's true geometries at N = 4: 64 -> 256 @56^2, 512 -> 2048 @7^2, 3x3 256 -> 256 @14^2, 3x3 / 2 128 -> 128 @56^2
+    (4, 64, 56, 56, 256, 1, 1, 0), (4, 512, 7, 7, 2048, 1, 1, 0), (4, 256, 14, 14, 256, 3, 1, 1), (4, 128, 56, 56, 128, 3, 2, 1),
 ]
 
 
@@ -502,12 +504,30 @@ def test_resnet50_batch256_properties(lib):
     assert torch.isfinite(out["dynamic_linear_weights"]).all()
     assert _completeness(x, out) <= 1e-4
     assert len(set(out["prediction"].tolist())) > 1          # non-degenerate synthetic task
+    # batch independence at the headline size, for everything the path returns: a sub-batch taken from the middle of the batch
+    # reproduces its rows of the full-batch result bit for bit -- logits, W(x) and maps
     sub = eng.explain(x[100:102])
     assert torch.equal(sub["logits"], out["logits"][100:102])
+    assert torch.equal(sub["dynamic_linear_weights"], out["dynamic_linear_weights"][100:102])
+    assert torch.equal(sub["contribution_map"], out["contribution_map"][100:102])
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     ref = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, "resnet50", detach=detach), x[100:102].cpu())
     assert rel(sub["logits"], ref["logits"]) <= 1e-4
     assert torch.equal(sub["prediction"].cpu(), ref["prediction"])
+    # W(x) and maps against the oracle at the headline size: four images from different positions of the batch (first tile,
+    # two interior positions that straddle tile boundaries of every layer, last image), gates pinned to the oracle's
+    # decisions (a free gate whose pre-activation is ~1e-13 opens differently under another summation order).
+    # The gates of the other 252 images are the path's own: images are independent, which the bit-equality above shows.
+    idx = [0, 77, 200, 255]
+    ref4 = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, "resnet50", detach=detach), x[idx].cpu())
+    own = eng.explain(x[idx], gates=_oracle_gates(net, x[idx], "resnet50"))
+    assert rel(own["logits"], ref4["logits"]) <= 1e-4 and torch.equal(own["prediction"].cpu(), ref4["prediction"])
+    assert rel(own["dynamic_linear_weights"], ref4["dynamic_linear_weights"]) <= 1e-4
+    assert rel(own["contribution_map"], ref4["contribution_map"]) <= 1e-4
+    assert rel(own["logits"], out["logits"][idx]) <= 1e-5                  # (replayed gates: a handful of numerically dead ReLUs may open differently)
+    # free gates, the same four images inside the batch-256 pass: bounded by the reference-vs-reference floor of ResNet-50
+    assert rel(out["dynamic_linear_weights"][idx], ref4["dynamic_linear_weights"]) <= 3e-3
+    assert rel(out["contribution_map"][idx], ref4["contribution_map"]) <= 3e-3
 
 
 # ------------------------------------------------------------------------------------------ transformer pieces
