@@ -197,11 +197,10 @@ class ResNetEngine:
             self.stem = [(_Conv(getattr(m, f"conv{i}"), getattr(m, f"bn{i}")), isinstance(getattr(m, f"relu{i}"), nn.ReLU))
                          for i in (1, 2, 3)]
             pool = m.avgpool
-            self.head_kind = "attnpool"
+            # pooled head, or the `attn_unpool` variant that projects every location and L2-normalises it (bcosattnpool.py:23-32)
+            self.head_kind = "attn_unpool" if getattr(m.attnpool, "attn_unpool", False) else "attnpool"
             self.head = None
             self.attnpool = m.attnpool
-            if getattr(m.attnpool, "attn_unpool", False):
-                raise BcosHipError("engine: attn_unpool heads run through the module path only")
         else:
             for attr in ("relu", "maxpool", "fc", "avgpool"):
                 if not hasattr(m, attr):
@@ -228,12 +227,37 @@ class ResNetEngine:
         self.logit_temperature = ll.logit_temperature if ll is not None else None
         self.supports_explain = True
         self._absmax_arena = ops.AbsmaxArena()      # per-pixel operand maxima of one pass (f16x2 contraction)
-        if self.head_kind == "attnpool":
+        if self.head_kind in ("attnpool", "attn_unpool"):
             self._refresh_attnpool()
+
+    def _attnpool_fingerprint(self):
+        ap = self.attnpool
+        projs = (ap.v_proj, ap.c_proj) if self.head_kind == "attn_unpool" else (ap.q_proj, ap.k_proj, ap.v_proj, ap.c_proj)
+        ts = [p.weight for p in projs] + [getattr(p, "bias", None) for p in projs] + [getattr(ap.c_proj, "b", None)]
+        return tuple((t.data_ptr(), t._version) if isinstance(t, torch.Tensor) else t for t in ts)
 
     def _refresh_attnpool(self):
         ap = self.attnpool
-        self._ap_fp = tuple((p.weight.data_ptr(), p.weight._version) for p in (ap.q_proj, ap.k_proj, ap.v_proj, ap.c_proj))
+        self._ap_fp = self._attnpool_fingerprint()
+        if self.head_kind == "attn_unpool":
+            # per location: v_proj (plain nn.Linear WITH its bias) -> c_proj (B-cosified by the converter: B-cos linear) -> L2
+            # normalisation with the norm held constant in explanation mode (bcosattnpool.py:23-32)
+            wv = ops.mark_static(ap.v_proj.weight.detach().clone().contiguous())
+            bv = ap.v_proj.bias
+            cp = ap.c_proj
+            if hasattr(cp, "_effective_weight_and_bias"):
+                wc, bc = cp._effective_weight_and_bias()
+                self.ap_cb = float(cp._b_value())
+            else:                                   # an un-converted (plain) c_proj: B = 1
+                wc, bc, self.ap_cb = cp.weight, cp.bias, 1.0
+            wc = ops.mark_static(wc.detach().clone().contiguous())
+            self.ap_w = dict(v=wv, c=wc)
+            self.ap_bias = dict(v=bv.detach().clone().contiguous() if bv is not None else None,
+                                c=bc.detach().clone().contiguous() if bc is not None else None)
+            C, D = wv.shape[1], wc.shape[0]
+            self.ap_cconv = ops.DgradPlan(wc.view(D, C, 1, 1), (1, 1), (0, 0), (1, 1))
+            self.ap_vconv = _HeadConv(ops.DgradPlan(wv.view(C, C, 1, 1), (1, 1), (0, 0), (1, 1)), C)
+            return
         # (c_proj may be a BcosifyLinear: .weight property); inference-constant copies: pre-split images, f16x2 contraction
         w = lambda lin: ops.mark_static(lin.weight.detach().clone().contiguous())   # noqa: E731
         self.ap_w = dict(q=w(ap.q_proj), k=w(ap.k_proj), v=w(ap.v_proj), c=w(ap.c_proj))
@@ -271,11 +295,8 @@ class ResNetEngine:
         for c in self._all_convs():
             if c.fingerprint() != c._fp:
                 c.refresh()
-        if self.head_kind == "attnpool":
-            ap = self.attnpool
-            fp = tuple((p.weight.data_ptr(), p.weight._version) for p in (ap.q_proj, ap.k_proj, ap.v_proj, ap.c_proj))
-            if fp != getattr(self, "_ap_fp", None):
-                self._refresh_attnpool()
+        if self.head_kind in ("attnpool", "attn_unpool") and self._attnpool_fingerprint() != getattr(self, "_ap_fp", None):
+            self._refresh_attnpool()
 
     def _consts(self, device):
         key = str(device)
@@ -354,8 +375,8 @@ class ResNetEngine:
                 rec.update(ts=ts, td=td, gated=bool(blk.relu), gate_t=gate_t, hws=hws, pre_pool_hw=pre_pool_hw)
                 st["blocks"].append(rec)
             cur = out
-        if self.head_kind == "attnpool":
-            emb = self._attnpool_forward(cur, st)
+        if self.head_kind in ("attnpool", "attn_unpool"):
+            emb = self._attnpool_forward(cur, st) if self.head_kind == "attnpool" else self._attn_unpool_forward(cur, st)
             if keep:
                 st["feat_hw"] = (cur.shape[1], cur.shape[2])
             return emb, st
@@ -388,7 +409,39 @@ class ResNetEngine:
             emb = emb + self.logit_bias
         return emb
 
-    def _attnpool_backward(self, st, cls, consume):
+    def _attn_unpool_forward(self, feat, st=None):
+        """BcosAttentionPool2d.forward, `attn_unpool` branch (bcosattnpool.py:23-32): every location of the feature map goes
+        through v_proj (plain, with bias) and the B-cos c_proj and is L2-normalised.  Returns [(HW), N, D'] like the
+        reference (batch is dim 1: a strided view of the [N, HW, D'] rows the kernels produce)."""
+        N, H, W, C = feat.shape
+        rows = N * H * W
+        D = self.ap_w["c"].shape[0]
+        v = torch.empty((rows, C), device=feat.device, dtype=torch.float32)
+        ops.tapconv(ops.ensure_absmax(feat.view(rows, C)), self.ap_w["v"], _linear_geom(rows, C, C), out=v, bias=self.ap_bias["v"])
+        y, t, _ = ops.linear_fwd(ops.ensure_absmax(v), self.ap_w["c"], bias=self.ap_bias["c"], b=self.ap_cb, want_scale=st is not None)
+        u, inv = ops.rows_normalize(y, want_y=True, want_inv=st is not None)
+        if st is not None:
+            st["ap_tc"], st["ap_inv"] = t, inv
+        if self.logit_temperature is not None or self.logit_bias is not None:
+            raise BcosHipError("engine: a LogitLayer behind an attn_unpool head is not supported")
+        return u.view(N, H * W, D).permute(1, 0, 2)
+
+    def _attn_unpool_backward(self, st, g_out, consume):
+        """Cotangent g_out [(HW), N, D'] of the un-pooled head output -> gradient w.r.t. v_proj's output at the HW positions
+        (explanation mode: the L2 norm and the B-cos scale of c_proj are constants, bcosattnpool.py:29-31)."""
+        t, inv = st["ap_tc"], st["ap_inv"]
+        if consume:
+            st["ap_tc"] = st["ap_inv"] = None
+        H, W = st["feat_hw"]
+        HW, N, D = g_out.shape
+        g_rows = g_out.permute(1, 0, 2).contiguous().view(N * HW, D)
+        zero = torch.zeros((N * HW,), device=g_rows.device, dtype=torch.float32)
+        g_y = ops.cosine_grad(g_rows, g_rows, zero, inv)                    # rows scaled by 1 / ||y||  (l = 0: inv * w)
+        g_lin = ops.mul(g_y, t) if t is not None else g_y                   # through the B-cos scale of c_proj
+        g_v = self.ap_cconv.run(ops.ensure_absmax(g_lin.view(N, H, W, D)), H, W)
+        return ops.ensure_absmax(g_v)
+
+    def _attnpool_backward(self, st, cls, consume, g_emb=None):
         """d emb[n, cls[n]] / d v_lin at the HW positions, with q and k detached (bcosattnpool.py:37-39): back through the
         plain c_proj, through the attention of the mean token (gradient w.r.t. v only), and the mean token's own v row
         spread over the positions it averages (tokens[0] = mean of the HW positions, :35).  The remaining step, through
@@ -400,8 +453,13 @@ class ResNetEngine:
         C = C3 // 3
         H, W = st["feat_hw"]
         D = self.ap_cT.shape[1]
-        g_emb = torch.zeros((N, D), device=qkv.device, dtype=torch.float32)
-        g_emb.scatter_(1, cls.view(-1, 1), 1.0 if self.logit_temperature is None else 1.0 / float(self.logit_temperature))
+        if g_emb is None:
+            g_emb = torch.zeros((N, D), device=qkv.device, dtype=torch.float32)
+            g_emb.scatter_(1, cls.view(-1, 1), 1.0 if self.logit_temperature is None else 1.0 / float(self.logit_temperature))
+        else:                    # an arbitrary cotangent of the embedding (e.g. the zero-shot cosine logit, clip_head.zeroshot_attribution)
+            g_emb = g_emb.to(device=qkv.device, dtype=torch.float32).contiguous()
+            if self.logit_temperature is not None:
+                g_emb = g_emb / float(self.logit_temperature)
         g_out = torch.zeros((N, T, C), device=qkv.device, dtype=torch.float32)
         g_out[:, 0] = ops.matmul_nt(g_emb, self.ap_cT)                    # g_emb @ W_c
         g_v = ops.attention_bwd_v(qkv, stats, g_out, self.ap_heads, (C // self.ap_heads) ** -0.5)
@@ -415,13 +473,28 @@ class ResNetEngine:
 
     @torch.no_grad()
     def explain(self, x: torch.Tensor, targets: Optional[torch.Tensor] = None, want_weights: bool = True,
-                gates=None) -> Dict[str, torch.Tensor]:
+                gates=None, cotangent=None) -> Dict[str, torch.Tensor]:
         """Forward in explanation mode + input-gradient pass of the explained logit of every image
         (batched bcos/common.py:163-181).  `targets` [N] int64 selects the logits (default: arg-max).
         `gates`: optional list of NHWC 0/1 tensors, one per ReLU in execution order, that REPLACE the v > 0
-        decisions (replay of gates recorded elsewhere; used by the gate-pinned parity test)."""
+        decisions (replay of gates recorded elsewhere; used by the gate-pinned parity test).
+        `cotangent` (attention-pool heads): a callable that receives the head output -- the embeddings [N, D], or [(HW), N, D']
+        for an `attn_unpool` head -- and returns d(scalar to explain) / d(head output) of the same shape; the input-gradient
+        pass then starts from it instead of from a one-hot coordinate (the zero-shot text logit of
+        interpretability/analyses/text_localisation.py:68-126: bcos_hip.clip_head.zeroshot_attribution)."""
         with ops.absmax_arena(self._absmax_arena, x.device):
             logits, st = self._run_forward(x, keep=True, gates=gates)
+            if cotangent is not None:
+                if self.head_kind not in ("attnpool", "attn_unpool"):
+                    raise BcosHipError("engine: `cotangent` needs an attention-pool head (CLIP image encoder)")
+                g_head = cotangent(logits)
+                if tuple(g_head.shape) != tuple(logits.shape):
+                    raise ValueError(f"cotangent: expected shape {tuple(logits.shape)}, got {tuple(g_head.shape)}")
+                wts, contrib = self._backward(x, st, None, want_weights, consume=True, g_head=g_head)
+                return dict(logits=logits, embedding=logits, dynamic_linear_weights=wts, contribution_map=contrib)
+            if self.head_kind == "attn_unpool":
+                raise BcosHipError("engine: an attn_unpool head has no class logits of its own: pass `cotangent` "
+                                   "(bcos_hip.clip_head.zeroshot_attribution builds it from the text embeddings)")
             pred, _ = ops.argmax_rows(logits)
             cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
             wts, contrib = self._backward(x, st, cls, want_weights, consume=True)
@@ -453,13 +526,15 @@ class ResNetEngine:
             out["dynamic_linear_weights"] = wall
         return out
 
-    def _backward(self, x, st, cls, want_weights: bool, consume: bool):
+    def _backward(self, x, st, cls, want_weights: bool, consume: bool, g_head=None):
         """Input-gradient pass of logit[cls[n]] for every image n over the state `st` of a kept forward; `consume` frees
         each saved multiplier as soon as it has been used (last / only pass over this state)."""
         # A "consumer" owns the g_lin tensors of the layers that read some activation X and can therefore
         # finish d logit / d X; its epilogue applies the multipliers of the block that PRODUCED X.
         if self.head_kind == "attnpool":
-            consumer = _Consumer(self.ap_vconv, self._attnpool_backward(st, cls, consume), None, None, 0)
+            consumer = _Consumer(self.ap_vconv, self._attnpool_backward(st, cls, consume, g_emb=g_head), None, None, 0)
+        elif self.head_kind == "attn_unpool":
+            consumer = _Consumer(self.ap_vconv, self._attn_unpool_backward(st, g_head, consume), None, None, 0)
         else:
             # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale
             g_head = ops.ensure_absmax(ops.head_onehot_grad(cls, st["tf"], self.logit_temperature))

@@ -27,7 +27,7 @@ BCOS_EPI_FORCE_POW = 2
 BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 TAPCONV_PARTS = 8
 
 
@@ -86,6 +86,8 @@ SIGNATURES = {
     "bcos_channel_axpby": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
+    "bcos_rows_normalize": (C.c_int, [_P, _P, _P, _L, _I, _P]),
+    "bcos_cosine_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_maxout_scale": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     "bcos_maxout_expand": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "bcos_prep_input": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -561,6 +561,26 @@ def weight_rownorm_scale(w2d, gain=None):
     return out
 
 
+def rows_normalize(x2d, want_y=True, want_inv=False):
+    """(x / ||x||_2 per row, 1 / ||x||_2 per row) of a [rows, C] tensor (include/bcos_hip.h: bcos_rows_normalize)."""
+    lib = _l.load()
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d) if want_y else None
+    inv = torch.empty((rows,), device=x2d.device, dtype=torch.float32) if want_inv else None
+    _l.check(lib.bcos_rows_normalize(_dev(x2d, "x"), _dev(y, "y"), _dev(inv, "inv"), rows, Cc, _stream()), "bcos_rows_normalize")
+    return y, inv
+
+
+def cosine_grad(u2d, w2d, l, inv, coef=None):
+    """coef * inv * (w - l u) per row: gradient of the cosine logit l = u . w w.r.t. the un-normalised feature (bcos_cosine_grad)."""
+    lib = _l.load()
+    rows, Cc = u2d.shape
+    out = torch.empty_like(u2d)
+    _l.check(lib.bcos_cosine_grad(_dev(u2d, "u"), _dev(w2d, "w"), _dev(l, "l"), _dev(inv, "inv"), _dev(coef, "coef"), _dev(out, "out"),
+                                  rows, Cc, _stream()), "bcos_cosine_grad")
+    return out
+
+
 def mul(a, b, out=None):
     lib = _l.load()
     if out is None:

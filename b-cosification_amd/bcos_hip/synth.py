@@ -246,8 +246,9 @@ def finish_clip_conversion(model: nn.Module, hip_pools: bool = True):
     return model
 
 
-def build_bcosified_clip_rn50(seed: int = 0):
+def build_bcosified_clip_rn50(seed: int = 0, attn_unpool: bool = False):
+    """`attn_unpool`: the head variant that keeps every location (model_config['attn_unpool'], bcosattnpool.py:61-77)."""
     from bcosify import BcosifyNetwork
-    cfg = clip_model_config()
+    cfg = dict(clip_model_config(), attn_unpool=True) if attn_unpool else clip_model_config()
     net = BcosifyNetwork(standard_clip_rn50(seed), cfg, add_channels=True, logit_layer=False)
     return finish_clip_conversion(net).eval()

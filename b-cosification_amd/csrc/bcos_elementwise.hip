@@ -350,6 +350,52 @@ extern "C" int bcos_weight_rownorm_scale(const float* w, const float* gain, floa
     return check_launch("weight_rownorm_kernel");
 }
 
+namespace {
+// y[r, :] = x[r, :] / ||x[r, :]||_2, inv[r] = 1 / ||x[r, :]||_2: one wavefront per row
+__global__ __launch_bounds__(TPB) void rows_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv,
+                                                             int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float* src = x + r * C;
+        float ss = 0.f;
+        for (int c = lane; c < C; c += 64) ss = fmaf(src[c], src[c], ss);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float nrm = sqrtf(ss);
+        if (y) for (int c = lane; c < C; c += 64) y[r * C + c] = src[c] / nrm;
+        if (inv && lane == 0) inv[r] = 1.0f / nrm;
+    }
+}
+
+// gradient of the cosine logit l = u . w (u = f / ||f||, given) w.r.t. f, times a per-row coefficient:
+// out[r, :] = coef[r] * inv[r] * (w[r, :] - l[r] * u[r, :])
+__global__ __launch_bounds__(TPB) void cosine_grad_kernel(const float* __restrict__ u, const float* __restrict__ w, const float* __restrict__ l,
+                                                          const float* __restrict__ inv, const float* __restrict__ coef,
+                                                          float* __restrict__ out, int64_t rows, int C) {
+    const int64_t n = rows * C, stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / C;
+        const float k = (coef ? coef[r] : 1.f) * inv[r];
+        out[i] = k * (w[i] - l[r] * u[i]);
+    }
+}
+}  // namespace
+
+extern "C" int bcos_rows_normalize(const float* x, float* y, float* inv_norm, int64_t rows, int C, void* stream) {
+    if (!x || (!y && !inv_norm) || rows <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_rows_normalize: bad argument");
+    hipLaunchKernelGGL(rows_normalize_kernel, dim3(grid_for(rows * 64)), dim3(TPB), 0, STREAM(stream), x, y, inv_norm, rows, C);
+    return check_launch("rows_normalize_kernel");
+}
+
+extern "C" int bcos_cosine_grad(const float* u, const float* w, const float* l, const float* inv_norm, const float* coef, float* out,
+                                int64_t rows, int C, void* stream) {
+    if (!u || !w || !l || !inv_norm || !out || rows <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_cosine_grad: bad argument");
+    hipLaunchKernelGGL(cosine_grad_kernel, dim3(grid_for(rows * C)), dim3(TPB), 0, STREAM(stream), u, w, l, inv_norm, coef, out, rows, C);
+    return check_launch("cosine_grad_kernel");
+}
+
 extern "C" int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {
     if (!a || !b || !out || n < 0) return bcos_set_error(BCOS_E_INVAL, "bcos_mul: bad argument");
     if (n == 0) return BCOS_OK;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 4
+#define BCOS_ABI_VERSION 5
 
 enum {
     BCOS_OK = 0,
@@ -306,6 +306,20 @@ int bcos_weight_rownorm_scale(const float* w, const float* gain, float* w_out,
 
 /* out[i] = a[i] * b[i] */
 int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* Row-wise L2 normalisation y[r,:] = x[r,:] / ||x[r,:]||_2 and / or its inverse norms inv_norm[r] (either may be NULL): the
+ * `attn_unpool` head of BcosAttentionPool2d (bcos/modules/bcosattnpool.py:23-32: x / x.norm(dim=-1), norm detached in
+ * explanation mode) and `outa / outa.norm(dim=-1)` of the zero-shot attribution
+ * (interpretability/analyses/text_localisation.py:76).  One wavefront per row.  (ABI v5) */
+int bcos_rows_normalize(const float* x, float* y, float* inv_norm, int64_t rows, int C, void* stream);
+
+/* Gradient of a cosine logit w.r.t. the un-normalised feature row f (text_localisation.py:76-78, 101:
+ * `img_features = outa / outa.norm(...)`, `logits = img_features @ zeroshot_weight`, `logits.max(1).values.backward`):
+ *   out[r,:] = coef[r] * inv_norm[r] * (w[r,:] - l[r] * u[r,:])
+ * with u = f / ||f|| (given), w[r,:] = the text embedding of the explained class of row r, l[r] = u[r,:] . w[r,:], coef[r] the
+ * (detached) pooling weight of the row (NULL = 1).  (ABI v5) */
+int bcos_cosine_grad(const float* u, const float* w, const float* l, const float* inv_norm, const float* coef, float* out,
+                     int64_t rows, int C, void* stream);
 
 /* Backward of the fused MaxOut: glin[r, c] = gy[r, c / M] * t[r, c] with t = the scale_out of a max_out launch
  * (gy [rows, Cout / M], t and glin [rows, Cout], Cout % 4 == 0): routes the gradient to the winning filter. */

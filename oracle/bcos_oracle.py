@@ -373,18 +373,30 @@ def bcos_attention_pool(sd, p, x, num_heads, detach=False):
 
 
 def clip_rn50_embed(sd, x6, b=2, detach=False, mean=CLIP_MEAN_ADDINVERSE, std=CLIP_STD_ADDINVERSE, num_heads=32,
-                    layers=CLIP_RN50_LAYERS, prefix="model."):
-    """bcosify.BcosifyNetwork.forward around ModifiedResNet.forward (CLIP/clip/model.py:139-154), B-cosified."""
+                    layers=CLIP_RN50_LAYERS, prefix="model.", attn_unpool=False, gate_log=None):
+    """bcosify.BcosifyNetwork.forward around ModifiedResNet.forward (CLIP/clip/model.py:139-154), B-cosified.
+    `attn_unpool`: the un-pooled head (returns (HW) x N x D').  `gate_log`, if given, receives the pre-activation of every
+    ReLU in execution order."""
+    def relu(t):
+        if gate_log is not None:
+            gate_log.append(t.detach())
+        return F.relu(t)
+
+    return _clip_rn50_embed(sd, x6, b, detach, mean, std, num_heads, layers, prefix, attn_unpool, relu)
+
+
+def _clip_rn50_embed(sd, x6, b, detach, mean, std, num_heads, layers, prefix, attn_unpool, relu):
+    F_relu = relu                  # (only the ReLU is observed; everything else is the reference's statement order)
     x = normalize6(x6, mean, std)
     for i, (stride, pad) in zip((1, 2, 3), ((2, 1), (1, 1), (1, 1))):
-        x = F.relu(_bnu(sd, f"{prefix}bn{i}", _bconv(sd, f"{prefix}conv{i}", x, stride, pad, b, detach)))
+        x = F_relu(_bnu(sd, f"{prefix}bn{i}", _bconv(sd, f"{prefix}conv{i}", x, stride, pad, b, detach)))
     x = F.avg_pool2d(x, 2)
     for li, nblocks in enumerate(layers, start=1):
         for bi in range(nblocks):
             p = f"{prefix}layer{li}.{bi}."
             stride = 2 if (li > 1 and bi == 0) else 1
-            out = F.relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, 1, 0, b, detach)))
-            out = F.relu(_bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, 1, 1, b, detach)))
+            out = F_relu(_bnu(sd, p + "bn1", _bconv(sd, p + "conv1", x, 1, 0, b, detach)))
+            out = F_relu(_bnu(sd, p + "bn2", _bconv(sd, p + "conv2", out, 1, 1, b, detach)))
             if stride > 1:
                 out = F.avg_pool2d(out, stride)
             out = _bnu(sd, p + "bn3", _bconv(sd, p + "conv3", out, 1, 0, b, detach))
@@ -392,7 +404,9 @@ def clip_rn50_embed(sd, x6, b=2, detach=False, mean=CLIP_MEAN_ADDINVERSE, std=CL
             if (p + "downsample.1.linear.weight") in sd:     # BcosSequential renumbers (AvgPool, conv, bn) -> 0, 1, 2
                 identity = F.avg_pool2d(x, stride) if stride > 1 else x
                 identity = _bnu(sd, p + "downsample.2", _bconv(sd, p + "downsample.1", identity, 1, 0, b, detach))
-            x = F.relu(out + identity)
+            x = F_relu(out + identity)
+    if attn_unpool:
+        return bcos_attention_unpool(sd, prefix + "attnpool.", x, b=b, detach=detach)
     return bcos_attention_pool(sd, prefix + "attnpool.", x, num_heads, detach)
 
 
@@ -416,6 +430,40 @@ def zeroshot_logits(features, text_weights, attn_unpool=False, cos_power=1):
         logits = logits * (logits.abs().detach() ** (cos_power - 1))
         logits = logits.sum(0)
     return logits
+
+
+def zeroshot_attribution(forward_fn, x6, zeroshot_weight, attn_unpool=False, pool_cosine=1, norm_max_cosine=False):
+    """compute_attributions of interpretability/analyses/text_localisation.py:68-104, tensor part, image by image:
+    forward in explanation mode, `img_features = outa / outa.norm(dim=-1)` (NOT detached), `logits = img_features @ W`,
+    the attn_unpool pooling variants (:80-99), `logits.max(1).values.backward(inputs=[img])`.
+    forward_fn(x, detach=True) -> head output.  Returns (gradients [N, 6, H, W], explained logit values [N])."""
+    grads, vals = [], []
+    for i in range(x6.shape[0]):
+        imga = x6[i:i + 1].detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            outa = forward_fn(imga, detach=True)
+            img_features = outa / outa.norm(dim=-1, keepdim=True)
+            logits = img_features @ zeroshot_weight
+            if attn_unpool:
+                logits = logits.reshape(-1, 1)
+                if pool_cosine == 0:
+                    num_features = logits.shape[0]
+                    logits = logits.reshape(-1, num_features)
+                    mask = torch.zeros_like(logits)
+                    mask[torch.arange(logits.shape[0]), logits.argmax(dim=1)] = 1.0
+                    logits = (logits * mask.detach()).reshape(1, num_features)
+                if norm_max_cosine:
+                    logits = logits / logits.abs().detach().max(dim=0, keepdim=True)[0]
+                if pool_cosine > 1:
+                    logits = logits * torch.pow(logits, pool_cosine - 1).abs().detach()
+                logits = logits.mean(dim=0)
+            if logits.dim() == 1:
+                logits = logits.unsqueeze(0)
+            val = logits.max(1).values
+            (g,) = torch.autograd.grad(val.sum(), imga)
+        grads.append(g.detach())
+        vals.append(val.detach().view(-1)[0])
+    return torch.cat(grads), torch.stack(vals)
 
 
 # ----------------------------------------------------------------------------------------------

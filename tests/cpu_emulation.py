@@ -243,6 +243,16 @@ def weight_rownorm_scale(w2d, gain=None):
     return out.view_as(w2d)
 
 
+def rows_normalize(x2d, want_y=True, want_inv=False):
+    nrm = x2d.norm(dim=1, keepdim=True)
+    return (x2d / nrm) if want_y else None, (1.0 / nrm.view(-1)) if want_inv else None
+
+
+def cosine_grad(u2d, w2d, l, inv, coef=None):
+    k = inv if coef is None else coef * inv
+    return k.view(-1, 1) * (w2d - l.view(-1, 1) * u2d)
+
+
 def contrib_map(x, gx):
     return (x * gx).sum(1)
 
@@ -425,7 +435,7 @@ def install(monkeypatch):
     from bcos_hip import ops
     for name in ("tapconv", "prep_input", "finalize_explanation", "avgpool2d_fwd", "avgpool2d_bwd",
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
-                 "weight_rownorm_scale", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
+                 "weight_rownorm_scale", "rows_normalize", "cosine_grad", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
                  "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand",

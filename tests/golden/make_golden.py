@@ -813,6 +813,99 @@ def clip_rn50_embeddings():
 
 
 # --------------------------------------------------------------------------------------------------------
+# Explanation of the zero-shot TEXT logit (interpretability/analyses/text_localisation.py:68-104), pooled and attn_unpool heads
+# --------------------------------------------------------------------------------------------------------
+def _reference_text_attribution(model, img, zeroshot_weight, pool_cosine=1, norm_max_cosine=False):
+    """The tensor statements of compute_attributions (text_localisation.py:73-104) on the reference's model classes."""
+    with torch.enable_grad(), model.explanation_mode():
+        imga = img[None].requires_grad_()
+        outa = model(imga)
+        img_features = outa / outa.norm(dim=-1, keepdim=True)
+        logits = img_features @ zeroshot_weight
+        if model.model.attnpool.attn_unpool:
+            logits = logits.reshape(-1, 1)
+            if pool_cosine == 0:
+                num_features = logits.shape[0]
+                logits = logits.reshape(-1, num_features)
+                max_locations = logits.argmax(dim=1)
+                mask = torch.zeros_like(logits)
+                for i in range(logits.shape[0]):
+                    mask[i, max_locations[i]] = 1.0
+                logits = logits * mask.detach()
+                logits = logits.reshape(1, num_features)
+            if norm_max_cosine:
+                logits = logits / logits.abs().detach().max(dim=0, keepdim=True)[0]
+            if pool_cosine > 1:
+                logits = logits * torch.pow(logits, pool_cosine - 1).abs().detach()
+            logits = logits.mean(dim=0)
+        if logits.dim() == 1:
+            logits = logits.unsqueeze(0)
+        val = logits.max(1).values
+        val.backward(inputs=[imga])
+        return imga.grad.detach()[0], val.detach().view(-1)[0], outa.detach()
+
+
+def clip_zeroshot_attribution():
+    import importlib
+    ref_clip = importlib.import_module("CLIP.clip.model")
+    cfg = synth.clip_model_config()
+    net = R.bcosify.BcosifyNetwork(synth.standard_clip_rn50(0, clip_module=ref_clip), cfg, add_channels=True, logit_layer=False)
+    synth.finish_clip_conversion(net, hip_pools=False)
+    net.eval()
+    x = synth.synthetic_images(4)
+    synth.calibrate(net, x)                          # the record of clip_rn50.npz (same seeds, same recipe)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    wt = torch.randn(1024, 16, generator=torch.Generator().manual_seed(99))
+    out = {}
+    grads, vals = [], []
+    for i in (0, 1):
+        g, v, _ = _reference_text_attribution(net, x[i].clone(), wt)
+        grads.append(g)
+        vals.append(v)
+    grads, vals = torch.stack(grads), torch.stack(vals)
+    og, ov = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd, xx, detach=detach), x[:2], wt)
+    REPORT["zeroshot_attr/oracle_pooled_grad"] = rel(og, grads)
+    REPORT["zeroshot_attr/oracle_pooled_value"] = rel(ov, vals)
+    with torch.backends.mkldnn.flags(enabled=False):
+        g2, _, _ = _reference_text_attribution(net, x[0].clone(), wt)
+    REPORT["zeroshot_attr/reference_self_pooled_grad"] = rel(g2, grads[0])
+    out.update(pooled_weights_0=grads[0].numpy(), pooled_maps=(x[:2] * grads).sum(1).numpy(), pooled_values=vals.numpy())
+    # the attn_unpool head on the same (calibrated) trunk
+    cfg_u = dict(cfg, attn_unpool=True)
+    net_u = R.bcosify.BcosifyNetwork(synth.standard_clip_rn50(0, clip_module=ref_clip), cfg_u, add_channels=True, logit_layer=False)
+    synth.finish_clip_conversion(net_u, hip_pools=False)
+    net_u.eval()
+    trunk = {k: v for k, v in sd.items() if ".attnpool." not in k}
+    missing = net_u.load_state_dict(trunk, strict=False)
+    assert all(".attnpool." in k for k in missing.missing_keys) and not missing.unexpected_keys, missing
+    sd_u = {k: v.detach().clone() for k, v in net_u.state_dict().items()}
+    w1 = wt[:, 3:4] / wt[:, 3:4].norm()             # ONE text embedding, unit norm (tokenize_text, :58-66)
+    variants = [(1, False), (2, False), (0, False), (2, True)]
+    for pc, nm in variants:
+        g, v, outa = _reference_text_attribution(net_u, x[0].clone(), w1, pool_cosine=pc, norm_max_cosine=nm)
+        og, ov = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd_u, xx, detach=detach, attn_unpool=True), x[:1], w1,
+                                        attn_unpool=True, pool_cosine=pc, norm_max_cosine=nm)
+        REPORT[f"zeroshot_attr/oracle_unpool_p{pc}_n{int(nm)}_grad"] = rel(og[0], g)
+        REPORT[f"zeroshot_attr/oracle_unpool_p{pc}_n{int(nm)}_value"] = rel(ov[0], v)
+        out[f"unpool_p{pc}_n{int(nm)}_map"] = (x[0] * g).sum(0).numpy()
+        out[f"unpool_p{pc}_n{int(nm)}_value"] = v.numpy()
+        # the reference against ITSELF with another convolution backend (oneDNN off): the floor free ReLU gates leave (SURVEY.md H1)
+        with torch.backends.mkldnn.flags(enabled=False):
+            g2, _, _ = _reference_text_attribution(net_u, x[0].clone(), w1, pool_cosine=pc, norm_max_cosine=nm)
+        REPORT[f"zeroshot_attr/reference_self_unpool_p{pc}_n{int(nm)}_map"] = rel((x[0] * g2).sum(0), (x[0] * g).sum(0))
+        REPORT[f"zeroshot_attr/reference_self_unpool_p{pc}_n{int(nm)}_grad"] = rel(g2, g)
+        if (pc, nm) == (2, False):
+            out["unpool_p2_n0_weights"] = g.numpy()
+            out["unpool_output_0"] = outa.numpy()            # (HW) x 1 x D'
+    np.savez_compressed(os.path.join(HERE, "clip_zeroshot_attr.npz"), **out)
+    with open(os.path.join(HERE, "clip_zeroshot_attr.json"), "w") as f_:
+        json.dump(dict(arch="clip_rn50", weight_seed=0, image_seed=123, n_images=4, text_seed=99, text_column_unpool=3,
+                       calibration="tests/golden/clip_rn50.npz (calib/*)", variants=[[pc, int(nm)] for pc, nm in variants],
+                       state_checksum=state_checksum(sd), state_checksum_unpool=state_checksum(sd_u),
+                       torch_version=torch.__version__), f_, indent=1)
+
+
+# --------------------------------------------------------------------------------------------------------
 # a13/a20 `attn_unpool` variant: per-location v_proj -> B-cos c_proj -> L2 normalise; head with cos_power
 # --------------------------------------------------------------------------------------------------------
 def attn_unpool_head():
@@ -922,7 +1015,7 @@ def localisation_grid():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "vitc", "vit_train", "clip", "unpool", "loc"]
+    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "vitc", "vit_train", "clip", "unpool", "zeroshot_attr", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -952,6 +1045,8 @@ if __name__ == "__main__":
         clip_rn50_embeddings()
     if "unpool" in which:
         attn_unpool_head()
+    if "zeroshot_attr" in which:
+        clip_zeroshot_attribution()
     if "loc" in which:
         localisation_grid()
     with open(rep_path, "w") as f:

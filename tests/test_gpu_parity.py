@@ -1424,3 +1424,80 @@ def test_dma_loop_bit_identical_to_register_loop(lib, golden_dir, monkeypatch):
         dma, regs = both(lambda: eng.explain(x))
         for key in ("logits", "dynamic_linear_weights", "contribution_map"):
             assert torch.equal(dma[key], regs[key]), (name, key)
+
+
+def test_clip_zeroshot_text_attribution_against_reference_golden(lib, golden_dir):
+    """Explanation of the zero-shot TEXT logit through the fused engine (bcos_hip.clip_head.zeroshot_attribution): the pooled
+    head and the attn_unpool head with its pooled-cosine variants (interpretability/analyses/text_localisation.py:68-104).
+    Fixture: attributions recorded with the reference's own statements (tests/golden/make_golden.py: clip_zeroshot_attribution).
+    Free ReLU gates: bounded by the reference-vs-reference floor of this 55-layer CNN -- the reference run twice on one host
+    (oneDNN on / off) disagrees with itself by 1.7e-3 (pooled) ... 4.2e-3 (un-pooled mean of 49 cosines whose gradients
+    largely cancel), recorded in oracle_vs_reference.json; the bound is max(2e-3, 3 x that floor).  With the oracle's gates
+    replayed W(x) and the maps hold 1e-4 against the oracle, which the CPU suite pins to the same fixture."""
+    floor = json.load(open(os.path.join(golden_dir, "oracle_vs_reference.json")))
+    free = lambda key: max(2e-3, 3.0 * floor[f"zeroshot_attr/reference_self_{key}"][0])      # noqa: E731
+    from bcos_hip import clip_head, engine, synth
+    meta = json.load(open(os.path.join(golden_dir, "clip_zeroshot_attr.json")))
+    data = np.load(os.path.join(golden_dir, "clip_zeroshot_attr.npz"))
+    calib = np.load(os.path.join(golden_dir, "clip_rn50.npz"))
+    cmeta = json.load(open(os.path.join(golden_dir, "clip_rn50.json")))
+    record = {k: torch.from_numpy(calib["calib/" + k]) for k in cmeta["calib_order"]}
+    x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+    wt = torch.randn(1024, 16, generator=torch.Generator().manual_seed(meta["text_seed"]))
+    w1 = (wt[:, 3:4] / wt[:, 3:4].norm()).to(DEV)
+    wt = wt.to(DEV)
+
+    def gates_of(sd, xs, unpool):
+        log = []
+        with torch.no_grad():
+            O.clip_rn50_embed(sd, xs.cpu(), detach=True, attn_unpool=unpool, gate_log=log)
+        return [(p > 0).float().permute(0, 2, 3, 1).contiguous().to(DEV) for p in log]
+
+    # ---- pooled head: max over 16 text classes ---------------------------------------------------------------------------
+    net = synth.build_bcosified_clip_rn50(seed=meta["weight_seed"])
+    synth.apply_calibration(net, record)
+    net = net.to(DEV)
+    eng = engine.attach(net)
+    out = clip_head.zeroshot_attribution(eng, x[:2], wt)
+    assert rel(out["logits"].max(1).values, data["pooled_values"]) <= 1e-4
+    assert rel(out["dynamic_linear_weights"][0], data["pooled_weights_0"]) <= free("pooled_grad")
+    assert rel(out["contribution_map"], data["pooled_maps"]) <= free("pooled_grad")
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    go, vo = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd, xx, detach=detach), x[:2].cpu(), wt.cpu())
+    pinned = clip_head.zeroshot_attribution(eng, x[:2], wt, gates=gates_of(sd, x[:2], False))
+    assert rel(pinned["dynamic_linear_weights"], go) <= 1e-4 and rel(pinned["contribution_map"], (x[:2].cpu() * go).sum(1)) <= 1e-4
+    assert torch.equal(pinned["explained_class_idx"].cpu(), out["explained_class_idx"].cpu())
+    # batch independence of the attribution, bit for bit
+    one = clip_head.zeroshot_attribution(eng, x[1:2], wt)
+    assert torch.equal(one["contribution_map"], out["contribution_map"][1:2])
+    del eng, net
+    # ---- attn_unpool head: one text embedding, the pooling variants of :80-99 -------------------------------------------------
+    net_u = synth.build_bcosified_clip_rn50(seed=meta["weight_seed"], attn_unpool=True)
+    synth.apply_calibration(net_u, record)
+    net_u = net_u.to(DEV)
+    eng_u = engine.attach(net_u)
+    assert eng_u.head_kind == "attn_unpool"
+    emb = eng_u.forward(x[:1])
+    assert emb.shape == (49, 1, 1024) and rel(emb, data["unpool_output_0"]) <= 1e-4
+    sd_u = {k: v.detach().cpu() for k, v in net_u.state_dict().items()}
+    gates_u = gates_of(sd_u, x[:1], True)
+    for pc, nm in meta["variants"]:
+        key = f"unpool_p{pc}_n{nm}"
+        ou = clip_head.zeroshot_attribution(eng_u, x[:1], w1, pool_cosine=pc, norm_max_cosine=bool(nm))
+        assert rel(ou["logits"].view(-1), data[key + "_value"].reshape(-1)) <= 1e-4, key
+        assert rel(ou["contribution_map"][0], data[key + "_map"]) <= free(key + "_map"), key
+        if key == "unpool_p2_n0":
+            assert rel(ou["dynamic_linear_weights"][0], data["unpool_p2_n0_weights"]) <= free(key + "_grad")
+        gr, _ = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd_u, xx, detach=detach, attn_unpool=True), x[:1].cpu(),
+                                       w1.cpu(), attn_unpool=True, pool_cosine=pc, norm_max_cosine=bool(nm))
+        pu = clip_head.zeroshot_attribution(eng_u, x[:1], w1, pool_cosine=pc, norm_max_cosine=bool(nm), gates=[g.clone() for g in gates_u])
+        # gates replayed.  The un-pooled attribution is ill-conditioned in fp32 on BOTH sides: the cosine gradient is orthogonal to
+        # the (twice normalised) location vector and the location gradients largely cancel in the pooled sum, so 1e-6 rounding
+        # shows up at the 1e-4 level -- with the EXACT fp32 MFMA contraction the path sits 0.7 ... 1.0e-4 from the fp32 CPU
+        # oracle (scripts/_zs_dbg.py: 6.9e-5 / 8.6e-5 / 1.0e-4 / 8.7e-5 for the four variants; default f16x2 contraction
+        # 7.4e-5 / 1.2e-4 / 1.4e-4 / 1.2e-4).  Bound 2e-4 here; the pooled head above holds 1e-4.
+        assert rel(pu["dynamic_linear_weights"], gr) <= 2e-4, (key, rel(pu["dynamic_linear_weights"], gr))
+    # the attn_unpool head of the nn.Module path gives the same output as the fused plan
+    engine.detach(net_u)
+    with torch.no_grad():
+        assert rel(net_u(x[:1]), emb) <= 1e-4

@@ -936,3 +936,66 @@ def test_absmax_arena_is_scoped_to_a_pass_and_stale_slices_are_refused():
     own = torch.zeros(4, dtype=torch.int32)
     ops._attach_absmax(t, own)
     assert ops.absmax_of(t) is own                                # per-tensor buffers never go stale this way
+
+
+def _clip_nets_from_golden(golden_dir, device="cpu"):
+    """The pooled and the attn_unpool CLIP RN50 encoders of tests/golden/clip_zeroshot_attr.npz: same seeded trunk, calibration
+    record of clip_rn50.npz; the un-pooled head keeps its seeded v_proj / c_proj."""
+    from bcos_hip import synth
+    meta = json.load(open(os.path.join(golden_dir, "clip_zeroshot_attr.json")))
+    calib = np.load(os.path.join(golden_dir, "clip_rn50.npz"))
+    cmeta = json.load(open(os.path.join(golden_dir, "clip_rn50.json")))
+    record = {k: torch.from_numpy(calib["calib/" + k]) for k in cmeta["calib_order"]}
+    nets = []
+    for unpool in (False, True):
+        net = synth.build_bcosified_clip_rn50(seed=meta["weight_seed"], attn_unpool=unpool)
+        synth.apply_calibration(net, record)
+        nets.append(net.to(device))
+    return nets[0], nets[1], meta, np.load(os.path.join(golden_dir, "clip_zeroshot_attr.npz"))
+
+
+def test_zeroshot_text_attribution_oracle_and_engine_plan(monkeypatch, golden_dir):
+    """Explanation of the zero-shot text logit (interpretability/analyses/text_localisation.py:68-104) through the pooled and
+    the attn_unpool head: (1) the oracle's restatement against the attributions recorded from the reference's own statements;
+    (2) the product's chain rule + fused plan (emulated kernels, 64 x 64 images) against the oracle, every pooling variant."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import clip_head, engine, synth
+    net, net_u, meta, data = _clip_nets_from_golden(golden_dir)
+    x = synth.synthetic_images(meta["n_images"], seed=meta["image_seed"])
+    wt = torch.randn(1024, 16, generator=torch.Generator().manual_seed(meta["text_seed"]))
+    w1 = wt[:, 3:4] / wt[:, 3:4].norm()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    sd_u = {k: v.detach() for k, v in net_u.state_dict().items()}
+    assert "model.attnpool.q_proj.weight" not in sd_u and "model.attnpool.c_proj.linear.weight" in sd_u
+    # (1) oracle pinned by the reference-recorded attributions (full size, image 0)
+    g, v = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd, xx, detach=detach), x[:1], wt)
+    assert rel(g[0], data["pooled_weights_0"]) <= 1e-5 and rel(v, data["pooled_values"][:1]) <= 1e-6
+    gu, vu = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd_u, xx, detach=detach, attn_unpool=True), x[:1], w1,
+                                    attn_unpool=True, pool_cosine=2)
+    assert rel(gu[0], data["unpool_p2_n0_weights"]) <= 1e-4 and rel(vu[0], data["unpool_p2_n0_value"]) <= 1e-5
+    # (2) product chain rule + plan on small images
+    xs = synth.synthetic_images(2, size=64, seed=5)
+    eng, eng_u = engine.ResNetEngine(net), engine.ResNetEngine(net_u)
+    assert eng_u.head_kind == "attn_unpool"
+    out = clip_head.zeroshot_attribution(eng, xs, wt)
+    go, vo = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd, xx, detach=detach), xs, wt)
+    assert rel(out["dynamic_linear_weights"], go) <= 1e-4 and rel(out["contribution_map"], (xs * go).sum(1)) <= 1e-4
+    assert rel(out["logits"].max(1).values, vo) <= 1e-4
+    tg = torch.tensor([5, 2])                       # an explicitly chosen text class
+    out_t = clip_head.zeroshot_attribution(eng, xs, wt, targets=tg)
+    assert torch.equal(out_t["explained_class_idx"], tg) and not torch.equal(out_t["contribution_map"], out["contribution_map"])
+    emb_u = eng_u.forward(xs)
+    assert emb_u.shape[1:] == (2, 1024) and rel(emb_u, O.clip_rn50_embed(sd_u, xs, attn_unpool=True)) <= 1e-4
+    for pc, nm in ((1, False), (2, False), (0, False), (2, True), (3, True)):
+        ou = clip_head.zeroshot_attribution(eng_u, xs, w1, pool_cosine=pc, norm_max_cosine=nm)
+        gr, vr = O.zeroshot_attribution(lambda xx, detach: O.clip_rn50_embed(sd_u, xx, detach=detach, attn_unpool=True), xs, w1,
+                                        attn_unpool=True, pool_cosine=pc, norm_max_cosine=nm)
+        assert rel(ou["dynamic_linear_weights"], gr) <= 1e-4, (pc, nm)
+        assert rel(ou["logits"].view(-1), vr) <= 1e-4, (pc, nm)
+    with pytest.raises(ValueError):
+        clip_head.zeroshot_attribution(eng_u, xs, wt)                     # an un-pooled head explains one text embedding
+    with pytest.raises(ValueError):
+        clip_head.zeroshot_attribution(eng_u, xs, w1, pool_cosine=0, norm_max_cosine=True)
+    from bcos_hip.lib import BcosHipError
+    with pytest.raises(BcosHipError):
+        eng_u.explain(xs)                                                  # no class logits of its own
