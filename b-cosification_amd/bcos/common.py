@@ -153,6 +153,34 @@ def gradient_to_image(image, linear_mapping, smooth=15, alpha_percentile=99.5, r
     per-pixel weight direction over the (r,g,b,1-r,1-g,1-b) channels, alpha = its L2 norm, zeroed where the
     contribution is negative, box-smoothed and clipped at the `alpha_percentile` quantile.
 
+    Rendered by the batched device kernel (bcos_hip.ops.render_explanations: per-pixel colour/alpha, LDS box filter, exact
+    quantile by radix select -- SURVEY.md section 8(f) N1).  There is no CPU formulation in this package: CPU tensors raise
+    (the torch restatement of the reference's statements is oracle.bcos_oracle.gradient_to_image, test infrastructure)."""
+    from bcos_hip import ops
+    from bcos_hip.lib import BcosHipError
+    if image.dim() != 3 or image.shape[0] != 6 or tuple(linear_mapping.shape) != tuple(image.shape):
+        raise ValueError(f"gradient_to_image: expected image and linear_mapping of shape [6, H, W], got {tuple(image.shape)} / "
+                         f"{tuple(linear_mapping.shape)}")
+    if smooth and smooth % 2 == 0:
+        raise BcosHipError("gradient_to_image: the device box filter needs an odd `smooth` (the reference's default is 15)")
+    rgba_t = ops.render_explanations(image.detach()[None].float().contiguous(), linear_mapping.detach()[None].float().contiguous(),
+                                     smooth=smooth, alpha_percentile=alpha_percentile)[0]
+    rgba = rgba_t.cpu().numpy()
+    if return_contribs:
+        return rgba, (image * linear_mapping).sum(0, keepdim=True).detach().cpu().numpy()
+    return rgba
+
+
+def plot_contribution_map(contribution_map, ax=None, vrange=None, vshift=0, hide_ticks=True, cmap="bwr",
+                              percentile=99.5):
+        return plot_contribution_map(contribution_map, ax, vrange, vshift, hide_ticks, cmap, percentile)
+
+
+def gradient_to_image(image, linear_mapping, smooth=15, alpha_percentile=99.5, return_contribs=False):
+    """RGBA rendering [H,W,4] of the dynamic linear mapping of one image (reference :387-436): colour = the
+    per-pixel weight direction over the (r,g,b,1-r,1-g,1-b) channels, alpha = its L2 norm, zeroed where the
+    contribution is negative, box-smoothed and clipped at the `alpha_percentile` quantile.
+
     Tensors on a HIP device are rendered by the batched device kernel (bcos_hip.ops.render_explanations: per-pixel
     colour/alpha, LDS box filter, exact quantile by radix select -- SURVEY.md section 8(f) N1); CPU tensors take the
     reference's torch formulation below."""

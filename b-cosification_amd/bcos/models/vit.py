@@ -42,20 +42,33 @@ class PatchRearrange(nn.Module):
 
 
 class PosEmbSinCos2d(nn.Module):
+    """Fixed 2-d sine / cosine position table of SimpleViT (reference bcos/models/vit.py:64-86): for patch (i, j) of an h x w
+    grid and frequencies w_k = T^(-k / (dim/4 - 1)), k < dim/4, the row [sin(j w), cos(j w), sin(i w), cos(i w)].
+    The table depends on (h, w, dim, T) only: it is built once per geometry / device and kept, so a forward pass launches
+    nothing for it (the reference rebuilds it -- meshgrid, pow, sin, cos, cat -- on every call)."""
+
     def __init__(self, temperature: Union[int, float] = 10_000):
         super().__init__()
         self.temperature = temperature
+        self._tables = {}
 
     def forward(self, patches: Tensor) -> Tensor:
-        h, w, dim = patches.shape[-3:]
-        device, dtype = patches.device, patches.dtype
-        y, x = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
-        assert (dim % 4) == 0, "feature dimension must be multiple of 4 for sincos emb"
-        omega = torch.arange(dim // 4, device=device) / (dim // 4 - 1)
-        omega = 1.0 / (self.temperature**omega)
-        y = y.flatten()[:, None] * omega[None, :]
-        x = x.flatten()[:, None] * omega[None, :]
-        return torch.cat((x.sin(), x.cos(), y.sin(), y.cos()), dim=1).type(dtype)
+        h, w, dim = (int(v) for v in patches.shape[-3:])
+        key = (h, w, dim, float(self.temperature), str(patches.device), patches.dtype)
+        table = self._tables.get(key)
+        if table is None:
+            if dim % 4:
+                raise AssertionError("feature dimension must be multiple of 4 for sincos emb")
+            quarter = dim // 4
+            freq = 1.0 / (self.temperature ** (torch.arange(quarter) / (quarter - 1)))      # w_k, evaluated as the reference does
+            col = torch.arange(w)[:, None] * freq[None, :]                              # [w, dim/4]: j w_k
+            row = torch.arange(h)[:, None] * freq[None, :]                              # [h, dim/4]: i w_k
+            table = torch.empty((h, w, 4, quarter), dtype=torch.float32)
+            table[:, :, 0], table[:, :, 1] = col.sin()[None], col.cos()[None]
+            table[:, :, 2], table[:, :, 3] = row.sin()[:, None], row.cos()[:, None]
+            table = table.reshape(h * w, dim).to(device=patches.device, dtype=patches.dtype)
+            self._tables[key] = table
+        return table
 
 
 class FeedForward(nn.Module):
