@@ -28,7 +28,7 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 ABI_VERSION = 5
-TAPCONV_PARTS = 8
+TAPCONV_PARTS = 9
 
 
 class BcosHipError(RuntimeError):
@@ -99,8 +99,8 @@ SIGNATURES = {
     "bcos_head_onehot_grad": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "bcos_argmax_rows": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "bcos_channel_affine": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
-    "bcos_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
-    "bcos_layernorm_bwd_detached": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "bcos_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "bcos_layernorm_bwd_detached": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_gelu_gate": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_groupnorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
@@ -109,8 +109,8 @@ SIGNATURES = {
     "bcos_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_groupnorm_bwd_detached": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "bcos_add_rows_bcast": (C.c_int, [_P, _P, _L, _L, _P]),
-    "bcos_attention_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "bcos_attention_bwd_v": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "bcos_attention_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "bcos_attention_bwd_v": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_finalize_explanation_patches": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "bcos_render_explanations": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "bcos_box_filter": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),

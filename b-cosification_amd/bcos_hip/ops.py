@@ -381,7 +381,7 @@ def linear_fwd(x2d, w, *, bias=None, b=2.0, want_scale=False, want_norm=False, m
     return out, scale, norm
 
 
-def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None):
+def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None, track_absmax=None):
     """Plain fp32 GEMM on the same kernel: out[rows,N] = a2d[rows,K] @ bt[N,K]^T (no B-cos scaling)."""
     rows, K = a2d.shape
     Nn = bt.shape[0]
@@ -389,7 +389,7 @@ def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None):
              TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Nn)
     if out is None:
         out = torch.empty((rows, Nn), device=a2d.device, dtype=torch.float32)
-    tapconv(a2d, bt, g, out=out, addend=addend, mul=mul)
+    tapconv(a2d, bt, g, out=out, addend=addend, mul=mul, track_absmax=track_absmax)
     return out
 
 
@@ -809,23 +809,30 @@ def channel_axpby(a, sa, b=None, mb=None, sb=None, out=None):
 
 
 # ---- transformer pieces (csrc/bcos_vit.hip) ----------------------------------------------------------------
-def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None):
+def _am_ptr(am):
+    return C.c_void_p(am.data_ptr()) if am is not None else None
+
+
+def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None, want_absmax=False):
+    """`want_absmax`: the kernel also emits the row maxima of y for the split-f16 contraction that reads it."""
     lib = _l.load()
     rows, D = x2d.shape
     y = out if out is not None else torch.empty_like(x2d)
     rstd = torch.empty((rows,), device=x2d.device, dtype=torch.float32) if want_rstd else None
-    _l.check(lib.bcos_layernorm_fwd(_dev(x2d, "x"), _dev(weight, "w"), _dev(bias, "b"), _dev(y, "y"), _dev(rstd, "rstd"), rows, D,
-                                    float(eps), _stream()), "bcos_layernorm_fwd")
+    am = _fused_absmax(y, want_absmax)
+    _l.check(lib.bcos_layernorm_fwd(_dev(x2d, "x"), _dev(weight, "w"), _dev(bias, "b"), _dev(y, "y"), _dev(rstd, "rstd"), _am_ptr(am),
+                                    rows, D, float(eps), _stream()), "bcos_layernorm_fwd")
     return y, rstd
 
 
-def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None):
+def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None, want_absmax2=False):
     lib = _l.load()
     rows, D = gy2d.shape
     o = (out if out is not None else torch.empty_like(gy2d)) if want_out else None
     o2 = torch.empty_like(gy2d) if want_out2 else None
+    am = _fused_absmax(o2, want_absmax2) if o2 is not None else None
     _l.check(lib.bcos_layernorm_bwd_detached(_dev(gy2d, "gy"), _dev(weight, "w"), _dev(rstd, "rstd"), _dev(addend, "addend"),
-                                             _dev(mul2, "mul2"), _dev(o, "out"), _dev(o2, "out2"), rows, D, _stream()),
+                                             _dev(mul2, "mul2"), _dev(o, "out"), _dev(o2, "out2"), _am_ptr(am), rows, D, _stream()),
              "bcos_layernorm_bwd_detached")
     return o, o2
 
@@ -904,25 +911,27 @@ def add_rows_bcast(x, pe):
     return x
 
 
-def attention_fwd(qkv, heads, scale, want_stats=False):
-    """qkv [B,T,3*H*64] -> out [B,T,H*64] (+ stats [B,H,T,2])."""
+def attention_fwd(qkv, heads, scale, want_stats=False, want_absmax=False):
+    """qkv [B,T,3*H*64] -> out [B,T,H*64] (+ stats [B,H,T,2]).  `want_absmax`: row maxima of out emitted by the kernel."""
     lib = _l.load()
     B, T, three_inner = qkv.shape
     inner = three_inner // 3
     out = torch.empty((B, T, inner), device=qkv.device, dtype=torch.float32)
     stats = torch.empty((B, heads, T, 2), device=qkv.device, dtype=torch.float32) if want_stats else None
-    _l.check(lib.bcos_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), _dev(stats, "stats"), B, T, heads, inner // heads,
+    am = _fused_absmax(out, want_absmax)           # zero-filled: the heads meet in an atomic max
+    _l.check(lib.bcos_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), _dev(stats, "stats"), _am_ptr(am), B, T, heads, inner // heads,
                                     float(scale), _stream()), "bcos_attention_fwd")
     return out, stats
 
 
-def attention_bwd_v(qkv, stats, gout, heads, scale):
+def attention_bwd_v(qkv, stats, gout, heads, scale, want_absmax=False):
     lib = _l.load()
     B, T, three_inner = qkv.shape
     inner = three_inner // 3
     gv = torch.empty((B, T, inner), device=qkv.device, dtype=torch.float32)
-    _l.check(lib.bcos_attention_bwd_v(_dev(qkv, "qkv"), _dev(stats, "stats"), _dev(gout, "gout"), _dev(gv, "gv"), B, T, heads,
-                                      inner // heads, float(scale), _stream()), "bcos_attention_bwd_v")
+    am = _fused_absmax(gv, want_absmax)
+    _l.check(lib.bcos_attention_bwd_v(_dev(qkv, "qkv"), _dev(stats, "stats"), _dev(gout, "gout"), _dev(gv, "gv"), _am_ptr(am), B, T,
+                                      heads, inner // heads, float(scale), _stream()), "bcos_attention_bwd_v")
     return gv
 
 

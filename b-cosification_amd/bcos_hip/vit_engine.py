@@ -43,7 +43,8 @@ class _Lin:
         self.bias = bias.detach().contiguous() if bias is not None else None
         self.cin, self.cout = w.shape[1], w.shape[0]
 
-    def fwd(self, x2d, *, addend=None, act=0, want_scale=False):
+    def fwd(self, x2d, *, addend=None, act=0, want_scale=False, track=False):
+        """`track`: emit the row maxima of y (its reader is another contraction)"""
         rows = x2d.shape[0]
         g = dict(N=1, H=1, W=rows, C=self.cin, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1, TH=1,
                  TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=self.cout)
@@ -51,11 +52,11 @@ class _Lin:
         t = torch.empty_like(y) if want_scale else None
         ops.tapconv(x2d, self.w, g, out=y, scale_out=t, bias=self.bias, addend=addend,
                     bcos_mode=BCOS_LINEAR_EPS if self.b != 1.0 else 0, b=self.b, relu=act,
-                    flags=BCOS_EPI_FORCE_POW if self.force_pow else 0)
+                    flags=BCOS_EPI_FORCE_POW if self.force_pow else 0, track_absmax=track and _F16X2)
         return y, t
 
-    def dgrad(self, glin, *, mul=None):
-        return ops.matmul_nt(glin, self.wt, mul=mul)
+    def dgrad(self, glin, *, mul=None, track=False):
+        return ops.matmul_nt(glin, self.wt, mul=mul, track_absmax=track and _F16X2)
 
 
 class _LN:
@@ -73,20 +74,36 @@ class _LN:
         self.eps = m.eps
 
     def fwd(self, x2d, keep):
-        return ops.layernorm_fwd(x2d, self.w, self.bias, self.eps, want_rstd=keep)
+        return ops.layernorm_fwd(x2d, self.w, self.bias, self.eps, want_rstd=keep, want_absmax=_F16X2)      # y feeds a contraction
 
     def bwd(self, gy, rstd, *, addend=None, mul2=None, want_out=True, want_out2=False):
-        return ops.layernorm_bwd_detached(gy, self.w, rstd, addend=addend, mul2=mul2, want_out=want_out, want_out2=want_out2)
+        return ops.layernorm_bwd_detached(gy, self.w, rstd, addend=addend, mul2=mul2, want_out=want_out, want_out2=want_out2,
+                                          want_absmax2=_F16X2 and want_out2)                                # out2 = g_lin feeds one
 
 
 import contextlib
 import os
 
 
+_F16X2 = os.environ.get("BCOS_VIT_F16X2", "1") != "0"
+
+
 def _absmax_policy():
-    """K = 192 / 768 contractions: the bf16x3 loop (no operand maxima to produce) is the faster one here; BCOS_VIT_ABSMAX=1
-    lets every launch emit maxima so that the K >= 256 readers take the f16x2 loop (development switch)."""
-    return contextlib.nullcontext() if os.environ.get("BCOS_VIT_ABSMAX") else ops.no_absmax()
+    """Round 3: every contraction of the plan runs the split-f16 loop with LDS-DMA staging (3 matrix products instead of the 6
+    of the bf16 split).  Its A operands need per-row maxima: GEMM epilogues emit them, LayerNorm / attention outputs get
+    them from one extra pass (`_mx`).  BCOS_VIT_F16X2=0 restores the round-2 plan (no maxima, bf16x3 everywhere)."""
+    return contextlib.nullcontext() if _F16X2 else ops.no_absmax()
+
+
+def _mx(t, src=None):
+    """operand maxima of a tensor a kernel other than a contraction produced: taken over from `src` (the tensor the kernel
+    emitted them for, of which `t` is a reshaped view) or computed in one extra pass"""
+    if not _F16X2:
+        return t
+    am = ops.absmax_of(src) if src is not None else None
+    if am is not None and ops.absmax_of(t) is None:
+        ops._attach_absmax(t, am)
+    return ops.ensure_absmax(t)
 
 
 class ViTEngine:
@@ -126,6 +143,7 @@ class ViTEngine:
         ll = net.logit_layer
         self.logit_bias = ll.logit_bias if ll is not None else None
         self.logit_temperature = ll.logit_temperature if ll is not None else None
+        self._absmax_arena = ops.AbsmaxArena()      # row maxima of one pass: one zero fill instead of one per tensor
         self.refresh()
 
     def _fingerprint(self):
@@ -194,30 +212,30 @@ class ViTEngine:
         T = gh * gw
         mean, std = self._consts(x.device)
         add_inverse = x.shape[1] == 3
-        xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse)
+        xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse, want_absmax=_F16X2)     # K = 2048 patch embedding
         # patch embedding = 16x16 / stride 16 B-cos conv with the linear layer's epsilon placement
         geom = ops.fwd_geom(N, H, W, 8, self.dim, p, p, p, p, 0, 0)
         tok = torch.empty((N * T, self.dim), device=x.device, dtype=torch.float32)
         t_embed = torch.empty_like(tok) if keep else None
         ops.tapconv(xn, self.embed_w, geom, out=tok, scale_out=t_embed, bias=self.embed_bias,
-                    bcos_mode=BCOS_LINEAR_EPS if self.embed_b != 1.0 else 0, b=self.embed_b)
+                    bcos_mode=BCOS_LINEAR_EPS if self.embed_b != 1.0 else 0, b=self.embed_b, track_absmax=False)
         ops.add_rows_bcast(tok, self._posemb(gh, gw, x.device))
         st = dict(x=x, add_inverse=add_inverse, N=N, T=T, t_embed=t_embed, blocks=[]) if keep else None
         cur = tok
         for blk in self.blocks:
             h, rstd1 = blk["ln1"].fwd(cur, keep)
-            qkv = ops.matmul_nt(h, blk["wqkv"])
-            a, stats = ops.attention_fwd(qkv.view(N, T, -1), blk["heads"], blk["scale"], want_stats=keep)
-            x1, t_out = blk["out"].fwd(a.view(N * T, -1), addend=cur, want_scale=keep)
+            qkv = ops.matmul_nt(_mx(h), blk["wqkv"], track_absmax=False)
+            a, stats = ops.attention_fwd(qkv.view(N, T, -1), blk["heads"], blk["scale"], want_stats=keep, want_absmax=_F16X2)
+            x1, t_out = blk["out"].fwd(_mx(a.view(N * T, -1), a), addend=cur, want_scale=keep)
             h2, rstd2 = blk["ln2"].fwd(x1, keep)
-            z, t1 = blk["l1"].fwd(h2, act=blk["act"], want_scale=keep)
+            z, t1 = blk["l1"].fwd(_mx(h2), act=blk["act"], want_scale=keep, track=True)          # z feeds linear2
             x2, t2 = blk["l2"].fwd(z, addend=x1, want_scale=keep)
             if keep:
                 st["blocks"].append(dict(rstd1=rstd1, qkv=qkv, stats=stats, t_out=t_out, rstd2=rstd2, t1=t1, t2=t2))
             cur = x2
         if self.gap_reorder:
             hN, rstd_h = self.head_ln.fwd(cur, keep)
-            f, t_head = self.head.fwd(hN, want_scale=keep)
+            f, t_head = self.head.fwd(_mx(hN), want_scale=keep)
             logits = ops.global_avgpool_logits(f.view(N, T, 1, -1), self.logit_temperature, self.logit_bias)
         else:
             pooled = ops.global_avgpool_logits(cur.view(N, T, 1, -1), None, None)
@@ -234,12 +252,12 @@ class ViTEngine:
 
     @torch.no_grad()
     def forward(self, x):
-        with _absmax_policy():
+        with _absmax_policy(), ops.absmax_arena(self._absmax_arena, x.device):
             return self._run_forward(x, keep=False)[0]
 
     @torch.no_grad()
     def explain(self, x, targets: Optional[torch.Tensor] = None, want_weights: bool = True) -> Dict[str, torch.Tensor]:
-        with _absmax_policy():
+        with _absmax_policy(), ops.absmax_arena(self._absmax_arena, x.device):
             return self._explain(x, targets, want_weights)
 
     def _explain(self, x, targets, want_weights):
@@ -251,7 +269,7 @@ class ViTEngine:
         t_last = st["blocks"][-1]["t2"] if nb else st["t_embed"]
         if self.gap_reorder:
             g_head = ops.head_onehot_grad(cls, st["t_head"].view(N, T, 1, -1), self.logit_temperature)     # [N,T,1,K]
-            g_hN = self.head.dgrad(g_head.view(N * T, -1))
+            g_hN = self.head.dgrad(_mx(g_head.view(N * T, -1)))
             g_x, g_lin = self.head_ln.bwd(g_hN, st["rstd_h"], mul2=t_last, want_out=True, want_out2=True)
         else:
             g_head = ops.head_onehot_grad(cls, st["t_head"].view(N, 1, 1, -1), self.logit_temperature)     # [N,1,1,K]
@@ -262,16 +280,17 @@ class ViTEngine:
         # invariant at the top of each block iteration: g_x = d logit / d (block output), g_lin = g_x * t2 of the block
         for bi in range(nb - 1, -1, -1):
             blk, rec = self.blocks[bi], st["blocks"][bi]
-            g_z = blk["l2"].dgrad(g_lin, mul=rec["t1"])                         # = g_lin of linear1 (GELU gate inside t1)
+            g_z = blk["l2"].dgrad(_mx(g_lin), mul=rec["t1"], track=True)        # = g_lin of linear1 (GELU gate inside t1)
             g_h2 = blk["l1"].dgrad(g_z)
             g_x1, g_lin_out = blk["ln2"].bwd(g_h2, rec["rstd2"], addend=g_x, mul2=rec["t_out"], want_out2=True)
-            g_a = blk["out"].dgrad(g_lin_out)
-            g_v = ops.attention_bwd_v(rec["qkv"].view(N, T, -1), rec["stats"], g_a.view(N, T, -1), blk["heads"], blk["scale"])
-            g_h = ops.matmul_nt(g_v.view(N * T, -1), blk["wv_t"])
+            g_a = blk["out"].dgrad(_mx(g_lin_out))
+            g_v = ops.attention_bwd_v(rec["qkv"].view(N, T, -1), rec["stats"], g_a.view(N, T, -1), blk["heads"], blk["scale"],
+                                      want_absmax=_F16X2)
+            g_h = ops.matmul_nt(_mx(g_v.view(N * T, -1), g_v), blk["wv_t"], track_absmax=False)
             t_prev = st["blocks"][bi - 1]["t2"] if bi > 0 else st["t_embed"]
             g_x, g_lin = blk["ln1"].bwd(g_h, rec["rstd1"], addend=g_x1, mul2=t_prev, want_out=bi > 0, want_out2=True)
             st["blocks"][bi] = None
-        gp = ops.matmul_nt(g_lin, self.embed_wt)                                # [N*T, p*p*8] patch-major input gradient
+        gp = ops.matmul_nt(_mx(g_lin), self.embed_wt, track_absmax=False)      # [N*T, p*p*8] patch-major input gradient
         _, std = self._consts(x.device)
         wts, contrib = ops.finalize_explanation_patches(gp, st["x"], std, self.patch, add_inverse=st["add_inverse"],
                                                         want_weights=want_weights, want_contrib=True)

@@ -100,7 +100,7 @@ template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;                                                                    \
     constexpr int TM = WM / 32, TN = WN / 32;                                                                              \
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;                \
-    constexpr int PN = BN > 128 ? BN / 128 : 1;                                                                            \
+    constexpr int PN = BN == 192 ? 3 : (BN > 128 ? BN / 128 : 1);                                                          \
     constexpr int SBM = BM / PM, SBN = BN / PN;                                                                            \
     constexpr int HM = WM / PM, HN = WN / PN;                                                                              \
     constexpr int TMP = TM / PM, TNP = TN / PN;                                                                            \
@@ -2197,7 +2197,7 @@ void plan_tiles(KArgs& p) {
 template <int BM, int BN, int WAVES_M>
 constexpr size_t epilogue_lds() {
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
-    constexpr int SBM = BM / PM, SBN = BN > 128 ? 128 : BN;
+    constexpr int SBM = BM / PM, SBN = BN == 192 ? 64 : (BN > 128 ? 128 : BN);
     return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20;
 }
 
@@ -2316,6 +2316,7 @@ BCOS_TC_LAUNCHER(bcos_tc_h2_256x64);
 BCOS_TC_LAUNCHER(bcos_tc_h2_256x32);
 BCOS_TC_LAUNCHER(bcos_tc_d_128x256);
 BCOS_TC_LAUNCHER(bcos_tc_d_128x128);
+BCOS_TC_LAUNCHER(bcos_tc_d_128x192);
 BCOS_TC_LAUNCHER(bcos_tc_d_128x64);
 BCOS_TC_LAUNCHER(bcos_tc_d_128x32);
 BCOS_TC_LAUNCHER(bcos_tc_d_256x64);
@@ -2342,6 +2343,9 @@ BCOS_TC_DEFINE(bcos_tc_d_128x256, (launch_d<128, 256, 4, 1>))
 #if BCOS_TC_IN(6)
 BCOS_TC_DEFINE(bcos_tc_d_128x128, (launch_d<128, 128, 4, 1>))
 BCOS_TC_DEFINE(bcos_tc_d_128x64, (launch_d<128, 64, 4, 1>))
+#endif
+#if BCOS_TC_IN(8)
+BCOS_TC_DEFINE(bcos_tc_d_128x192, (launch_d<128, 192, 4, 1>))
 #endif
 #if BCOS_TC_IN(7)
 BCOS_TC_DEFINE(bcos_tc_d_256x64, (launch_d<256, 64, 4, 1>))
@@ -2751,6 +2755,9 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             const int64_t c1 = (t1 + SLOTS - 1) / SLOTS, c2 = 2 * ((t2 + SLOTS - 1) / SLOTS);
             bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && p.Ktot >= 1024));
             if (force) wide = g.Cout > 128 && force[4] == '2';
+            // 129 ... 192 columns (the 192-wide linears of the SimpleViTs: to_out, linear2, their gradients): ONE tile of 192 columns
+            // (six accumulator tiles per wave) instead of 128 + a half-empty second 128
+            if (dma && g.Cout > 128 && g.Cout <= 192 && !force) return bcos_tc_d_128x192(&p, norm, s);
             if (wide) return dma ? bcos_tc_d_128x256(&p, norm, s) : bcos_tc_h2_128x256(&p, norm, s);
             return dma ? bcos_tc_d_128x128(&p, norm, s) : bcos_tc_h2_128x128(&p, norm, s);
         }

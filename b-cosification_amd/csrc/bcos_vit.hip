@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <initializer_list>
+#include <atomic>
 #include "bcos_hip.h"
 #include "bcos_internal.h"
 
@@ -30,57 +32,133 @@ __device__ inline float wave_sum(float v) {
 }
 
 // ---- LayerNorm over the last dimension, one wavefront per row -----------------------------------------------
+__device__ inline unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ inline unsigned abs_bits4(const f32x4 v) {
+    return max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
+               max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
+}
+
+// Rows of up to 256 floats (D % 4 == 0): the row lives in ONE float4 per lane -- read once, two wavefront reductions, written
+// once, 16-byte accesses -- and the row's max |y| (what the split-f16 contraction reading y scales its operand by) falls out
+// of the registers.  Other widths take the strided loop.
+template <bool VEC>
 __global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y,
-                                                            float* __restrict__ rstd_out, int64_t rows, int D,
-                                                            float eps) {
+                                                            float* __restrict__ rstd_out, unsigned* __restrict__ absmax_out,
+                                                            int64_t rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
-    for (int64_t r = wave; r < rows; r += nwaves) {
-        const float* src = x + r * D;
-        float s = 0.f;
-        for (int c = lane; c < D; c += 64) s += src[c];
-        const float mean = wave_sum(s) / (float)D;
-        float v = 0.f;
-        for (int c = lane; c < D; c += 64) { const float d = src[c] - mean; v = fmaf(d, d, v); }
-        const float var = wave_sum(v) / (float)D;
-        const float sd = sqrtf(var + eps);
-        float* dst = y + r * D;
-        for (int c = lane; c < D; c += 64) {
-            float o = (src[c] - mean) / sd;
-            if (w) o *= w[c];
-            if (b) o += b[c];
-            dst[c] = o;
+    if constexpr (VEC) {
+        const bool on = lane * 4 < D;
+        f32x4 wv = {1.f, 1.f, 1.f, 1.f}, bv = {0.f, 0.f, 0.f, 0.f};
+        if (on && w) wv = *reinterpret_cast<const f32x4*>(w + lane * 4);
+        if (on && b) bv = *reinterpret_cast<const f32x4*>(b + lane * 4);
+        for (int64_t r = wave; r < rows; r += nwaves) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (on) v = *reinterpret_cast<const f32x4*>(x + r * D + lane * 4);
+            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)D;
+            f32x4 d = v - mean;
+            if (!on) d = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float var = wave_sum(fmaf(d[0], d[0], d[1] * d[1]) + fmaf(d[2], d[2], d[3] * d[3])) / (float)D;
+            const float sd = sqrtf(var + eps);
+            f32x4 o = {d[0] / sd, d[1] / sd, d[2] / sd, d[3] / sd};
+            o = o * wv + bv;
+            if (on) *reinterpret_cast<f32x4*>(y + r * D + lane * 4) = o;
+            if (rstd_out && lane == 0) rstd_out[r] = 1.0f / sd;
+            if (absmax_out) {
+                const unsigned m = wave_max_u32(on ? abs_bits4(o) : 0u);
+                if (lane == 0) absmax_out[r] = m;
+            }
         }
-        if (rstd_out && lane == 0) rstd_out[r] = 1.0f / sd;
+    } else {
+        for (int64_t r = wave; r < rows; r += nwaves) {
+            const float* src = x + r * D;
+            float s = 0.f;
+            for (int c = lane; c < D; c += 64) s += src[c];
+            const float mean = wave_sum(s) / (float)D;
+            float v = 0.f;
+            for (int c = lane; c < D; c += 64) { const float d = src[c] - mean; v = fmaf(d, d, v); }
+            const float var = wave_sum(v) / (float)D;
+            const float sd = sqrtf(var + eps);
+            float* dst = y + r * D;
+            unsigned m = 0u;
+            for (int c = lane; c < D; c += 64) {
+                float o = (src[c] - mean) / sd;
+                if (w) o *= w[c];
+                if (b) o += b[c];
+                dst[c] = o;
+                m = max(m, __float_as_uint(o) & 0x7fffffffu);
+            }
+            if (rstd_out && lane == 0) rstd_out[r] = 1.0f / sd;
+            if (absmax_out) {
+                m = wave_max_u32(m);
+                if (lane == 0) absmax_out[r] = m;
+            }
+        }
     }
 }
 
 // explanation mode: the variance is a constant, the mean is not (centered_norms.py:204-215):
 //   y = w * (x - mean(x)) / std   =>   gx = h - mean(h),  h = gy * w / std
 // out = gx (+ addend); out2 = out * mul2 (the scale of the B-cos layer that produced x), both optional extras.
+template <bool VEC>
 __global__ __launch_bounds__(TPB) void layernorm_bwd_detached_kernel(const float* __restrict__ gy,
                                                                      const float* __restrict__ w,
                                                                      const float* __restrict__ rstd,
                                                                      const float* __restrict__ addend,
                                                                      const float* __restrict__ mul2,
                                                                      float* __restrict__ out, float* __restrict__ out2,
-                                                                     int64_t rows, int D) {
+                                                                     unsigned* __restrict__ absmax2_out, int64_t rows, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
-    for (int64_t r = wave; r < rows; r += nwaves) {
-        const float* g = gy + r * D;
-        const float rs = rstd[r];
-        float s = 0.f;
-        for (int c = lane; c < D; c += 64) s += g[c] * (w ? w[c] : 1.f) * rs;
-        const float mh = wave_sum(s) / (float)D;
-        for (int c = lane; c < D; c += 64) {
-            float o = g[c] * (w ? w[c] : 1.f) * rs - mh;
-            if (addend) o += addend[r * D + c];
-            if (out) out[r * D + c] = o;
-            if (out2) out2[r * D + c] = mul2 ? o * mul2[r * D + c] : o;
+    if constexpr (VEC) {
+        const bool on = lane * 4 < D;
+        f32x4 wv = {1.f, 1.f, 1.f, 1.f};
+        if (on && w) wv = *reinterpret_cast<const f32x4*>(w + lane * 4);
+        for (int64_t r = wave; r < rows; r += nwaves) {
+            const int64_t off = r * D + lane * 4;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f}, ad = {0.f, 0.f, 0.f, 0.f}, m2 = {1.f, 1.f, 1.f, 1.f};
+            if (on) g = *reinterpret_cast<const f32x4*>(gy + off);
+            if (on && addend) ad = *reinterpret_cast<const f32x4*>(addend + off);
+            if (on && mul2) m2 = *reinterpret_cast<const f32x4*>(mul2 + off);
+            const float rs = rstd[r];
+            const f32x4 h = g * wv * rs;
+            const float mh = wave_sum((h[0] + h[1]) + (h[2] + h[3])) / (float)D;
+            const f32x4 o = h - mh + ad;
+            const f32x4 o2 = o * m2;
+            if (on && out) *reinterpret_cast<f32x4*>(out + off) = o;
+            if (on && out2) *reinterpret_cast<f32x4*>(out2 + off) = o2;
+            if (absmax2_out) {
+                const unsigned m = wave_max_u32(on ? abs_bits4(o2) : 0u);
+                if (lane == 0) absmax2_out[r] = m;
+            }
+        }
+    } else {
+        for (int64_t r = wave; r < rows; r += nwaves) {
+            const float* g = gy + r * D;
+            const float rs = rstd[r];
+            float s = 0.f;
+            for (int c = lane; c < D; c += 64) s += g[c] * (w ? w[c] : 1.f) * rs;
+            const float mh = wave_sum(s) / (float)D;
+            unsigned m = 0u;
+            for (int c = lane; c < D; c += 64) {
+                float o = g[c] * (w ? w[c] : 1.f) * rs - mh;
+                if (addend) o += addend[r * D + c];
+                if (out) out[r * D + c] = o;
+                const float o2 = mul2 ? o * mul2[r * D + c] : o;
+                if (out2) out2[r * D + c] = o2;
+                m = max(m, __float_as_uint(o2) & 0x7fffffffu);
+            }
+            if (absmax2_out) {
+                m = wave_max_u32(m);
+                if (lane == 0) absmax2_out[r] = m;
+            }
         }
     }
 }
@@ -136,8 +214,8 @@ constexpr int ATPB = 512;
 template <bool BWD>
 __global__ __launch_bounds__(ATPB) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ zsrc,
                                                              float* __restrict__ out, float* __restrict__ stats_out,
-                                                             const float* __restrict__ stats_in, int B, int T, int H,
-                                                             float scale) {
+                                                             const float* __restrict__ stats_in, unsigned* __restrict__ absmax_out,
+                                                             int B, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Tpad = (T + 31) & ~31;
     const int zld = Tpad + 4;
@@ -247,12 +325,18 @@ __global__ __launch_bounds__(ATPB) void attention_mfma_kernel(const float* __res
         if (y < T) {
             const float rl = BWD ? 1.0f : 1.0f / l_run;
             float* orow = out + ((int64_t)b * T + y) * inner + h * DH + 4 * hf;    // d = 32 dt + 8 g + 4 hf + c
+            unsigned mx = 0u;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<f32x4*>(orow + 8 * g) =
-                    f32x4{o0[4 * g] * rl, o0[4 * g + 1] * rl, o0[4 * g + 2] * rl, o0[4 * g + 3] * rl};
-                *reinterpret_cast<f32x4*>(orow + 32 + 8 * g) =
-                    f32x4{o1[4 * g] * rl, o1[4 * g + 1] * rl, o1[4 * g + 2] * rl, o1[4 * g + 3] * rl};
+                const f32x4 va = f32x4{o0[4 * g] * rl, o0[4 * g + 1] * rl, o0[4 * g + 2] * rl, o0[4 * g + 3] * rl};
+                const f32x4 vb = f32x4{o1[4 * g] * rl, o1[4 * g + 1] * rl, o1[4 * g + 2] * rl, o1[4 * g + 3] * rl};
+                *reinterpret_cast<f32x4*>(orow + 8 * g) = va;
+                *reinterpret_cast<f32x4*>(orow + 32 + 8 * g) = vb;
+                mx = max(mx, max(abs_bits4(va), abs_bits4(vb)));
+            }
+            if (absmax_out) {         // max |out| of the token row over this head's 64 columns; the heads meet in one atomic max (zeroed buffer)
+                mx = max(mx, (unsigned)__shfl_xor((int)mx, 32));
+                if (hf == 0) atomicMax(absmax_out + (int64_t)b * T + y, mx);
             }
             if (!BWD && stats_out && hf == 0) {
                 float* st = stats_out + (((int64_t)b * H + h) * T + y) * 2;
@@ -547,21 +631,35 @@ __global__ __launch_bounds__(256) void attention_bwd_full_kernel(const float* __
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
+static bool ln_vec_ok(int D, std::initializer_list<const void*> ptrs) {
+    uintptr_t bits = 0;
+    for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);
+    return D % 4 == 0 && D <= 256 && (bits & 15) == 0;
+}
+
 extern "C" int bcos_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_out,
-                                  int64_t rows, int D, float eps, void* stream) {
+                                  uint32_t* y_absmax, int64_t rows, int D, float eps, void* stream) {
     if (!x || !y || rows <= 0 || D <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_layernorm_fwd: bad argument");
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), x, weight, bias, y,
-                       rstd_out, rows, D, eps);
+    if (ln_vec_ok(D, {x, weight, bias, y}))
+        hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), x, weight, bias, y,
+                           rstd_out, y_absmax, rows, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), x, weight, bias, y,
+                           rstd_out, y_absmax, rows, D, eps);
     return check_launch("layernorm_fwd_kernel");
 }
 
 extern "C" int bcos_layernorm_bwd_detached(const float* gy, const float* weight, const float* rstd, const float* addend,
-                                           const float* mul2, float* out, float* out2, int64_t rows, int D,
+                                           const float* mul2, float* out, float* out2, uint32_t* out2_absmax, int64_t rows, int D,
                                            void* stream) {
-    if (!gy || !rstd || (!out && !out2) || rows <= 0 || D <= 0)
+    if (!gy || !rstd || (!out && !out2) || rows <= 0 || D <= 0 || (out2_absmax && !out2))
         return bcos_set_error(BCOS_E_INVAL, "bcos_layernorm_bwd_detached: bad argument");
-    hipLaunchKernelGGL(layernorm_bwd_detached_kernel, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), gy, weight,
-                       rstd, addend, mul2, out, out2, rows, D);
+    if (ln_vec_ok(D, {gy, weight, addend, mul2, out, out2}))
+        hipLaunchKernelGGL(layernorm_bwd_detached_kernel<true>, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), gy, weight,
+                           rstd, addend, mul2, out, out2, out2_absmax, rows, D);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_detached_kernel<false>, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), gy, weight,
+                           rstd, addend, mul2, out, out2, out2_absmax, rows, D);
     return check_launch("layernorm_bwd_detached_kernel");
 }
 
@@ -580,7 +678,7 @@ extern "C" int bcos_add_rows_bcast(float* x, const float* pe, int64_t total, int
 }
 
 static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, float* stats_out, const float* stats_in,
-                       int B, int T, int H, float scale, void* stream) {
+                       unsigned* absmax_out, int B, int T, int H, float scale, void* stream) {
     const int Tpad = (T + 31) & ~31;
     const size_t bytes = ((size_t)Tpad * AT_XLD + (size_t)DH * (Tpad + 4) + 2 * (size_t)Tpad) * sizeof(float);
     if (bytes > 160 * 1024) return bcos_set_error(BCOS_E_NOSUP, "attention: sequence too long for the LDS-resident kernel");
@@ -591,26 +689,26 @@ static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, f
     if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute(attention)", err);
     if (bwd)
         hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((unsigned)(B * H)), dim3(ATPB), bytes, STREAM(stream), qkv, z, out,
-                           stats_out, stats_in, B, T, H, scale);
+                           stats_out, stats_in, absmax_out, B, T, H, scale);
     else
         hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((unsigned)(B * H)), dim3(ATPB), bytes, STREAM(stream), qkv, z, out,
-                           stats_out, stats_in, B, T, H, scale);
+                           stats_out, stats_in, absmax_out, B, T, H, scale);
     return check_launch(bwd ? "attention_mfma_kernel<bwd>" : "attention_mfma_kernel<fwd>");
 }
 
-extern "C" int bcos_attention_fwd(const float* qkv, float* out, float* stats, int B, int T, int H, int Dh, float scale,
-                                  void* stream) {
+extern "C" int bcos_attention_fwd(const float* qkv, float* out, float* stats, uint32_t* out_absmax, int B, int T, int H, int Dh,
+                                  float scale, void* stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_attention_fwd: bad argument");
     if (Dh != DH) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_fwd: head dimension must be 64");
-    return attn_launch(false, qkv, nullptr, out, stats, nullptr, B, T, H, scale, stream);
+    return attn_launch(false, qkv, nullptr, out, stats, nullptr, out_absmax, B, T, H, scale, stream);
 }
 
-extern "C" int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout, float* gv, int B, int T,
-                                    int H, int Dh, float scale, void* stream) {
+extern "C" int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout, float* gv, uint32_t* gv_absmax, int B,
+                                    int T, int H, int Dh, float scale, void* stream) {
     if (!qkv || !stats || !gout || !gv || B <= 0 || T <= 0 || H <= 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_attention_bwd_v: bad argument");
     if (Dh != DH) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_bwd_v: head dimension must be 64");
-    return attn_launch(true, qkv, gout, gv, nullptr, stats, B, T, H, scale, stream);
+    return attn_launch(true, qkv, gout, gv, nullptr, stats, gv_absmax, B, T, H, scale, stream);
 }
 
 extern "C" int bcos_finalize_explanation_patches(const float* gp, const float* x, const float* std6, float* weights_out,

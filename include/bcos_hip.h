@@ -443,15 +443,18 @@ int bcos_channel_axpby(const float* a, const float* sa, const float* b, const fl
 
 /* LayerNorm over the last dimension D of x [rows, D] (weight / bias may be NULL); rstd_out (NULL or [rows]) keeps
  * 1/sqrt(var+eps) for the backward.  Forward of DetachableLayerNorm (bcos/modules/norms/centered_norms.py:197-224;
- * the value does not depend on explanation mode). */
-int bcos_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_out,
+ * the value does not depend on explanation mode).  y_absmax (NULL or [rows], ABI v5): the fp32 bit pattern of max_c |y[r,c]|,
+ * the operand scale source of the split-f16 contraction that reads y (bcos_operands.a_absmax). */
+int bcos_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_out, uint32_t* y_absmax,
                        int64_t rows, int D, float eps, void* stream);
 
 /* Input gradient of DetachableLayerNorm in explanation mode (variance constant, mean differentiable,
  * centered_norms.py:204-215):  g = gy * weight * rstd - mean_D(gy * weight * rstd)  (+ addend);
- * out = g, out2 = g * mul2 (either may be NULL; mul2 NULL -> out2 = g). */
+ * out = g, out2 = g * mul2 (either may be NULL; mul2 NULL -> out2 = g); out2_absmax (NULL or [rows], ABI v5): row maxima of
+ * out2 as in bcos_layernorm_fwd. */
 int bcos_layernorm_bwd_detached(const float* gy, const float* weight, const float* rstd, const float* addend,
-                                const float* mul2, float* out, float* out2, int64_t rows, int D, void* stream);
+                                const float* mul2, float* out, float* out2, uint32_t* out2_absmax, int64_t rows, int D,
+                                void* stream);
 
 /* DetachableGroupNorm2d (bcos/modules/norms/centered_norms.py:93-160; the conv stems of the ViT-C models) on NHWC tensors
  * x [N, HW, C]: group g owns channels [g C/G, (g+1) C/G) of every pixel; per (image, group): biased variance, eps inside the
@@ -471,13 +474,15 @@ int bcos_gelu_gate(const float* x, float* y, float* gate_out, int64_t n, void* s
 int bcos_add_rows_bcast(float* x, const float* pe, int64_t total, int64_t period, void* stream);
 
 /* softmax(q k^T * scale) v per (batch, head), head dim 64.  qkv [B, T, 3*H*64] ordered (q | k | v) x (h d) like
- * vit.py:145-146; out [B, T, H*64]; stats (NULL or [B, H, T, 2]) = (row max, 1 / row sum) for the backward. */
-int bcos_attention_fwd(const float* qkv, float* out, float* stats, int B, int T, int H, int Dh, float scale, void* stream);
+ * vit.py:145-146; out [B, T, H*64]; stats (NULL or [B, H, T, 2]) = (row max, 1 / row sum) for the backward.
+ * out_absmax (NULL or [B*T], ZERO-FILLED by the caller, ABI v5): row maxima of out (one atomic max per head and row). */
+int bcos_attention_fwd(const float* qkv, float* out, float* stats, uint32_t* out_absmax, int B, int T, int H, int Dh, float scale,
+                       void* stream);
 
 /* Gradient w.r.t. v with q, k detached (vit.py:148-151, bcosattnpool.py:37-39): gv = attn^T gout, attn recomputed from
- * qkv and stats. gout, gv: [B, T, H*64]. */
-int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout, float* gv, int B, int T, int H, int Dh,
-                         float scale, void* stream);
+ * qkv and stats. gout, gv: [B, T, H*64]; gv_absmax as out_absmax of bcos_attention_fwd. */
+int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout, float* gv, uint32_t* gv_absmax, int B, int T,
+                         int H, int Dh, float scale, void* stream);
 
 /* -- training-mode backward of the token path (nothing detached; SURVEY.md section 8(f) N4 for the ViT family) ---------- */
 /* LayerNorm over the last dimension (centered_norms.py:187-245 outside explanation mode = F.layer_norm's gradient):

@@ -462,7 +462,7 @@ def maxout_scale(lin2d, norm, Cout, max_out, b, groups=1, want_scale=False, want
     return y, (s if want_scale else None), (arg.to(torch.int32) if want_argmax else None)
 
 
-def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None):
+def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None, want_absmax=False):
     var, mean = torch.var_mean(x2d.double(), dim=-1, unbiased=False, keepdim=True)
     sd = (var + eps).sqrt()
     y = (x2d.double() - mean) / sd
@@ -473,7 +473,7 @@ def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None):
     return y.float(), ((1 / sd).float().view(-1) if want_rstd else None)
 
 
-def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None):
+def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None, want_absmax2=False):
     h = gy2d.double() * (weight.double() if weight is not None else 1.0) * rstd.double().view(-1, 1)
     g = h - h.mean(-1, keepdim=True)
     if addend is not None:
@@ -499,14 +499,14 @@ def _attn_probs(qkv, heads, scale):
     return torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1), v, inner
 
 
-def attention_fwd(qkv, heads, scale, want_stats=False):
+def attention_fwd(qkv, heads, scale, want_stats=False, want_absmax=False):
     p, v, inner = _attn_probs(qkv, heads, scale)
     B, T, _ = qkv.shape
     out = (p @ v).transpose(1, 2).reshape(B, T, inner).float()
     return out, (torch.zeros(B, heads, T, 2) if want_stats else None)
 
 
-def attention_bwd_v(qkv, stats, gout, heads, scale):
+def attention_bwd_v(qkv, stats, gout, heads, scale, want_absmax=False):
     p, v, inner = _attn_probs(qkv, heads, scale)
     B, T, _ = qkv.shape
     g = gout.view(B, T, heads, inner // heads).transpose(1, 2).double()

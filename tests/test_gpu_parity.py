@@ -1398,7 +1398,8 @@ def test_dma_loop_bit_identical_to_register_loop(lib, golden_dir, monkeypatch):
     cases = [(3, 13, 64, 200, 1, 1, 0), (2, 15, 32, 52, 3, 2, 1), (1, 9, 256, 24, 1, 1, 0), (2, 28, 128, 512, 1, 1, 0),
              (5, 7, 512, 384, 3, 1, 1), (2, 14, 256, 256, 3, 1, 1), (6, 14, 1024, 256, 1, 1, 0), (2, 33, 8, 64, 7, 2, 3),
              (40, 30, 64, 64, 3, 1, 1), (40, 30, 256, 64, 1, 1, 0), (3, 12, 20, 40, 3, 1, 1), (2, 20, 16, 128, 5, 1, 2),
-             (9, 28, 128, 128, 3, 1, 1), (1, 5, 2048, 1000, 1, 1, 0)]
+             (9, 28, 128, 128, 3, 1, 1), (1, 5, 2048, 1000, 1, 1, 0), (7, 14, 192, 192, 1, 1, 0), (3, 20, 768, 152, 1, 1, 0),
+             (2, 17, 64, 192, 3, 1, 1)]
     for (N, H, Cin, Cout, k, st, pd) in cases:
         x = ops.ensure_absmax(torch.randn(N, H, H, Cin, generator=g).to(DEV))
         w = ops.mark_static((torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV))
