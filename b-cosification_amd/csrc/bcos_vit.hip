@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include <initializer_list>
 #include <atomic>
 #include "bcos_hip.h"
@@ -347,6 +348,252 @@ __global__ __launch_bounds__(ATPB) void attention_mfma_kernel(const float* __res
     }
 }
 
+// ---- the same attention on the f16 matrix pipe (round 3) -------------------------------------------------------------------------
+// Same structure -- one workgroup per (image, head), the walked operand X and the transposed value operand Z^T resident in LDS,
+// a wavefront owns 32 Y rows, the probabilities never leave the register file -- but both products run as THREE
+// v_mfma_f32_32x32x16_f16 on exact two-way splits (x 2^e = h + l, h, l fp16: l_a h_b + h_a l_b + h_a h_b, fp32 accumulation;
+// the arithmetic of the contraction kernel, csrc/bcos_tapconv.hip) instead of fp32 MFMAs at 1/16 of the rate:
+//   * X rows (keys fwd / queries bwd) and Z^T rows (one per feature d) are scaled per row by a power of two, split ONCE by the
+//     loading pass and kept in LDS as (h | l) planes -- the same bytes as the fp32 images they replace;
+//   * Y rows are split once per tile in registers; the probabilities (<= 1) are split per chunk after a fixed 2^14;
+//   * the powers of two are undone exactly: per X row inside the softmax argument, per Y row in the same factor, per d at the end.
+// The k index of both contractions is stored permuted (the middle two 4-blocks of every 16 swapped) so that a lane's 8 k values
+// of one matrix instruction are one ds_read_b128 for the LDS operand and plain register order for the register operand.
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af16x4 __attribute__((ext_vector_type(4)));
+constexpr int AH_XROW = 144;        // bytes per X row and plane: 64 f16 + 16 (16 rows at distinct 16-byte bank groups)
+
+__device__ __forceinline__ void split_scale_exp(unsigned maxbits, float& sc, float& inv) {
+    unsigned E = maxbits >> 23;
+    E = E < 15u ? 15u : E;
+    sc = __uint_as_float((268u - E) << 23);      // max * sc in [2^14, 2^15)
+    inv = __uint_as_float((E - 14u) << 23);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restrict__ qkv, const float* __restrict__ zsrc,
+                                                           float* __restrict__ out, float* __restrict__ stats_out,
+                                                           const float* __restrict__ stats_in, unsigned* __restrict__ absmax_out,
+                                                           int B, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Tpad = (T + 31) & ~31;
+    const int zrow = Tpad * 2 + 16;                     // bytes per Z^T row and plane
+    char* sXh = reinterpret_cast<char*>(smem);
+    char* sXl = sXh + (size_t)Tpad * AH_XROW;
+    char* sZh = sXl + (size_t)Tpad * AH_XROW;
+    char* sZl = sZh + (size_t)DH * zrow;
+    float* sXinv = reinterpret_cast<float*>(sZl + (size_t)DH * zrow);     // [Tpad]
+    float* sZinv = sXinv + Tpad;                                          // [64]
+    unsigned* sZmax = reinterpret_cast<unsigned*>(sZinv + DH);            // [64]
+    float* sS = reinterpret_cast<float*>(sZmax + DH);                     // [Tpad][2]   (backward only)
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int inner = H * DH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* base = qkv + (int64_t)b * T * 3 * inner + h * DH;
+    const float* xsrc = base + (BWD ? 0 : inner);      // K (forward) / Q (backward), row stride 3*inner
+    const float* ysrc = base + (BWD ? inner : 0);      // Q (forward) / K (backward)
+    const float* zrow0 = BWD ? zsrc + (int64_t)b * T * inner + h * DH : base + 2 * inner;
+    const int zstride = BWD ? inner : 3 * inner;
+
+    if (tid < DH) sZmax[tid] = 0u;
+    __syncthreads();
+    // pass 1: X rows -> scaled (h | l) planes; per-d maxima of Z.  A thread keeps its 16-byte column c4 = tid % 16 throughout.
+    const int c4 = tid & 15;
+    const int xpos = (16 * (c4 >> 2) + 4 * (((c4 & 3) == 1) ? 2 : ((c4 & 3) == 2) ? 1 : (c4 & 3))) * 2;     // byte offset of d block c4
+    {
+        unsigned zm[4] = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < Tpad * (DH / 4); i += ATPB) {
+            const int t = i >> 4;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
+            if (t < T) {
+                xv = *reinterpret_cast<const f32x4*>(xsrc + (int64_t)t * 3 * inner + c4 * 4);
+                zv = *reinterpret_cast<const f32x4*>(zrow0 + (int64_t)t * zstride + c4 * 4);
+            }
+            unsigned m = abs_bits4(xv);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            float sc, inv;
+            split_scale_exp(m, sc, inv);
+            af16x4 hh, ll;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = xv[q] * sc;
+                hh[q] = (_Float16)v;
+                ll[q] = (_Float16)(v - (float)hh[q]);
+                zm[q] = max(zm[q], __float_as_uint(zv[q]) & 0x7fffffffu);
+            }
+            *reinterpret_cast<af16x4*>(sXh + t * AH_XROW + xpos) = hh;
+            *reinterpret_cast<af16x4*>(sXl + t * AH_XROW + xpos) = ll;
+            if (c4 == 0) sXinv[t] = inv;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicMax(&sZmax[c4 * 4 + q], zm[q]);
+    }
+    if (BWD) {
+        const float* st = stats_in + ((int64_t)b * H + h) * T * 2;
+        for (int i = tid; i < Tpad; i += ATPB) {
+            sS[2 * i] = i < T ? st[2 * i] : INFINITY;          // padded query rows: exp(s - inf) * 0 = 0
+            sS[2 * i + 1] = i < T ? st[2 * i + 1] : 0.f;
+        }
+    }
+    __syncthreads();
+    // pass 2: Z -> scaled, split, transposed planes (token index permuted like d above)
+    {
+        float zsc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float inv;
+            split_scale_exp(sZmax[c4 * 4 + q], zsc[q], inv);
+            if (tid < 16) sZinv[c4 * 4 + q] = inv;
+        }
+        for (int i = tid; i < Tpad * (DH / 4); i += ATPB) {
+            const int t = i >> 4;
+            f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+            if (t < T) zv = *reinterpret_cast<const f32x4*>(zrow0 + (int64_t)t * zstride + c4 * 4);
+            const int tb = (t >> 2) & 3;
+            const int tpos = ((t & ~15) + 4 * (tb == 1 ? 2 : tb == 2 ? 1 : tb) + (t & 3)) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = zv[q] * zsc[q];
+                const _Float16 hh = (_Float16)v;
+                *reinterpret_cast<_Float16*>(sZh + (c4 * 4 + q) * zrow + tpos) = hh;
+                *reinterpret_cast<_Float16*>(sZl + (c4 * 4 + q) * zrow + tpos) = (_Float16)(v - (float)hh);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int col = lane & 31, hf = lane >> 5;
+    const int ntiles = Tpad / 32;
+    for (int tile = wave; tile < ntiles; tile += ATPB / 64) {
+        const int y = tile * 32 + col;                 // the Y row (query fwd / key bwd) of this lane
+        f32x4 yf[8];
+        unsigned ym = 0u;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            yf[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (y < T) yf[g] = *reinterpret_cast<const f32x4*>(ysrc + (int64_t)y * 3 * inner + 8 * g + 4 * hf);
+            ym = max(ym, abs_bits4(yf[g]));
+        }
+        ym = max(ym, (unsigned)__shfl_xor((int)ym, 32));
+        float ysc, yinv;
+        split_scale_exp(ym, ysc, yinv);
+        af16x8 yh[4], yl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = yf[2 * j + (q >> 2)][q & 3] * ysc;
+                yh[j][q] = (_Float16)v;
+                yl[j][q] = (_Float16)(v - (float)yh[j][q]);
+            }
+        const float sfac = scale * yinv;
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int chunk = 0; chunk < ntiles; ++chunk) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const char* xh = sXh + (chunk * 32 + col) * AH_XROW + 16 * hf;
+            const char* xl = sXl + (chunk * 32 + col) * AH_XROW + 16 * hf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const af16x8 ah = *reinterpret_cast<const af16x8*>(xh + 32 * j);
+                const af16x8 al = *reinterpret_cast<const af16x8*>(xl + 32 * j);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, yh[j], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, yl[j], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, yh[j], sacc, 0, 0, 0);
+            }
+            // register r <-> X row  chunk*32 + 8(r>>2) + 4hf + (r&3); undo the X row's power of two
+            float pr[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xi = *reinterpret_cast<const f32x4*>(sXinv + chunk * 32 + 8 * g + 4 * hf);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pr[4 * g + c] = sacc[4 * g + c] * sfac * xi[c];
+            }
+            if (!BWD) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int x = chunk * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                    pr[r] = x < T ? pr[r] : -INFINITY;
+                    mx = fmaxf(mx, pr[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run, mx);          // finite: every chunk holds at least one valid key
+                const float alpha = expf(m_run - m_new);
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pr[r] = expf(pr[r] - m_new); sum += pr[r]; }
+                sum += __shfl_xor(sum, 32);
+                l_run = l_run * alpha + sum;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* st = sS + 2 * (chunk * 32 + 8 * g + 4 * hf);
+                    const f32x4 s01 = *reinterpret_cast<const f32x4*>(st), s23 = *reinterpret_cast<const f32x4*>(st + 4);
+                    pr[4 * g + 0] = expf(pr[4 * g + 0] - s01[0]) * s01[1];
+                    pr[4 * g + 1] = expf(pr[4 * g + 1] - s01[2]) * s01[3];
+                    pr[4 * g + 2] = expf(pr[4 * g + 2] - s23[0]) * s23[1];
+                    pr[4 * g + 3] = expf(pr[4 * g + 3] - s23[2]) * s23[3];
+                }
+            }
+            const char* zh = sZh + col * zrow + (chunk * 32 + 8 * hf) * 2;
+            const char* zl = sZl + col * zrow + (chunk * 32 + 8 * hf) * 2;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                af16x8 ph, pl;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = pr[8 * m2 + q] * 16384.0f;
+                    ph[q] = (_Float16)v;
+                    pl[q] = (_Float16)(v - (float)ph[q]);
+                }
+                const af16x8 zh0 = *reinterpret_cast<const af16x8*>(zh + 32 * m2), zl0 = *reinterpret_cast<const af16x8*>(zl + 32 * m2);
+                const af16x8 zh1 = *reinterpret_cast<const af16x8*>(zh + 32 * zrow + 32 * m2);
+                const af16x8 zl1 = *reinterpret_cast<const af16x8*>(zl + 32 * zrow + 32 * m2);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(zl0, ph, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(zl1, ph, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh0, pl, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh1, pl, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh0, ph, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh1, ph, o1, 0, 0, 0);
+            }
+        }
+        if (y < T) {
+            const float rl = (BWD ? 1.0f : 1.0f / l_run) * (1.0f / 16384.0f);
+            float* orow = out + ((int64_t)b * T + y) * inner + h * DH + 4 * hf;    // d = 32 dt + 8 g + 4 hf + c
+            unsigned mx = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 za = *reinterpret_cast<const f32x4*>(sZinv + 8 * g + 4 * hf) * rl;
+                const f32x4 zb = *reinterpret_cast<const f32x4*>(sZinv + 32 + 8 * g + 4 * hf) * rl;
+                const f32x4 va = f32x4{o0[4 * g] * za[0], o0[4 * g + 1] * za[1], o0[4 * g + 2] * za[2], o0[4 * g + 3] * za[3]};
+                const f32x4 vb = f32x4{o1[4 * g] * zb[0], o1[4 * g + 1] * zb[1], o1[4 * g + 2] * zb[2], o1[4 * g + 3] * zb[3]};
+                *reinterpret_cast<f32x4*>(orow + 8 * g) = va;
+                *reinterpret_cast<f32x4*>(orow + 32 + 8 * g) = vb;
+                mx = max(mx, max(abs_bits4(va), abs_bits4(vb)));
+            }
+            if (absmax_out) {
+                mx = max(mx, (unsigned)__shfl_xor((int)mx, 32));
+                if (hf == 0) atomicMax(absmax_out + (int64_t)b * T + y, mx);
+            }
+            if (!BWD && stats_out && hf == 0) {
+                float* st = stats_out + (((int64_t)b * H + h) * T + y) * 2;
+                st[0] = m_run;
+                st[1] = 1.0f / l_run;
+            }
+        }
+    }
+}
+
 // ---- end of the ViT explanation pass: patch-major gradient -> W(x) NCHW + contribution map -----------------
 // gp: [N, gh, gw, ps, ps, Cpad] (the input gradient of the patch embedding, one row per patch, "(p1 p2 c)" order
 // of vit.py:291 with c padded); x: network input [N, Cx, H, W]
@@ -680,6 +927,25 @@ extern "C" int bcos_add_rows_bcast(float* x, const float* pe, int64_t total, int
 static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, float* stats_out, const float* stats_in,
                        unsigned* absmax_out, int B, int T, int H, float scale, void* stream) {
     const int Tpad = (T + 31) & ~31;
+    // f16 matrix pipe (default) or the exact-fp32 MFMA form of rounds 1-2 (BCOS_ATTENTION=f32; also what the f32 contraction mode means)
+    const char* sel = getenv("BCOS_ATTENTION");
+    if (!(sel && sel[0] == 'f' && sel[1] == '3')) {
+        const size_t hb = 2 * (size_t)Tpad * AH_XROW + 2 * (size_t)DH * (Tpad * 2 + 16) + ((size_t)Tpad + 2 * DH + 2 * (size_t)Tpad) * 4;
+        if (hb <= 160 * 1024) {
+            const void* fn2 = bwd ? reinterpret_cast<const void*>(attention_h2_kernel<true>)
+                                  : reinterpret_cast<const void*>(attention_h2_kernel<false>);
+            static std::atomic<size_t> lds_hw2[2];
+            hipError_t e2 = bcos_ensure_dynamic_lds(fn2, hb, lds_hw2[bwd ? 1 : 0]);
+            if (e2 != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute(attention)", e2);
+            if (bwd)
+                hipLaunchKernelGGL(attention_h2_kernel<true>, dim3((unsigned)(B * H)), dim3(ATPB), hb, STREAM(stream), qkv, z, out,
+                                   stats_out, stats_in, absmax_out, B, T, H, scale);
+            else
+                hipLaunchKernelGGL(attention_h2_kernel<false>, dim3((unsigned)(B * H)), dim3(ATPB), hb, STREAM(stream), qkv, z, out,
+                                   stats_out, stats_in, absmax_out, B, T, H, scale);
+            return check_launch(bwd ? "attention_h2_kernel<bwd>" : "attention_h2_kernel<fwd>");
+        }
+    }
     const size_t bytes = ((size_t)Tpad * AT_XLD + (size_t)DH * (Tpad + 4) + 2 * (size_t)Tpad) * sizeof(float);
     if (bytes > 160 * 1024) return bcos_set_error(BCOS_E_NOSUP, "attention: sequence too long for the LDS-resident kernel");
     const void* fn = bwd ? reinterpret_cast<const void*>(attention_mfma_kernel<true>)
