@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from bcos_hip import ops
-from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_NORM_ONLY, BCOS_LINEAR_EPS, BCOS_NONE,
+from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_NORM_ONLY, BCOS_EPI_UNIT_NORM_W, BCOS_LINEAR_EPS, BCOS_NONE,
                           BcosHipError)
 
 
@@ -79,6 +79,49 @@ class UnitNormFn(Function):
         need_w, need_s = ctx.needs_input_grad[0], ctx.has_gain and ctx.needs_input_grad[1]
         gw, gg = ops.weight_rownorm_bwd(w2, g.contiguous().view(w2.shape[0], -1), gain, want_gw=need_w, want_ggain=need_s)
         return (gw.view_as(g) if gw is not None else None), (gg.view(ctx.scale_shape) if gg is not None else None)
+
+
+FOLD_UNIT_NORM = True      # False: training steps of native layers project their weights with a separate launch again (UnitNormFn)
+
+
+def _unit(cfg):
+    """(epilogue flag, col_scale) of a launch whose unit-norm weight projection is folded into the contraction (FoldedUnitNormFn)"""
+    return (BCOS_EPI_UNIT_NORM_W if cfg.get("unit_w") else 0), cfg.get("unit_gain")
+
+
+class FoldedUnitNormFn(Function):
+    """A native B-cos layer (unit-norm filters, bcosconv2d.py:26-35 / bcoslinear.py:25-27) in TRAINING mode, where the
+    projection w / ||w|| is recomputed on every call: ONE forward launch on the raw weights -- the contraction gathers ||w_c||
+    from the weight rows it stages anyway and scales its accumulator columns (BCOS_EPI_UNIT_NORM_W; the optional trainable
+    `scale` rides in col_scale) -- instead of a projection kernel that writes a W-sized tensor which the contraction then reads.
+    The backward materialises the projected weights once for the input-gradient plan and chains the weight gradient through
+    the projection (bcos_weight_rownorm_bwd) like UnitNormFn did.  `inner` = BcosConv2dFn | BcosLinearFn."""
+
+    @staticmethod
+    def forward(ctx, x, w_raw, scale, cfg, b_param, inner):
+        gain = scale.detach().reshape(-1).contiguous() if scale is not None else None
+        ctx.fold = (w_raw.detach(), gain, tuple(scale.shape) if scale is not None else None, inner)
+        return inner.forward(ctx, x, w_raw.detach(), None, dict(cfg, unit_w=True, unit_gain=gain), b_param)
+
+    @staticmethod
+    def backward(ctx, gy):
+        w_raw, gain, scale_shape, inner = ctx.fold
+        w2 = w_raw.contiguous().view(w_raw.shape[0], -1)
+        ctx.w_eff = ops.weight_rownorm_scale(w2, gain).view_as(w_raw)              # for the input-gradient plan
+        gx, g_eff, _, _, gbp = inner.backward(ctx, gy)
+        gw = gg = None
+        if g_eff is not None:
+            gw, gg = ops.weight_rownorm_bwd(w2, g_eff.contiguous().view(w2.shape[0], -1), gain, want_gw=True,
+                                            want_ggain=gain is not None and ctx.needs_input_grad[2])
+            gw = gw.view_as(w_raw)
+            gg = gg.view(scale_shape) if gg is not None else None
+        return gx, gw, gg, None, gbp, None
+
+
+def folds_projection(lin, detach) -> bool:
+    """training step of a native layer whose raw weight is trained: FoldedUnitNormFn applies"""
+    return bool(FOLD_UNIT_NORM and lin.bias is None and not detach and lin.weight.requires_grad
+                and wants_projection_grad(lin, lin.weight, getattr(lin, "scale", None)))
 
 
 def wants_projection_grad(module, *params) -> bool:
@@ -191,9 +234,10 @@ class BcosConv2dFn(Function):
                             dilation[0], dilation[1])
         if groups > 1:
             geom.update(groups=groups, a_pitch=Cin, out_pitch=Cout_all, norm_pitch=groups)
+        uflag, ugain = _unit(cfg)
         ops.tapconv(xh, wk, geom, out=y, scale_out=scale, norm_out=norm, bias=bias, bcos_mode=mode, b=b,
-                    flags=(0 if fused else BCOS_EPI_NORM_ONLY) | (BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0),
-                    **({"track_absmax": False} if groups > 1 else {}))
+                    flags=(0 if fused else BCOS_EPI_NORM_ONLY) | (BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0) | uflag,
+                    col_scale=ugain, **({"track_absmax": False} if groups > 1 else {}))
         argmax = None
         if not fused:
             Cout = Cout_all // max_out
@@ -230,8 +274,9 @@ class BcosConv2dFn(Function):
         need_wb = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
         t_full = torch.empty((N, Ho, Wo, Cout_all), device=x.device, dtype=torch.float32) if (need_grad or need_wb) else None
         gm = ops.fwd_geom(N, H, W, wk.shape[3], Cout_all, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1])
+        uflag, ugain = _unit(cfg)
         ops.tapconv(xh, wk, gm, out=y, scale_out=t_full, bias=bias, bcos_mode=BCOS_NONE if b == 1.0 else BCOS_CONV_EPS, b=b,
-                    flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0, max_out=M)
+                    flags=(BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0) | uflag, col_scale=ugain, max_out=M)
         ctx.cfg, ctx.in_shape, ctx.w_eff, ctx.train, ctx.geom, ctx.need_bp = cfg, in_shape, w_eff, False, geom, False
         keep_x = xh if need_wb else None                # explanation-mode weight gradient (scale held constant)
         ctx.save_for_backward(*(t for t in (t_full, keep_x) if t is not None))
@@ -350,6 +395,7 @@ class BcosLinearFn(Function):
         argmax = None
         norm = None
         mo_fused = max_out in (2, 4) and Cout_all % 4 == 0 and not train
+        uflag, ugain = _unit(cfg)
         if mo_fused:
             rows = x2.shape[0]
             y = torch.empty((rows, Cout_all // max_out), device=x.device, dtype=torch.float32)
@@ -357,10 +403,10 @@ class BcosLinearFn(Function):
             g = dict(N=1, H=1, W=rows, C=x2.shape[1], P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
                      TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout_all)
             ops.tapconv(x2, wk, g, out=y, scale_out=scale, bias=bias, bcos_mode=BCOS_NONE if b == 1.0 else BCOS_LINEAR_EPS, b=b,
-                        flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0, max_out=max_out)
+                        flags=(BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0) | uflag, col_scale=ugain, max_out=max_out)
         elif max_out == 1:
             y, scale, norm = ops.linear_fwd(x2, wk, bias=bias, b=b, want_scale=want_scale, want_norm=train,
-                                            flags=BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0)
+                                            flags=(BCOS_EPI_FORCE_POW if cfg.get("force_pow") else 0) | uflag, col_scale=ugain)
         else:
             rows = x2.shape[0]
             lin = torch.empty((rows, Cout_all), device=x.device, dtype=torch.float32)
@@ -368,7 +414,7 @@ class BcosLinearFn(Function):
             g = dict(N=1, H=1, W=rows, C=x2.shape[1], P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
                      TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout_all)
             ops.tapconv(x2, wk, g, out=lin, norm_out=norm, bias=bias,
-                        bcos_mode=BCOS_NONE if b == 1.0 else BCOS_LINEAR_EPS, b=b, flags=BCOS_EPI_NORM_ONLY)
+                        bcos_mode=BCOS_NONE if b == 1.0 else BCOS_LINEAR_EPS, b=b, flags=BCOS_EPI_NORM_ONLY | uflag, col_scale=ugain)
             y, scale, argmax = ops.maxout_scale(lin, norm, Cout_all // max_out, max_out, b, want_scale=want_scale,
                                                 want_argmax=need_grad or need_w or need_b)
         ctx.cfg = cfg

@@ -152,10 +152,13 @@ class BcosConv2d(DetachableModule):
         lin = self.linear
         if lin.padding_mode != "zeros":
             raise NotImplementedError("only zero padding is implemented by the HIP kernels")
-        w, bias = self._effective_weight_and_bias()
         cfg = dict(stride=tuple(lin.stride), padding=tuple(lin.padding), dilation=tuple(lin.dilation),
                    groups=lin.groups, b=self._b_value(), max_out=self.max_out, detach=self.detach,
                    cache=self._wcache, w_src=lin.weight)
+        if isinstance(lin, NormedConv2d) and lin.use_weight_norm and _hipfn.folds_projection(lin, self.detach):
+            # training step of a native layer: the unit-norm projection is folded into the contraction (one forward launch)
+            return _hipfn.FoldedUnitNormFn.apply(in_tensor, lin.weight, lin.scale, cfg, _hipfn.learnable_b(self), _hipfn.BcosConv2dFn)
+        w, bias = self._effective_weight_and_bias()
         return _hipfn.BcosConv2dFn.apply(in_tensor, w, bias, cfg, _hipfn.learnable_b(self))
 
     def calc_patch_norms(self, in_tensor: Tensor) -> Tensor:

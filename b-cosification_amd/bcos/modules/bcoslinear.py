@@ -92,9 +92,13 @@ class BcosLinear(DetachableModule):
         return cached[1]
 
     def forward(self, in_tensor: Tensor) -> Tensor:
-        w, bias = self._effective_weight_and_bias()
+        lin = self.linear
         cfg = dict(b=self._b_value(), max_out=self.max_out, detach=self.detach, cache=self._wcache,
-                   w_src=self.linear.weight)
+                   w_src=lin.weight)
+        if isinstance(lin, NormedLinear) and _hipfn.folds_projection(lin, self.detach):
+            # training step of a native layer: the unit-norm projection is folded into the contraction (one forward launch)
+            return _hipfn.FoldedUnitNormFn.apply(in_tensor, lin.weight, None, cfg, _hipfn.learnable_b(self), _hipfn.BcosLinearFn)
+        w, bias = self._effective_weight_and_bias()
         return _hipfn.BcosLinearFn.apply(in_tensor, w, bias, cfg, _hipfn.learnable_b(self))
 
     def extra_repr(self) -> str:

@@ -27,6 +27,7 @@ BCOS_EPI_FORCE_POW = 2
 BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
+BCOS_EPI_UNIT_NORM_W = 32
 ABI_VERSION = 5
 TAPCONV_PARTS = 9
 
@@ -45,7 +46,7 @@ class TapconvGeom(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2", "relu_gate",
-        "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax", "mul_norm", "mul_csc", "mul_csh")] + [
+        "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax", "mul_norm", "mul_csc", "mul_csh", "col_scale")] + [
         ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32), ("max_out", C.c_int32), ("addend_sub", C.c_int32)]
 
 
@@ -86,6 +87,7 @@ SIGNATURES = {
     "bcos_channel_axpby": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
+    "bcos_weight_row_invnorm": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_rows_normalize": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "bcos_cosine_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_maxout_scale": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),

@@ -231,7 +231,8 @@ def _out_absmax(t: Optional[torch.Tensor], pixels: int):
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
             gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0, contraction=None,
-            track_absmax=None, track_absmax2=None, max_out=1, mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0):
+            track_absmax=None, track_absmax2=None, max_out=1, mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0,
+            col_scale=None):
     """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv_ops).
     `addend_sub` = s > 1: `addend` is the dense [N, ceil(OH/s), ceil(OW/s), pitch] tensor of the output pixels on the s-grid.
     `contraction`: None = the library default, or 'f32' / 'bf16x3' / 'f16x2' for this call.
@@ -246,7 +247,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     e = Epilogue()
     tensors = dict(bias=bias, ch_scale=ch_scale, ch_shift=ch_shift, addend=addend, mul=mul, mul2=mul2,
                    gate2=gate2, relu_gate=relu_gate, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out,
-                   mul_norm=mul_norm, mul_csc=mul_csc, mul_csh=mul_csh)
+                   mul_norm=mul_norm, mul_csc=mul_csc, mul_csh=mul_csh, col_scale=col_scale)
     for k, t in tensors.items():
         p = _dev(t, f"tapconv.{k}", contiguous=False)
         setattr(e, k, p.value if p is not None else None)
@@ -263,7 +264,8 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     o.a = _dev(a, "tapconv.a", contiguous=False).value
     o.wt = _dev(wt, "tapconv.wt").value
     o.contraction = {"f32": _l.CONTRACT_F32, "bf16x3": _l.CONTRACT_BF16X3, "f16x2": _l.CONTRACT_F16X2}[mode]
-    static = getattr(wt, "_bcos_static", False) and not _NO_PRESPLIT
+    # (BCOS_EPI_UNIT_NORM_W: the launch reads the RAW fp32 weight rows to gather their norms -- no pre-split image is used)
+    static = getattr(wt, "_bcos_static", False) and not _NO_PRESPLIT and not (int(flags) & _l.BCOS_EPI_UNIT_NORM_W)
     keep = []
     if mode == "f16x2":
         # outputs carry their per-pixel maxima for the launch that will read them as its A operand
@@ -364,7 +366,7 @@ def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=Non
 
 
 def linear_fwd(x2d, w, *, bias=None, b=2.0, want_scale=False, want_norm=False, mode=BCOS_LINEAR_EPS,
-               addend=None, out=None, flags=0):
+               addend=None, out=None, flags=0, col_scale=None):
     """Fused B-cos linear.  x2d [rows,Cin], w [Cout,Cin] -> y [rows,Cout]."""
     rows, Cin = x2d.shape
     Cout = w.shape[0]
@@ -377,7 +379,7 @@ def linear_fwd(x2d, w, *, bias=None, b=2.0, want_scale=False, want_norm=False, m
     if float(b) == 1.0:
         mode = BCOS_NONE
     tapconv(x2d, w, g, out=out, scale_out=scale, norm_out=norm, bias=bias, addend=addend, bcos_mode=mode, b=b,
-            flags=flags)
+            flags=flags, col_scale=col_scale)
     return out, scale, norm
 
 

@@ -383,6 +383,29 @@ __global__ __launch_bounds__(TPB) void cosine_grad_kernel(const float* __restric
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(TPB) void weight_row_invnorm_kernel(const float* __restrict__ w, const float* __restrict__ gain,
+                                                                 float* __restrict__ inv, int rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * TPB) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float* src = w + (int64_t)r * cols;
+        float ss = 0.f;
+        for (int64_t c = lane; c < cols; c += 64) ss = fmaf(src[c], src[c], ss);       // (the summation order of weight_rownorm_kernel)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) inv[r] = (gain ? gain[r] : 1.f) / sqrtf(ss);
+    }
+}
+}  // namespace
+
+extern "C" int bcos_weight_row_invnorm(const float* w, const float* gain, float* inv, int rows, int64_t cols, void* stream) {
+    if (!w || !inv || rows <= 0 || cols <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_weight_row_invnorm: bad argument");
+    hipLaunchKernelGGL(weight_row_invnorm_kernel, dim3(grid_for((int64_t)rows * 64)), dim3(TPB), 0, STREAM(stream), w, gain, inv, rows, cols);
+    return check_launch("weight_row_invnorm_kernel");
+}
+
 extern "C" int bcos_rows_normalize(const float* x, float* y, float* inv_norm, int64_t rows, int C, void* stream) {
     if (!x || (!y && !inv_norm) || rows <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_rows_normalize: bad argument");
     hipLaunchKernelGGL(rows_normalize_kernel, dim3(grid_for(rows * 64)), dim3(TPB), 0, STREAM(stream), x, y, inv_norm, rows, C);

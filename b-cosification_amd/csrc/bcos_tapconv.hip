@@ -125,6 +125,14 @@ template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
     const auto& e = p.e;                                                                                                   \
     (void)g; (void)e;
 
+// [BN] floats behind the epilogue's transpose buffer and row records: 1 / ||w_c|| of the tile's columns (BCOS_EPI_UNIT_NORM_W)
+template <int BM, int BN, int WAVES_M>
+__device__ __forceinline__ float* epi_col_table(float* smem) {
+    constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
+    constexpr int SBM = BM / PM, SBN = BN == 192 ? 64 : (BN > 128 ? 128 : BN);
+    return smem + SBM * (SBN + 4) + BM * 5;
+}
+
 // General epilogue (include/bcos_hip.h: bcos_epilogue), every feature decided at run time; shared by the fp32, split-bf16 and
 // split-f16 main loops.  `ss` = per-lane partial row sums in MFMA fragment layout, or `ROWSS` = partial row sums in staging
 // layout.  SCALED (split-f16 loop): accumulators carry the power-of-two operand scales; `AINV` (staging layout) holds the
@@ -236,6 +244,9 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
         coladd = ((cls / g.out_sw) * g.OW + cls % g.out_sw) * g.out_pitch + (col - cls * g.out_cgroup);
     }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
+    // col_scale (the unit-norm projection 1 / ||w_c|| of NormedConv2d / NormedLinear, folded into the contraction) multiplies
+    // the accumulator ahead of everything else: it rides in the column factor the scaled loop applies anyway
+    const bool col_pre = SCALED || e.col_scale != nullptr || (e.flags & BCOS_EPI_UNIT_NORM_W);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = col + q < Cout ? col + q : 0;
@@ -243,6 +254,13 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
         if (e.ch_scale) csc4[q] = e.ch_scale[c];
         if (e.ch_shift) csh4[q] = e.ch_shift[c];
         if (SCALED) cinv4[q] = p.wt2_cinv[c];
+        if (e.col_scale) cinv4[q] *= e.col_scale[c];
+    }
+    if (!SCALED && (e.flags & BCOS_EPI_UNIT_NORM_W)) {       // 1 / ||w_c|| gathered by the main loop (tile columns, local index)
+        const float* sCol = epi_col_table<BM, BN, WAVES_M>(smem);
+        const int lc = ((cq * 4) / HN) * WN + pn * HN + (cq * 4) % HN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cinv4[q] *= sCol[lc + q < BN ? lc + q : 0];
     }
     f32x4 mcsc4 = {1.f, 1.f, 1.f, 1.f}, mcsh4 = {0.f, 0.f, 0.f, 0.f};
     if (mul_from_act) {
@@ -310,6 +328,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                 if (pix < 0 || col >= Cout) continue;
                 f32x4 val = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
                 if (SCALED) val = val * sAinv[row] * cinv4;
+                else if (col_pre) val = val * cinv4;
                 val += bias4;
                 f32x4 tf = {0.f, 0.f, 0.f, 0.f};
                 for (int u0 = 0; u0 < 4; u0 += M_) {
@@ -338,6 +357,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                 idx[u] = (ok[u] ? pix : 0) * g.out_pitch + coladd;
                 v[u] = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
                 if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
+                else if (col_pre) v[u] = v[u] * cinv4;
                 rinv[u] = NORM ? sRinv[row] : 1.f;
                 nrm[u] = NORM ? sNorm[row] : 1.f;
                 ad[u] = in.ad[u];
@@ -414,6 +434,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                     const int64_t idx = pix * g.out_pitch + col + q;
                     float v = sC[lrow * LDC + cq * 4 + q];
                     if (SCALED) v = v * sAinv[row] * cinv4[q];
+                    else if (col_pre) v = v * cinv4[q];
                     v += bias4[q];
                     float s = 1.f;
                     if (NORM && !norm_only) {
@@ -895,6 +916,12 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
             rb[j] = v;
         }
     };
+    // BCOS_EPI_UNIT_NORM_W: sum of squares of every weight row of the tile, gathered from the staging registers the rows pass
+    // through anyway (the unit-norm projection of NormedConv2d / NormedLinear fused into the contraction, bcosconv2d.py:26-35)
+    const bool unit_w = (p.e.flags & BCOS_EPI_UNIT_NORM_W) != 0;
+    float colss[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) colss[j] = 0.f;
     auto store_step = [&](int buf) {
         float* sA = smem + buf * BUF;
         float* sB = sA + BM * LDS_LD;
@@ -902,8 +929,10 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
         for (int j = 0; j < A_LD; ++j)
             *reinterpret_cast<f32x4*>(sA + (r0 + 32 * j) * LDS_LD + chunk * 4) = ra[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j)
+        for (int j = 0; j < B_LD; ++j) {
             *reinterpret_cast<f32x4*>(sB + (r0 + 32 * j) * LDS_LD + chunk * 4) = rb[j];
+            if (unit_w) colss[j] = fmaf(rb[j][0], rb[j][0], fmaf(rb[j][1], rb[j][1], fmaf(rb[j][2], rb[j][2], fmaf(rb[j][3], rb[j][3], colss[j]))));
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -963,6 +992,15 @@ __device__ __forceinline__ void tile_body(const KArgs& p, float* smem, const int
         __syncthreads();
     }
 
+    if (unit_w) {        // 1 / ||w_c|| of the tile's columns: the 8 chunk lanes of a staging row meet, one value per column
+        float* sCol = epi_col_table<BM, BN, WAVES_M>(smem);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            float t = colss[j];
+            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+            if (chunk == 0) sCol[r0 + 32 * j] = 1.0f / sqrtf(t);
+        }
+    }
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, acc, ss, nullptr, nullptr, m0, n0, tile_n);
 }
 
@@ -1117,6 +1155,10 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     float rowss[BM / 32];            // only the first A_LD entries are used (tile_epilogue reads them in staging layout)
 #pragma unroll
     for (int j = 0; j < BM / 32; ++j) rowss[j] = 0.f;
+    const bool unit_w = !PRE && (p.e.flags & BCOS_EPI_UNIT_NORM_W) != 0;      // see tile_body
+    float colss[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) colss[j] = 0.f;
     auto store_step = [&](const f32x4 (&ra)[A_LD], const f32x4 (&rb)[B_LD], int buf) {
         char* base = lds + buf * BUF;
 #pragma unroll
@@ -1132,8 +1174,10 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
         if (!PRE)
 #pragma unroll
         for (int j = 0; j < B_LD; ++j)
-            if (!B_HALF || r0 < BN)
+            if (!B_HALF || r0 < BN) {
                 split_store(rb[j], base + B_BASE + (r0 + 64 * j) * X3_ROW + ((chunk * 8) ^ (((r0 >> 3) & 1) << 4)), B_SPLIT);
+                if (unit_w) colss[j] = fmaf(rb[j][0], rb[j][0], fmaf(rb[j][1], rb[j][1], fmaf(rb[j][2], rb[j][2], fmaf(rb[j][3], rb[j][3], colss[j]))));
+            }
     };
 
     f32x16 acc[TM][TN];
@@ -1230,6 +1274,15 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
     if (ks < nk) tail_step(ks, ra1, rb1, ra0, rb0, bf0, bf1);
     if (ks + 1 < nk) tail_step(ks + 1, ra0, rb0, ra1, rb1, bf1, bf0);
     if (ks + 2 < nk) tail_step(ks + 2, ra1, rb1, ra0, rb0, bf0, bf1);
+    if (unit_w) {
+        float* sCol = epi_col_table<BM, BN, WAVES_M>(smem);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            float t = colss[j];
+            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2);
+            if (chunk == 0 && (!B_HALF || r0 < BN)) sCol[r0 + 64 * j] = 1.0f / sqrtf(t);
+        }
+    }
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, false>(p, smem, acc, nullptr, NORM ? rowss : nullptr, nullptr, m0, n0, tile_n);
 }
 
@@ -2198,7 +2251,7 @@ template <int BM, int BN, int WAVES_M>
 constexpr size_t epilogue_lds() {
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
     constexpr int SBM = BM / PM, SBN = BN == 192 ? 64 : (BN > 128 ? 128 : BN);
-    return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20;
+    return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20 + (size_t)BN * 4;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -2585,7 +2638,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         if ((epi->max_out != 2 && epi->max_out != 4) || g.Cout % 4 != 0)
             return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: fused MaxOut needs max_out in {2, 4} and Cout % 4 == 0");
         if (epi->addend || epi->mul || epi->mul2 || epi->gate2 || epi->relu_gate || epi->out2 || epi->ch_scale || epi->ch_shift ||
-            epi->relu || epi->out_absmax || epi->out2_absmax || (epi->flags & ~(BCOS_EPI_FORCE_POW)))
+            epi->relu || epi->out_absmax || epi->out2_absmax || (epi->flags & ~(BCOS_EPI_FORCE_POW | BCOS_EPI_UNIT_NORM_W)))
             return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: fused MaxOut supports bias, the B-cos scale, out, scale_out and norm_out only");
         if ((reinterpret_cast<uintptr_t>(epi->scale_out) & 15))
             return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: scale_out must be 16-byte aligned");
@@ -2678,14 +2731,15 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         p.wt_bytes = (unsigned)(wt_bytes < lim ? wt_bytes : 0);
         const int64_t w3b = split_bytes(G * g.Cout, p.Ktot);
         // (grouped launches index the image by global weight row: a group's rows must start on a 32-row fragment tile)
-        p.wt3 = (p.x3 && wt3 && w3b < lim && !(reinterpret_cast<uintptr_t>(wt3) & 15) && (G == 1 || g.Cout % 32 == 0)) ? wt3 : nullptr;
+        const bool unit_w = (epi->flags & BCOS_EPI_UNIT_NORM_W) != 0;     // norms come from the fp32 weight rows in the staging registers
+        p.wt3 = (p.x3 && !unit_w && wt3 && w3b < lim && !(reinterpret_cast<uintptr_t>(wt3) & 15) && (G == 1 || g.Cout % 32 == 0)) ? wt3 : nullptr;
         p.wt3_bytes = (unsigned)(w3b < lim ? w3b : 0);
         const int64_t w2b = h2_image_bytes(g.Cout, p.Ktot), pixb = (int64_t)g.N * g.H * g.W * 4;
         // below K = 256 a launch is HBM-bound and the bf16x3 loop (no operand maxima to produce) is as fast, unless the caller
         // insists on f16x2; at K = 256 the six bf16 products still occupy a third of the SIMD cycles (14^2 layers of ResNet-50:
         // -12 % per launch with three f16 products).  The stem's K is all taps over 8 channels: compute-bound at any K.
         const bool h2_pays = p.Ktot >= 256 || (g.C <= 16 && p.Ktot >= 128) || ops->contraction == BCOS_CONTRACT_F16X2;
-        if (mode == 2 && G == 1 && h2_pays && p.x3 && ops->a_absmax && ops->wt_f16x2 && w2b < lim && pixb < lim &&
+        if (mode == 2 && G == 1 && h2_pays && !unit_w && p.x3 && ops->a_absmax && ops->wt_f16x2 && w2b < lim && pixb < lim &&
             !(reinterpret_cast<uintptr_t>(ops->wt_f16x2) & 15)) {
             p.h2 = 1;
             p.a_absmax = ops->a_absmax;
@@ -2710,7 +2764,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         const int64_t obytes = (int64_t)g.N * g.OH * g.OW * p.g.out_pitch * 4;
         const bool norm_l = e.bcos_mode != BCOS_NONE;
         const bool off = getenv("BCOS_EPI_GENERIC") != nullptr;                 // development / test switch (read per call)
-        bool ok = !off && p.vec_ok && g.Cout % 4 == 0 && obytes < ((int64_t)1 << 31) && e.max_out <= 1 && e.out != nullptr &&
+        bool ok = !off && p.vec_ok && g.Cout % 4 == 0 && obytes < ((int64_t)1 << 31) && e.max_out <= 1 && e.out != nullptr && !e.col_scale && !(e.flags & BCOS_EPI_UNIT_NORM_W) &&
                   !e.gate2 && !e.relu_gate && !(e.flags & (BCOS_EPI_NORM_ONLY | BCOS_EPI_FORCE_POW)) &&
                   ((reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.ch_scale) | reinterpret_cast<uintptr_t>(e.ch_shift)) & 15) == 0;
         int ef = 0;

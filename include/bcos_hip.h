@@ -99,6 +99,9 @@ typedef struct bcos_tapconv_geom {
  * channel c, idx = pix*out_pitch + c).  NULL pointers / zero flags switch a stage off.
  * Stages run in this order:
  *     v = acc
+ *     v *= col_scale[c]                              unit-norm projection of NormedConv2d / NormedLinear folded into the contraction:
+ *                                                    conv(x, w / ||w||) = conv(x, w) / ||w_c|| per output channel (bcosconv2d.py:26-35,
+ *                                                    bcoslinear.py:25-27); col_scale from bcos_weight_row_invnorm (ABI v5)
  *     v += bias[c]                                   nn.Conv2d bias (bcosifyconv2d.py:18-31)
  *     s = bcos_scale(v, norm[m]); v *= s             B-cos transform (bcos_mode, b)
  *     v *= ch_scale[c]; s *= ch_scale[c]             BatchNormUncentered2d eval: weight/sqrt(var+eps)
@@ -136,6 +139,7 @@ typedef struct bcos_epilogue {
     const float* mul_norm;  /* BCOS_EPI_MUL_FROM_ACT: patch norms [N*OH*OW] of the layer whose activation `mul` holds */
     const float* mul_csc;   /* ... its ch_scale [Cout] (NULL = 1) */
     const float* mul_csh;   /* ... its ch_shift [Cout] (NULL = 0) */
+    const float* col_scale; /* NULL or [Cout] (grouped launches: [G Cout]): factor of every accumulator column, applied first (ABI v5) */
     int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
     int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */
@@ -172,6 +176,14 @@ typedef struct bcos_epilogue {
  * from mul_norm / mul_csc / mul_csh.  The forward launch of such a layer then writes out + norm_out only: one
  * output-sized HBM write less (the explanation pass reads `a` where it would have read t). */
 #define BCOS_EPI_MUL_FROM_ACT 16
+/* Unit-norm weight projection fused into the contraction (NormedConv2d / NormedLinear, bcos/modules/bcosconv2d.py:26-35,
+ * bcoslinear.py:25-27: w_hat = w / ||w||_2 per output unit, recomputed on every call): `wt` holds the RAW weights; the launch
+ * gathers sum_k w[c,k]^2 of its tile's weight rows from the staging registers they pass through and multiplies every
+ * accumulator column by 1 / ||w_c|| (times col_scale[c], the optional trainable `scale`) ahead of the other stages --
+ * conv(x, w / ||w||) = conv(x, w) / ||w_c||.  No projected weight tensor is written or read.  Runs on the fp32 / bf16x3 loops
+ * with on-the-fly operand splits (weights that change every step have no pre-split image); inference keeps a cached
+ * col_scale from bcos_weight_row_invnorm and the pre-split image of the raw weights instead.  (ABI v5) */
+#define BCOS_EPI_UNIT_NORM_W 32
 
 /* -- library -------------------------------------------------------------------------- */
 
@@ -303,6 +315,11 @@ int bcos_linear_dgrad(const float* gylin, const float* wT, float* gx,
  * projection (bcosconv2d.py:28-35, bcoslinear.py:25-27).  One wavefront per row. */
 int bcos_weight_rownorm_scale(const float* w, const float* gain, float* w_out,
                               int rows, int64_t cols, void* stream);
+
+/* inv[r] = gain[r] / ||w[r,:]||_2  (gain NULL = 1): the per-filter factor bcos_epilogue.col_scale takes when the unit-norm
+ * projection is folded into the contraction instead of being written out as a projected weight tensor (one read of w, `rows`
+ * floats written).  (ABI v5) */
+int bcos_weight_row_invnorm(const float* w, const float* gain, float* inv, int rows, int64_t cols, void* stream);
 
 /* out[i] = a[i] * b[i] */
 int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -15,7 +15,7 @@ from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
             ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
             b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None, max_out=1,
-            mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0):
+            mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0, col_scale=None):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
     g = dict(a_pitch=0, out_pitch=0, norm_pitch=0, out_cgroup=0, groups=0)
@@ -33,7 +33,8 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
                     bias=None if bias is None else bias[k * Cout:(k + 1) * Cout],
                     ch_scale=None if ch_scale is None else ch_scale[k * Cout:(k + 1) * Cout],
                     ch_shift=None if ch_shift is None else ch_shift[k * Cout:(k + 1) * Cout], addend=cols(addend, k), mul=cols(mul, k),
-                    mul2=cols(mul2, k), gate2=cols(gate2, k), relu_gate=cols(relu_gate, k), bcos_mode=bcos_mode, b=b, relu=relu, flags=flags)
+                    mul2=cols(mul2, k), gate2=cols(gate2, k), relu_gate=cols(relu_gate, k), bcos_mode=bcos_mode, b=b, relu=relu, flags=flags,
+                    col_scale=None if col_scale is None else col_scale[k * Cout:(k + 1) * Cout])
         return
     N, H, W, C = g["N"], g["H"], g["W"], g["C"]
     P, Q, TH, TW, Cout = g["P"], g["Q"], g["TH"], g["TW"], g["Cout"]
@@ -54,6 +55,10 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
             acc += torch.einsum("npqc,oc->npqo", patch, w[:, th, tw].double())
             ss += (patch * patch).sum(-1)
     v = acc
+    if flags & 32:        # BCOS_EPI_UNIT_NORM_W: every accumulator column divided by the norm of its (raw) weight row
+        v = v / w.reshape(Cout, -1).double().norm(dim=1)
+    if col_scale is not None:
+        v = v * col_scale.double()
     if bias is not None:
         v = v + bias.double()
     if max_out > 1:       # fused MaxOut (include/bcos_hip.h: bcos_epilogue.max_out): out narrow, scale_out at the winner

@@ -1502,3 +1502,75 @@ def test_clip_zeroshot_text_attribution_against_reference_golden(lib, golden_dir
     engine.detach(net_u)
     with torch.no_grad():
         assert rel(net_u(x[:1]), emb) <= 1e-4
+
+
+def test_unit_norm_projection_folded_into_the_contraction(lib):
+    """north_star: "fuse the unit-norm weight projection, the input . w_hat contraction and the |cos|^(B-1) scaling into one pass".
+    (1) C ABI: a launch on the RAW weights with BCOS_EPI_UNIT_NORM_W (norms gathered in the main loop) and one with a
+    col_scale from bcos_weight_row_invnorm both equal the launch on weights projected by bcos_weight_rownorm_scale -- conv
+    (ragged Cout, MaxOut, grouped) and linear, bf16x3 and fp32 loops.  (2) nn.Module path: a training step of native
+    BcosConv2d / BcosLinear (unit-norm filters, trainable `scale`) runs ONE forward launch per layer through
+    FoldedUnitNormFn; outputs and every gradient equal the separate-projection path (UnitNormFn)."""
+    import ctypes as C
+    from bcos_hip import ops
+    from bcos_hip import lib as blib
+    from bcos.modules import BcosConv2d, BcosLinear, _hipfn
+    g = torch.Generator().manual_seed(77)
+    L = blib.load()
+    for (N, H, Cin, Cout, k, st, pd, groups, mo) in [(2, 9, 16, 20, 3, 1, 1, 1, 1), (3, 8, 32, 136, 1, 1, 0, 1, 1), (2, 7, 12, 24, 3, 2, 1, 1, 2),
+                                                   (2, 8, 16, 32, 3, 1, 1, 2, 1)]:
+        x = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+        w = (torch.randn(Cout, k, k, Cin // groups, generator=g) * 0.3).to(DEV)
+        gain = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+        w_hat = ops.weight_rownorm_scale(w.view(Cout, -1), gain).view_as(w)
+        inv = torch.empty(Cout, device=DEV)
+        blib.check(L.bcos_weight_row_invnorm(C.c_void_p(w.data_ptr()), C.c_void_p(gain.data_ptr()), C.c_void_p(inv.data_ptr()), Cout,
+                                             w[0].numel(), None), "row_invnorm")
+        assert rel(inv, gain / w.view(Cout, -1).norm(dim=1)) <= 1e-6
+        geom = ops.fwd_geom(N, H, H, Cin // groups, Cout // groups, k, k, st, st, pd, pd)
+        if groups > 1:
+            geom.update(groups=groups, a_pitch=Cin, out_pitch=Cout, norm_pitch=groups)
+        Ho = geom["P"]
+        prev = blib.get_contraction_mode()
+        try:
+            for mode in ("bf16x3", "f32"):
+                blib.set_contraction_mode(mode)
+                outs = []
+                for variant in ("projected", "flag", "col_scale"):
+                    y = torch.full((N, Ho, Ho, Cout // mo), float("nan"), device=DEV)
+                    sc = torch.full((N, Ho, Ho, Cout), float("nan"), device=DEV)
+                    kw = dict(out=y, scale_out=sc, bcos_mode=blib.BCOS_CONV_EPS, b=2.0, max_out=mo, track_absmax=False)
+                    if variant == "projected":
+                        ops.tapconv(x, w_hat, geom, **kw)
+                    elif variant == "flag":
+                        ops.tapconv(x, w, geom, flags=blib.BCOS_EPI_UNIT_NORM_W, col_scale=gain, **kw)
+                    else:
+                        ops.tapconv(x, w, geom, col_scale=inv, **kw)
+                    outs.append((y, sc))
+                for y, sc in outs[1:]:
+                    assert rel(y, outs[0][0]) <= 2e-6 and rel(sc, outs[0][1]) <= 2e-6, (mode, N, H, Cin, Cout, k, groups, mo)
+        finally:
+            blib.set_contraction_mode(prev)
+    # nn.Module path, training step
+    torch.manual_seed(3)
+    for make, xs in ((lambda: BcosConv2d(16, 24, 3, padding=1, max_out=2), (4, 16, 10, 10)), (lambda: BcosConv2d(12, 20, 3, stride=2, padding=1), (3, 12, 9, 9)),
+                     (lambda: BcosLinear(48, 40), (5, 7, 48))):
+        m = make().to(DEV).train()
+        if hasattr(m.linear, "set_scale"):
+            m.linear.set_scale(m.linear.weight.detach() * 1.7, trainable=True)
+        x = torch.randn(*xs, generator=g).to(DEV)
+        res = {}
+        for fold in (True, False):
+            _hipfn.FOLD_UNIT_NORM = fold
+            try:
+                m.zero_grad()
+                xr = x.clone().requires_grad_(True)
+                y = m(xr)
+                y.square().sum().backward()
+                res[fold] = (y.detach(), xr.grad, m.linear.weight.grad.clone(),
+                             m.linear.scale.grad.clone() if getattr(m.linear, "scale", None) is not None else None)
+            finally:
+                _hipfn.FOLD_UNIT_NORM = True
+        for a, b_ in zip(res[True], res[False]):
+            if a is not None:
+                assert rel(a, b_) <= 1e-5, type(m).__name__

@@ -999,3 +999,35 @@ def test_zeroshot_text_attribution_oracle_and_engine_plan(monkeypatch, golden_di
     from bcos_hip.lib import BcosHipError
     with pytest.raises(BcosHipError):
         eng_u.explain(xs)                                                  # no class logits of its own
+
+
+def test_linear_b_schedule_hook_and_learnable_b_setup(monkeypatch):
+    """N4 remainder (bcos/training/hooks.py:7-35, trainer.py:447-474): `setup_b_parameters` turns every layer's exponent into a
+    parameter at b_at_start + 1e-6; with `linear_b` the gradient the layers compute for it is replaced by -batch_size until the
+    end value is reached (zero afterwards), and an exponent that fell below the start is put back."""
+    cpu_emulation.install(monkeypatch)
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.training import Hook, setup_b_parameters
+    torch.manual_seed(0)
+    net = nn.Sequential(BcosifyConv2d(8, 12, 3, padding=1, b=2), BcosifyConv2d(12, 8, 1, b=2))
+    assert setup_b_parameters(net, dict(fix_b=True)) == []
+    ps = setup_b_parameters(net, dict(fix_b=False, linear_b=True, b_at_start=1, b_at_end=1.5))
+    assert len(ps) == 2 and all(isinstance(m.b, nn.Parameter) and abs(float(m.b) - (1 + 1e-6)) < 1e-7 for m in net)
+    x = torch.randn(5, 8, 6, 6)
+    net(x).square().mean().backward()
+    assert all(float(m.b.grad) == -5.0 for m in net) and net[0].batch_size == 5          # the ramp: -batch_size
+    opt = torch.optim.SGD(ps, lr=0.05)
+    opt.step()                                                                           # b += lr * batch_size = 0.25
+    assert all(abs(float(m.b) - 1.25) < 1e-5 for m in net)
+    opt.zero_grad()
+    net(x).square().mean().backward()
+    opt.step()                                                                           # 1.5: the end value
+    opt.zero_grad()
+    net(x).square().mean().backward()
+    assert all(float(m.b.grad) == 0.0 for m in net)                                      # the ramp is over
+    with torch.no_grad():
+        net[0].b.fill_(0.5)
+    h = Hook(net[0], start=1, end=1.5)
+    net[0].batch_size = 3
+    g = h(torch.ones(()))
+    assert abs(float(net[0].b) - (1 + 1e-6)) < 1e-7 and float(g) == -3.0                 # put back on the ramp's first point
