@@ -74,6 +74,16 @@ int main(void) {
     EXPECT(bcos_conv2d_wgrad(buf, buf, buf, 1, 4, 4, 8, 6, 4, 4, 8, 0, 1, 1, 1, 1, 0, 0, 1, 1, 0, NULL), BCOS_E_INVAL);
     EXPECT(bcos_colsum(buf, NULL, NULL, NULL, buf, 4, 6, NULL), BCOS_E_INVAL);
     EXPECT(bcos_channel_axpby(buf, buf, buf, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);
+    /* ABI v5 entry points */
+    EXPECT(bcos_rows_normalize(NULL, buf, NULL, 4, 8, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_rows_normalize(buf, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);                       /* neither output */
+    EXPECT(bcos_cosine_grad(buf, buf, NULL, buf, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_weight_row_invnorm(buf, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_weight_row_invnorm(buf, NULL, buf, 0, 8, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_layernorm_fwd(NULL, NULL, NULL, buf, NULL, am, 4, 8, 1e-5f, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_layernorm_bwd_detached(buf, NULL, buf, NULL, NULL, buf, NULL, am, 4, 8, NULL), BCOS_E_INVAL);   /* maxima of an absent out2 */
+    EXPECT(bcos_attention_fwd(buf, NULL, NULL, am, 1, 4, 1, 64, 1.0f, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_attention_bwd_v(buf, buf, buf, buf, am, 1, 4, 1, 32, 1.0f, NULL), BCOS_E_NOSUP);               /* head dimension */
     free(buf); free(am);
     if (failures) { printf("%d failure(s)\n", failures); return 1; }
     printf("abi_validation: ok\n");
