@@ -1574,3 +1574,35 @@ def test_unit_norm_projection_folded_into_the_contraction(lib):
         for a, b_ in zip(res[True], res[False]):
             if a is not None:
                 assert rel(a, b_) <= 1e-5, type(m).__name__
+
+
+def test_rebuilt_multipliers_fall_back_to_stored_ones_for_large_bn_shifts(lib, golden_dir, monkeypatch):
+    """The multiplier of conv1 / conv2 of a block is rebuilt from the kept activation (BCOS_EPI_MUL_FROM_ACT) only while the BN
+    shift is small against the BN scale: where |bn_scale s lin| << |bn_shift| the rebuild's subtraction cancels.  A network
+    with BN biases 40x those of the synthetic recipe (the regime of real checkpoints) must take the stored multipliers --
+    bit-identical to BCOS_STORE_T -- and hold the usual bounds against the oracle; the unmodified network keeps rebuilding."""
+    from bcos_hip import engine, synth
+    import importlib
+    net, meta, data = _golden_net(golden_dir, "resnet18_e2e")
+    eng = engine.attach(net)
+    assert all(c.rebuild_ok for blk in eng.blocks for c in blk.convs[:-1])          # the recipe nulls every bias: no shift at all
+    gb = torch.Generator().manual_seed(9)
+    for m in net.modules():                                                         # a `use_bias` network: BN biases of a few units
+        if type(m).__name__ == "BatchNormUncentered2d":
+            m.bias = torch.nn.Parameter((torch.randn(m.num_features, generator=gb) * 3.0).to(DEV))
+    x = synth.synthetic_images(4, seed=meta["image_seed"]).to(DEV)
+    out = eng.explain(x)
+    assert not any(c.rebuild_ok for blk in eng.blocks for c in blk.convs[:-1])      # refreshed: large shifts -> stored multipliers
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, meta["arch"], detach=detach), x.cpu())
+    assert rel(out["logits"], ref["logits"]) <= 1e-4
+    pinned = eng.explain(x, gates=_oracle_gates(net, x, meta["arch"]))
+    assert rel(pinned["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
+    # forcing the rebuild on this network is what the fallback avoids: measurably further from the oracle
+    monkeypatch.setattr(engine, "_REBUILD_MAX_SHIFT", 1e30)
+    eng.refresh()
+    forced = eng.explain(x, gates=_oracle_gates(net, x, meta["arch"]))
+    e_forced = rel(forced["dynamic_linear_weights"], ref["dynamic_linear_weights"])
+    e_stored = rel(pinned["dynamic_linear_weights"], ref["dynamic_linear_weights"])
+    assert e_stored <= e_forced * 1.5 + 1e-7, (e_stored, e_forced)
+    print(f"rebuild at large BN shifts: W(x) relL2 vs oracle stored {e_stored:.2e}, rebuilt {e_forced:.2e}")
