@@ -120,6 +120,20 @@ class ViTEngine:
         if m.patch_size[0] != m.patch_size[1]:
             raise BcosHipError("vit engine: square patches only")
         self.embed_mod = m.to_patch_embedding.linear
+        # conv-stem models (vitc_*: bcos/models/vit.py:342-426): [B-cos conv 3x3 -> DetachableGroupNorm2d -> MyGELU] x 4 / 6 take
+        # the 224^2 image to a 14^2 map that is tokenised with patch size 1
+        self.stem = []
+        stem = getattr(m.to_patch_embedding, "conv_stem", None)
+        if stem is not None:
+            from bcos.modules.norms.centered_norms import DetachableGroupNorm2d
+            from .engine import _Conv
+            mods = list(stem.children())
+            if len(mods) % 3:
+                raise BcosHipError("vit engine: conv stem must be (conv, norm, activation) triples")
+            for conv, gn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
+                if not isinstance(gn, DetachableGroupNorm2d) or not isinstance(act, (MyGELU, nn.Identity)):
+                    raise BcosHipError(f"vit engine: unsupported conv-stem layer ({type(gn).__name__}, {type(act).__name__})")
+                self.stem.append(dict(conv=_Conv(conv, None), gn=gn, gelu=isinstance(act, MyGELU)))
         self.blocks = []
         for enc in m.transformer.children():
             act = enc.ff.net.act
@@ -164,11 +178,19 @@ class ViTEngine:
         w, bias = e._effective_weight_and_bias()
         p = self.patch
         dim = w.shape[0]
-        if w.shape[1] != p * p * 6:
-            raise BcosHipError("vit engine: patch embedding must take 6-channel patches")
-        w4 = torch.nn.functional.pad(w.detach().view(dim, p, p, 6), (0, 2))           # [dim, p, p, 8]
+        for layer in self.stem:
+            layer["conv"].refresh()
+            gn = layer["gn"]
+            layer.update(gw=gn.weight.detach().contiguous() if gn.weight is not None else None,
+                         gb=gn.bias.detach().contiguous() if gn.bias is not None else None, groups=gn.num_groups, eps=gn.eps)
+        cin = self.stem[-1]["conv"].cout if self.stem else 6          # channels of the tensor that is cut into patches
+        cpad = (cin + 3) & ~3 if self.stem else 8
+        if w.shape[1] != p * p * cin:
+            raise BcosHipError(f"vit engine: patch embedding must take {cin}-channel patches")
+        self.embed_cpad = cpad
+        w4 = torch.nn.functional.pad(w.detach().view(dim, p, p, cin), (0, cpad - cin))  # [dim, p, p, cpad]
         self.embed_w = ops.mark_static(w4.contiguous())                               # inference constants: pre-split images are kept
-        self.embed_wt = ops.mark_static(w4.reshape(dim, p * p * 8).t().contiguous())  # [p*p*8, dim]
+        self.embed_wt = ops.mark_static(w4.reshape(dim, p * p * cpad).t().contiguous())  # [p*p*cpad, dim]
         self.embed_bias = bias.detach().contiguous() if bias is not None else None
         self.embed_b = e._b_value()
         self.dim = dim
@@ -208,19 +230,30 @@ class ViTEngine:
         x = x if x.is_contiguous() else x.contiguous()
         N, _, H, W = x.shape
         p = self.patch
-        gh, gw = H // p, W // p
-        T = gh * gw
         mean, std = self._consts(x.device)
         add_inverse = x.shape[1] == 3
         xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse, want_absmax=_F16X2)     # K = 2048 patch embedding
-        # patch embedding = 16x16 / stride 16 B-cos conv with the linear layer's epsilon placement
-        geom = ops.fwd_geom(N, H, W, 8, self.dim, p, p, p, p, 0, 0)
+        stem_st = []
+        for layer in self.stem:          # conv stem: B-cos conv, GroupNorm (variance held constant in explanation mode), GELU gate
+            hw_in = (xn.shape[1], xn.shape[2])
+            y, t = layer["conv"].fwd(xn, relu=False, want_scale=keep, track=False)
+            yn, rstd = ops.groupnorm_fwd(y, layer["groups"], layer["gw"], layer["gb"], layer["eps"], want_rstd=keep)
+            gate = None
+            if layer["gelu"]:
+                yn, gate = ops.gelu_gate(yn, want_gate=keep, out=yn)
+            xn = _mx(yn) if layer is self.stem[-1] else ops.ensure_absmax(yn) if _F16X2 else yn
+            stem_st.append(dict(t=t, rstd=rstd, gate=gate, hw_in=hw_in))
+        H, W = xn.shape[1], xn.shape[2]
+        gh, gw = H // p, W // p
+        T = gh * gw
+        # patch embedding = p x p / stride p B-cos conv with the linear layer's epsilon placement
+        geom = ops.fwd_geom(N, H, W, self.embed_cpad, self.dim, p, p, p, p, 0, 0)
         tok = torch.empty((N * T, self.dim), device=x.device, dtype=torch.float32)
         t_embed = torch.empty_like(tok) if keep else None
         ops.tapconv(xn, self.embed_w, geom, out=tok, scale_out=t_embed, bias=self.embed_bias,
                     bcos_mode=BCOS_LINEAR_EPS if self.embed_b != 1.0 else 0, b=self.embed_b, track_absmax=False)
         ops.add_rows_bcast(tok, self._posemb(gh, gw, x.device))
-        st = dict(x=x, add_inverse=add_inverse, N=N, T=T, t_embed=t_embed, blocks=[]) if keep else None
+        st = dict(x=x, add_inverse=add_inverse, N=N, T=T, t_embed=t_embed, blocks=[], stem=stem_st, tok_hw=(H, W)) if keep else None
         cur = tok
         for blk in self.blocks:
             h, rstd1 = blk["ln1"].fwd(cur, keep)
@@ -290,10 +323,30 @@ class ViTEngine:
             t_prev = st["blocks"][bi - 1]["t2"] if bi > 0 else st["t_embed"]
             g_x, g_lin = blk["ln1"].bwd(g_h, rec["rstd1"], addend=g_x1, mul2=t_prev, want_out=bi > 0, want_out2=True)
             st["blocks"][bi] = None
-        gp = ops.matmul_nt(_mx(g_lin), self.embed_wt, track_absmax=False)      # [N*T, p*p*8] patch-major input gradient
+        gp = ops.matmul_nt(_mx(g_lin), self.embed_wt, track_absmax=False)      # [N*T, p*p*cpad] patch-major input gradient
         _, std = self._consts(x.device)
-        wts, contrib = ops.finalize_explanation_patches(gp, st["x"], std, self.patch, add_inverse=st["add_inverse"],
-                                                        want_weights=want_weights, want_contrib=True)
+        if self.stem:
+            # conv-stem models: patch size 1, so gp IS the NHWC gradient w.r.t. the stem's output; back through
+            # (GELU gate, GroupNorm with constant variance, B-cos scale, convolution) of every stem layer
+            if self.patch != 1:
+                raise BcosHipError("vit engine: conv stems are tokenised with patch size 1")
+            Hs, Ws = st["tok_hw"]
+            g = gp.view(N, Hs, Ws, -1)
+            for layer, rec in zip(reversed(self.stem), reversed(st["stem"])):
+                cout = layer["conv"].cout
+                g = g[..., :cout].contiguous() if g.shape[-1] != cout else g
+                if rec["gate"] is not None:
+                    g = ops.mul(g, rec["gate"])
+                g = ops.groupnorm_bwd_detached(g, layer["groups"], layer["gw"], rec["rstd"])
+                g = ops.mul(g, rec["t"]) if rec["t"] is not None else g
+                hi, wi = rec["hw_in"]
+                g = layer["conv"].dgrad.run(ops.ensure_absmax(g) if _F16X2 else g, hi, wi)
+            gxn = g if g.shape[-1] == 8 else torch.nn.functional.pad(g, (0, 8 - g.shape[-1]))
+            wts, contrib = ops.finalize_explanation(gxn.contiguous(), st["x"], std, add_inverse=st["add_inverse"],
+                                                    want_weights=want_weights, want_contrib=True)
+        else:
+            wts, contrib = ops.finalize_explanation_patches(gp, st["x"], std, self.patch, add_inverse=st["add_inverse"],
+                                                            want_weights=want_weights, want_contrib=True)
         return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
                     contribution_map=contrib)
 

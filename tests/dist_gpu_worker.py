@@ -174,12 +174,27 @@ def run_unpool(rank, world, n_global):
                 sharded_equals_unsharded=bool(torch.equal(gathered, full)), rel_vs_oracle=rel(gathered, ref))
 
 
+def run_percalib(rank, world, n_global):
+    """Every rank builds AND calibrates its own replica (no broadcast): do the replicas agree?  (They must in deployment; under
+    8-process time-slicing of one device about one process in a hundred was seen to end with different BatchNorm statistics,
+    DESIGN.md section 6 -- kept as a non-strict xfail so that a recurrence is recorded, not hidden by the broadcast.)"""
+    net = synth.build_bcosified_resnet("resnet50").to(DEV)
+    with torch.no_grad():
+        for _ in range(max(1, n_global)):
+            synth.calibrate(net, synth.synthetic_images(8).to(DEV))
+    digest = {k: (float(v.double().abs().sum()), float(v.double().sum())) for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    all_d = [None] * world
+    dist.all_gather_object(all_d, digest)
+    diff = [f"rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]
+    return dict(config="percalib", world=world, shard=[0, 0], replicas_identical=not diff, replica_diff=diff[:8])
+
+
 def main():
     config, n_global, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     rank, _, world = bdist.init(backend="gloo")
     torch.cuda.set_device(0)
     t0 = time.time()
-    verdict = {"r50": run_resnet50, "clip": run_clip, "unpool": run_unpool}[config](rank, world, n_global)
+    verdict = {"r50": run_resnet50, "clip": run_clip, "unpool": run_unpool, "percalib": run_percalib}[config](rank, world, n_global)
     verdict["seconds"] = round(time.time() - t0, 1)
     all_v = [None] * world
     dist.all_gather_object(all_v, verdict)

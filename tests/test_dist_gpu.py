@@ -68,6 +68,16 @@ def test_attn_unpool_outputs_gather_along_batch_dim(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="8 processes time-slicing ONE device: independently calibrated replicas were seen to differ "
+                                        "about once in a hundred processes (DESIGN.md section 6); not reproduced with torch alone "
+                                        "(scripts/probe/var_stress_torch_only.py: 0 of 960 000 reductions), so a stray write of this "
+                                        "repo's kernels is not excluded -- this test records recurrences instead of hiding them")
+def test_independently_calibrated_replicas_agree(tmp_path):
+    v = _launch("percalib", 3, tmp_path)          # 8 ranks x 3 calibration passes each, no parameter broadcast
+    assert v["replicas_identical"], json.dumps(v)
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_self_launched():
     """`python bench.py --gpus 2 ...` as the driver types it for N = 1 (no torchrun around it): the parent starts the two ranks
     as a child process group before touching the GPU, the ranks exchange rank 0's parameters + digests, run the step with

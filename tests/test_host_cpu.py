@@ -462,6 +462,16 @@ def run_vitc_goldens(golden_dir, dev, tol):
     assert np.array_equal(out["prediction"].cpu().numpy(), data["prediction"])
     assert rel(out["contribution_map"], data["contribution_map"]) <= 1e-4
     assert rel(out["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
+    # the fused whole-network plan covers the conv stem too (round 3): same outputs through bcos_hip.vit_engine
+    from bcos_hip import vit_engine
+    eng = vit_engine.attach(net)
+    assert len(eng.stem) == 4 and eng.patch == 1
+    fused = eng.explain(x)
+    assert rel(fused["logits"], data["logits"]) <= 1e-4
+    assert np.array_equal(fused["prediction"].cpu().numpy(), data["prediction"])
+    assert rel(fused["contribution_map"], data["contribution_map"]) <= 1e-4
+    assert rel(fused["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
+    assert rel(eng.forward(x), data["logits"]) <= 1e-4
 
 
 def run_vit_training_goldens(golden_dir, dev, tol):
