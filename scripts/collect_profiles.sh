@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash scripts/collect_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash scripts/collect_profiles.sh r03'
 # Writes gpurun_out/prof_<tag>/{stats,fetch,write,...}/ and gpurun_out/profiles_<tag>/ (the summaries to copy into profiles/).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -31,4 +31,41 @@ for spec in "resnet50 --forward-only" "resnet18" "vit_ti --batch 512" "vit_ti --
   f=$(find "$OUT/stats_${name}" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$SUM/${TAG}_kernel_stats_${name}.csv"
 done
+# 5. SQ counters of three representative contraction launches (one counter group per pass): A = GEMM-shaped 3x3-class launch
+#    M = 50176, K = 2304, N = 256; B = forward 64 -> 256 @56^2 (residual + ReLU + stored multiplier); C = forward 256 -> 1024 @14^2
+{
+  echo "SQ counters of three representative tapconv launches (scripts/_pmc.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass;"
+  echo "counters other than SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE are in units of 4 cycles).  derived: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES /"
+  echo "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"
+  echo "== A 3x3-class K=2304 (M=50176, N=256, 128x256 tiles, split-f16 loop with LDS-DMA staging)"
+  MKN=50176,2304,256 bash scripts/_pmc.sh ${TAG}pmcA 2>/dev/null
+  echo "== B fwd 64->256 @56^2 (residual + ReLU + stored multiplier)"
+  PMC_SCRIPT=pmc_fwd.py CIN=64 COUT=256 HH=56 bash scripts/_pmc.sh ${TAG}pmcB 2>/dev/null
+  echo "== C fwd 256->1024 @14^2"
+  PMC_SCRIPT=pmc_fwd.py CIN=256 COUT=1024 HH=14 bash scripts/_pmc.sh ${TAG}pmcC 2>/dev/null
+} > "$SUM/${TAG}_pmc_raw.txt"
+cd "$ROOT"
+python3 - "$SUM/${TAG}_pmc_raw.txt" > "$SUM/${TAG}_pmc_summary.txt" <<'PY'
+import sys
+txt = open(sys.argv[1]).read()
+print(txt.rstrip())
+blocks = txt.split("== ")[1:]
+print()
+for b in blocks:
+    lines = b.strip().splitlines()
+    vals = {}
+    for ln in lines[1:]:
+        p = ln.split()
+        if len(p) == 2:
+            try: vals[p[0]] = float(p[1])
+            except ValueError: pass
+    durs = [float(ln.split()[1]) for ln in lines if ln.startswith("dur_us")]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
+        busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * vals["GRBM_GUI_ACTIVE"] / 8)
+        wc = vals.get("SQ_WAVE_CYCLES", 0) or 1
+        print(f"derived [{lines[0][:40]}]: MFMA busy {100 * busy:.1f} % of SIMD cycles; duration under the profiler {min(durs) if durs else float('nan'):.1f} us; "
+              f"wave cycles: issuing {100 * vals.get('SQ_ACTIVE_INST_ANY', 0) / wc:.1f} % / issue-stalled {100 * vals.get('SQ_WAIT_INST_ANY', 0) / wc:.1f} % / "
+              f"waiting on a counter or barrier {100 * vals.get('SQ_WAIT_ANY', 0) / wc:.1f} %; VALU {vals.get('SQ_INSTS_VALU', 0):.0f} SALU {vals.get('SQ_INSTS_SALU', 0):.0f} "
+              f"MFMA {vals.get('SQ_INSTS_MFMA', 0):.0f} LDS {vals.get('SQ_INSTS_LDS', 0):.0f} VMEM {vals.get('SQ_INSTS_VMEM', 0):.0f} instructions")
+PY
 ls -la "$SUM"
