@@ -635,12 +635,13 @@ def prep_input(x_nchw, mean6, std6, cpad=8, add_inverse=False, want_absmax=False
     return out
 
 
-def finalize_explanation(gxn, x_nchw, std6, add_inverse=False, want_weights=True, want_contrib=True):
+def finalize_explanation(gxn, x_nchw, std6, add_inverse=False, want_weights=True, want_contrib=True, weights_out=None, contrib_out=None):
+    """`weights_out` / `contrib_out`: write into these [N,6,H,W] / [N,H,W] tensors (slices of a larger batch) instead of new ones."""
     lib = _l.load()
     N, H, W, cpad = gxn.shape
     Cx = x_nchw.shape[1]
-    wout = torch.empty((N, 6, H, W), device=gxn.device, dtype=torch.float32) if want_weights else None
-    cout = torch.empty((N, H, W), device=gxn.device, dtype=torch.float32) if want_contrib else None
+    wout = (weights_out if weights_out is not None else torch.empty((N, 6, H, W), device=gxn.device, dtype=torch.float32)) if want_weights else None
+    cout = (contrib_out if contrib_out is not None else torch.empty((N, H, W), device=gxn.device, dtype=torch.float32)) if want_contrib else None
     _l.check(lib.bcos_finalize_explanation(_dev(gxn, "gxn"), _dev(x_nchw, "x"), _dev(std6, "std"), _dev(wout, "w"),
                                            _dev(cout, "c"), N, Cx, H, W, cpad, int(add_inverse), _stream()),
              "bcos_finalize_explanation")

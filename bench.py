@@ -13,7 +13,7 @@ Besides the contract fields the JSON line carries
   roofline      fp32-MFMA roofline of the dominant kernel family (tapconv_kernel): algorithmic FLOP of the B-cos
                 contractions of one step (17.22 GFLOP/image) / the time spent in those launches,
                 measured live with HIP events on the launch stream inside the timed region (around every contraction
-                launch of every 5th timed step: on every step the 240 events cost 0.9 ms = 2 % of the step);
+                launch of every 10th timed step, which runs on ONE stream so that an event pair times its own launch only);
   cpu_baseline  the CPU oracle (the PyTorch-CPU restatement of the reference's path) timed on this host's cores on
                 a bounded sample (rank 0, N = 1 only).
 """
@@ -265,16 +265,21 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP events on the launch stream around every contraction launch of a SAMPLE of the timed steps (every 5th: the
+    # HIP events on the launch stream around every contraction launch of a SAMPLE of the timed steps (every 10th: the
     # two events per launch cost ~7 us of stream time each, 0.9 ms per step if taken on every step)
-    EVENT_STRIDE = 5
+    EVENT_STRIDE = 10
     event_steps = [] if args.no_kernel_events else [i for i in range(args.steps) if i % EVENT_STRIDE == 0]
     events = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i in event_steps:
+            # the steps that carry the per-launch HIP events run their launches on ONE stream: with the engine's two sub-batch
+            # streams (bcos_hip/engine.py: _SUBBATCH_STREAMS) launches overlap and an event pair would time its neighbour too
             ops.KERNEL_TIMING = []
+            sub = getattr(eng, "subbatch_streams", 1)
+            eng.subbatch_streams = 1
             step(eager=True)
+            eng.subbatch_streams = sub
             events += ops.KERNEL_TIMING
             ops.KERNEL_TIMING = None
         else:
@@ -376,6 +381,7 @@ def main():
                                f"batch {args.batch} per GPU, 224x224x6 (AddInverse), calibrated random-init weights",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "contraction": contraction,
                    "launch": "hipGraph replay (event-carrying steps eager)" if captured is not None else "eager",
+                   "sub_batch_streams": int(getattr(eng, "subbatch_streams", 1)),
                    "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                    "backend": dist.get_backend() if dist.is_initialized() else "none",
                    "replicas_identical": (not replica_diff) if world > 1 else None,

@@ -174,11 +174,16 @@ def prep_input(x, mean6, std6, cpad=8, add_inverse=False, want_absmax=False):
     return F.pad(xn.permute(0, 2, 3, 1), (0, cpad - 6)).contiguous()
 
 
-def finalize_explanation(gxn, x, std6, add_inverse=False, want_weights=True, want_contrib=True):
+def finalize_explanation(gxn, x, std6, add_inverse=False, want_weights=True, want_contrib=True, weights_out=None, contrib_out=None):
     if add_inverse:
         x = torch.cat([x, 1 - x], 1)
     w = gxn[..., :6].permute(0, 3, 1, 2) / std6.view(1, 6, 1, 1)
-    return (w.contiguous() if want_weights else None), ((x * w).sum(1) if want_contrib else None)
+    wo, co = (w.contiguous() if want_weights else None), ((x * w).sum(1) if want_contrib else None)
+    if weights_out is not None and wo is not None:
+        wo = weights_out.copy_(wo)
+    if contrib_out is not None and co is not None:
+        co = contrib_out.copy_(co)
+    return wo, co
 
 
 def avgpool2d_fwd(x, k, s, p, out=None):
