@@ -158,6 +158,8 @@ class ViTEngine:
         self.logit_bias = ll.logit_bias if ll is not None else None
         self.logit_temperature = ll.logit_temperature if ll is not None else None
         self._absmax_arena = ops.AbsmaxArena()      # row maxima of one pass: one zero fill instead of one per tensor
+        from .engine import _SUBBATCH_STREAMS
+        self.subbatch_streams, self._side = _SUBBATCH_STREAMS, None
         self.refresh()
 
     def _fingerprint(self):
@@ -283,15 +285,55 @@ class ViTEngine:
             st.update(rstd_h=rstd_h, t_head=t_head)
         return logits, st
 
+    def _sub_batches(self, x, fn):
+        """Run fn(sub_batch_index, lo, hi, arena) for contiguous sub-batches on side streams (bcos_hip/engine.py: _SUBBATCH_STREAMS:
+        images are independent, the sub-batches fill each other's launch tails) or once on the caller's stream."""
+        from .engine import _SUBBATCH_MIN
+        S = int(self.subbatch_streams)
+        N = x.shape[0]
+        if S <= 1 or not x.is_cuda or N < S * _SUBBATCH_MIN or torch.cuda.is_current_stream_capturing():
+            return [fn(0, N, self._absmax_arena)]
+        if self._side is None or len(self._side[0]) < S:
+            self._side = ([torch.cuda.Stream() for _ in range(S)], [ops.AbsmaxArena() for _ in range(S)])
+        streams, arenas = self._side
+        cur = torch.cuda.current_stream()
+        outs = []
+        for i in range(S):
+            streams[i].wait_stream(cur)
+            with torch.cuda.stream(streams[i]):
+                outs.append(fn((N * i) // S, (N * (i + 1)) // S, arenas[i]))
+        for st in streams[:S]:
+            cur.wait_stream(st)
+        for o in outs:
+            for t in (o.values() if isinstance(o, dict) else [o]):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+        return outs
+
     @torch.no_grad()
     def forward(self, x):
-        with _absmax_policy(), ops.absmax_arena(self._absmax_arena, x.device):
-            return self._run_forward(x, keep=False)[0]
+        x = x.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+
+        def one(lo, hi, arena):
+            with _absmax_policy(), ops.absmax_arena(arena, x.device):
+                return self._run_forward(x[lo:hi], keep=False)[0]
+        outs = self._sub_batches(x, one)
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
 
     @torch.no_grad()
     def explain(self, x, targets: Optional[torch.Tensor] = None, want_weights: bool = True) -> Dict[str, torch.Tensor]:
-        with _absmax_policy(), ops.absmax_arena(self._absmax_arena, x.device):
-            return self._explain(x, targets, want_weights)
+        x = x.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        tg = None if targets is None else targets.to(device=x.device, dtype=torch.int64).contiguous()
+
+        def one(lo, hi, arena):
+            with _absmax_policy(), ops.absmax_arena(arena, x.device):
+                return self._explain(x[lo:hi], None if tg is None else tg[lo:hi], want_weights)
+        outs = self._sub_batches(x, one)
+        if len(outs) == 1:
+            return outs[0]
+        return {k: (torch.cat([o[k] for o in outs]) if outs[0][k] is not None else None) for k in outs[0]}
 
     def _explain(self, x, targets, want_weights):
         logits, st = self._run_forward(x, keep=True)
