@@ -28,8 +28,8 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 BCOS_EPI_UNIT_NORM_W = 32
-ABI_VERSION = 5
-TAPCONV_PARTS = 9
+ABI_VERSION = 6
+TAPCONV_PARTS = 11
 
 
 class BcosHipError(RuntimeError):
@@ -52,7 +52,7 @@ class Epilogue(C.Structure):
 
 class Operands(C.Structure):
     _fields_ = [("a", C.c_void_p), ("a_absmax", C.c_void_p), ("wt", C.c_void_p), ("wt_bf16x3", C.c_void_p),
-                ("wt_f16x2", C.c_void_p), ("contraction", C.c_int32)]
+                ("wt_f16x2", C.c_void_p), ("contraction", C.c_int32), ("a_imgmax", C.c_void_p)]
 
 
 CONTRACT_DEFAULT, CONTRACT_F32, CONTRACT_BF16X3, CONTRACT_F16X2 = 0, 1, 2, 3
@@ -66,6 +66,7 @@ SIGNATURES = {
     "bcos_get_contraction_mode": (C.c_int, []),
     "bcos_tapconv": (C.c_int, [_P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
     "bcos_tapconv_ops": (C.c_int, [C.POINTER(Operands), C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
+    "bcos_image_absmax": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights_f16x2": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_conv": (C.c_int, [_P, _P, _I, _I, _I, _P]),

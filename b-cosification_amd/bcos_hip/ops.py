@@ -98,6 +98,10 @@ def _image_of(wt: torch.Tensor, attr: str, make):
     if cached is None or cached[0] != wt._version:
         cached = (wt._version, make(wt))
         setattr(wt, attr, cached)
+        # The image is made on the CURRENT stream and cached for every later launch, whichever stream that one runs on (the
+        # engines process sub-batches on side streams): complete it before anyone else can pick it up.  Once per weight tensor.
+        if wt.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(wt.device).synchronize()
     return cached[1]
 
 
@@ -196,6 +200,21 @@ def absmax_of(t: torch.Tensor) -> Optional[torch.Tensor]:
     return rec[0]
 
 
+PATCH_LOOP = os.environ.get("BCOS_PATCH", "1") != "0"     # development / test switch: 3 x 3 launches keep the per-tap loops
+
+
+def image_absmax(am: torch.Tensor, n_images: int, pixels_per_image: int) -> torch.Tensor:
+    """Per-image maxima [N] of a per-pixel maxima tensor (include/bcos_hip.h: bcos_image_absmax), cached on it: the maxima of a
+    tensor are complete once its producer has been enqueued, and a fresh side tensor is attached whenever the tensor is rewritten."""
+    rec = getattr(am, "_bcos_imgmax", None)
+    if rec is not None and rec[1] == (n_images, pixels_per_image):
+        return rec[0]
+    out = torch.empty(n_images, device=am.device, dtype=torch.int32)
+    _l.check(_l.load().bcos_image_absmax(am.data_ptr(), out.data_ptr(), n_images, pixels_per_image, _stream()), "bcos_image_absmax")
+    am._bcos_imgmax = (out, (n_images, pixels_per_image))
+    return out
+
+
 def drop_absmax(t: torch.Tensor):
     if hasattr(t, "_bcos_absmax"):
         del t._bcos_absmax
@@ -281,6 +300,13 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
                 and (ktot >= F16X2_MIN_K or (int(g.C) <= 16 and ktot >= 128) or contraction == "f16x2")):
             o.a_absmax = am_a.data_ptr()
             taps = int(g.TH) * int(g.TW)               # the image is stored in the K order of a launch with this tap count
+            if (PATCH_LOOP and int(g.TH) == 3 and int(g.TW) == 3 and int(g.in_sh) == 1 and int(g.in_sw) == 1 and int(g.dstep_h) == 1
+                    and int(g.dstep_w) == 1 and int(g.C) % 16 == 0 and int(g.Cout) > 32 and int(g.groups) <= 1):
+                # 3 x 3 launches contract over an LDS-resident input patch with one operand scale per image (include/bcos_hip.h:
+                # bcos_operands.a_imgmax): the per-image maxima, once per tensor
+                im = image_absmax(am_a, int(g.N), int(g.H) * int(g.W))
+                o.a_imgmax = im.data_ptr()
+                keep.append(im)
             o.wt_f16x2 = _image_of(wt, f"_bcos_wt2_t{taps}", lambda w: split_weights_f16x2(w, taps)).data_ptr()
         elif static:
             o.wt_bf16x3 = _image_of(wt, "_bcos_wt3", split_weights).data_ptr()
@@ -447,6 +473,8 @@ class DgradPlan:
             base = (rh * sw + rw) * pitch
             wc[base:base + self.Cin, h0 - dh0:h0 - dh0 + th, w0 - dw0:w0 - dw0 + tw] = wt
         mark_static(wc)
+        if wc.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(wc.device).synchronize()      # cached for launches on other streams too (see _image_of)
         self._d2s[pitch] = (wc, TH, TW, dh0, dw0)
         return self._d2s[pitch]
 

@@ -66,6 +66,7 @@ struct KArgs {
     unsigned a_bytes, wt_bytes;   // operand sizes for the buffer descriptors of the split-bf16 path (< 2 GiB there)
     const unsigned* a_absmax;     // split-f16 path: per-pixel max |A| bit patterns (the operand scale source)
     unsigned absmax_bytes;
+    const unsigned* a_imgmax;     // ... per-image maxima of those (input-patch loop, tile_body_p), else NULL
     const void* wt2;              // split-f16 path: pre-split, pre-scaled weights in MFMA fragment order (bcos_split_weights_f16x2)
     unsigned wt2_bytes;
     const float* wt2_cinv;        // ... their inverse column scales [padded Cout]
@@ -2159,6 +2160,338 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, NORM ? ss : nullptr, nullptr, a_inv, m0, n0, tile_n);
 }
 
+// ---- split-f16 contraction over an LDS-RESIDENT INPUT PATCH (round 3, multi-tap launches) --------------------------------------
+// tile_body_d moves and converts every input element once per TAP (9 x for a 3 x 3 layer, 16 x for the depth-to-space stem
+// gradient): the fp32 -> (h, l) split and the A traffic into LDS are what its narrow multi-tap launches wait on.  Here the
+// K walk is the same (16-channel chunk major, tap inner) but the A operand of a chunk is the tile's input PATCH: the union of the
+// pixels its BM rows touch over all taps, laid out as rows of a virtually zero-padded image (PW = (Q - 1) s + TW pixels per
+// row, HP = (P - 1) s + TH rows per image), loaded and split ONCE per chunk -- global -> registers -> (h, l) f16 -> LDS, NI items
+// of (pixel, 8 channels) per thread, issued a chunk ahead -- and then read as MFMA fragments by every tap: row r, tap (th, tw)
+// is patch pixel base[r] + th PW + tw.  Halo pixels are zeros in the patch, so no tap needs a bounds check.
+//   * LDS: four planes [h | l] x [k-half] of 16 bytes per pixel (a fragment read is one conflict-free ds_read_b128 per plane:
+//     consecutive rows are consecutive pixels), single-buffered (one extra barrier per chunk), + a ring of three B slots fed by
+//     LDS-DMA exactly as in tile_body_d (one raw barrier + one counted vmcnt per step).
+//   * no per-step A traffic, no per-step vector work: the waves are free to be laid out 2 x 2 (a 64 x 128 wave tile reads
+//     12 fragments for 24 matrix instructions; tile_body_d's 32 x 256 wave tiles read 18).
+//   * operand scale: ONE power of two per IMAGE (max over the image's per-pixel maxima), not per row -- a pixel serves rows
+//     with different tap sets, and a per-tile scale would make an image's bits depend on its batch neighbours.  Elements
+//     within 2^-17 of their image's max keep the full 22 bits, smaller ones an absolute error <= 2^-40 of that max.  Same
+//     product order per accumulator (l_a h_b, h_a l_b, h_a h_b) and the same K walk as the other split-f16 loops; results agree
+//     with them to fp32 rounding, not bit for bit (different scale, patch norm summed per pixel then per tap).
+#ifndef P_KO
+#define P_KO 0                    // development knock-outs (timing only, wrong results): 1 no patch refill, 2 no B DMA in the steady loop, 4 one barrier per chunk only, 8 no fragment reads after the first step, 16 first product only, 32 no vmcnt waits, 64 no image maxima
+#endif
+#ifndef P_NSLOT
+#define P_NSLOT 3                 // B ring slots: 3 = the DMA of step ks + 2 is issued in step ks (two steps to land), 2 = of step ks + 1 (one step)
+#endif
+#ifndef P_DBUF
+#define P_DBUF 0                  // 1 = two patch buffers: the refill of chunk c + 1 is written during chunk c, no barrier at the end of a chunk
+#endif
+#ifndef P_OPT
+#define P_OPT 3                   // development switches: 1 = DMA issue behind the fragment reads (else ahead of them), 2 = refill converted at tap 3 (else at the end of the chunk)
+#endif
+template <int BM, int BN, int PXL>
+constexpr size_t p_lds_bytes() { return (size_t)PXL * 64 * (1 + P_DBUF) + P_NSLOT * (size_t)(BN / 32) * 2048 + 1024 + (size_t)BM * 8 + 128; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int NT = NTHREADS>
+__device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NW = NT / 64;
+    static_assert(WAVES_M * WAVES_N == NW && BM % (NT / 4) == 0, "wave layout");
+    constexpr int PX = PXL;                         // physical pixels the patch buffer holds (PR rows of a power-of-two pitch); the NI items
+                                                    // per thread cover the PR x PW pixels that are used
+    constexpr int PLANE = PX * 16;                  // bytes of one (split half, k-half) plane
+    constexpr int NBLK = (BN / 32) * 2;             // 1-KB fragment blocks of B per step: (32-column tile, plane)
+    constexpr int LB = (NBLK + NW - 1) / NW;        // B DMA instructions per wave per step
+    constexpr int BSLOT = (BN / 32) * 2048;
+    constexpr int NP = 2 * NI;                      // global loads per thread per patch refill
+    constexpr unsigned OOB = 0x80000000u;
+    char* lds = reinterpret_cast<char*>(smem);
+    char* ring = lds + 4 * PLANE * (1 + P_DBUF);
+    char* s_dummy = ring + P_NSLOT * BSLOT;
+    int* s_base = reinterpret_cast<int*>(s_dummy + 1024);                 // [BM] (patch row << 16) | rotated column of the row's tap (0, 0)
+    float* s_rowinv = reinterpret_cast<float*>(s_base + BM);             // [BM] inverse operand scale of the row (its image's)
+    unsigned* s_imgmax = reinterpret_cast<unsigned*>(s_rowinv + BM);     // [16]
+    float* s_imgscale = reinterpret_cast<float*>(s_imgmax + 16);         // [16]
+    float* s_pixss = reinterpret_cast<float*>(ring);                     // [PX] per-pixel sums of squares (after the loop: the ring is free)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const bcos_tapconv_geom& g = p.g;
+    const int H = g.H, W = g.W, st = g.in_sh;
+    const int HP = (g.P - 1) * st + g.TH, PW = (g.Q - 1) * st + g.TW;
+    // Patch rows have a power-of-two pitch and are ROTATED: logical column cc of patch row jr sits at physical column
+    // (cc + jr Q) & (pitch - 1).  Consecutive GEMM rows (j -> j + 1, and (i, Q - 1) -> (i + 1, 0)) are then consecutive 16-byte
+    // slots modulo the pitch for every tap, so a fragment read (16 rows per LDS pass) is bank-conflict free; with the rows
+    // stored back to back the two halo columns between (i, Q - 1) and (i + 1, 0) cost a 2-way conflict on every pass.
+    const int LP = 32 - __builtin_clz((unsigned)(PW - 1) | 1u);
+    const int cmask = (1 << LP) - 1;
+    const int ntaps = g.TH * g.TW;
+    const int nk = (p.nchunks + 3) / 4;
+    const int nch = g.C / 16;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt2), 0, p.wt2_bytes, 0x00020000);
+
+    // the tile's rows [m0, m0 + BM) span images n_first .. n_last and the virtual input rows G0 .. G0 + PR - 1
+    const int n_first = m0 / p.PQ;
+    const int i_first = (m0 - n_first * p.PQ) / g.Q;
+    const int G0 = n_first * HP + i_first * st;
+    const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+    const int n_last = m_last / p.PQ;
+    const int i_last = (m_last - n_last * p.PQ) / g.Q;
+    const int PR = n_last * HP + i_last * st + g.TH - G0;
+    if (tid < 16) s_imgmax[tid] = n_first + tid <= n_last ? p.a_imgmax[n_first + tid] : 0u;      // (at most 16 images per tile: patch_fits)
+    __syncthreads();
+    for (int r = tid; r < BM; r += NT) {
+        const int m = m0 + r;
+        int base = 0;
+        float inv = 1.0f;
+        if (m < p.M) {
+            const int n = m / p.PQ;
+            const int rem = m - n * p.PQ;
+            const int i = rem / g.Q;
+            const int jj = rem - i * g.Q;
+            const int jr = n * HP + i * st - G0;
+            base = (jr << 16) | ((jj * st + jr * g.Q) & cmask);
+            unsigned E = s_imgmax[(n - n_first) & 15] >> 23;
+            E = E < 15u ? 15u : E;
+            inv = __uint_as_float((E - 14u) << 23);
+        }
+        s_base[r] = base;
+        s_rowinv[r] = inv;
+    }
+    if (tid < 16) {
+        unsigned E = s_imgmax[tid] >> 23;          // biased exponent of the image max (the bit patterns carry no sign)
+        E = E < 15u ? 15u : E;
+        s_imgscale[tid] = __uint_as_float((268u - E) << 23);       // max * scale in [2^14, 2^15)
+    }
+    __syncthreads();
+
+    // this thread's NI items of the patch: item q = tid + NT it is (used pixel q >> 1 in row-major order of the PR x PW patch,
+    // k-half q & 1): 8 channels = two 16-byte loads, stored at the pixel's rotated physical position
+    unsigned voff[NI];
+    float isc[NI];
+    int idst[NI];                    // byte offset of the item in the h half (the l half at + 2 PLANE), or -1: no such pixel
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int px = (tid >> 1) + (NT / 2) * it;
+        const int jr = px / PW;
+        const int cc = px - jr * PW;
+        const int G = G0 + jr;
+        const int n = G / HP;
+        const int ih = G - n * HP + g.dh0, iw = cc + g.dw0;
+        const bool ok = jr < PR && n < g.N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        voff[it] = ok ? ((unsigned)((n * H + ih) * W + iw) * (unsigned)g.a_pitch + (tid & 1) * 8u) * 4u : OOB;
+        int k = n - n_first;
+        k = k < 0 ? 0 : (k > 15 ? 15 : k);
+        isc[it] = s_imgscale[k];
+        idst[it] = jr < PR ? (tid & 1) * PLANE + (((jr << LP) + ((cc + jr * g.Q) & cmask)) << 4) : -1;
+    }
+    f32x4 xr[NI][2];
+    float pss[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) pss[it] = 0.f;
+    auto load_items = [&](int soff) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            xr[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)voff[it], soff, 0));
+            xr[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(voff[it] + 16u), soff, 0));
+        }
+    };
+    // the refill in two halves: registers -> (h, l) f16 registers as soon as the loads have landed (vector work in the shadow of a
+    // step's matrix instructions), registers -> LDS at the end of the chunk, behind the barrier that retires the old patch
+    f16x8 ph[NI], pl[NI];
+    auto convert_items = [&]() {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float x = xr[it][q >> 2][q & 3];
+                if (NORM) pss[it] = fmaf(x, x, pss[it]);
+                const float xs = x * isc[it];
+                const _Float16 hh = (_Float16)xs;
+                ph[it][q] = hh;
+                pl[it][q] = (_Float16)(xs - (float)hh);
+            }
+        }
+    };
+    auto write_items = [&](int buf_off, bool publish) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+            if (idst[it] >= 0) {
+                *reinterpret_cast<f16x8*>(lds + buf_off + idst[it]) = ph[it];
+                *reinterpret_cast<f16x8*>(lds + buf_off + idst[it] + 2 * PLANE) = pl[it];
+            }
+        if (publish) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the raw s_barrier that publishes the patch does not wait for LDS writes;
+                                                                             //  with two buffers the fragment reads of the following taps do)
+    };
+    const int b_tile0 = n0 >> 5;
+    auto issue_b = [&](int ks, int slot_off) {
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int blk = wave + NW * j;
+            if (NBLK % NW == 0 || blk < NBLK) {
+                const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(ring + slot_off + blk * 1024), 16, lane * 16, soff, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(s_dummy), 16, (int)OOB, 0, 0, 0);   // keeps every wave's DMA count equal
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int a_row[TM], a_c0[TM];         // fragment row: byte offset of its patch row in its k-half plane of the h half; rotated column of tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int b = s_base[wave_m * WM + i * 32 + (lane & 31)];
+        a_row[i] = (lane >> 5) * PLANE + (((b >> 16) << LP) << 4);
+        a_c0[i] = b & 0xffff;
+    }
+    const int b_frag = (wave_n * TN) * 2048 + lane * 16;
+    // A fragments of tap (th, tw): patch row + th, rotated column + tw + th Q; the l half (first product) and the h half are read
+    // at different points of a step
+    f16x8 a_h[TM], a_l[TM];
+    int pbuf = 0;                    // byte offset of the patch buffer of the current chunk (two buffers: P_DBUF)
+    auto a_addr = [&](int i, int th, int tw) -> const char* {
+        return lds + pbuf + a_row[i] + ((th << LP) << 4) + (((a_c0[i] + tw + th * g.Q) & cmask) << 4);
+    };
+    auto read_al = [&](int th, int tw) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_l[i] = *reinterpret_cast<const f16x8*>(a_addr(i, th, tw) + 2 * PLANE);
+    };
+    auto read_ah = [&](int th, int tw) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_h[i] = *reinterpret_cast<const f16x8*>(a_addr(i, th, tw));
+    };
+    auto barrier = []() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // prologue: chunk 0 of the patch, B of steps 0 and 1 (nk >= 4)
+    constexpr int AHEAD = P_NSLOT - 1;               // the DMA of step ks + AHEAD is issued in step ks
+    load_items(0);
+    issue_b(0, 0);
+    if constexpr (AHEAD == 2) issue_b(1, BSLOT);
+    wait_vmcnt<AHEAD * LB>();
+    convert_items();
+    write_items(0, true);
+    int ks = 0;
+    int boff = 0, boff_nx = BSLOT, boff_in = AHEAD == 2 ? 2 * BSLOT : BSLOT;
+    // One step = one tap of the chunk.  The taps of a chunk are expanded at compile time (NTAPS, square tap grids): every wait
+    // count is then a constant, and the compiler's own s_waitcnt for the refill registers sees how many DMA instructions were
+    // issued behind their loads -- inside a run-time tap loop it assumes none and waits for the DMAs issued a moment ago.
+    // LAST: the last chunk (no refill; its last two taps issue no B).
+    constexpr int TWC = NTAPS == 4 ? 2 : NTAPS == 9 ? 3 : 4;
+    constexpr int TCONV = 3;           // the refill loads are forced complete by the wait at the top of tap 3
+    static_assert(NTAPS == TWC * TWC && NTAPS > TCONV, "square tap grids");
+    f16x8 bf[2][TN];
+    auto step = [&]<int T, bool LAST>(int c) {
+        constexpr int th = T / TWC, tw = T % TWC;
+        // B(ks) has landed: the queue behind it holds B(ks + 1) and, for two steps after a refill was issued, its NP loads
+        if constexpr (!(P_KO & 32)) {
+            constexpr int BEHIND = (AHEAD - 1) * LB;          // B(ks + 1) where the ring is three slots deep
+            if constexpr (LAST) {
+                if constexpr (T + 1 < NTAPS) wait_vmcnt<BEHIND>(); else wait_vmcnt<0>();
+            } else {
+                if constexpr ((T == 1 || (T == 2 && AHEAD == 2)) && !(P_KO & 1)) wait_vmcnt<BEHIND + NP>(); else wait_vmcnt<BEHIND>();
+            }
+        }
+        if constexpr (!(P_KO & 4) || T == 0) barrier();      // every wave's B blocks of step ks (and the patch writes of this chunk) are visible; the slot of step ks + 2 is free
+        constexpr bool ISSUE = !LAST || T + AHEAD < NTAPS;
+        constexpr bool REFILL = T == 0 && !LAST && !(P_KO & 1);
+        if constexpr (!(P_OPT & 1)) {
+            if constexpr (ISSUE) { if (!(P_KO & 2) || ks == 0) issue_b(ks + AHEAD, boff_in); }
+            if constexpr (REFILL) load_items((c + 1) * 64);
+        }
+        if constexpr (T == 0) read_al(0, 0);      // (later taps: read behind the previous step's first product; the patch does not change inside a chunk)
+        // Product-major over the wave's accumulators: a dependent v_mfma never sits directly behind its producer.  Fragment reads
+        // in the order of first use: l_a and h_b for the first product, then h_a, l_b; the NEXT tap's l_a goes into the registers
+        // the first product has just released and lands under the other two products.
+        const char* bb = ring + boff + b_frag;
+        if (!(P_KO & 8) || ks == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(bb + j * 2048);
+            read_ah(th, tw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[1][j] = *reinterpret_cast<const f16x8*>(bb + j * 2048 + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P_OPT & 1) {     // the DMA of step ks + 2 (and, first tap, the refill loads) behind the fragment reads: their issue time hides the reads' latency
+            if constexpr (ISSUE) { if (!(P_KO & 2) || ks == 0) issue_b(ks + AHEAD, boff_in); }
+            if constexpr (REFILL) load_items((c + 1) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[i], bf[0][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (T + 1 < NTAPS && !(P_KO & 8)) read_al((T + 1) / TWC, (T + 1) % TWC);
+        if constexpr ((P_OPT & 2) && T == TCONV && !LAST && !(P_KO & 1)) convert_items();
+        if constexpr (P_DBUF && (P_OPT & 2) && T == TCONV + 1 && !LAST && !(P_KO & 1)) write_items(4 * PLANE - pbuf, false);   // the other buffer: last read in chunk c - 1
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 1; pr < ((P_KO & 16) ? 1 : 3); ++pr)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[i], bf[pr == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ++ks;
+        if constexpr (AHEAD == 2) { const int o = boff; boff = boff_nx; boff_nx = boff_in; boff_in = o; }
+        else { const int o = boff; boff = boff_in; boff_in = o; }
+    };
+    auto chunk = [&]<bool LAST, int... Ts>(int c, std::integer_sequence<int, Ts...>) {
+        (step.template operator()<Ts, LAST>(c), ...);
+        if constexpr (!LAST && !(P_KO & 1) && !P_DBUF) {
+            barrier();                 // every wave is done reading this chunk's patch
+            if constexpr (!(P_OPT & 2)) convert_items();
+            write_items(0, true);
+        }
+        if constexpr (P_DBUF) pbuf = 4 * PLANE - pbuf;
+    };
+    for (int c = 0; c + 1 < nch; ++c) chunk.template operator()<false>(c, std::make_integer_sequence<int, NTAPS>{});
+    chunk.template operator()<true>(nch - 1, std::make_integer_sequence<int, NTAPS>{});
+    __syncthreads();                   // patch and ring are free
+    float rowss[BM / (NT / 4)], a_inv[BM / (NT / 4)];
+    if (NORM) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const float v = pss[it] + __shfl_xor(pss[it], 1);
+            if (!(tid & 1) && idst[it] >= 0) s_pixss[idst[it] >> 4] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < BM / (NT / 4); ++j) {
+            const int b = s_base[(tid >> 2) + (NT / 4) * j];
+            const int jr = b >> 16, c0 = b & 0xffff;
+            float v = 0.f;
+            for (int t = tid & 3; t < ntaps; t += 4) {
+                const int th = t / g.TW;
+                const int tw = t - th * g.TW;
+                v += s_pixss[((jr + th) << LP) + ((c0 + tw + th * g.Q) & cmask)];
+            }
+            rowss[j] = v;              // staging layout: the 4 lanes of a row hold partial sums
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BM / (NT / 4); ++j) a_inv[j] = s_rowinv[(tid >> 2) + (NT / 4) * j];
+    __syncthreads();                   // the epilogue reuses all of it
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n);
+}
+
 // Narrow split-f16 tiles (128 x 64, 128 x 32: the stem, the 56^2 3x3 layers) hold 16-32 accumulator registers per wave and run
 // 6-12 matrix instructions per 16-k step: their steps wait on load latency, not on a pipe.  The FORWARD kernels of these
 // tiles are compiled for three resident workgroups per CU (168 registers): same-node A/B on ResNet-50, stem forward
@@ -2212,6 +2545,15 @@ __global__ __launch_bounds__(NTHREADS, (X3 >= 3 && NORM && BN <= H2_NARROW_BN &&
             else tile_body<BMS, BN, WMS, WNS, NORM>(p, smem, p.rows_big + tile_m * BMS, gcol + tile_n * BN, tile_n);
         }
     }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS>
+__global__ __launch_bounds__(NTHREADS, 2) void tappatch_kernel(const KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile = xcd_remap(blockIdx.x, p.n_big);
+    const int tile_m = tile / p.tiles_n;
+    const int tile_n = tile - tile_m * p.tiles_n;
+    tile_body_p<BM, BN, WAVES_M, WAVES_N, NORM, NI, PXL, NTAPS>(p, smem, tile_m * BM, tile_n * BN, tile_n);
 }
 
 // (An 8-wavefront / 512-thread form of the split-f16 loop -- same tile and LDS images, eight waves of 64 x 32 with 32
@@ -2348,6 +2690,47 @@ int launch_d(const KArgs& base, bool norm, hipStream_t stream) {
     return BCOS_OK;
 }
 
+// split-f16 launches over an LDS-resident input patch (tile_body_p); every tile has BM rows
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NI, int PXL, int NTAPS>
+int launch_p(const KArgs& base, bool norm, hipStream_t stream) {
+    KArgs p = base;
+    p.tiles_n = (p.g.Cout + BN - 1) / BN;
+    p.n_big = ((p.M + BM - 1) / BM) * p.tiles_n;
+    p.n_small = 0;
+    p.rows_big = p.M;
+    size_t lds = p_lds_bytes<BM, BN, PXL>();
+    const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
+    if (lds_epi > lds) lds = lds_epi;
+    const dim3 grid((unsigned)p.n_big), block(NTHREADS);
+    static std::atomic<size_t> lds_hw[2];
+    auto launch = [&](auto k, int which) -> hipError_t {
+        hipError_t e2 = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_hw[which]);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+        return hipSuccess;
+    };
+    hipError_t err = norm ? launch(tappatch_kernel<BM, BN, WAVES_M, WAVES_N, true, NI, PXL, NTAPS>, 0)
+                          : launch(tappatch_kernel<BM, BN, WAVES_M, WAVES_N, false, NI, PXL, NTAPS>, 1);
+    if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
+    err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);
+    return BCOS_OK;
+}
+
+// Does the input patch of every BM-row tile of the launch fit `px` pixels?  Upper bound over the tile positions: a tile touches
+// at most R = (BM + Q - 2) / Q + 1 output rows, which cross at most ceil((R - 1) / P) image boundaries (TH - s extra virtual rows each)
+inline bool patch_fits(const bcos_tapconv_geom& g, int BM, int items_px, int lds_px) {
+    const int s = g.in_sh;
+    const int R = (BM + g.Q - 2) / g.Q + 1;
+    const int nb = (R - 1 + g.P - 1) / g.P;
+    const int extra = g.TH > s ? g.TH - s : 0;
+    const int64_t rows = (int64_t)(R - 1) * s + g.TH + (int64_t)nb * extra;
+    const int pw = (g.Q - 1) * s + g.TW;
+    int pitch = 1;
+    while (pitch < pw) pitch <<= 1;                                  // (rows are stored with a power-of-two pitch, rotated: tile_body_p)
+    return rows * pw <= items_px && rows * pitch <= lds_px && (int64_t)g.P * g.Q * 14 >= BM;      // (at most 16 images per tile)
+}
+
 }  // namespace
 
 // The file is compiled either whole or in slices (-DBCOS_TAPCONV_PART=k, bcos_hip/lib.py: build): slice 0 carries the C ABI
@@ -2374,6 +2757,11 @@ BCOS_TC_LAUNCHER(bcos_tc_d_128x64);
 BCOS_TC_LAUNCHER(bcos_tc_d_128x32);
 BCOS_TC_LAUNCHER(bcos_tc_d_256x64);
 BCOS_TC_LAUNCHER(bcos_tc_d_256x32);
+BCOS_TC_LAUNCHER(bcos_tc_p_128x256_a);
+BCOS_TC_LAUNCHER(bcos_tc_p_128x128_a);
+BCOS_TC_LAUNCHER(bcos_tc_p_128x128_b);
+BCOS_TC_LAUNCHER(bcos_tc_p_128x128_c);
+BCOS_TC_LAUNCHER(bcos_tc_p_256x64_a);
 #define BCOS_TC_DEFINE(name, call) BCOS_TC_LAUNCHER(name) { return call(*static_cast<const KArgs*>(kargs), norm != 0, s); }
 #if BCOS_TC_IN(1)
 BCOS_TC_DEFINE(bcos_tc_cfg_128x128, (launch_cfg<128, 128, 2, 2>))
@@ -2404,6 +2792,16 @@ BCOS_TC_DEFINE(bcos_tc_d_128x192, (launch_d<128, 192, 4, 1>))
 BCOS_TC_DEFINE(bcos_tc_d_256x64, (launch_d<256, 64, 4, 1>))
 BCOS_TC_DEFINE(bcos_tc_d_256x32, (launch_d<256, 32, 4, 1>))
 BCOS_TC_DEFINE(bcos_tc_d_128x32, (launch_d<128, 32, 4, 1>))
+#endif
+// input-patch configurations: <BM, BN, waves M x N, items per thread (128 pixels each), LDS pixels, taps>
+#if BCOS_TC_IN(9)
+BCOS_TC_DEFINE(bcos_tc_p_128x256_a, (launch_p<128, 256, 2, 2, 2, 256, 9>))      // 14^2: 15 rows of 16
+BCOS_TC_DEFINE(bcos_tc_p_256x64_a, (launch_p<256, 64, 4, 1, 5, 640, 9>))        // 56^2: 10 rows of 58 (pitch 64)
+#endif
+#if BCOS_TC_IN(10)
+BCOS_TC_DEFINE(bcos_tc_p_128x128_a, (launch_p<128, 128, 2, 2, 2, 256, 9>))      // 14^2
+BCOS_TC_DEFINE(bcos_tc_p_128x128_b, (launch_p<128, 128, 2, 2, 2, 448, 9>))      // 7^2: 28 rows of 9 (pitch 16)
+BCOS_TC_DEFINE(bcos_tc_p_128x128_c, (launch_p<128, 128, 2, 2, 3, 320, 9>))      // 28^2: 10 rows of 30 (pitch 32)
 #endif
 #if BCOS_TC_IN(0)
 BCOS_TC_DEFINE(bcos_tc_h2_128x64, (launch_h2<128, 64, 2, 2>))
@@ -2583,6 +2981,29 @@ __global__ __launch_bounds__(256) void rows_absmax_kernel(const float* __restric
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void image_absmax_kernel(const unsigned* __restrict__ absmax, unsigned* __restrict__ out, int hw) {
+    __shared__ unsigned s_max[4];
+    const unsigned* src = absmax + (size_t)blockIdx.x * hw;
+    unsigned v = 0u;
+    for (int i = threadIdx.x; i < hw; i += 256) v = max(v, src[i]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+}
+}  // namespace
+
+extern "C" int bcos_image_absmax(const uint32_t* absmax, uint32_t* out, int n_images, int pixels_per_image, void* stream) {
+    if (!absmax || !out || n_images <= 0 || pixels_per_image <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_image_absmax: bad argument");
+    hipLaunchKernelGGL(image_absmax_kernel, dim3((unsigned)n_images), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), absmax, out,
+                       pixels_per_image);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("image_absmax launch", err);
+    return BCOS_OK;
+}
+
 extern "C" int bcos_rows_absmax(const float* x, uint32_t* out, int64_t rows, int C, int pitch, void* stream) {
     if (!x || !out || rows <= 0 || C <= 0 || C % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_rows_absmax: bad argument");
     if (pitch == 0) pitch = C;
@@ -2600,13 +3021,13 @@ extern "C" int bcos_rows_absmax(const float* x, uint32_t* out, int64_t rows, int
 
 extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                             const bcos_epilogue* epi, void* stream) {
-    bcos_operands o = {a, nullptr, wt, nullptr, nullptr, BCOS_CONTRACT_DEFAULT};
+    bcos_operands o = {a, nullptr, wt, nullptr, nullptr, BCOS_CONTRACT_DEFAULT, nullptr};
     return bcos_tapconv_ops(&o, geom, epi, stream);
 }
 
 extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void* wt3, const bcos_tapconv_geom* geom,
                                      const bcos_epilogue* epi, void* stream) {
-    bcos_operands o = {a, nullptr, wt, wt3, nullptr, BCOS_CONTRACT_DEFAULT};
+    bcos_operands o = {a, nullptr, wt, wt3, nullptr, BCOS_CONTRACT_DEFAULT, nullptr};
     return bcos_tapconv_ops(&o, geom, epi, stream);
 }
 
@@ -2743,6 +3164,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             !(reinterpret_cast<uintptr_t>(ops->wt_f16x2) & 15)) {
             p.h2 = 1;
             p.a_absmax = ops->a_absmax;
+            p.a_imgmax = ops->a_imgmax;
             p.absmax_bytes = (unsigned)pixb;
             p.wt2 = ops->wt_f16x2;
             p.wt2_bytes = (unsigned)w2b;
@@ -2797,6 +3219,23 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         // staging of the split-f16 loop: LDS-DMA (tile_body_d, default) or registers (tile_body_h2: BCOS_H2_LOOP=regs); same bits
         const char* loop = getenv("BCOS_H2_LOOP");
         const bool dma = !(loop && loop[0] == 'r');
+        {
+            // multi-tap launches over an LDS-resident input patch (tile_body_p).  The choice depends on the layer's geometry alone,
+            // never on the batch: the patch loop rounds differently from the per-tap loops (one operand scale per image), and an
+            // image's bits must not depend on how many images share its launch.  BCOS_PATCH=0: development / test switch.
+            const char* pe = getenv("BCOS_PATCH");
+            const int ntaps = g.TH * g.TW;
+            const bool geom_ok = ntaps == 9 && g.TH == 3 && g.C % X3_BK == 0 && g.in_sh == g.in_sw && (g.in_sh == 1 || g.in_sh == 2) &&
+                                 g.dstep_h == 1 && g.dstep_w == 1 && p.g.a_pitch >= g.C;
+            if (dma && geom_ok && p.a_imgmax && !(pe && pe[0] == '0')) {
+                const char* pw_ = getenv("BCOS_PATCH_WIDE");
+                if (g.Cout > 128 && g.Cout <= 256 && patch_fits(g, 128, 256, 256) && !(pw_ && pw_[0] == '0')) return bcos_tc_p_128x256_a(&p, norm, s);
+                if (g.Cout > 64 && patch_fits(g, 128, 256, 256)) return bcos_tc_p_128x128_a(&p, norm, s);
+                if (g.Cout > 64 && patch_fits(g, 128, 256, 448)) return bcos_tc_p_128x128_b(&p, norm, s);
+                if (g.Cout > 64 && patch_fits(g, 128, 384, 320)) return bcos_tc_p_128x128_c(&p, norm, s);
+                if (g.Cout > 32 && g.Cout <= 64 && patch_fits(g, 256, 640, 640)) return bcos_tc_p_256x64_a(&p, norm, s);
+            }
+        }
         if (g.Cout > 64) {
             // 128 x 256 tiles stage half the A bytes per MFMA; they pay when they do not cost an extra round of tiles
             // (measured on the ResNet-50 shapes: M = 50176, N = 256: -3 %; M = 12544, N = 512: +17 % -> stays 128 x 128)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 5
+#define BCOS_ABI_VERSION 6
 
 enum {
     BCOS_OK = 0,
@@ -223,6 +223,11 @@ typedef struct bcos_operands {
     const void* wt_bf16x3;      /* NULL or the image made by bcos_split_weights                                    */
     const void* wt_f16x2;       /* NULL or the image made by bcos_split_weights_f16x2                              */
     int32_t contraction;        /* BCOS_CONTRACT_*                                                                  */
+    const uint32_t* a_imgmax;   /* NULL or [N]: max over the pixels of image n of a_absmax (bcos_image_absmax; ABI v6).  With
+                                   it, 3 x 3 launches of the f16x2 contraction run over an LDS-resident input patch (every input
+                                   element loaded and split once per 16 channels instead of once per tap) with ONE operand scale
+                                   per image: elements within 2^-17 of their image's max keep 22 bits, smaller ones an absolute
+                                   error <= 2^-40 of that max.  An image's results do not depend on its batch neighbours.      */
 } bcos_operands;
 
 /* -- contraction kernels (LDS-tiled implicit GEMM on the matrix cores) ---------------------------------------- */
@@ -247,6 +252,8 @@ int bcos_split_weights_f16x2_conv(const float* wt, void* image, int rows, int ta
 /* out[r] = fp32 bit pattern of max_c |x[r*pitch + c]|, c < C (C % 4 == 0; pitch 0 = C): the `a_absmax` of a tensor whose
  * producer is not a bcos_tapconv epilogue (network input, pooling, attention ...).  One pass over x. */
 int bcos_rows_absmax(const float* x, uint32_t* out, int64_t rows, int C, int pitch, void* stream);
+/* out[n] = max over p < pixels_per_image of absmax[n * pixels_per_image + p]: bcos_operands.a_imgmax from a_absmax (ABI v6). */
+int bcos_image_absmax(const uint32_t* absmax, uint32_t* out, int n_images, int pixels_per_image, void* stream);
 
 /* Pre-split weights for the bf16x3 contraction.  Weights are constant at inference (NormedConv2d / BcosifyConv2d
  * weights only change in training, bcosconv2d.py:26-35), so their exact 3-way bf16 split is done once:

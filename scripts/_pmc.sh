@@ -11,7 +11,7 @@ for c in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_
 import csv,sys
 agg={}
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'tapconv' in r['Kernel_Name']:
+    if 'tapconv' in r['Kernel_Name'] or 'tappatch' in r['Kernel_Name']:
         agg.setdefault(r['Counter_Name'],[]).append(float(r['Counter_Value']))
 for k,v in agg.items(): print(k, v[-1])
 PY
@@ -20,5 +20,5 @@ f=$(find $R/gpurun_out/${TAG}_SQ_BUSY* -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'tapconv' in r['Kernel_Name']: print('dur_us', (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3, 'grid', r['Grid_Size_X'])
+    if 'tapconv' in r['Kernel_Name'] or 'tappatch' in r['Kernel_Name']: print('dur_us', (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3, 'grid', r['Grid_Size_X'])
 PY

@@ -12,6 +12,12 @@ SHAPES = [(14, 256, 256, 3, 1), (28, 128, 128, 3, 1), (56, 64, 64, 3, 1), (7, 51
           (28, 512, 128, 1, 1), (28, 128, 512, 1, 1), (56, 256, 64, 1, 1), (7, 2048, 512, 1, 1), (7, 512, 2048, 1, 1), (224, 8, 64, 7, 2)]
 if os.environ.get("QUICK"):
     SHAPES = SHAPES[:5]
+if os.environ.get("PSHAPES") == "1":       # the multi-tap shapes
+    SHAPES = [(14, 256, 256, 3, 1), (28, 128, 128, 3, 1), (56, 64, 64, 3, 1), (7, 512, 512, 3, 1), (28, 128, 128, 3, 2), (14, 256, 256, 3, 2)]
+if os.environ.get("PSHAPES") == "3":
+    SHAPES = [(14, 256, 256, 3, 1), (28, 128, 128, 3, 1), (56, 64, 64, 3, 1), (7, 512, 512, 3, 1)]
+if os.environ.get("PSHAPES") == "2":
+    SHAPES = [(14, 256, 256, 3, 1)]
 g = torch.Generator().manual_seed(0)
 rows = []
 for (H, Cin, Cout, k, st) in SHAPES:

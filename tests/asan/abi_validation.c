@@ -59,6 +59,9 @@ int main(void) {
     EXPECT(bcos_split_weights_f16x2_conv(buf, buf, 8, 0, 16, NULL), BCOS_E_INVAL);
     EXPECT(bcos_rows_absmax(buf, am, 4, 6, 0, NULL), BCOS_E_INVAL);                               /* C % 4 */
     EXPECT(bcos_rows_absmax(NULL, am, 4, 8, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_image_absmax(NULL, am, 2, 4, NULL), BCOS_E_INVAL);                                /* ABI v6 */
+    EXPECT(bcos_image_absmax(am, am, 0, 4, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_image_absmax(am, am, 2, 0, NULL), BCOS_E_INVAL);
     EXPECT(bcos_conv2d_fwd(buf, buf, NULL, buf, NULL, NULL, 1, 8, 4, 4, 8, 3, 3, 0, 1, 1, 1, 1, 1, 2.0f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_conv2d_fwd(NULL, buf, NULL, buf, NULL, NULL, 1, 8, 4, 4, 8, 3, 3, 1, 1, 1, 1, 1, 1, 2.0f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_linear_fwd(buf, NULL, NULL, buf, NULL, NULL, 4, 8, 8, 2.0f, NULL), BCOS_E_INVAL);

@@ -74,7 +74,9 @@ def run_resnet50(rank, world, n_global):
     verdict = dict(config="resnet50", world=world, n_global=n_global, shard=[lo, hi], replicas_identical=not replica_diff,
                    gathered_shape=list(res["contribution_map"].shape),
                    overlapped_equals_gather=bool(torch.equal(packed["logits"], res["logits"])
-                                                 and torch.equal(packed["contribution_map"], res["contribution_map"])))
+                                                 and torch.equal(packed["contribution_map"], res["contribution_map"])),
+                   overlapped_vs_gather=[rel(packed["logits"], res["logits"]), rel(packed["contribution_map"], res["contribution_map"]),
+                                         (packed["contribution_map"] != res["contribution_map"]).flatten(1).any(1).nonzero().flatten().tolist()[:16]])
     del mine, packed, pipe
     free_others(rank)
     if rank == 0:

@@ -42,7 +42,7 @@ def _launch(config, n_global, tmp_path, world=WORLD, timeout=1500):
 def test_config5_resnet50_global1024_sharded_over_8_ranks(tmp_path):
     v = _launch("r50", 1024, tmp_path)
     assert v["gathered_shape"] == [1024, 224, 224] and v["shards"] == [[128 * r, 128 * (r + 1)] for r in range(8)]
-    assert v["overlapped_equals_gather"] and v["replicas_identical"]
+    assert v["overlapped_equals_gather"] and v["replicas_identical"], json.dumps(v)
     assert v["sharded_equals_unsharded"], json.dumps(v)                       # same bits as one pass over all 1024 images
     assert v["rel_logits_vs_oracle"] <= 1e-4 and v["classes_equal_oracle"], v
     assert v["rel_maps_vs_oracle"] <= 3e-3, v                     # free ReLU gates: the ResNet-50 map floor (H1)

@@ -1379,6 +1379,8 @@ def test_dma_loop_bit_identical_to_register_loop(lib, golden_dir, monkeypatch):
     from bcos_hip import engine, ops, synth
     g = torch.Generator().manual_seed(31)
 
+    monkeypatch.setenv("BCOS_PATCH", "0")       # (the input-patch loop of the multi-tap launches has its own test below)
+
     def both(fn):
         monkeypatch.delenv("BCOS_H2_LOOP", raising=False)
         dma = fn()
@@ -1425,6 +1427,77 @@ def test_dma_loop_bit_identical_to_register_loop(lib, golden_dir, monkeypatch):
         dma, regs = both(lambda: eng.explain(x))
         for key in ("logits", "dynamic_linear_weights", "contribution_map"):
             assert torch.equal(dma[key], regs[key]), (name, key)
+
+
+def test_patch_loop_against_per_tap_loop_and_fp64(lib, monkeypatch):
+    """Round 3: multi-tap launches (3x3, 4x4-union gradients, 2x2 parity classes) contract over an LDS-resident input PATCH
+    (csrc/bcos_tapconv.hip: tile_body_p): every input element is loaded and split once per 16-channel chunk instead of once per
+    tap, with ONE operand scale per image.  Same K walk and product order as the per-tap loops, different rounding of small
+    elements and of the patch-norm sums: outputs agree with the per-tap loop (BCOS_PATCH=0) to fp32 rounding and sit as close to
+    an fp64 evaluation as it does.  Shapes: the ResNet geometries (7^2 ... 56^2, 64 ... 512 channels), ragged rows / columns, tiles
+    that span several images, stride 2, the gradient forms; images of very different magnitude in one batch (the scale is per
+    image) and bit-identity of an image's results across batch positions / batch sizes."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(47)
+
+    def both(fn):
+        monkeypatch.delenv("BCOS_PATCH", raising=False)
+        patch = fn()
+        monkeypatch.setenv("BCOS_PATCH", "0")
+        taps = fn()
+        monkeypatch.delenv("BCOS_PATCH", raising=False)
+        return patch, taps
+
+    cases = [(5, 7, 512, 384, 3, 1, 1), (3, 14, 256, 256, 3, 1, 1), (2, 14, 256, 200, 3, 1, 1), (3, 28, 128, 128, 3, 1, 1),
+             (2, 56, 64, 64, 3, 1, 1), (9, 9, 64, 48, 3, 1, 1), (2, 28, 128, 128, 3, 2, 1), (4, 14, 256, 256, 3, 2, 1),
+             (2, 17, 64, 192, 3, 1, 1), (2, 20, 16, 128, 5, 1, 2), (3, 12, 32, 40, 3, 1, 0), (2, 15, 32, 52, 3, 2, 1),
+             (20, 6, 48, 64, 3, 1, 1)]
+    for (N, H, Cin, Cout, k, st, pd) in cases:
+        mag = torch.logspace(-3, 3, N).view(N, 1, 1, 1)                    # images six decades apart
+        x = ops.ensure_absmax((torch.randn(N, H, H, Cin, generator=g) * mag).to(DEV))
+        w = ops.mark_static((torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV))
+        Ho = ops.conv_out_size(H, k, st, pd)
+
+        def run():
+            y, sc, nrm = ops.conv2d_fwd(x, w, stride=(st, st), padding=(pd, pd), relu=False, want_scale=True, want_norm=True,
+                                        track_absmax=True)
+            return y, sc, nrm, ops.absmax_of(y).view(torch.float32)
+        pa, ta = both(run)
+        xd, wd = x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2)
+        lin = torch.nn.functional.conv2d(xd, wd, stride=st, padding=pd)
+        nrm64 = (torch.nn.functional.conv2d(xd * xd, torch.ones(1, Cin, k, k, device=DEV, dtype=torch.float64), stride=st, padding=pd) + 1e-6).sqrt()
+        y64 = (lin * lin.abs() / nrm64).permute(0, 2, 3, 1)
+        for n in range(N):                                                 # per image: every magnitude is held to the same bound
+            e_p, e_t = rel(pa[0][n].double(), y64[n]), rel(ta[0][n].double(), y64[n])
+            assert e_p <= max(2e-6, 1.5 * e_t), ("fwd", N, H, Cin, Cout, k, st, n, e_p, e_t)
+            assert rel(pa[2][n].double().flatten(), nrm64[n].flatten()) <= 1e-6
+        for a, b in zip(pa, ta):
+            assert torch.isfinite(a).all()
+            assert rel(a, b) <= 2e-6, ("fwd", N, H, Cin, Cout, k, st, rel(a, b))
+        # an image's results do not depend on its batch position or on the batch size
+        monkeypatch.delenv("BCOS_PATCH", raising=False)
+        perm = torch.arange(N - 1, -1, -1)
+        xp = ops.ensure_absmax(x[perm.to(DEV)].contiguous())
+        yp = ops.conv2d_fwd(xp, w, stride=(st, st), padding=(pd, pd), relu=False, want_scale=False, want_norm=False)[0]
+        assert torch.equal(yp, pa[0][perm.to(DEV)]), ("position", N, H, Cin, Cout, k, st)
+        y1 = ops.conv2d_fwd(ops.ensure_absmax(x[N - 1:].contiguous()), w, stride=(st, st), padding=(pd, pd), relu=False,
+                            want_scale=False, want_norm=False)[0]
+        assert torch.equal(y1, pa[0][N - 1:]), ("batch size", N, H, Cin, Cout, k, st)
+        plan = ops.DgradPlan(w.permute(0, 3, 1, 2).contiguous(), (st, st), (pd, pd))
+        gl = ops.ensure_absmax((torch.randn(N, Ho, Ho, Cout, generator=g) * mag).to(DEV))
+        mul = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+
+        def run_b():
+            out = plan.run(gl, H, H, mul=mul, track_absmax=True)
+            return out, ops.absmax_of(out).view(torch.float32)
+        pb, tb = both(run_b)
+        g64 = torch.nn.functional.conv_transpose2d(gl.double().permute(0, 3, 1, 2), wd, stride=st, padding=pd,
+                                                   output_padding=H - ((Ho - 1) * st - 2 * pd + k)).permute(0, 2, 3, 1) * mul.double()
+        for n in range(N):
+            e_p, e_t = rel(pb[0][n].double(), g64[n]), rel(tb[0][n].double(), g64[n])
+            assert e_p <= max(2e-6, 1.5 * e_t), ("bwd", N, H, Cin, Cout, k, st, n, e_p, e_t)
+        for a, b in zip(pb, tb):
+            assert rel(a, b) <= 2e-6, ("bwd", N, H, Cin, Cout, k, st, rel(a, b))
 
 
 def test_clip_zeroshot_text_attribution_against_reference_golden(lib, golden_dir):
