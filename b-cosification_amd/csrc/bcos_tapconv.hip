@@ -76,7 +76,32 @@ struct KArgs {
     int vec_ok;     // every per-element epilogue tensor is 16-byte addressable (pitch % 4 == 0, aligned bases)
     int epi_kind;   // 0 = general epilogue, k + 1 = specialisation k of EPI_KINDS_FWD (norm launches) / EPI_KINDS_BWD (tile_epilogue_fast)
     unsigned out_bytes;   // size of the [N*OH*OW][out_pitch] epilogue tensors (epi_kind > 0: < 2 GiB)
+    // 2-D row tiles (input-patch loop on wide images, tile_body_p<..., T2D>): tile t = (image t / t2_nb, block t % t2_nb) and row r of a
+    // tile is position (r / t2_bw, r % t2_bw) of that t2_bh x t2_bw block of the row grid; 0 = rows are m = n P Q + i Q + j
+    int t2_bw, t2_nbx, t2_nb, t2_rows;
 };
+
+// row r of the tile at m0 -> (image, grid position), false: the tile has no such row (shared by the epilogues)
+template <typename P>
+__device__ __forceinline__ bool tile_row_nij(const P& p, int m0, int r, int& n, int& i, int& jj) {
+    if (p.t2_bw > 0) {
+        const int t = m0 / p.t2_rows;
+        n = t / p.t2_nb;
+        const int b = t - n * p.t2_nb;
+        const int by = b / p.t2_nbx;
+        const int ri = r / p.t2_bw;
+        i = by * (p.t2_rows / p.t2_bw) + ri;
+        jj = (b - by * p.t2_nbx) * p.t2_bw + (r - ri * p.t2_bw);
+        return i < p.g.P && jj < p.g.Q;
+    }
+    const int m = m0 + r;
+    if (m >= p.M) return false;
+    n = m / p.PQ;
+    const int rem = m - n * p.PQ;
+    i = rem / p.g.Q;
+    jj = rem - i * p.g.Q;
+    return true;
+}
 
 // max over groups of G consecutive lanes (G = 8, 16, 32; groups aligned to G) on the vector ALU (DPP), no LDS traffic.
 // After the call the lanes with (lane % G) == group_max_lane<G>() hold the group's max.
@@ -150,13 +175,9 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
     float* sRinv = sNorm + BM;                                     // [BM] 1 / norm
     float* sAinv = sRinv + BM;                                     // [BM] inverse operand scale of the row (SCALED)
     for (int r = tid; r < BM; r += NT) {
-        const int m = m0 + r;
         int64_t pix = -1, apix = -1;
-        if (m < p.M) {
-            const int n = m / p.PQ;
-            const int rem = m - n * p.PQ;
-            const int i = rem / g.Q;
-            const int jj = rem - i * g.Q;
+        int n, i, jj;
+        if (tile_row_nij(p, m0, r, n, i, jj)) {
             pix = ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
             if (!NORM && e.addend_sub > 1) {     // subsampled addend: this row's pixel in [N, ceil(OH / s), ceil(OW / s)] or -1
                 const int s = e.addend_sub;
@@ -530,15 +551,9 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
     float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
     const int out_pitch = g.out_pitch;
     for (int r = tid; r < BM; r += NT) {
-        const int m = m0 + r;
         int pix = -1;
-        if (m < p.M) {
-            const int n = m / p.PQ;
-            const int rem = m - n * p.PQ;
-            const int i = rem / g.Q;
-            const int jj = rem - i * g.Q;
-            pix = (n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
-        }
+        int n = 0, i = 0, jj = 0;
+        if (tile_row_nij(p, m0, r, n, i, jj)) pix = (n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
         sRow[r].pix = pix;
         sRow[r].off = pix >= 0 ? (unsigned)pix * (unsigned)out_pitch * 4u : OOB;
         if (!NORM && e.addend_sub > 1) {
@@ -547,10 +562,7 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
             const int s = e.addend_sub;
             unsigned aoff = OOB;
             if (pix >= 0) {
-                const int n = m / p.PQ;
-                const int rem = m - n * p.PQ;
-                const int i = rem / g.Q;
-                const int h = i * g.out_sh + g.out_h0, w = (rem - i * g.Q) * g.out_sw + g.out_w0;
+                const int h = i * g.out_sh + g.out_h0, w = jj * g.out_sw + g.out_w0;
                 if (h % s == 0 && w % s == 0)
                     aoff = (unsigned)((n * ((g.OH + s - 1) / s) + h / s) * ((g.OW + s - 1) / s) + w / s) * (unsigned)out_pitch * 4u;
             }
@@ -2188,12 +2200,12 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
 #define P_DBUF 0                  // 1 = two patch buffers: the refill of chunk c + 1 is written during chunk c, no barrier at the end of a chunk
 #endif
 #ifndef P_OPT
-#define P_OPT 3                   // development switches: 1 = DMA issue behind the fragment reads (else ahead of them), 2 = refill converted at tap 3 (else at the end of the chunk)
+#define P_OPT 7                   // development switches: 1 = DMA issue behind the fragment reads (else ahead of them), 2 = refill converted from tap 3 on (else at the end of the chunk), 4 = ... one item per tap (else all at tap 3)
 #endif
 template <int BM, int BN, int PXL>
 constexpr size_t p_lds_bytes() { return (size_t)PXL * 64 * (1 + P_DBUF) + P_NSLOT * (size_t)(BN / 32) * 2048 + 1024 + (size_t)BM * 8 + 128; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int NT = NTHREADS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int T2BW = 0, int NT = NTHREADS>
 __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -2222,7 +2234,12 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const bcos_tapconv_geom& g = p.g;
     const int H = g.H, W = g.W, st = g.in_sh;
-    const int HP = (g.P - 1) * st + g.TH, PW = (g.Q - 1) * st + g.TW;
+    // T2BW > 0: the tile is a (BM / T2BW) x T2BW block of ONE image's row grid (wide images: the rows of a linear tile would drag whole
+    // image rows into the patch); the patch is then the block's own halo'd window and `rotq` (the rotation per patch row) its width
+    constexpr bool T2D = T2BW > 0;
+    constexpr int T2BH = T2D ? BM / (T2D ? T2BW : 1) : 0;
+    const int HP = (g.P - 1) * st + g.TH, PW = T2D ? (T2BW - 1) * st + g.TW : (g.Q - 1) * st + g.TW;
+    const int rotq = T2D ? T2BW : g.Q;
     // Patch rows have a power-of-two pitch and are ROTATED: logical column cc of patch row jr sits at physical column
     // (cc + jr Q) & (pitch - 1).  Consecutive GEMM rows (j -> j + 1, and (i, Q - 1) -> (i + 1, 0)) are then consecutive 16-byte
     // slots modulo the pitch for every tap, so a fragment read (16 rows per LDS pass) is bank-conflict free; with the rows
@@ -2236,27 +2253,48 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt2), 0, p.wt2_bytes, 0x00020000);
 
-    // the tile's rows [m0, m0 + BM) span images n_first .. n_last and the virtual input rows G0 .. G0 + PR - 1
-    const int n_first = m0 / p.PQ;
-    const int i_first = (m0 - n_first * p.PQ) / g.Q;
-    const int G0 = n_first * HP + i_first * st;
-    const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
-    const int n_last = m_last / p.PQ;
-    const int i_last = (m_last - n_last * p.PQ) / g.Q;
-    const int PR = n_last * HP + i_last * st + g.TH - G0;
+    // linear tiles: the rows [m0, m0 + BM) span images n_first .. n_last and the virtual input rows G0 .. G0 + PR - 1;
+    // 2-D tiles: one image, the block's first input row / column ih0 / iw0 (before the tap offset)
+    int n_first, n_last, G0, PR, ih0 = 0, iw0 = 0;
+    if constexpr (T2D) {
+        const int t = m0 / BM;
+        n_first = n_last = t / p.t2_nb;
+        const int b = t - n_first * p.t2_nb;
+        const int by = b / p.t2_nbx;
+        ih0 = by * T2BH * st;
+        iw0 = (b - by * p.t2_nbx) * T2BW * st;
+        G0 = 0;
+        PR = (T2BH - 1) * st + g.TH;
+    } else {
+        n_first = m0 / p.PQ;
+        const int i_first = (m0 - n_first * p.PQ) / g.Q;
+        G0 = n_first * HP + i_first * st;
+        const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+        n_last = m_last / p.PQ;
+        const int i_last = (m_last - n_last * p.PQ) / g.Q;
+        PR = n_last * HP + i_last * st + g.TH - G0;
+    }
     if (tid < 16) s_imgmax[tid] = n_first + tid <= n_last ? p.a_imgmax[n_first + tid] : 0u;      // (at most 16 images per tile: patch_fits)
     __syncthreads();
     for (int r = tid; r < BM; r += NT) {
-        const int m = m0 + r;
         int base = 0;
         float inv = 1.0f;
-        if (m < p.M) {
-            const int n = m / p.PQ;
-            const int rem = m - n * p.PQ;
-            const int i = rem / g.Q;
-            const int jj = rem - i * g.Q;
-            const int jr = n * HP + i * st - G0;
-            base = (jr << 16) | ((jj * st + jr * g.Q) & cmask);
+        int n = n_first, jr = -1, jc = 0;
+        if constexpr (T2D) {
+            jr = (r / T2BW) * st;             // (rows outside the image contract zeros and are dropped by the epilogue)
+            jc = (r % T2BW) * st;
+        } else {
+            const int m = m0 + r;
+            if (m < p.M) {
+                n = m / p.PQ;
+                const int rem = m - n * p.PQ;
+                const int i = rem / g.Q;
+                jr = n * HP + i * st - G0;
+                jc = (rem - i * g.Q) * st;
+            }
+        }
+        if (jr >= 0) {
+            base = (jr << 16) | ((jc + jr * rotq) & cmask);
             unsigned E = s_imgmax[(n - n_first) & 15] >> 23;
             E = E < 15u ? 15u : E;
             inv = __uint_as_float((E - 14u) << 23);
@@ -2281,15 +2319,23 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
         const int px = (tid >> 1) + (NT / 2) * it;
         const int jr = px / PW;
         const int cc = px - jr * PW;
-        const int G = G0 + jr;
-        const int n = G / HP;
-        const int ih = G - n * HP + g.dh0, iw = cc + g.dw0;
+        int n, ih, iw;
+        if constexpr (T2D) {
+            n = n_first;
+            ih = ih0 + jr + g.dh0;
+            iw = iw0 + cc + g.dw0;
+        } else {
+            const int G = G0 + jr;
+            n = G / HP;
+            ih = G - n * HP + g.dh0;
+            iw = cc + g.dw0;
+        }
         const bool ok = jr < PR && n < g.N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
         voff[it] = ok ? ((unsigned)((n * H + ih) * W + iw) * (unsigned)g.a_pitch + (tid & 1) * 8u) * 4u : OOB;
         int k = n - n_first;
         k = k < 0 ? 0 : (k > 15 ? 15 : k);
         isc[it] = s_imgscale[k];
-        idst[it] = jr < PR ? (tid & 1) * PLANE + (((jr << LP) + ((cc + jr * g.Q) & cmask)) << 4) : -1;
+        idst[it] = jr < PR ? (tid & 1) * PLANE + (((jr << LP) + ((cc + jr * rotq) & cmask)) << 4) : -1;
     }
     f32x4 xr[NI][2];
     float pss[NI];
@@ -2305,19 +2351,20 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     // the refill in two halves: registers -> (h, l) f16 registers as soon as the loads have landed (vector work in the shadow of a
     // step's matrix instructions), registers -> LDS at the end of the chunk, behind the barrier that retires the old patch
     f16x8 ph[NI], pl[NI];
-    auto convert_items = [&]() {
+    auto convert_item = [&](auto it_c) {
+        constexpr int it = decltype(it_c)::value;
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float x = xr[it][q >> 2][q & 3];
-                if (NORM) pss[it] = fmaf(x, x, pss[it]);
-                const float xs = x * isc[it];
-                const _Float16 hh = (_Float16)xs;
-                ph[it][q] = hh;
-                pl[it][q] = (_Float16)(xs - (float)hh);
-            }
+        for (int q = 0; q < 8; ++q) {
+            const float x = xr[it][q >> 2][q & 3];
+            if (NORM) pss[it] = fmaf(x, x, pss[it]);
+            const float xs = x * isc[it];
+            const _Float16 hh = (_Float16)xs;
+            ph[it][q] = hh;
+            pl[it][q] = (_Float16)(xs - (float)hh);
         }
+    };
+    auto convert_items = [&]() {
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (convert_item(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, NI>{});
     };
     auto write_items = [&](int buf_off, bool publish) {
 #pragma unroll
@@ -2363,7 +2410,7 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     f16x8 a_h[TM], a_l[TM];
     int pbuf = 0;                    // byte offset of the patch buffer of the current chunk (two buffers: P_DBUF)
     auto a_addr = [&](int i, int th, int tw) -> const char* {
-        return lds + pbuf + a_row[i] + ((th << LP) << 4) + (((a_c0[i] + tw + th * g.Q) & cmask) << 4);
+        return lds + pbuf + a_row[i] + ((th << LP) << 4) + (((a_c0[i] + tw + th * rotq) & cmask) << 4);
     };
     auto read_al = [&](int th, int tw) {
 #pragma unroll
@@ -2394,7 +2441,7 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     // LAST: the last chunk (no refill; its last two taps issue no B).
     constexpr int TWC = NTAPS == 4 ? 2 : NTAPS == 9 ? 3 : 4;
     constexpr int TCONV = 3;           // the refill loads are forced complete by the wait at the top of tap 3
-    static_assert(NTAPS == TWC * TWC && NTAPS > TCONV, "square tap grids");
+    static_assert(NTAPS == TWC * TWC && NTAPS > TCONV && (!(P_OPT & 4) || TCONV + NI <= NTAPS), "square tap grids; one converted item per tap");
     f16x8 bf[2][TN];
     auto step = [&]<int T, bool LAST>(int c) {
         constexpr int th = T / TWC, tw = T % TWC;
@@ -2438,7 +2485,14 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[i], bf[0][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (T + 1 < NTAPS && !(P_KO & 8)) read_al((T + 1) / TWC, (T + 1) % TWC);
-        if constexpr ((P_OPT & 2) && T == TCONV && !LAST && !(P_KO & 1)) convert_items();
+        // the refill's conversion, one item per step from tap TCONV on: ~30 vector instructions in the shadow of the step's second and third product
+        if constexpr ((P_OPT & 2) && !LAST && !(P_KO & 1)) {
+            if constexpr (P_OPT & 4) {
+                if constexpr (T >= TCONV && T - TCONV < NI) convert_item(std::integral_constant<int, (T >= TCONV && T - TCONV < NI) ? T - TCONV : 0>{});
+            } else if constexpr (T == TCONV) {
+                convert_items();
+            }
+        }
         if constexpr (P_DBUF && (P_OPT & 2) && T == TCONV + 1 && !LAST && !(P_KO & 1)) write_items(4 * PLANE - pbuf, false);   // the other buffer: last read in chunk c - 1
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2481,7 +2535,7 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
             for (int t = tid & 3; t < ntaps; t += 4) {
                 const int th = t / g.TW;
                 const int tw = t - th * g.TW;
-                v += s_pixss[((jr + th) << LP) + ((c0 + tw + th * g.Q) & cmask)];
+                v += s_pixss[((jr + th) << LP) + ((c0 + tw + th * rotq) & cmask)];
             }
             rowss[j] = v;              // staging layout: the 4 lanes of a row hold partial sums
         }
@@ -2547,13 +2601,13 @@ __global__ __launch_bounds__(NTHREADS, (X3 >= 3 && NORM && BN <= H2_NARROW_BN &&
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int T2BW>
 __global__ __launch_bounds__(NTHREADS, 2) void tappatch_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = xcd_remap(blockIdx.x, p.n_big);
     const int tile_m = tile / p.tiles_n;
     const int tile_n = tile - tile_m * p.tiles_n;
-    tile_body_p<BM, BN, WAVES_M, WAVES_N, NORM, NI, PXL, NTAPS>(p, smem, tile_m * BM, tile_n * BN, tile_n);
+    tile_body_p<BM, BN, WAVES_M, WAVES_N, NORM, NI, PXL, NTAPS, T2BW>(p, smem, tile_m * BM, tile_n * BN, tile_n);
 }
 
 // (An 8-wavefront / 512-thread form of the split-f16 loop -- same tile and LDS images, eight waves of 64 x 32 with 32
@@ -2691,11 +2745,19 @@ int launch_d(const KArgs& base, bool norm, hipStream_t stream) {
 }
 
 // split-f16 launches over an LDS-resident input patch (tile_body_p); every tile has BM rows
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NI, int PXL, int NTAPS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NI, int PXL, int NTAPS, int T2BW = 0>
 int launch_p(const KArgs& base, bool norm, hipStream_t stream) {
     KArgs p = base;
     p.tiles_n = (p.g.Cout + BN - 1) / BN;
     p.n_big = ((p.M + BM - 1) / BM) * p.tiles_n;
+    if constexpr (T2BW > 0) {          // 2-D row tiles: (BM / T2BW) x T2BW blocks of every image's row grid
+        constexpr int BH = BM / T2BW;
+        p.t2_bw = T2BW;
+        p.t2_rows = BM;
+        p.t2_nbx = (p.g.Q + T2BW - 1) / T2BW;
+        p.t2_nb = p.t2_nbx * ((p.g.P + BH - 1) / BH);
+        p.n_big = p.g.N * p.t2_nb * p.tiles_n;
+    }
     p.n_small = 0;
     p.rows_big = p.M;
     size_t lds = p_lds_bytes<BM, BN, PXL>();
@@ -2709,8 +2771,8 @@ int launch_p(const KArgs& base, bool norm, hipStream_t stream) {
         hipLaunchKernelGGL(k, grid, block, lds, stream, p);
         return hipSuccess;
     };
-    hipError_t err = norm ? launch(tappatch_kernel<BM, BN, WAVES_M, WAVES_N, true, NI, PXL, NTAPS>, 0)
-                          : launch(tappatch_kernel<BM, BN, WAVES_M, WAVES_N, false, NI, PXL, NTAPS>, 1);
+    hipError_t err = norm ? launch(tappatch_kernel<BM, BN, WAVES_M, WAVES_N, true, NI, PXL, NTAPS, T2BW>, 0)
+                          : launch(tappatch_kernel<BM, BN, WAVES_M, WAVES_N, false, NI, PXL, NTAPS, T2BW>, 1);
     if (err != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", err);
     err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("tapconv launch", err);
@@ -2762,6 +2824,7 @@ BCOS_TC_LAUNCHER(bcos_tc_p_128x128_a);
 BCOS_TC_LAUNCHER(bcos_tc_p_128x128_b);
 BCOS_TC_LAUNCHER(bcos_tc_p_128x128_c);
 BCOS_TC_LAUNCHER(bcos_tc_p_256x64_a);
+BCOS_TC_LAUNCHER(bcos_tc_p2_256x32_t16);
 #define BCOS_TC_DEFINE(name, call) BCOS_TC_LAUNCHER(name) { return call(*static_cast<const KArgs*>(kargs), norm != 0, s); }
 #if BCOS_TC_IN(1)
 BCOS_TC_DEFINE(bcos_tc_cfg_128x128, (launch_cfg<128, 128, 2, 2>))
@@ -2797,6 +2860,7 @@ BCOS_TC_DEFINE(bcos_tc_d_128x32, (launch_d<128, 32, 4, 1>))
 #if BCOS_TC_IN(9)
 BCOS_TC_DEFINE(bcos_tc_p_128x256_a, (launch_p<128, 256, 2, 2, 2, 256, 9>))      // 14^2: 15 rows of 16
 BCOS_TC_DEFINE(bcos_tc_p_256x64_a, (launch_p<256, 64, 4, 1, 5, 640, 9>))        // 56^2: 10 rows of 58 (pitch 64)
+BCOS_TC_DEFINE(bcos_tc_p2_256x32_t16, (launch_p<256, 32, 4, 1, 3, 608, 16, 16>))   // 4 x 4 taps (the depth-to-space stem gradient): 16 x 16 blocks, 19 rows of 19 (pitch 32)
 #endif
 #if BCOS_TC_IN(10)
 BCOS_TC_DEFINE(bcos_tc_p_128x128_a, (launch_p<128, 128, 2, 2, 2, 256, 9>))      // 14^2
@@ -3111,6 +3175,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     p.x3 = mode >= 1 ? 1 : 0;
     p.h2 = 0;
     p.a_absmax = nullptr;
+    p.a_imgmax = nullptr;
+    p.t2_bw = p.t2_nbx = p.t2_nb = p.t2_rows = 0;
     p.absmax_bytes = 0;
     p.wt2 = nullptr;
     p.wt2_bytes = 0;
@@ -3225,15 +3291,19 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // image's bits must not depend on how many images share its launch.  BCOS_PATCH=0: development / test switch.
             const char* pe = getenv("BCOS_PATCH");
             const int ntaps = g.TH * g.TW;
-            const bool geom_ok = ntaps == 9 && g.TH == 3 && g.C % X3_BK == 0 && g.in_sh == g.in_sw && (g.in_sh == 1 || g.in_sh == 2) &&
+            const bool geom_ok = ((ntaps == 9 && g.TH == 3) || (ntaps == 16 && g.TH == 4)) && g.C % X3_BK == 0 && g.in_sh == g.in_sw && (g.in_sh == 1 || g.in_sh == 2) &&
                                  g.dstep_h == 1 && g.dstep_w == 1 && p.g.a_pitch >= g.C;
             if (dma && geom_ok && p.a_imgmax && !(pe && pe[0] == '0')) {
+                if (ntaps == 16) {
+                    if (g.Cout <= 32 && g.in_sh == 1) return bcos_tc_p2_256x32_t16(&p, norm, s);
+                } else {
                 const char* pw_ = getenv("BCOS_PATCH_WIDE");
                 if (g.Cout > 128 && g.Cout <= 256 && patch_fits(g, 128, 256, 256) && !(pw_ && pw_[0] == '0')) return bcos_tc_p_128x256_a(&p, norm, s);
                 if (g.Cout > 64 && patch_fits(g, 128, 256, 256)) return bcos_tc_p_128x128_a(&p, norm, s);
                 if (g.Cout > 64 && patch_fits(g, 128, 256, 448)) return bcos_tc_p_128x128_b(&p, norm, s);
                 if (g.Cout > 64 && patch_fits(g, 128, 384, 320)) return bcos_tc_p_128x128_c(&p, norm, s);
                 if (g.Cout > 32 && g.Cout <= 64 && patch_fits(g, 256, 640, 640)) return bcos_tc_p_256x64_a(&p, norm, s);
+                }
             }
         }
         if (g.Cout > 64) {

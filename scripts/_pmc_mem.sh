@@ -11,7 +11,7 @@ for c in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_REQ_sum TCC_HI
 import csv,sys
 agg={}
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'tapconv' in r['Kernel_Name']:
+    if 'tapconv' in r['Kernel_Name'] or 'tappatch' in r['Kernel_Name']:
         agg.setdefault(r['Counter_Name'],[]).append(float(r['Counter_Value']))
 for k,v in agg.items(): print(k, v[-1])
 PY

@@ -31,10 +31,10 @@ for spec in "resnet50 --forward-only" "resnet18" "vit_ti --batch 512" "vit_ti --
   f=$(find "$OUT/stats_${name}" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$SUM/${TAG}_kernel_stats_${name}.csv"
 done
-# 5. SQ counters of three representative contraction launches (one counter group per pass): A = GEMM-shaped 3x3-class launch
+# 5. SQ counters of four representative contraction launches (one counter group per pass): A = GEMM-shaped 3x3-class launch
 #    M = 50176, K = 2304, N = 256; B = forward 64 -> 256 @56^2 (residual + ReLU + stored multiplier); C = forward 256 -> 1024 @14^2
 {
-  echo "SQ counters of three representative tapconv launches (scripts/_pmc.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass;"
+  echo "SQ counters of four representative contraction launches (scripts/_pmc.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass;"
   echo "counters other than SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE are in units of 4 cycles).  derived: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES /"
   echo "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"
   echo "== A 3x3-class K=2304 (M=50176, N=256, 128x256 tiles, split-f16 loop with LDS-DMA staging)"
@@ -43,6 +43,8 @@ done
   PMC_SCRIPT=pmc_fwd.py CIN=64 COUT=256 HH=56 bash scripts/_pmc.sh ${TAG}pmcB 2>/dev/null
   echo "== C fwd 256->1024 @14^2"
   PMC_SCRIPT=pmc_fwd.py CIN=256 COUT=1024 HH=14 bash scripts/_pmc.sh ${TAG}pmcC 2>/dev/null
+  echo "== D fwd 3x3 256->256 @14^2 (M=50176, K=2304, N=256: the input-patch loop, tile_body_p)"
+  PMC_SCRIPT=pmc_conv.py bash scripts/_pmc.sh ${TAG}pmcD 2>/dev/null
 } > "$SUM/${TAG}_pmc_raw.txt"
 cd "$ROOT"
 python3 - "$SUM/${TAG}_pmc_raw.txt" > "$SUM/${TAG}_pmc_summary.txt" <<'PY'

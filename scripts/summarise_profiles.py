@@ -6,7 +6,7 @@ import csv, glob, json, os, shutil, sys
 
 out, summ, tag = sys.argv[1:4]
 STEPS_PROFILED = 3          # --steps 2 --warmup 1
-KERNELS = ("tapconv_kernel", "skinny_kernel", "skinny_group_kernel")     # the contraction launches bench.py brackets with HIP events
+KERNELS = ("tapconv_kernel", "tappatch_kernel", "skinny_kernel", "skinny_group_kernel")     # the contraction launches bench.py brackets with HIP events
 LAUNCHES_PER_STEP = 117     # ResNet-50 forward + explanation: 54 forward + 63 input-gradient launches (stem gradient fused)
 
 
@@ -39,7 +39,7 @@ def pmc_sum(d, counter):
 fetch, nf = pmc_sum(os.path.join(out, "fetch"), "FETCH_SIZE")
 write, nw = pmc_sum(os.path.join(out, "write"), "WRITE_SIZE")
 res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
-       "note": "contraction kernels (tapconv_kernel<*>, skinny_kernel); the small calibration launches (8 images) are included "
+       "note": "contraction kernels (tapconv_kernel<*>, tappatch_kernel<*>, skinny_kernel); the small calibration launches (8 images) are included "
                "in the sums and contribute < 3 % of the bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts "
                "128-B requests as 64 B), counters in KB",
        "fetch_size_kb_sum": fetch, "write_size_kb_sum": write, "steps": STEPS_PROFILED, "launches_per_step": LAUNCHES_PER_STEP,
