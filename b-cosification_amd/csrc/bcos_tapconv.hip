@@ -2196,6 +2196,9 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
 #ifndef P_NSLOT
 #define P_NSLOT 3                 // B ring slots: 3 = the DMA of step ks + 2 is issued in step ks (two steps to land), 2 = of step ks + 1 (one step)
 #endif
+#ifndef P_WGS3
+#define P_WGS3 0                  // 1 = the 32-column configuration (depth-to-space stem gradient) is compiled for three resident workgroups per CU
+#endif
 #ifndef P_DBUF
 #define P_DBUF 0                  // 1 = two patch buffers: the refill of chunk c + 1 is written during chunk c, no barrier at the end of a chunk
 #endif
@@ -2602,7 +2605,7 @@ __global__ __launch_bounds__(NTHREADS, (X3 >= 3 && NORM && BN <= H2_NARROW_BN &&
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int T2BW>
-__global__ __launch_bounds__(NTHREADS, 2) void tappatch_kernel(const KArgs p) {
+__global__ __launch_bounds__(NTHREADS, (BN <= 32 && P_WGS3) ? 3 : 2) void tappatch_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = xcd_remap(blockIdx.x, p.n_big);
     const int tile_m = tile / p.tiles_n;

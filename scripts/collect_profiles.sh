@@ -12,12 +12,17 @@ export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline"
 # 1. the headline command as the driver runs it (CPU baseline included)
 python3 bench.py --steps 20 --warmup 5 > "$SUM/${TAG}_bench.json" 2> "$OUT/bench.err"
-# 2. kernel stats + HBM counters of the same workload (counters in their own passes, MI355X_MICROARCH.md)
+# 2. kernel stats + HBM counters of the same workload (counters in their own passes, MI355X_MICROARCH.md).  The profiled runs keep
+#    every launch on ONE stream (BCOS_SUBBATCH_STREAMS=1: 117 contraction launches per step, each over the whole batch) -- the form
+#    bench.py's own event-carrying steps use -- so that a launch in the trace is the launch bench.py's HIP events bracket; with the
+#    default two sub-batch streams a step is 234 half-batch launches that overlap in time.
+export BCOS_SUBBATCH_STREAMS=1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$SUM/${TAG}_bench_under_rocprof.json" 2> "$OUT/stats.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/write.err"
 cd "$ROOT"
+unset BCOS_SUBBATCH_STREAMS
 python3 scripts/summarise_profiles.py "$OUT" "$SUM" "$TAG"
 # 3. per-launch table of the same step: TFLOP/s and GB/s per layer geometry, with the bound each launch sits on
 LAYERS_CSV="$SUM/${TAG}_layers.csv" python3 scripts/layer_report.py > "$SUM/${TAG}_layers.txt" 2> "$OUT/layers.err"

@@ -38,7 +38,7 @@ def pmc_sum(d, counter):
 
 fetch, nf = pmc_sum(os.path.join(out, "fetch"), "FETCH_SIZE")
 write, nw = pmc_sum(os.path.join(out, "write"), "WRITE_SIZE")
-res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+res = {"source": "BCOS_SUBBATCH_STREAMS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
        "note": "contraction kernels (tapconv_kernel<*>, tappatch_kernel<*>, skinny_kernel); the small calibration launches (8 images) are included "
                "in the sums and contribute < 3 % of the bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts "
                "128-B requests as 64 B), counters in KB",
