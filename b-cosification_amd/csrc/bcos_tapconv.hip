@@ -3051,22 +3051,36 @@ __global__ __launch_bounds__(256) void rows_absmax_kernel(const float* __restric
 }  // namespace
 
 namespace {
-__global__ __launch_bounds__(256) void image_absmax_kernel(const unsigned* __restrict__ absmax, unsigned* __restrict__ out, int hw) {
-    __shared__ unsigned s_max[4];
+__global__ __launch_bounds__(1024) void image_absmax_kernel(const unsigned* __restrict__ absmax, unsigned* __restrict__ out, int hw) {
+    // one workgroup of 16 waves per image, four independent loads in flight per thread: the kernel is one load latency long
+    __shared__ unsigned s_max[16];
     const unsigned* src = absmax + (size_t)blockIdx.x * hw;
     unsigned v = 0u;
-    for (int i = threadIdx.x; i < hw; i += 256) v = max(v, src[i]);
+    for (int i0 = 0; i0 < hw; i0 += 4096) {
+        unsigned u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * 1024 + (int)threadIdx.x;
+            u[q] = i < hw ? src[i] : 0u;
+        }
+        v = max(max(v, u[0]), max(max(u[1], u[2]), u[3]));
+    }
 #pragma unroll
     for (int o = 32; o; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    if (threadIdx.x < 16) {
+        unsigned m = s_max[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) out[blockIdx.x] = m;
+    }
 }
 }  // namespace
 
 extern "C" int bcos_image_absmax(const uint32_t* absmax, uint32_t* out, int n_images, int pixels_per_image, void* stream) {
     if (!absmax || !out || n_images <= 0 || pixels_per_image <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_image_absmax: bad argument");
-    hipLaunchKernelGGL(image_absmax_kernel, dim3((unsigned)n_images), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), absmax, out,
+    hipLaunchKernelGGL(image_absmax_kernel, dim3((unsigned)n_images), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), absmax, out,
                        pixels_per_image);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("image_absmax launch", err);

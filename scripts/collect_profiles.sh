@@ -24,8 +24,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" --
 cd "$ROOT"
 unset BCOS_SUBBATCH_STREAMS
 python3 scripts/summarise_profiles.py "$OUT" "$SUM" "$TAG"
-# 3. per-launch table of the same step: TFLOP/s and GB/s per layer geometry, with the bound each launch sits on
-LAYERS_CSV="$SUM/${TAG}_layers.csv" python3 scripts/layer_report.py > "$SUM/${TAG}_layers.txt" 2> "$OUT/layers.err"
+# 3. per-launch table of the same step: TFLOP/s and GB/s per layer geometry, with the bound each launch sits on (single stream, as above:
+#    an event pair around a launch must not time a neighbour on the other sub-batch stream)
+BCOS_SUBBATCH_STREAMS=1 LAYERS_CSV="$SUM/${TAG}_layers.csv" python3 scripts/layer_report.py > "$SUM/${TAG}_layers.txt" 2> "$OUT/layers.err"
 # 4. the other BASELINE.json configurations: bench line + kernel stats each
 for spec in "resnet50 --forward-only" "resnet18" "vit_ti --batch 512" "vit_ti --batch 512 --forward-only" "clip_rn50" "clip_rn50 --forward-only"; do
   name=$(echo $spec | tr -d '-' | tr ' ' '_')
