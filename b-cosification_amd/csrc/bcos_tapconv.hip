@@ -119,6 +119,15 @@ __device__ __forceinline__ unsigned group_max_u32(unsigned v) {
 }
 template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
 
+// column parts of an epilogue: 192 -> 3 x 64, 256 -> 2 x 128; EPI_SPLIT_128 (development switch): 128 -> 2 x 64, which halves the
+// transpose buffer (35 instead of 68 KB) so that three 128 x 128 workgroups fit a CU's LDS
+#ifndef EPI_SPLIT_128
+#define EPI_SPLIT_128 0
+#endif
+#ifndef D_WGS3
+#define D_WGS3 0                  // 1 = the 128 x 128 LDS-DMA kernels are compiled for three resident workgroups per CU (needs EPI_SPLIT_128)
+#endif
+template <int BN> constexpr int epi_pn() { return BN == 192 ? 3 : (BN > 128 ? BN / 128 : ((EPI_SPLIT_128 && BN == 128) ? 2 : 1)); }
 // tile / part geometry of an epilogue (shared by the functions below)
 // part (pm, pn) = accumulator tiles i in [pm*TM/PM, ...), j in [pn*TN/PN, ...) of EVERY wave, so each wave retires half
 // of its accumulator registers per part; local row l of a part is tile row (l / HM) * WM + pm * HM + l % HM
@@ -126,7 +135,7 @@ template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;                                                                    \
     constexpr int TM = WM / 32, TN = WN / 32;                                                                              \
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;                \
-    constexpr int PN = BN == 192 ? 3 : (BN > 128 ? BN / 128 : 1);                                                          \
+    constexpr int PN = epi_pn<BN>();                                                                                       \
     constexpr int SBM = BM / PM, SBN = BN / PN;                                                                            \
     constexpr int HM = WM / PM, HN = WN / PN;                                                                              \
     constexpr int TMP = TM / PM, TNP = TN / PN;                                                                            \
@@ -155,7 +164,7 @@ template <int G> constexpr int group_max_lane() { return G == 32 ? 16 : 0; }
 template <int BM, int BN, int WAVES_M>
 __device__ __forceinline__ float* epi_col_table(float* smem) {
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
-    constexpr int SBM = BM / PM, SBN = BN == 192 ? 64 : (BN > 128 ? 128 : BN);
+    constexpr int SBM = BM / PM, SBN = BN / epi_pn<BN>();
     return smem + SBM * (SBN + 4) + BM * 5;
 }
 
@@ -2573,7 +2582,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 // tiles on 256 CUs x 2 resident workgroups the last "round" otherwise runs at ~50 % occupancy (e.g. 784 tiles
 // = 1.53 rounds cost 2 rounds).  Results are bit-identical for any split: an output element's k-order is fixed.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int X3>     // X3: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 with pre-split weights, 3 split-f16 (register staging), 4 split-f16 (LDS-DMA staging)
-__global__ __launch_bounds__(NTHREADS, (X3 >= 3 && NORM && BN <= H2_NARROW_BN && BM <= 128) ? H2_NARROW_WGS : 2) void tapconv_kernel(const KArgs p) {
+__global__ __launch_bounds__(NTHREADS, ((X3 >= 3 && NORM && BN <= H2_NARROW_BN && BM <= 128) ? H2_NARROW_WGS : (D_WGS3 && X3 == 4 && BM == 128 && BN == 128) ? 3 : 2)) void tapconv_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     if (bid < p.n_big) {
@@ -2649,7 +2658,7 @@ void plan_tiles(KArgs& p) {
 template <int BM, int BN, int WAVES_M>
 constexpr size_t epilogue_lds() {
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
-    constexpr int SBM = BM / PM, SBN = BN == 192 ? 64 : (BN > 128 ? 128 : BN);
+    constexpr int SBM = BM / PM, SBN = BN / epi_pn<BN>();
     return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20 + (size_t)BN * 4;
 }
 
