@@ -165,7 +165,22 @@ class _Block:
 
     def __init__(self, block):
         names = [n for n in ("conv1", "conv2", "conv3") if hasattr(block, n)]
+        # Blocks with grouped or MaxOut convolutions (ResNeXt-style `groups`, bcosconv2d.py:84-140, 166-170) are HYBRID nodes of the plan:
+        # the block runs layer by layer on the nn.Module path (one fused HIP launch per layer: bcos/modules/_hipfn.py) and its input
+        # gradient comes from that path's own backward; the blocks around it stay fused.
+        self.hybrid = any(getattr(getattr(block, n), "linear", None) is not None and
+                          (getattr(block, n).linear.groups != 1 or getattr(getattr(block, n), "max_out", 1) != 1) for n in names)
+        ds0 = getattr(block, "downsample", None)
+        if ds0 is not None:
+            self.hybrid = self.hybrid or any(getattr(m, "linear", None) is not None and (m.linear.groups != 1 or getattr(m, "max_out", 1) != 1)
+                                             for m in ds0.children())
+        self.module = block
+        self.k_first = 0
+        if self.hybrid:
+            self.convs, self.shortcut, self.pool, self.shortcut_pool, self.relu = [], None, 0, 0, True
+            return
         self.convs = [_Conv(getattr(block, n), getattr(block, n.replace("conv", "bn"))) for n in names]
+        self.k_first = self.convs[0].k_fwd
         relus = [getattr(block, r) for r in ("relu", "relu1", "relu2", "relu3") if hasattr(block, r)]
         self.relu = all(isinstance(r, nn.ReLU) for r in relus)
         if not self.relu and not all(isinstance(r, nn.Identity) for r in relus):
@@ -336,6 +351,8 @@ class ResNetEngine:
         add_inverse = x.shape[1] == 3
         xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse, want_absmax=True)
         gates = list(gates) if gates is not None else None
+        if gates is not None and any(b.hybrid for b in self.blocks):
+            raise BcosHipError("engine: replayed ReLU gates are not available for networks with grouped / MaxOut blocks")
         st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3], stem_ts=[], stem_hws=[], blocks=[]) if keep else None
         a = xn
         need = lambda k: k >= ops.F16X2_MIN_K      # noqa: E731  will the reader of a tensor use its per-pixel maxima?
@@ -348,7 +365,7 @@ class ResNetEngine:
                 st["stem_ts"].append(t)
         k, s, p = self.pool
         cur = ops.avgpool2d_fwd(a, k, s, p)
-        if need(self.blocks[0].convs[0].k_fwd):
+        if need(self.blocks[0].k_first):
             ops.ensure_absmax(cur)
         if keep:
             st["a0_hw"] = (a.shape[1], a.shape[2])
@@ -356,6 +373,13 @@ class ResNetEngine:
         for bi, blk in enumerate(self.blocks):
             inp = cur
             rec = dict(in_hw=(inp.shape[1], inp.shape[2])) if keep else None
+            if blk.hybrid:
+                k_after = (self.blocks[bi + 1].k_first if bi + 1 < len(self.blocks)
+                           else (self.head.k_fwd if self.head is not None else ops.F16X2_MIN_K))
+                cur = self._hybrid_forward(blk, inp, rec, need(k_after))
+                if keep:
+                    st["blocks"].append(rec)
+                continue
             h = inp
             ts, hws = [], []
             for ci, c in enumerate(blk.convs[:-1]):
@@ -380,7 +404,7 @@ class ResNetEngine:
             # the block's ReLU decision travels in the low mantissa bit of the stored multiplier (include/bcos_hip.h:
             # BCOS_EPI_SCALE_GATE_LSB): the explanation pass reads no separate gate tensor
             if bi + 1 < len(self.blocks):
-                k_next = self.blocks[bi + 1].convs[0].k_fwd
+                k_next = self.blocks[bi + 1].k_first
             else:
                 k_next = self.head.k_fwd if self.head is not None else ops.F16X2_MIN_K
             out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates, track=need(k_next),
@@ -404,6 +428,33 @@ class ResNetEngine:
         if keep:
             st.update(tf=tf, feat_hw=(cur.shape[1], cur.shape[2]))
         return logits, st
+
+    @staticmethod
+    def _hybrid_forward(blk, inp, rec, track):
+        """A grouped / MaxOut block on the nn.Module path: NHWC tensor in, NHWC tensor out.  With `rec` (explanation pass) the
+        block runs in explanation mode under autograd and (input leaf, output) are kept for `torch.autograd.grad`."""
+        xin = inp.permute(0, 3, 1, 2)               # the module path's logical NCHW view of the channels-last tensor
+        if rec is None:
+            with torch.no_grad():
+                y = blk.module(xin)
+        else:
+            xin = xin.detach().requires_grad_(True)
+            mods = [m for m in blk.module.modules() if hasattr(m, "set_explanation_mode")]
+            prev = [m.is_in_explanation_mode for m in mods]
+            for m in mods:
+                m.set_explanation_mode(True)
+            try:
+                with torch.enable_grad():
+                    y = blk.module(xin)
+            finally:
+                for m, was in zip(mods, prev):
+                    m.set_explanation_mode(was)
+            rec.update(hybrid=(xin, y))
+        out = y.detach().permute(0, 2, 3, 1)
+        out = out if out.is_contiguous() else out.contiguous()
+        if track:
+            ops.ensure_absmax(out)
+        return out
 
     def _attnpool_forward(self, feat, st=None):
         """BcosAttentionPool2d.forward, pooled mode (bcosattnpool.py:33-59): tokens = [mean; HW positions], plain q/k/v
@@ -629,6 +680,16 @@ class ResNetEngine:
         for bi in range(nb - 1, -1, -1):
             blk, rec = self.blocks[bi], st["blocks"][bi]
             H, W = st["blocks"][bi + 1]["in_hw"] if bi + 1 < nb else st["feat_hw"]
+            if blk.hybrid:
+                # raw d logit / d out_b from the layers that read it, then the module path's own backward through the block
+                v, _ = consumer.run(H, W, t_main=None, td=None, gated=False, track=False)
+                xin, y = rec["hybrid"]
+                gx = torch.autograd.grad(y, xin, v.permute(0, 3, 1, 2), retain_graph=not consume)[0]
+                if consume:
+                    rec["hybrid"] = None
+                gx = gx.permute(0, 2, 3, 1)
+                consumer = _RawConsumer(gx if gx.is_contiguous() else gx.contiguous())
+                continue
             # v = d logit / d out_b;  G_main = v * t_last (bn scale, ReLU gate and s of the block's last conv),
             # G_sc = v * gate(out_b) [* t_d]  for the shortcut
             G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gated=rec["gated"], gate_t=rec["gate_t"],
@@ -718,6 +779,31 @@ class _Consumer:
             addend = self.g_sc
         out = self.conv.dgrad.run(g, H, W, addend=addend, track_absmax=track, track_absmax2=track2, **kw)
         return out, (out2 if out2 is not None else out)
+
+
+class _RawConsumer:
+    """d logit / d X already computed (X feeds a hybrid block): applies the multipliers of the block that produced X with plain
+    elementwise launches."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def run(self, H, W, t_main, td, gated, gate_t=None, track=None, track2=None):
+        g = self.g
+        if t_main is None:
+            return g, g
+        out = g * t_main
+        out2 = g
+        if gated:       # the ReLU decision of the producing block: its gate tensor, or the low mantissa bit of its multiplier
+            gate = (gate_t > 0) if gate_t is not None else (t_main.view(torch.int32) & 1).bool()
+            out2 = g * gate
+        if td is not None:
+            out2 = out2 * td
+        if track:
+            ops.ensure_absmax(out)
+        if track2:
+            ops.ensure_absmax(out2)
+        return out, out2
 
 
 class CapturedPass:

@@ -1502,6 +1502,39 @@ def test_patch_loop_against_per_tap_loop_and_fp64(lib, monkeypatch):
             assert rel(a, b) <= 2e-6, ("bwd", N, H, Cin, Cout, k, st, rel(a, b))
 
 
+def test_engine_with_grouped_and_maxout_blocks(lib):
+    """Networks with grouped / MaxOut B-cos convolutions in the fused plan (hybrid blocks: bcos_hip/engine.py: _hybrid_forward): same
+    logits, W(x) and maps as the pure nn.Module explanation; batch large enough for the two sub-batch streams."""
+    from bcos_hip import engine, synth
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    net = synth.build_bcosified_resnet("resnet18")
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        blk = net.model.layer2[1]
+        blk.conv1 = BcosifyConv2d(128, 128, 3, 1, 1, groups=2, b=2)
+        blk.conv1.linear.weight.copy_(torch.randn(blk.conv1.linear.weight.shape, generator=g) / (9 * 64) ** 0.5)
+        blk = net.model.layer3[1]
+        blk.conv2 = BcosifyConv2d(256, 256, 3, 1, 1, max_out=2, b=2)
+        blk.conv2.linear.weight.copy_(torch.randn(blk.conv2.linear.weight.shape, generator=g) / (9 * 256) ** 0.5)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        synth.calibrate(net, synth.synthetic_images(8).to(DEV))
+    x = synth.synthetic_images(64, seed=77, size=96).to(DEV)
+    ref = net.explain_batch(x)                                      # no engine attached: autograd over the modules
+    eng = engine.attach(net)
+    try:
+        assert sum(b.hybrid for b in eng.blocks) == 2
+        out = net.explain_batch(x)
+        assert rel(out["logits"], ref["logits"]) <= 1e-5
+        assert torch.equal(out["prediction"], ref["prediction"])
+        assert rel(out["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 2e-4      # (free ReLU gates, 18 layers)
+        assert rel(out["contribution_map"], ref["contribution_map"]) <= 2e-4
+        one = eng.explain(x[40:41])
+        assert torch.equal(one["contribution_map"], out["contribution_map"][40:41])            # an image's bits: independent of the batch
+    finally:
+        engine.detach(net)
+
+
 def test_clip_zeroshot_text_attribution_against_reference_golden(lib, golden_dir):
     """Explanation of the zero-shot TEXT logit through the fused engine (bcos_hip.clip_head.zeroshot_attribution): the pooled
     head and the attn_unpool head with its pooled-cosine variants (interpretability/analyses/text_localisation.py:68-104).

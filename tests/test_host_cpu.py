@@ -597,6 +597,45 @@ def test_fused_engine_plan_against_oracle(monkeypatch, arch):
     assert rel(eng.forward(x), ref["logits"]) <= 1e-5
 
 
+def test_fused_engine_plan_with_grouped_and_maxout_blocks(monkeypatch):
+    """Round 3: networks with grouped or MaxOut B-cos convolutions (bcosconv2d.py:84-140, 166-170) attach to the
+    fused plan too -- such a block is a hybrid node that runs layer by layer on the nn.Module path inside the plan (bcos_hip/engine.py:
+    _hybrid_forward, _RawConsumer) while the stem, the other blocks and the head stay fused.  Same logits, W(x) and maps as the pure
+    nn.Module explanation of the same network."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import engine, synth
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    net = synth.build_bcosified_resnet("resnet18")
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "linear") and isinstance(m.linear, nn.Conv2d):
+                m.linear.weight.mul_(3.0)
+        blk = net.model.layer2[1]                                   # 3x3 128 -> 128, two groups
+        blk.conv1 = BcosifyConv2d(128, 128, 3, 1, 1, groups=2, b=2)
+        blk.conv1.linear.weight.copy_(torch.randn(blk.conv1.linear.weight.shape, generator=g) * (3.0 / (9 * 64) ** 0.5))
+        blk = net.model.layer3[1]                                   # 3x3 256 -> 256 as the max over two filters per unit
+        blk.conv2 = BcosifyConv2d(256, 256, 3, 1, 1, max_out=2, b=2)
+        blk.conv2.linear.weight.copy_(torch.randn(blk.conv2.linear.weight.shape, generator=g) * (3.0 / (9 * 256) ** 0.5))
+    net = net.eval()
+    x = synth.synthetic_images(2, size=64)
+    ref = net.explain_batch(x)                                      # no engine attached: autograd over the modules
+    eng = engine.ResNetEngine(net)
+    assert [b.hybrid for b in eng.blocks] == [False, False, False, True, False, True, False, False]
+    out = eng.explain(x)
+    assert rel(out["logits"], ref["logits"]) <= 1e-5
+    assert torch.equal(out["prediction"], ref["prediction"])
+    assert rel(out["dynamic_linear_weights"], ref["dynamic_linear_weights"]) <= 1e-4
+    assert rel(out["contribution_map"], ref["contribution_map"]) <= 1e-4
+    assert rel(eng.forward(x), ref["logits"]) <= 1e-5
+    tgt = torch.tensor([3, 997])
+    assert rel(eng.explain(x, targets=tgt)["contribution_map"], net.explain_batch(x, targets=tgt)["contribution_map"]) <= 1e-4
+    multi = eng.explain_targets(x, torch.tensor([[1, 2], [3, 4]]))  # the kept forward is walked twice (retain_graph)
+    assert rel(multi["contribution_maps"][:, 1], eng.explain(x, targets=torch.tensor([2, 4]))["contribution_map"]) <= 1e-5
+    with pytest.raises(Exception, match="gates"):
+        eng.explain(x, gates=[torch.ones(1)])
+
+
 def test_synthetic_recipe_is_deterministic():
     from bcos_hip import synth
     a, b = synth.build_bcosified_resnet("resnet18"), synth.build_bcosified_resnet("resnet18")
