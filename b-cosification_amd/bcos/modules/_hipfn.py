@@ -183,6 +183,20 @@ def learnable_b(module):
     return b if isinstance(b, torch.Tensor) and b.requires_grad and torch.is_grad_enabled() else None
 
 
+def _scale_bwd_cols(g2, y2, s2, norm, mode, cfg, want_bgrad):
+    """ops.train_scale_bwd over [rows, C] operands of ANY width: the kernel moves float4, so ragged widths are padded to a multiple
+    of four columns (g = y = 0, s = 1 contribute nothing to the row sums or to the exponent gradient) and cut back."""
+    co = g2.shape[1]
+    pad = (-co) % 4
+    if pad:
+        g2, y2, s2 = F.pad(g2, (0, pad)), F.pad(y2, (0, pad)), F.pad(s2, (0, pad), value=1.0)
+    glin, rnorm, bgrad = ops.train_scale_bwd(g2.contiguous(), y2.contiguous(), s2.contiguous(), norm, mode, float(cfg["b"]),
+                                             bool(cfg.get("force_pow")), want_bgrad=want_bgrad)
+    if pad:
+        glin = glin[:, :co].contiguous()
+    return glin, rnorm, bgrad
+
+
 class BcosConv2dFn(Function):
     """y = bcos_conv(x): see module docstring.  cfg keys: stride, padding, dilation, groups, b, max_out,
     detach, cache (WeightCache), w_src (the parameter the cache is keyed on)."""
@@ -305,17 +319,15 @@ class BcosConv2dFn(Function):
             # dense copies of the group's slices (a rarely used path: clarity over launch count)
             Cout = g.shape[3]
             cout_g, cin_g = Cout // groups, Cin // groups
-            if cout_g % 4:
-                raise NotImplementedError("training-mode backward needs out_channels / groups % 4 == 0")
             yh = to_nhwc(y_cl)
             glin = torch.empty((N, Ho, Wo, Cout), device=g.device, dtype=torch.float32)
             addend_g = [None] * groups
             btot = None
             for gi in range(groups):
                 sl = slice(gi * cout_g, (gi + 1) * cout_g)
-                gl_g, rn_g, bg = ops.train_scale_bwd(g[..., sl].reshape(-1, cout_g).contiguous(), yh[..., sl].reshape(-1, cout_g).contiguous(),
-                                                     scale[..., sl].reshape(-1, cout_g).contiguous(), norm[..., gi].reshape(-1).contiguous(),
-                                                     BCOS_CONV_EPS, float(cfg["b"]), bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
+                gl_g, rn_g, bg = _scale_bwd_cols(g[..., sl].reshape(-1, cout_g), yh[..., sl].reshape(-1, cout_g),
+                                                 scale[..., sl].reshape(-1, cout_g), norm[..., gi].reshape(-1).contiguous(),
+                                                 BCOS_CONV_EPS, cfg, ctx.need_bp)
                 glin[..., sl] = gl_g.view(N, Ho, Wo, cout_g)
                 if bg is not None:
                     btot = bg if btot is None else btot + bg
@@ -327,11 +339,8 @@ class BcosConv2dFn(Function):
             addend = addend_g
         elif ctx.train:
             Cout = g.shape[3]
-            if Cout % 4:
-                raise NotImplementedError("training-mode backward needs out_channels % 4 == 0")
-            glin, rnorm, bgrad = ops.train_scale_bwd(g.view(-1, Cout), to_nhwc(y_cl).view(-1, Cout), scale.view(-1, Cout),
-                                                     norm.view(-1), BCOS_CONV_EPS, float(cfg["b"]), bool(cfg.get("force_pow")),
-                                                     want_bgrad=ctx.need_bp)
+            glin, rnorm, bgrad = _scale_bwd_cols(g.reshape(-1, Cout), to_nhwc(y_cl).reshape(-1, Cout), scale.reshape(-1, Cout),
+                                                 norm.view(-1), BCOS_CONV_EPS, cfg, ctx.need_bp)
             glin = glin.view(N, Ho, Wo, Cout)
             if ctx.need_bp:
                 gbp = (bgrad * float(cfg.get("b_chain", 1.0))).view(())
@@ -447,15 +456,7 @@ class BcosLinearFn(Function):
         addend = None
         gbp = None
         if ctx.train:
-            co = g2.shape[1]
-            if co % 4:      # the scale-derivative kernel moves float4: pad the columns (g = y = 0, s = 1 contribute nothing)
-                pad = (-co) % 4
-                glin, rnorm, bgrad = ops.train_scale_bwd(F.pad(g2, (0, pad)), F.pad(y, (0, pad)), F.pad(scale, (0, pad), value=1.0), norm,
-                                                         BCOS_LINEAR_EPS, float(cfg["b"]), bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
-                glin = glin[:, :co].contiguous()
-            else:
-                glin, rnorm, bgrad = ops.train_scale_bwd(g2, y, scale, norm, BCOS_LINEAR_EPS, float(cfg["b"]),
-                                                         bool(cfg.get("force_pow")), want_bgrad=ctx.need_bp)
+            glin, rnorm, bgrad = _scale_bwd_cols(g2, y, scale, norm, BCOS_LINEAR_EPS, cfg, ctx.need_bp)
             if ctx.need_bp:
                 gbp = (bgrad * float(cfg.get("b_chain", 1.0))).view(())
             if need_x:      # gradient through ||x||: x * dL/dnorm / ||x||, added by the dgrad epilogue

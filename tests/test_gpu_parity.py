@@ -1502,6 +1502,39 @@ def test_patch_loop_against_per_tap_loop_and_fp64(lib, monkeypatch):
             assert rel(a, b) <= 2e-6, ("bwd", N, H, Cin, Cout, k, st, rel(a, b))
 
 
+def test_training_gradients_with_ragged_output_widths(lib):
+    """N4 remainder: training-mode layers whose out_channels (per group) is not a multiple of four.  The scale-derivative
+    kernel moves float4; ragged widths are padded to four columns for that launch and cut back (bcos/modules/_hipfn.py:
+    _scale_bwd_cols).  Input, weight and bias gradients against the oracle's autograd (CPU, fp64)."""
+    from oracle import bcos_oracle as O
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    g = torch.Generator().manual_seed(91)
+    for (cin, cout, k, st, pd, groups, bias) in [(8, 6, 3, 1, 1, 1, True), (16, 12, 3, 1, 1, 2, False), (8, 10, 1, 1, 0, 1, True), (12, 9, 3, 2, 1, 1, False)]:
+        m = BcosifyConv2d(cin, cout, k, st, pd, groups=groups, b=2)
+        if bias:                                    # (what from_standard_module attaches, bcosifyconv2d.py:18-31)
+            m.linear.bias = torch.nn.Parameter(torch.randn(cout, generator=g) * 0.1)
+        m = m.to(DEV).train()
+        with torch.no_grad():
+            m.linear.weight.copy_((torch.randn(m.linear.weight.shape, generator=g) / (k * k * cin / groups) ** 0.5).to(DEV))
+        x = torch.randn(3, cin, 9, 9, generator=g)
+        r = torch.randn(3, cout, O.F.conv2d(x, m.linear.weight.detach().cpu(), None, st, pd, groups=groups).shape[2],
+                        O.F.conv2d(x, m.linear.weight.detach().cpu(), None, st, pd, groups=groups).shape[3], generator=g)
+        xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = m(xg)
+        (y * r.to(DEV)).sum().backward()
+        xd = x.double().requires_grad_(True)
+        wd = m.linear.weight.detach().cpu().double().requires_grad_(True)
+        bd = m.linear.bias.detach().cpu().double().requires_grad_(True) if bias else None
+        yd = O.bcos_conv2d(xd, wd, bd, stride=st, padding=pd, groups=groups, b=2)
+        (yd * r.double()).sum().backward()
+        what = (cin, cout, k, st, groups)
+        assert rel(y, yd) <= 1e-5, what
+        assert rel(xg.grad, xd.grad) <= 1e-5, what
+        assert rel(m.linear.weight.grad, wd.grad) <= 1e-5, what
+        if bias:
+            assert rel(m.linear.bias.grad, bd.grad) <= 1e-5, what
+
+
 def test_engine_with_grouped_and_maxout_blocks(lib):
     """Networks with grouped / MaxOut B-cos convolutions in the fused plan (hybrid blocks: bcos_hip/engine.py: _hybrid_forward): same
     logits, W(x) and maps as the pure nn.Module explanation; batch large enough for the two sub-batch streams."""
