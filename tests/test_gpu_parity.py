@@ -1502,6 +1502,32 @@ def test_patch_loop_against_per_tap_loop_and_fp64(lib, monkeypatch):
             assert rel(a, b) <= 2e-6, ("bwd", N, H, Cin, Cout, k, st, rel(a, b))
 
 
+def test_patch_loop_rectangular_images(lib, monkeypatch):
+    """The input-patch loop on non-square images (row pitch, rotation and tile spans use P, Q, H, W separately): forward and input
+    gradient against the per-tap loop and fp64, linear tiles (narrow images) and 2-D tiles (wide ones)."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(3)
+    for (N, H, W, Cin, Cout) in [(3, 10, 23, 64, 128), (2, 31, 9, 32, 64), (2, 12, 90, 32, 64), (5, 7, 14, 128, 256)]:
+        x = ops.ensure_absmax(torch.randn(N, H, W, Cin, generator=g).to(DEV))
+        w = ops.mark_static((torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV))
+        monkeypatch.delenv("BCOS_PATCH", raising=False)
+        y_p = ops.conv2d_fwd(x, w, stride=(1, 1), padding=(1, 1), relu=False, want_norm=True)
+        monkeypatch.setenv("BCOS_PATCH", "0")
+        y_t = ops.conv2d_fwd(x, w, stride=(1, 1), padding=(1, 1), relu=False, want_norm=True)
+        monkeypatch.delenv("BCOS_PATCH", raising=False)
+        xd, wd = x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2)
+        lin = torch.nn.functional.conv2d(xd, wd, padding=1)
+        nrm = (torch.nn.functional.conv2d(xd * xd, torch.ones(1, Cin, 3, 3, device=DEV, dtype=torch.float64), padding=1) + 1e-6).sqrt()
+        y64 = (lin * lin.abs() / nrm).permute(0, 2, 3, 1)
+        assert rel(y_p[0], y64) <= 2e-6 and rel(y_p[0], y_t[0]) <= 2e-6, (N, H, W, Cin, Cout, rel(y_p[0], y64))
+        assert rel(y_p[2].double().flatten(), nrm.flatten()) <= 1e-6
+        plan = ops.DgradPlan(w.permute(0, 3, 1, 2).contiguous(), (1, 1), (1, 1))
+        gl = ops.ensure_absmax(torch.randn(N, H, W, Cout, generator=g).to(DEV))
+        gx = plan.run(gl, H, W)
+        g64 = torch.nn.functional.conv_transpose2d(gl.double().permute(0, 3, 1, 2), wd, padding=1).permute(0, 2, 3, 1)
+        assert rel(gx, g64) <= 2e-6, (N, H, W, Cin, Cout, rel(gx, g64))
+
+
 def test_training_gradients_with_ragged_output_widths(lib):
     """N4 remainder: training-mode layers whose out_channels (per group) is not a multiple of four.  The scale-derivative
     kernel moves float4; ragged widths are padded to four columns for that launch and cut back (bcos/modules/_hipfn.py:
