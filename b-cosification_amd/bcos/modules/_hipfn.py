@@ -151,6 +151,7 @@ class WeightCache:
         if self._fwd is None:
             w4 = w_eff if w_eff.dim() == 4 else w_eff[:, :, None, None]
             self._fwd = ops.mark_static(_pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous())
+            ops.publish_cached(self._fwd)          # (made on this stream, read by launches on any stream later)
         return self._fwd
 
     def dgrad(self, w_eff, src, stride, padding, dilation, groups):
@@ -167,6 +168,7 @@ class WeightCache:
                 if r:
                     wg = torch.cat([wg, wg.new_zeros((r,) + tuple(wg.shape[1:]))], 0)
                 plans.append(ops.DgradPlan(wg, stride, padding, dilation))
+            ops.publish_cached(w4)
             self._dgrad[k] = plans
         return self._dgrad[k]
 

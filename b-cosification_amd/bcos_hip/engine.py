@@ -109,6 +109,7 @@ class _Conv:
         self.rebuild_ok = True
         if self.ch_shift is not None and self.ch_scale is not None:
             self.rebuild_ok = bool(float(self.ch_shift.abs().max()) <= _REBUILD_MAX_SHIFT * float(self.ch_scale.abs().median()))
+        ops.publish_cached(self.w_fwd)      # (a refresh inside a sub-batch pass runs on that pass's side stream; the other one reads the result)
 
     def out_hw(self, H, W):
         return (ops.conv_out_size(H, self.k[0], self.stride[0], self.padding[0], self.dilation[0]),

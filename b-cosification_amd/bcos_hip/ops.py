@@ -93,15 +93,19 @@ def split_weights_f16x2(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
     return out
 
 
+def publish_cached(t: torch.Tensor):
+    """A device object that has just been made on the CURRENT stream and is about to be cached for later launches, whichever stream
+    those run on (the engines process sub-batches on side streams): complete it first.  Once per cached object."""
+    if t is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def _image_of(wt: torch.Tensor, attr: str, make):
     cached = getattr(wt, attr, None)
     if cached is None or cached[0] != wt._version:
         cached = (wt._version, make(wt))
         setattr(wt, attr, cached)
-        # The image is made on the CURRENT stream and cached for every later launch, whichever stream that one runs on (the
-        # engines process sub-batches on side streams): complete it before anyone else can pick it up.  Once per weight tensor.
-        if wt.is_cuda and not torch.cuda.is_current_stream_capturing():
-            torch.cuda.current_stream(wt.device).synchronize()
+        publish_cached(cached[1])
     return cached[1]
 
 
@@ -474,8 +478,7 @@ class DgradPlan:
             base = (rh * sw + rw) * pitch
             wc[base:base + self.Cin, h0 - dh0:h0 - dh0 + th, w0 - dw0:w0 - dw0 + tw] = wt
         mark_static(wc)
-        if wc.is_cuda and not torch.cuda.is_current_stream_capturing():
-            torch.cuda.current_stream(wc.device).synchronize()      # cached for launches on other streams too (see _image_of)
+        publish_cached(wc)
         self._d2s[pitch] = (wc, TH, TW, dh0, dw0)
         return self._d2s[pitch]
 

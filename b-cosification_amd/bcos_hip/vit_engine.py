@@ -170,6 +170,7 @@ class ViTEngine:
     def _ensure_fresh(self):
         if self._fingerprint() != self._fp:
             self.refresh()
+            ops.publish_cached(self.embed_w)    # (a refresh inside a sub-batch pass runs on that pass's side stream; the other one reads the result)
 
     def refresh(self):
         from bcos.modules.bcoslinear import BcosLinear
