@@ -138,12 +138,15 @@ def cpu_baseline(net, arch, n_images, budget_s=30.0):
     env_threads = os.environ.get("BCOS_CPU_BASELINE_THREADS")
     cands = sorted({c for c in ((int(env_threads),) if env_threads else (32, 64, _physical_cores(), avail)) if 1 <= c <= avail}) or [avail]
     sweep = {}
+    best = 0.0
     for c in cands:
         torch.set_num_threads(c)
-        run(xs[:4])
-        sweep[c] = round(8 / run(xs), 2)
-        if 8 / sweep[c] > 20.0:                      # a collapsed pool (seconds per image): do not try larger ones
+        t2 = run(xs[:2])                             # two-image probe (and this pool size's warm-up)
+        if best > 0.0 and t2 / 2.0 > 3.0 / best:     # more than 3 x slower per image than the best so far: torch's intra-op pool has
+            sweep[c] = round(2 / t2, 2)              # collapsed (it only gets worse with more threads: 0.05 images/s at 256) -- stop here
             break
+        sweep[c] = round(8 / run(xs), 2)
+        best = max(best, sweep[c])
     cores = max(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     rate = sweep[cores]
@@ -159,7 +162,7 @@ def cpu_baseline(net, arch, n_images, budget_s=30.0):
                 thread_sweep_images_per_s={str(k): v for k, v in sweep.items()},
                 sample=f"forward+explanation (and, separately, forward-only) of one batch of {n} images in chunks of {CH}, best of 2 timed "
                        f"passes after a warm-up (the other pass: {n / t_fe[1]:.1f} images/s), torch {torch.__version__} CPU fp32 with "
-                       f"{cores} threads = the fastest of the sweep {sweep} (8-image passes) on {_host_description()}"
+                       f"{cores} threads = the fastest of the sweep {sweep} (8-image passes; the sweep stops at the first pool size more than 3 x slower than the best, timed on 2 images) on {_host_description()}"
                        + ("" if n >= 256 else f"; BASELINE.md section 4 asks for batch 256: {n} images timed to stay within ~{budget_s:.0f} s "
                                                "of CPU work, throughput is per image"))
 
