@@ -2837,6 +2837,7 @@ BCOS_TC_LAUNCHER(bcos_tc_p_128x128_b);
 BCOS_TC_LAUNCHER(bcos_tc_p_128x128_c);
 BCOS_TC_LAUNCHER(bcos_tc_p_256x64_a);
 BCOS_TC_LAUNCHER(bcos_tc_p2_256x32_t16);
+BCOS_TC_LAUNCHER(bcos_tc_p2_256x32_t9);
 BCOS_TC_LAUNCHER(bcos_tc_p2_256x64_b32);
 #define BCOS_TC_DEFINE(name, call) BCOS_TC_LAUNCHER(name) { return call(*static_cast<const KArgs*>(kargs), norm != 0, s); }
 #if BCOS_TC_IN(1)
@@ -2874,6 +2875,7 @@ BCOS_TC_DEFINE(bcos_tc_d_128x32, (launch_d<128, 32, 4, 1>))
 BCOS_TC_DEFINE(bcos_tc_p_128x256_a, (launch_p<128, 256, 2, 2, 2, 256, 9>))      // 14^2: 15 rows of 16
 BCOS_TC_DEFINE(bcos_tc_p_256x64_a, (launch_p<256, 64, 4, 1, 5, 640, 9>))        // 56^2: 10 rows of 58 (pitch 64)
 BCOS_TC_DEFINE(bcos_tc_p2_256x64_b32, (launch_p<256, 64, 4, 1, 3, 640, 9, 32>))      // 3 x 3 on wide images: 8 x 32 blocks, 10 rows of 34 (pitch 64)
+BCOS_TC_DEFINE(bcos_tc_p2_256x32_t9, (launch_p<256, 32, 4, 1, 3, 576, 9, 16>))     // 3 x 3 with <= 32 output channels on wide images (CLIP stem, 32 -> 32 @112^2): 16 x 16 blocks, 18 rows of 18
 BCOS_TC_DEFINE(bcos_tc_p2_256x32_t16, (launch_p<256, 32, 4, 1, 3, 608, 16, 16>))   // 4 x 4 taps (the depth-to-space stem gradient): 16 x 16 blocks, 19 rows of 19 (pitch 32)
 #endif
 #if BCOS_TC_IN(10)
@@ -3334,6 +3336,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 // wider images (112^2: the 3 x 3 stem convolutions of the CLIP ResNets): 8 x 32 blocks.  (At 56^2 the linear tiles win,
                 // 224 against 253 us: the blocks leave an eighth of the rows empty there.)
                 if (g.Cout > 32 && g.Cout <= 64 && g.in_sh == 1 && g.Q > 64) return bcos_tc_p2_256x64_b32(&p, norm, s);
+                if (g.Cout > 8 && g.Cout <= 32 && g.in_sh == 1 && g.Q > 64) return bcos_tc_p2_256x32_t9(&p, norm, s);
                 }
             }
         }

@@ -1452,7 +1452,7 @@ def test_patch_loop_against_per_tap_loop_and_fp64(lib, monkeypatch):
              (2, 56, 64, 64, 3, 1, 1), (9, 9, 64, 48, 3, 1, 1), (2, 28, 128, 128, 3, 2, 1), (4, 14, 256, 256, 3, 2, 1),
              (2, 17, 64, 192, 3, 1, 1), (2, 20, 16, 128, 5, 1, 2), (3, 12, 32, 40, 3, 1, 0), (2, 15, 32, 52, 3, 2, 1),
              (20, 6, 48, 64, 3, 1, 1), (2, 33, 8, 64, 7, 2, 3), (3, 64, 8, 64, 7, 2, 3),     # (7 x 7 / 2 over 8 channels: the depth-to-space gradient, 4 x 4 taps in 2-D tiles)
-             (2, 80, 32, 64, 3, 1, 1), (1, 112, 32, 48, 3, 1, 1)]                               # (wide images: 3 x 3 in 8 x 32 blocks)
+             (2, 80, 32, 64, 3, 1, 1), (1, 112, 32, 48, 3, 1, 1), (2, 72, 32, 32, 3, 1, 1), (1, 100, 16, 24, 3, 1, 1)]   # (wide images: 3 x 3 in 8 x 32 / 16 x 16 blocks)
     for (N, H, Cin, Cout, k, st, pd) in cases:
         mag = torch.logspace(-3, 3, N).view(N, 1, 1, 1)                    # images six decades apart
         x = ops.ensure_absmax((torch.randn(N, H, H, Cin, generator=g) * mag).to(DEV))
