@@ -3321,7 +3321,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // image's bits must not depend on how many images share its launch.  BCOS_PATCH=0: development / test switch.
             const char* pe = getenv("BCOS_PATCH");
             const int ntaps = g.TH * g.TW;
-            const bool geom_ok = ((ntaps == 9 && g.TH == 3) || (ntaps == 16 && g.TH == 4)) && g.C % X3_BK == 0 && g.in_sh == g.in_sw && (g.in_sh == 1 || g.in_sh == 2) &&
+            const bool geom_ok = ((ntaps == 9 && g.TH == 3) || (ntaps == 16 && g.TH == 4)) && g.C % X3_BK == 0 && g.in_sh == 1 && g.in_sw == 1 &&
                                  g.dstep_h == 1 && g.dstep_w == 1 && p.g.a_pitch >= g.C;
             if (dma && geom_ok && p.a_imgmax && !(pe && pe[0] == '0')) {
                 if (ntaps == 16) {
