@@ -224,7 +224,7 @@ typedef struct bcos_operands {
     const void* wt_f16x2;       /* NULL or the image made by bcos_split_weights_f16x2                              */
     int32_t contraction;        /* BCOS_CONTRACT_*                                                                  */
     const uint32_t* a_imgmax;   /* NULL or [N]: max over the pixels of image n of a_absmax (bcos_image_absmax; ABI v6).  With
-                                   it, 3 x 3 launches of the f16x2 contraction run over an LDS-resident input patch (every input
+                                   it, stride-1 3 x 3 launches (and the 4 x 4 tap union of a depth-to-space gradient) of the f16x2 contraction run over an LDS-resident input patch (every input
                                    element loaded and split once per 16 channels instead of once per tap) with ONE operand scale
                                    per image: elements within 2^-17 of their image's max keep 22 bits, smaller ones an absolute
                                    error <= 2^-40 of that max.  An image's results do not depend on its batch neighbours.      */

@@ -1502,6 +1502,21 @@ def test_patch_loop_against_per_tap_loop_and_fp64(lib, monkeypatch):
             assert rel(a, b) <= 2e-6, ("bwd", N, H, Cin, Cout, k, st, rel(a, b))
 
 
+def test_c_abi_image_absmax(lib):
+    """bcos_image_absmax (ABI v6) through the C ABI: per-image maxima of per-pixel maxima, image sizes on either side of the
+    kernel's 4096-pixel stride, bit-exact (integer maxima of fp32 bit patterns)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(12)
+    for (n, hw) in [(1, 1), (3, 49), (256, 196), (5, 3136), (2, 4096), (3, 5000), (2, 12544)]:
+        x = (torch.randn(n * hw, generator=g).abs() * torch.logspace(-6, 6, n).repeat_interleave(hw)).to(DEV)
+        am = x.view(torch.int32)
+        out = torch.full((n,), -1, device=DEV, dtype=torch.int32)
+        assert lib.bcos_image_absmax(C.c_void_p(am.data_ptr()), C.c_void_p(out.data_ptr()), n, hw, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, am.view(n, hw).max(1).values)
+    assert lib.bcos_image_absmax(None, C.c_void_p(out.data_ptr()), 1, 1, None) != 0
+
+
 def test_patch_loop_rectangular_images(lib, monkeypatch):
     """The input-patch loop on non-square images (row pitch, rotation and tile spans use P, Q, H, W separately): forward and input
     gradient against the per-tap loop and fp64, linear tiles (narrow images) and 2-D tiles (wide ones)."""
