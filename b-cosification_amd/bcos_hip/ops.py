@@ -304,9 +304,10 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
                 and (ktot >= F16X2_MIN_K or (int(g.C) <= 16 and ktot >= 128) or contraction == "f16x2")):
             o.a_absmax = am_a.data_ptr()
             taps = int(g.TH) * int(g.TW)               # the image is stored in the K order of a launch with this tap count
-            if (PATCH_LOOP and ((taps == 9 and int(g.TH) == 3 and (int(g.Cout) > 32 or (int(g.Cout) > 8 and int(g.Q) > 64))) or (taps == 16 and int(g.TH) == 4 and int(g.Cout) <= 32))
-                    and int(g.in_sh) == 1 and int(g.in_sw) == 1 and int(g.dstep_h) == 1 and int(g.dstep_w) == 1
-                    and int(g.C) % 16 == 0 and int(g.groups) <= 1):
+            patchable = (((taps == 9 and int(g.TH) == 3 and (int(g.Cout) > 32 or (int(g.Cout) > 8 and int(g.Q) > 64)))
+                          or (taps == 16 and int(g.TH) == 4 and int(g.Cout) <= 32))
+                         and int(g.in_sh) == 1 and int(g.in_sw) == 1 and int(g.dstep_h) == 1 and int(g.dstep_w) == 1 and int(g.C) % 16 == 0)
+            if PATCH_LOOP and int(g.groups) <= 1 and (patchable or taps >= 25):      # (>= 25 taps, the 7 x 7 stem: image maxima replace the per-row scan of the taps)
                 # 3 x 3 launches (and the 4 x 4 tap union of a depth-to-space input gradient) contract over an LDS-resident input
                 # patch with one operand scale per image (include/bcos_hip.h: bcos_operands.a_imgmax): the per-image maxima, once per tensor
                 im = image_absmax(am_a, int(g.N), int(g.H) * int(g.W))

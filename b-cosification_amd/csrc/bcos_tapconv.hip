@@ -1793,7 +1793,10 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     char* s_dummy = lds + D_NSLOT * SLOT + BM * 4;                                           // 1 KB: target of the dummy B DMAs
     unsigned* s_tapoff = reinterpret_cast<unsigned*>(lds + D_NSLOT * SLOT + BM * 4 + 1024);    // [tap][BM] byte offsets (without the lane's chunk)
     {
-        // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 lanes of a row share the taps
+        // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 lanes of a row share the taps.
+        // Launches with 25 or more taps that were given per-image maxima (the 7 x 7 stem: 49 taps = 13 dependent-latency loads per
+        // lane and tile before the first DMA) take the row's IMAGE maximum instead (bcos_operands.a_imgmax, as the patch loop does)
+        const bool img_scale = p.a_imgmax != nullptr && g.TH * g.TW >= 25;
         unsigned rmax[A_LD];
         int pix0[A_LD];
 #pragma unroll
@@ -1807,6 +1810,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
                 const int jj = rem - i * g.Q;
                 a_nbase[j] = ((unsigned)n * H * W * a_pitch + chunk * 4) * 4u;
                 pix0[j] = n * H * W;
+                if (img_scale) rmax[j] = p.a_imgmax[n];
                 a_ih0[j] = i * g.in_sh + g.dh0;
                 a_iw0[j] = jj * g.in_sw + g.dw0;
             } else {
@@ -1817,7 +1821,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             }
         }
         const int ntaps = g.TH * g.TW;
-        for (int t = chunk; t < ntaps; t += 4) {
+        for (int t = chunk; t < (img_scale ? 0 : ntaps); t += 4) {
             const int th = t / g.TW, tw = t - th * g.TW;
             const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
 #pragma unroll
@@ -3320,6 +3324,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // never on the batch: the patch loop rounds differently from the per-tap loops (one operand scale per image), and an
             // image's bits must not depend on how many images share its launch.  BCOS_PATCH=0: development / test switch.
             const char* pe = getenv("BCOS_PATCH");
+            if (pe && pe[0] == '0') p.a_imgmax = nullptr;      // (per-row scales everywhere: the per-tap loops as they were)
             const int ntaps = g.TH * g.TW;
             const bool geom_ok = ((ntaps == 9 && g.TH == 3) || (ntaps == 16 && g.TH == 4)) && g.C % X3_BK == 0 && g.in_sh == 1 && g.in_sw == 1 &&
                                  g.dstep_h == 1 && g.dstep_w == 1 && p.g.a_pitch >= g.C;

@@ -18,6 +18,8 @@ if os.environ.get("PSHAPES") == "3":
     SHAPES = [(14, 256, 256, 3, 1), (28, 128, 128, 3, 1), (56, 64, 64, 3, 1), (7, 512, 512, 3, 1)]
 if os.environ.get("PSHAPES") == "4":
     SHAPES = [(56, 64, 64, 3, 1), (112, 32, 64, 3, 1)]
+if os.environ.get("PSHAPES") == "5":
+    SHAPES = [(224, 8, 64, 7, 2)]
 if os.environ.get("PSHAPES") == "2":
     SHAPES = [(14, 256, 256, 3, 1)]
 g = torch.Generator().manual_seed(0)
