@@ -2290,8 +2290,75 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
         const int i_last = (m_last - n_last * p.PQ) / g.Q;
         PR = n_last * HP + i_last * st + g.TH - G0;
     }
-    if (tid < 16) s_imgmax[tid] = n_first + tid <= n_last ? p.a_imgmax[n_first + tid] : 0u;      // (at most 16 images per tile: patch_fits)
-    __syncthreads();
+    // (the tile's image maxima: the OLDEST memory operation of the prologue, so that waiting for it leaves the loads below in flight)
+    const unsigned my_imgmax = (tid < 16 && n_first + tid <= n_last) ? p.a_imgmax[n_first + tid] : 0u;      // (at most 16 images per tile: patch_fits)
+    // this thread's NI items of the patch: item q = tid + NT it is (used pixel q >> 1 in row-major order of the PR x PW patch,
+    // k-half q & 1): 8 channels = two 16-byte loads, stored at the pixel's rotated physical position
+    unsigned voff[NI];
+    float isc[NI];
+    int iimg[NI];                    // image of the item (index into the tile's image scales)
+    int idst[NI];                    // byte offset of the item in the h half (the l half at + 2 PLANE), or -1: no such pixel
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int px = (tid >> 1) + (NT / 2) * it;
+        const int jr = px / PW;
+        const int cc = px - jr * PW;
+        int n, ih, iw;
+        if constexpr (T2D) {
+            n = n_first;
+            ih = ih0 + jr + g.dh0;
+            iw = iw0 + cc + g.dw0;
+        } else {
+            const int G = G0 + jr;
+            n = G / HP;
+            ih = G - n * HP + g.dh0;
+            iw = cc + g.dw0;
+        }
+        const bool ok = jr < PR && n < g.N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        voff[it] = ok ? ((unsigned)((n * H + ih) * W + iw) * (unsigned)g.a_pitch + (tid & 1) * 8u) * 4u : OOB;
+        int k = n - n_first;
+        iimg[it] = k < 0 ? 0 : (k > 15 ? 15 : k);
+        idst[it] = jr < PR ? (tid & 1) * PLANE + (((jr << LP) + ((cc + jr * rotq) & cmask)) << 4) : -1;
+    }
+    f32x4 xr[NI][2];
+    float pss[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) pss[it] = 0.f;
+    auto load_items = [&](int soff) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            xr[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)voff[it], soff, 0));
+            xr[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(voff[it] + 16u), soff, 0));
+        }
+    };
+    const int b_tile0 = n0 >> 5;
+    auto issue_b = [&](int ks, int slot_off) {
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int blk = wave + NW * j;
+            if (NBLK % NW == 0 || blk < NBLK) {
+                const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(ring + slot_off + blk * 1024), 16, lane * 16, soff, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(s_dummy), 16, (int)OOB, 0, 0, 0);   // keeps every wave's DMA count equal
+            }
+        }
+    };
+
+    // The first chunk's loads and the first B blocks go out BEFORE the rest of the prologue (image scales, row table: two barriers
+    // and a few hundred integer instructions), which then runs under their latency instead of ahead of it.
+    constexpr int AHEAD = P_NSLOT - 1;               // the DMA of step ks + AHEAD is issued in step ks
+    load_items(0);
+    issue_b(0, 0);
+    if constexpr (AHEAD == 2) issue_b(1, BSLOT);
+    // (barriers of the prologue: LDS traffic only -- __syncthreads() would also wait for the loads and DMAs issued above)
+    auto lds_barrier = []() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if (tid < 16) s_imgmax[tid] = my_imgmax;
+    lds_barrier();
     for (int r = tid; r < BM; r += NT) {
         int base = 0;
         float inv = 1.0f;
@@ -2323,47 +2390,10 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
         E = E < 15u ? 15u : E;
         s_imgscale[tid] = __uint_as_float((268u - E) << 23);       // max * scale in [2^14, 2^15)
     }
-    __syncthreads();
+    lds_barrier();
+#pragma unroll
+    for (int it = 0; it < NI; ++it) isc[it] = s_imgscale[iimg[it]];
 
-    // this thread's NI items of the patch: item q = tid + NT it is (used pixel q >> 1 in row-major order of the PR x PW patch,
-    // k-half q & 1): 8 channels = two 16-byte loads, stored at the pixel's rotated physical position
-    unsigned voff[NI];
-    float isc[NI];
-    int idst[NI];                    // byte offset of the item in the h half (the l half at + 2 PLANE), or -1: no such pixel
-#pragma unroll
-    for (int it = 0; it < NI; ++it) {
-        const int px = (tid >> 1) + (NT / 2) * it;
-        const int jr = px / PW;
-        const int cc = px - jr * PW;
-        int n, ih, iw;
-        if constexpr (T2D) {
-            n = n_first;
-            ih = ih0 + jr + g.dh0;
-            iw = iw0 + cc + g.dw0;
-        } else {
-            const int G = G0 + jr;
-            n = G / HP;
-            ih = G - n * HP + g.dh0;
-            iw = cc + g.dw0;
-        }
-        const bool ok = jr < PR && n < g.N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-        voff[it] = ok ? ((unsigned)((n * H + ih) * W + iw) * (unsigned)g.a_pitch + (tid & 1) * 8u) * 4u : OOB;
-        int k = n - n_first;
-        k = k < 0 ? 0 : (k > 15 ? 15 : k);
-        isc[it] = s_imgscale[k];
-        idst[it] = jr < PR ? (tid & 1) * PLANE + (((jr << LP) + ((cc + jr * rotq) & cmask)) << 4) : -1;
-    }
-    f32x4 xr[NI][2];
-    float pss[NI];
-#pragma unroll
-    for (int it = 0; it < NI; ++it) pss[it] = 0.f;
-    auto load_items = [&](int soff) {
-#pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            xr[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)voff[it], soff, 0));
-            xr[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(voff[it] + 16u), soff, 0));
-        }
-    };
     // the refill in two halves: registers -> (h, l) f16 registers as soon as the loads have landed (vector work in the shadow of a
     // step's matrix instructions), registers -> LDS at the end of the chunk, behind the barrier that retires the old patch
     f16x8 ph[NI], pl[NI];
@@ -2392,20 +2422,6 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
         if (publish) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the raw s_barrier that publishes the patch does not wait for LDS writes;
                                                                              //  with two buffers the fragment reads of the following taps do)
     };
-    const int b_tile0 = n0 >> 5;
-    auto issue_b = [&](int ks, int slot_off) {
-#pragma unroll
-        for (int j = 0; j < LB; ++j) {
-            const int blk = wave + NW * j;
-            if (NBLK % NW == 0 || blk < NBLK) {
-                const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(ring + slot_off + blk * 1024), 16, lane * 16, soff, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(s_dummy), 16, (int)OOB, 0, 0, 0);   // keeps every wave's DMA count equal
-            }
-        }
-    };
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -2441,11 +2457,7 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
         asm volatile("" ::: "memory");
     };
 
-    // prologue: chunk 0 of the patch, B of steps 0 and 1 (nk >= 4)
-    constexpr int AHEAD = P_NSLOT - 1;               // the DMA of step ks + AHEAD is issued in step ks
-    load_items(0);
-    issue_b(0, 0);
-    if constexpr (AHEAD == 2) issue_b(1, BSLOT);
+    // prologue: chunk 0 of the patch (its loads and the B blocks of steps 0 and 1 were issued at the top; nk >= 4)
     wait_vmcnt<AHEAD * LB>();
     convert_items();
     write_items(0, true);
