@@ -28,7 +28,7 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 BCOS_EPI_UNIT_NORM_W = 32
-ABI_VERSION = 6
+ABI_VERSION = 7
 TAPCONV_PARTS = 11
 
 
@@ -52,7 +52,7 @@ class Epilogue(C.Structure):
 
 class Operands(C.Structure):
     _fields_ = [("a", C.c_void_p), ("a_absmax", C.c_void_p), ("wt", C.c_void_p), ("wt_bf16x3", C.c_void_p),
-                ("wt_f16x2", C.c_void_p), ("contraction", C.c_int32), ("a_imgmax", C.c_void_p)]
+                ("wt_f16x2", C.c_void_p), ("contraction", C.c_int32), ("a_imgmax", C.c_void_p), ("a_imgmin", C.c_void_p)]
 
 
 CONTRACT_DEFAULT, CONTRACT_F32, CONTRACT_BF16X3, CONTRACT_F16X2 = 0, 1, 2, 3
@@ -64,9 +64,12 @@ SIGNATURES = {
     "bcos_last_error_string": (C.c_char_p, []),
     "bcos_set_contraction_mode": (C.c_int, [_I]),
     "bcos_get_contraction_mode": (C.c_int, []),
+    "bcos_set_option": (C.c_int, [_I, _L]),
+    "bcos_get_option": (C.c_int, [_I, C.POINTER(C.c_int64)]),
     "bcos_tapconv": (C.c_int, [_P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
     "bcos_tapconv_ops": (C.c_int, [C.POINTER(Operands), C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
     "bcos_image_absmax": (C.c_int, [_P, _P, _I, _I, _P]),
+    "bcos_image_absrange": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights_f16x2": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_conv": (C.c_int, [_P, _P, _I, _I, _I, _P]),
@@ -189,7 +192,56 @@ def load():
     mode = os.environ.get("BCOS_CONTRACTION", "").lower()
     if mode in _MODE_CODES:
         lib.bcos_set_contraction_mode(_MODE_CODES[mode])
+    # The library itself never reads the environment (include/bcos_hip.h: bcos_set_option).  For the A/B scripts under scripts/
+    # the HOST layer translates BCOS_OPT_<NAME>=<int> once, here, into option calls.
+    for name in OPTIONS:
+        val = os.environ.get("BCOS_OPT_" + name.upper())
+        if val is not None:
+            set_option(name, int(val))
+    _loaded_options.update({name: get_option(name) for name in OPTIONS})
     return lib
+
+
+_loaded_options = {}
+
+
+def reset_options():
+    """Every option back to the value it had when the library was loaded (defaults + BCOS_OPT_* of the environment)."""
+    for name, val in _loaded_options.items():
+        set_option(name, val)
+
+
+# include/bcos_hip.h: enum bcos_option
+OPTIONS = {"tail_split": 0, "d_one_wg": 1, "epi_generic": 2, "h2_loop": 3, "patch": 4, "patch_wide": 5, "h2_tile": 6, "h2_tall": 7,
+           "h2_tall_min": 8, "attention_f32": 9, "split_limit": 10, "balance": 11, "split_k": 12, "patch_levels": 13}
+
+
+def set_option(name: str, value: int):
+    """Process-wide development / test switch of the library (bcos_set_option); returns the previous value."""
+    old = get_option(name)
+    check(load().bcos_set_option(OPTIONS[name], int(value)), f"bcos_set_option({name}, {value})")
+    return old
+
+
+def get_option(name: str) -> int:
+    out = C.c_int64(0)
+    check(load().bcos_get_option(OPTIONS[name], C.byref(out)), f"bcos_get_option({name})")
+    return out.value
+
+
+class option:
+    """`with lib.option("patch", 0): ...` -- an option changed for the duration of a block (tests, A/B scripts)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 _MODE_NAMES = {0: "f32", 1: "bf16x3", 2: "f16x2"}

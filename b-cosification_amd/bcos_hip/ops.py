@@ -208,13 +208,15 @@ PATCH_LOOP = os.environ.get("BCOS_PATCH", "1") != "0"     # development / test s
 
 
 def image_absmax(am: torch.Tensor, n_images: int, pixels_per_image: int) -> torch.Tensor:
-    """Per-image maxima [N] of a per-pixel maxima tensor (include/bcos_hip.h: bcos_image_absmax), cached on it: the maxima of a
-    tensor are complete once its producer has been enqueued, and a fresh side tensor is attached whenever the tensor is rewritten."""
+    """Per-image range [2, N] (row 0: maxima, row 1: minima over the nonzero pixels) of a per-pixel maxima tensor
+    (include/bcos_hip.h: bcos_image_absrange), cached on it: the maxima of a tensor are complete once its producer has been
+    enqueued; the cache is dropped whenever the side tensor is handed to a producer again (_out_absmax)."""
     rec = getattr(am, "_bcos_imgmax", None)
     if rec is not None and rec[1] == (n_images, pixels_per_image):
         return rec[0]
-    out = torch.empty(n_images, device=am.device, dtype=torch.int32)
-    _l.check(_l.load().bcos_image_absmax(am.data_ptr(), out.data_ptr(), n_images, pixels_per_image, _stream()), "bcos_image_absmax")
+    out = torch.empty(2, n_images, device=am.device, dtype=torch.int32)
+    _l.check(_l.load().bcos_image_absrange(am.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), n_images, pixels_per_image, _stream()),
+             "bcos_image_absrange")
     am._bcos_imgmax = (out, (n_images, pixels_per_image))
     return out
 
@@ -248,6 +250,8 @@ def _out_absmax(t: Optional[torch.Tensor], pixels: int):
     if am is None or am.numel() != pixels:
         am = _new_absmax(pixels, t.device)
         _attach_absmax(t, am)
+    elif hasattr(am, "_bcos_imgmax"):
+        del am._bcos_imgmax            # the maxima are about to grow: per-image values cached from an earlier fill are stale
     return am
 
 
@@ -311,7 +315,8 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
                 # 3 x 3 launches (and the 4 x 4 tap union of a depth-to-space input gradient) contract over an LDS-resident input
                 # patch with one operand scale per image (include/bcos_hip.h: bcos_operands.a_imgmax): the per-image maxima, once per tensor
                 im = image_absmax(am_a, int(g.N), int(g.H) * int(g.W))
-                o.a_imgmax = im.data_ptr()
+                o.a_imgmax = im[0].data_ptr()
+                o.a_imgmin = im[1].data_ptr()
                 keep.append(im)
             o.wt_f16x2 = _image_of(wt, f"_bcos_wt2_t{taps}", lambda w: split_weights_f16x2(w, taps)).data_ptr()
         elif static:

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include "bcos_hip.h"
 #include "bcos_internal.h"
 
@@ -23,6 +24,48 @@ int bcos_set_hip_error(const char* what, hipError_t err) {
 }
 
 extern "C" int bcos_version(void) { return BCOS_ABI_VERSION; }
+
+// -- option table (include/bcos_hip.h: bcos_option) ------------------------------------------------------------------------
+namespace {
+struct OptSpec { int64_t def, lo, hi; };
+constexpr int64_t TWO31 = (int64_t)1 << 31;
+constexpr OptSpec OPT_SPECS[BCOS_OPT_COUNT] = {
+    {1, 0, 1},                       // TAIL_SPLIT
+    {0, 0, 8},                       // D_ONE_WG
+    {0, 0, 1},                       // EPI_GENERIC
+    {0, 0, 1},                       // H2_LOOP
+    {1, 0, 1},                       // PATCH
+    {1, 0, 1},                       // PATCH_WIDE
+    {0, 0, 2},                       // H2_TILE
+    {1, 0, 1},                       // H2_TALL
+    {2 * 256 * 512, 0, TWO31},       // H2_TALL_MIN
+    {0, 0, 1},                       // ATTENTION_F32
+    {TWO31, 1 << 16, TWO31},         // SPLIT_LIMIT
+    {1, 0, 1},                       // BALANCE
+    {1, 0, 1},                       // SPLIT_K
+    {1, 0, 1},                       // PATCH_LEVELS
+};
+std::atomic<int64_t> g_opts[BCOS_OPT_COUNT] = {
+    OPT_SPECS[0].def, OPT_SPECS[1].def, OPT_SPECS[2].def, OPT_SPECS[3].def, OPT_SPECS[4].def, OPT_SPECS[5].def, OPT_SPECS[6].def,
+    OPT_SPECS[7].def, OPT_SPECS[8].def, OPT_SPECS[9].def, OPT_SPECS[10].def, OPT_SPECS[11].def, OPT_SPECS[12].def, OPT_SPECS[13].def};
+static_assert(BCOS_OPT_COUNT == 14, "one OPT_SPECS row and one initialiser per option");
+}  // namespace
+
+int64_t bcos_option(int option) { return g_opts[option].load(std::memory_order_relaxed); }
+
+extern "C" int bcos_set_option(int option, int64_t value) {
+    if (option < 0 || option >= BCOS_OPT_COUNT) return bcos_set_error(BCOS_E_INVAL, "bcos_set_option: unknown option");
+    if (value < OPT_SPECS[option].lo || value > OPT_SPECS[option].hi)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_set_option: value outside the option's range");
+    g_opts[option].store(value, std::memory_order_relaxed);
+    return BCOS_OK;
+}
+
+extern "C" int bcos_get_option(int option, int64_t* value) {
+    if (option < 0 || option >= BCOS_OPT_COUNT || !value) return bcos_set_error(BCOS_E_INVAL, "bcos_get_option: bad argument");
+    *value = bcos_option(option);
+    return BCOS_OK;
+}
 
 extern "C" const char* bcos_last_error_string(void) { return g_err; }
 

@@ -7,6 +7,9 @@
 int bcos_set_error(int code, const char* msg);
 // record a HIP runtime error; returns BCOS_E_LAUNCH
 int bcos_set_hip_error(const char* what, hipError_t err);
+// current value of a bcos_option (include/bcos_hip.h); `option` must be a valid enumerator
+#include <stdint.h>
+int64_t bcos_option(int option);
 
 
 struct bcos_tapconv_geom;

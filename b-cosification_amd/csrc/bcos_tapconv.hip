@@ -67,6 +67,9 @@ struct KArgs {
     const unsigned* a_absmax;     // split-f16 path: per-pixel max |A| bit patterns (the operand scale source)
     unsigned absmax_bytes;
     const unsigned* a_imgmax;     // ... per-image maxima of those (input-patch loop, tile_body_p), else NULL
+    const unsigned* a_imgmin;     // ... per-image minima over the NONZERO pixels of those (dynamic range inside an image), else NULL
+    int lvl_on;                   // input-patch loop: 1 = one pass per operand-scale level present in a tile (BCOS_OPT_PATCH_LEVELS)
+    int lvl_off;                  // input-patch loop: byte offset, inside the dynamic LDS, of the row-level table (beyond everything the epilogue uses)
     const void* wt2;              // split-f16 path: pre-split, pre-scaled weights in MFMA fragment order (bcos_split_weights_f16x2)
     unsigned wt2_bytes;
     const float* wt2_cinv;        // ... their inverse column scales [padded Cout]
@@ -151,9 +154,12 @@ template <int BN> constexpr int epi_pn() { return BN == 192 ? 3 : (BN > 128 ? BN
 // entry they are live across the whole main loop, the kernel exceeds the 102 scalar registers by > 100, and every
 // use of a spilled pointer inside the per-element loop becomes a v_readlane on the vector ALU.
 // (KArgs is the kernel's only explicit argument, so it sits at offset 0 of the segment.)
+// `kpin`: NULL inside a kernel; the segment pointer handed down where the epilogue runs in an out-of-line function
+// (tile_body_p_more) -- llvm.amdgcn.kernarg.segment.ptr is NULL outside kernels.
+typedef const __attribute__((address_space(4))) struct KArgs* KArgsSegPtr;
 #define BCOS_EPI_KARGS                                                                                                     \
     const __attribute__((address_space(4))) KArgs* kp =                                                                    \
-        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();                            \
+        kpin ? kpin : (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();              \
     asm volatile("" : "+s"(kp));                                                                                           \
     const __attribute__((address_space(4))) KArgs& p = *kp;                                                                \
     const auto& g = p.g;                                                                                                   \
@@ -174,8 +180,11 @@ __device__ __forceinline__ float* epi_col_table(float* smem) {
 // inverse row scales, p.wt2_cinv the inverse column scales.
 //   epi_rows_generic: per-row metadata (output pixel, patch norm, inverse scales) into LDS behind the transpose buffer;
 //   epi_part_generic: one part of the tile, LDS transpose buffer -> epilogue math -> tensors.
+// `lvl` (input-patch loop on images of wide dynamic range, tile_body_p): NULL, or one byte per tile row -- only the rows whose byte
+// equals `pass` belong to this pass of the tile; the others are dropped like rows beyond M
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
-__device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0) {
+__device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0,
+                                                 const unsigned char* lvl, const int pass, KArgsSegPtr kpin) {
     BCOS_EPI_SHAPE
     BCOS_EPI_KARGS
     float* sC = smem;
@@ -186,7 +195,7 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
     for (int r = tid; r < BM; r += NT) {
         int64_t pix = -1, apix = -1;
         int n, i, jj;
-        if (tile_row_nij(p, m0, r, n, i, jj)) {
+        if (tile_row_nij(p, m0, r, n, i, jj) && (lvl == nullptr || lvl[r] == pass)) {
             pix = ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
             if (!NORM && e.addend_sub > 1) {     // subsampled addend: this row's pixel in [N, ceil(OH / s), ceil(OW / s)] or -1
                 const int s = e.addend_sub;
@@ -234,7 +243,8 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
-__device__ __forceinline__ void epi_part_generic(float* smem, const int pm, const int pn, const int part, const int n0, const int tile_n) {
+__device__ __forceinline__ void epi_part_generic(float* smem, const int pm, const int pn, const int part, const int n0, const int tile_n,
+                                                 KArgsSegPtr kpin) {
     BCOS_EPI_SHAPE
     BCOS_EPI_KARGS
     float* sC = smem;
@@ -551,7 +561,8 @@ struct __attribute__((aligned(16))) EpiRow { unsigned off; float rinv; float ain
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
-__device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0) {
+__device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0,
+                                              const unsigned char* lvl, const int pass, KArgsSegPtr kpin) {
     BCOS_EPI_SHAPE
     BCOS_EPI_KARGS
     constexpr unsigned OOB = 0x80000000u;
@@ -562,7 +573,8 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
     for (int r = tid; r < BM; r += NT) {
         int pix = -1;
         int n = 0, i = 0, jj = 0;
-        if (tile_row_nij(p, m0, r, n, i, jj)) pix = (n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+        if (tile_row_nij(p, m0, r, n, i, jj) && (lvl == nullptr || lvl[r] == pass))
+            pix = (n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
         sRow[r].pix = pix;
         sRow[r].off = pix >= 0 ? (unsigned)pix * (unsigned)out_pitch * 4u : OOB;
         if (!NORM && e.addend_sub > 1) {
@@ -613,7 +625,8 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT, int EF>
-__device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const int pn, const int part, const int n0, const int tile_n) {
+__device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const int pn, const int part, const int n0, const int tile_n,
+                                              KArgsSegPtr kpin) {
     BCOS_EPI_SHAPE
     BCOS_EPI_KARGS
     constexpr unsigned OOB = 0x80000000u;
@@ -792,14 +805,16 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
 // Tiles larger than 128 x 128 are drained in 128 x 128 parts (one part = half the accumulators of every wave) so that the
 // LDS transpose buffer stays at 66 KB and two workgroups fit a CU.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT = NTHREADS>
-__device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
+__device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
                                               const float* ss, const float* ROWSS, const float* AINV, const int m0, const int n0,
-                                              const int tile_n) {
+                                              const int tile_n, const unsigned char* lvl = nullptr, const int pass = 0) {
     BCOS_EPI_SHAPE
     const int kind = p.epi_kind;
+    KArgsSegPtr kpin = nullptr;          // (see BCOS_EPI_KARGS)
+    if constexpr (!std::is_same_v<std::remove_cvref_t<decltype(p)>, KArgs>) kpin = &p;
     // (all waves are past the last barrier of the main loop: the staging buffers are free)
-    if (kind) epi_rows_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0);
-    else epi_rows_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0);
+    if (kind) epi_rows_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0, lvl, pass, kpin);
+    else epi_rows_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0, lvl, pass, kpin);
     float* sC = smem;
     // (the parts are expanded at compile time: a loop the optimiser declines to unroll would index the accumulators at run time)
     auto drain = [&](auto part_c) {
@@ -820,17 +835,17 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, float* smem, f32x1
 #define BCOS_EPI_CASE(I)                                                                                                     \
     case I + 1:                                                                                                              \
         epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, (NORM ? EPI_KINDS_FWD[I] : EPI_KINDS_BWD[I])>(smem, pm, pn, part, \
-                                                                                                                n0, tile_n); \
+                                                                                                                n0, tile_n, kpin); \
         break;
 #define BCOS_EPI_CASE_FWD(I)                                                                                                 \
     case I + 1:                                                                                                              \
         if constexpr (NORM)                                                                                                  \
-            epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, EPI_KINDS_FWD[I]>(smem, pm, pn, part, n0, tile_n);     \
+            epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, EPI_KINDS_FWD[I]>(smem, pm, pn, part, n0, tile_n, kpin); \
         break;
         switch (kind) {
             BCOS_EPI_CASE(0) BCOS_EPI_CASE(1) BCOS_EPI_CASE(2) BCOS_EPI_CASE(3) BCOS_EPI_CASE(4) BCOS_EPI_CASE(5)
             BCOS_EPI_CASE(6) BCOS_EPI_CASE_FWD(7)
-            default: epi_part_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, pm, pn, part, n0, tile_n);
+            default: epi_part_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, pm, pn, part, n0, tile_n, kpin);
         }
 #undef BCOS_EPI_CASE
 #undef BCOS_EPI_CASE_FWD
@@ -1323,6 +1338,7 @@ __device__ __forceinline__ void tile_body_x3(const KArgs& p, float* smem, const 
 //     reads): the four waves share one copy instead of each fetching its own fragments through the texture path;
 //   * the activation split costs ~4 VALU per element (scale, 2 converts, 1 mixed FMA) instead of ~9;
 //   * tiles of 256 x 128 / 128 x 256 (8 accumulator tiles per wave) halve the bytes staged per MFMA.
+constexpr int LVL_STEP = 12;       // operand-scale ladder of the per-image scales: a row is computed with a scale within 2^LVL_STEP of its own maximum (tile_body_p)
 constexpr int H2_MAX_TAPS = 16;    // channel-chunk-major K walk for up to this many taps (offset table: taps x BM x 4 bytes of LDS)
 #ifndef H2_KO
 #define H2_KO 0                   // development knock-outs (timing only, wrong results): 1 no MFMA, 2 no split VALU, 4 no global loads in the loop, 8 no fragment reads
@@ -1794,9 +1810,13 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     unsigned* s_tapoff = reinterpret_cast<unsigned*>(lds + D_NSLOT * SLOT + BM * 4 + 1024);    // [tap][BM] byte offsets (without the lane's chunk)
     {
         // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 lanes of a row share the taps.
-        // Launches with 25 or more taps that were given per-image maxima (the 7 x 7 stem: 49 taps = 13 dependent-latency loads per
-        // lane and tile before the first DMA) take the row's IMAGE maximum instead (bcos_operands.a_imgmax, as the patch loop does)
-        const bool img_scale = p.a_imgmax != nullptr && g.TH * g.TW >= 25;
+        // Launches with 25 or more taps that were given the per-image range of those maxima (the 7 x 7 stem: 49 taps = 13
+        // dependent-latency loads per lane and tile before the first DMA) take the row's IMAGE maximum instead -- for the rows of
+        // images whose nonzero pixels all lie within 2^LVL_STEP of that maximum (then it is within 2^LVL_STEP of every row's own
+        // maximum too, and every row keeps the full 22 bits: the B-cos network input [x, 1 - x] always qualifies); the rows of
+        // other images scan their taps.  Either way the scale of a row is a function of its image alone.
+        const bool img_scale = p.a_imgmax != nullptr && p.a_imgmin != nullptr && g.TH * g.TW >= 25;
+        bool scan = !img_scale;
         unsigned rmax[A_LD];
         int pix0[A_LD];
 #pragma unroll
@@ -1810,7 +1830,11 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
                 const int jj = rem - i * g.Q;
                 a_nbase[j] = ((unsigned)n * H * W * a_pitch + chunk * 4) * 4u;
                 pix0[j] = n * H * W;
-                if (img_scale) rmax[j] = p.a_imgmax[n];
+                if (img_scale) {
+                    const unsigned mx = p.a_imgmax[n], mn = p.a_imgmin[n];
+                    const unsigned Ei = max(mx >> 23, 15u);
+                    if (Ei - min(mn >> 23, Ei) <= (unsigned)LVL_STEP) rmax[j] = mx; else scan = true;
+                }
                 a_ih0[j] = i * g.in_sh + g.dh0;
                 a_iw0[j] = jj * g.in_sw + g.dw0;
             } else {
@@ -1821,15 +1845,19 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             }
         }
         const int ntaps = g.TH * g.TW;
-        for (int t = chunk; t < (img_scale ? 0 : ntaps); t += 4) {
-            const int th = t / g.TW, tw = t - th * g.TW;
-            const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+        // (the four lanes of a row take the same decision; a pixel maximum never exceeds its image's, so a row that already holds
+        //  its image maximum is not changed by lanes of the same wave that scan)
+        if (scan) {
+            for (int t = chunk; t < ntaps; t += 4) {
+                const int th = t / g.TW, tw = t - th * g.TW;
+                const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
 #pragma unroll
-            for (int j = 0; j < A_LD; ++j) {
-                const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
-                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)(pix0[j] + ih * W + iw) * 4u : OOB, 0, 0);
-                rmax[j] = max(rmax[j], v);
+                for (int j = 0; j < A_LD; ++j) {
+                    const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)(pix0[j] + ih * W + iw) * 4u : OOB, 0, 0);
+                    rmax[j] = max(rmax[j], v);
+                }
             }
         }
 #pragma unroll
@@ -2219,10 +2247,16 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
 #define P_OPT 7                   // development switches: 1 = DMA issue behind the fragment reads (else ahead of them), 2 = refill converted from tap 3 on (else at the end of the chunk), 4 = ... one item per tap (else all at tap 3)
 #endif
 template <int BM, int BN, int PXL>
-constexpr size_t p_lds_bytes() { return (size_t)PXL * 64 * (1 + P_DBUF) + P_NSLOT * (size_t)(BN / 32) * 2048 + 1024 + (size_t)BM * 8 + 128; }
+constexpr size_t p_lds_bytes() { return (size_t)PXL * 64 * (1 + P_DBUF) + P_NSLOT * (size_t)(BN / 32) * 2048 + 1024 + (size_t)BM * 8 + 192; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int T2BW = 0, int NT = NTHREADS>
-__device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int T2BW, bool MORE>
+__device__ __noinline__ void tile_body_p_more(const __attribute__((address_space(4))) KArgs* kp, unsigned lds_base, int m0, int n0, int tile_n, int pass, unsigned lvl_mask);
+
+// MORE = false: the tile's first (normally only) pass, inlined into the kernel.  MORE = true: a further pass of a tile whose rows span
+// several operand-scale levels (see "Dynamic range" below), run from tile_body_p_more -- an out-of-line function, so that the loop
+// over the levels and what it keeps live cost the common path nothing.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int T2BW = 0, bool MORE = false, int NT = NTHREADS, typename PT>
+__device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int m0, const int n0, const int tile_n, int pass = 0, unsigned lvl_mask = 1u) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NW = NT / 64;
@@ -2242,13 +2276,18 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     float* s_rowinv = reinterpret_cast<float*>(s_base + BM);             // [BM] inverse operand scale of the row (its image's)
     unsigned* s_imgmax = reinterpret_cast<unsigned*>(s_rowinv + BM);     // [16]
     float* s_imgscale = reinterpret_cast<float*>(s_imgmax + 16);         // [16]
+    unsigned* s_imgmin = reinterpret_cast<unsigned*>(s_imgscale + 16);   // [16]
+    // beyond everything the epilogue touches (KArgs.lvl_off): the level of every tile row and the set of levels present (wide images)
+    unsigned char* s_lvl = reinterpret_cast<unsigned char*>(lds + p.lvl_off);     // [BM]
+    unsigned* s_lvlmask = reinterpret_cast<unsigned*>(lds + p.lvl_off + BM);
+    unsigned* s_pixmax = reinterpret_cast<unsigned*>(lds);               // [PX] per-pixel maxima (wide images; before the first patch is written)
     float* s_pixss = reinterpret_cast<float*>(ring);                     // [PX] per-pixel sums of squares (after the loop: the ring is free)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const bcos_tapconv_geom& g = p.g;
+    const auto& g = p.g;
     const int H = g.H, W = g.W, st = g.in_sh;
     // T2BW > 0: the tile is a (BM / T2BW) x T2BW block of ONE image's row grid (wide images: the rows of a linear tile would drag whole
     // image rows into the patch); the patch is then the block's own halo'd window and `rotq` (the rotation per patch row) its width
@@ -2292,18 +2331,18 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     }
     // (the tile's image maxima: the OLDEST memory operation of the prologue, so that waiting for it leaves the loads below in flight)
     const unsigned my_imgmax = (tid < 16 && n_first + tid <= n_last) ? p.a_imgmax[n_first + tid] : 0u;      // (at most 16 images per tile: patch_fits)
+    const unsigned my_imgmin = (tid < 16 && n_first + tid <= n_last && p.a_imgmin) ? p.a_imgmin[n_first + tid] : 0u;   // (not given: range unknown = wide)
     // this thread's NI items of the patch: item q = tid + NT it is (used pixel q >> 1 in row-major order of the PR x PW patch,
     // k-half q & 1): 8 channels = two 16-byte loads, stored at the pixel's rotated physical position
     unsigned voff[NI];
     float isc[NI];
     int iimg[NI];                    // image of the item (index into the tile's image scales)
     int idst[NI];                    // byte offset of the item in the h half (the l half at + 2 PLANE), or -1: no such pixel
-#pragma unroll
-    for (int it = 0; it < NI; ++it) {
+    // item `it` -> its pixel: patch row / column, image and input coordinates; false: no such pixel in the input (halo, padding)
+    auto item_pixel = [&](int it, int& jr, int& cc, int& n, int& ih, int& iw) {
         const int px = (tid >> 1) + (NT / 2) * it;
-        const int jr = px / PW;
-        const int cc = px - jr * PW;
-        int n, ih, iw;
+        jr = px / PW;
+        cc = px - jr * PW;
         if constexpr (T2D) {
             n = n_first;
             ih = ih0 + jr + g.dh0;
@@ -2314,7 +2353,12 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
             ih = G - n * HP + g.dh0;
             iw = cc + g.dw0;
         }
-        const bool ok = jr < PR && n < g.N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        return jr < PR && n < g.N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    };
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        int jr, cc, n, ih, iw;
+        const bool ok = item_pixel(it, jr, cc, n, ih, iw);
         voff[it] = ok ? ((unsigned)((n * H + ih) * W + iw) * (unsigned)g.a_pitch + (tid & 1) * 8u) * 4u : OOB;
         int k = n - n_first;
         iimg[it] = k < 0 ? 0 : (k > 15 ? 15 : k);
@@ -2357,8 +2401,78 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    if (tid < 16) s_imgmax[tid] = my_imgmax;
+    if (tid < 16) { s_imgmax[tid] = my_imgmax; s_imgmin[tid] = my_imgmin; }
     lds_barrier();
+    // Dynamic range INSIDE the tile's images.  One operand scale per image keeps the full 22 bits of the elements within 2^-17 of the
+    // image maximum only; a row whose whole tap window is far darker than its image's brightest pixel (a blob on a dark background,
+    // the sparse gradients of the explanation pass) would be computed with an absolute error of 2^-40 of that maximum -- large next
+    // to its own patch.  So the scales form a LADDER: row r of image n belongs to level l(r) = floor((E_n - E_r) / LVL_STEP), E the
+    // exponents of the image maximum and of the row's maximum over its taps (from the per-pixel maxima `a_absmax`), and the tile is
+    // contracted once per level present, level l with the scale 2^(l LVL_STEP) above the image's, each pass writing its own rows
+    // (a row of level l reads no pixel brighter than 2^-(l LVL_STEP) of the image maximum, so nothing it reads overflows; brighter
+    // pixels are clamped).  Level, scale and result of a row are functions of its image alone -- not of the tile or the batch.
+    // Images whose nonzero pixels all lie within 2^LVL_STEP of the maximum (`a_imgmin`: every synthetic benchmark input, most
+    // activations) have level 0 everywhere and take none of this.
+    bool wide = MORE;
+    if constexpr (!MORE) {
+        for (int k = 0; k <= n_last - n_first && k < 16; ++k) {
+            const unsigned Ei = max(s_imgmax[k] >> 23, 15u);
+            wide = wide || Ei - min(s_imgmin[k] >> 23, Ei) > (unsigned)LVL_STEP;
+        }
+        wide = __builtin_amdgcn_readfirstlane((int)(wide && p.lvl_on)) != 0;      // (every thread read the same table)
+    }
+    const unsigned char* lvl_rows = wide ? s_lvl : nullptr;
+    if (!MORE && wide) {
+        const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.a_absmax), 0, p.absmax_bytes, 0x00020000);
+        if (tid == 0) *s_lvlmask = 0u;
+        if (!(tid & 1)) {
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                int jr, cc, n, ih, iw;
+                const bool ok = item_pixel(it, jr, cc, n, ih, iw);
+                const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)((n * H + ih) * W + iw) * 4u : OOB, 0, 0);
+                if (idst[it] >= 0) s_pixmax[idst[it] >> 4] = v;
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < BM; r += NT) {
+            int n = n_first, jr = -1, jc = 0;
+            if constexpr (T2D) {
+                jr = (r / T2BW) * st;
+                jc = (r % T2BW) * st;
+            } else {
+                const int m = m0 + r;
+                if (m < p.M) {
+                    n = m / p.PQ;
+                    const int rem = m - n * p.PQ;
+                    const int i = rem / g.Q;
+                    jr = n * HP + i * st - G0;
+                    jc = (rem - i * g.Q) * st;
+                }
+            }
+            int level = 0;
+            if (jr >= 0) {
+                const int c0 = (jc + jr * rotq) & cmask;
+                unsigned rmax = 0u;
+                for (int t = 0; t < ntaps; ++t) {
+                    const int th = t / g.TW, tw = t - th * g.TW;
+                    rmax = max(rmax, s_pixmax[((jr + th) << LP) + ((c0 + tw + th * rotq) & cmask)]);
+                }
+                const unsigned Ei = max(s_imgmax[(n - n_first) & 15] >> 23, 15u);
+                const unsigned Er = min(max(rmax >> 23, 1u), Ei);
+                const unsigned lmax = (Ei - 15u) / LVL_STEP;                       // the scale's exponent stays representable
+                level = rmax ? (int)min(min((Ei - Er) / LVL_STEP, lmax), 31u) : 0;   // (an all-zero window is exact at any level)
+                atomicOr(s_lvlmask, 1u << level);
+            }
+            s_lvl[r] = (unsigned char)level;
+        }
+        __syncthreads();
+        lvl_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)*s_lvlmask);
+        if (lvl_mask == 0u) lvl_mask = 1u;
+        pass = __builtin_ctz(lvl_mask);
+        lvl_mask >>= pass;
+    }
+
     for (int r = tid; r < BM; r += NT) {
         int base = 0;
         float inv = 1.0f;
@@ -2380,6 +2494,7 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
             base = (jr << 16) | ((jc + jr * rotq) & cmask);
             unsigned E = s_imgmax[(n - n_first) & 15] >> 23;
             E = E < 15u ? 15u : E;
+            E -= (unsigned)(pass * LVL_STEP);      // (>= 15: a level never exceeds (E - 15) / LVL_STEP)
             inv = __uint_as_float((E - 14u) << 23);
         }
         s_base[r] = base;
@@ -2388,11 +2503,13 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
     if (tid < 16) {
         unsigned E = s_imgmax[tid] >> 23;          // biased exponent of the image max (the bit patterns carry no sign)
         E = E < 15u ? 15u : E;
-        s_imgscale[tid] = __uint_as_float((268u - E) << 23);       // max * scale in [2^14, 2^15)
+        const unsigned Es = 268u - E + (unsigned)(pass * LVL_STEP);
+        s_imgscale[tid] = __uint_as_float((Es > 254u ? 254u : Es) << 23);       // max * scale in [2^14, 2^15) at level 0
     }
     lds_barrier();
 #pragma unroll
     for (int it = 0; it < NI; ++it) isc[it] = s_imgscale[iimg[it]];
+    const bool clamp_h = pass > 0;         // brighter pixels than this level's rows read: keep them finite
 
     // the refill in two halves: registers -> (h, l) f16 registers as soon as the loads have landed (vector work in the shadow of a
     // step's matrix instructions), registers -> LDS at the end of the chunk, behind the barrier that retires the old patch
@@ -2403,7 +2520,8 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
         for (int q = 0; q < 8; ++q) {
             const float x = xr[it][q >> 2][q & 3];
             if (NORM) pss[it] = fmaf(x, x, pss[it]);
-            const float xs = x * isc[it];
+            float xs = x * isc[it];
+            if (clamp_h) xs = __builtin_amdgcn_fmed3f(xs, -32768.f, 32768.f);      // (uniform branch; only passes above level 0)
             const _Float16 hh = (_Float16)xs;
             ph[it][q] = hh;
             pl[it][q] = (_Float16)(xs - (float)hh);
@@ -2571,7 +2689,37 @@ __device__ __forceinline__ void tile_body_p(const KArgs& p, float* smem, const i
 #pragma unroll
     for (int j = 0; j < BM / (NT / 4); ++j) a_inv[j] = s_rowinv[(tid >> 2) + (NT / 4) * j];
     __syncthreads();                   // the epilogue reuses all of it
-    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n);
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n, lvl_rows, pass);
+    if constexpr (!MORE) {      // the other levels present, if any
+        lvl_mask >>= 1;
+        if (lvl_mask)
+            tile_body_p_more<BM, BN, WAVES_M, WAVES_N, NORM, NI, PXL, NTAPS, T2BW, true>(
+                (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr(),      // (KArgs is the kernel's only argument)
+                (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem, m0, n0, tile_n, pass + 1, lvl_mask);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NI, int PXL, int NTAPS, int T2BW, bool MORE>
+__device__ __noinline__ void tile_body_p_more(const __attribute__((address_space(4))) KArgs* kp, unsigned lds_base, int m0, int n0, int tile_n, int pass, unsigned lvl_mask) {
+    // (arguments of a non-kernel function arrive in vector registers: every one of them is wave-uniform)
+    {
+        const uint64_t v = (uint64_t)(uintptr_t)kp;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        kp = (const __attribute__((address_space(4))) KArgs*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
+    lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_base);
+    m0 = __builtin_amdgcn_readfirstlane(m0);
+    n0 = __builtin_amdgcn_readfirstlane(n0);
+    tile_n = __builtin_amdgcn_readfirstlane(tile_n);
+    pass = __builtin_amdgcn_readfirstlane(pass);
+    lvl_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)lvl_mask);
+    // (the kernel's dynamic LDS, handed over as its LDS offset so that the address space stays known on this side of the call)
+    float* smem = (float*)(__attribute__((address_space(3))) float*)(uintptr_t)lds_base;
+    for (; lvl_mask; ++pass, lvl_mask >>= 1) {
+        if (!(lvl_mask & 1u)) continue;
+        __syncthreads();                   // the previous pass's epilogue is done with the LDS
+        tile_body_p<BM, BN, WAVES_M, WAVES_N, NORM, NI, PXL, NTAPS, T2BW, MORE>(*kp, smem, m0, n0, tile_n, pass, 0u);
+    }
 }
 
 // Narrow split-f16 tiles (128 x 64, 128 x 32: the stem, the 56^2 3x3 layers) hold 16-32 accumulator registers per wave and run
@@ -2656,7 +2804,7 @@ void plan_tiles(KArgs& p) {
     // Measured policy (ResNet-50 layer shapes, split-bf16 kernel): the split pays from two full rounds on (e.g. 1568
     // tiles: -5 %); below that a CU left with a single resident workgroup runs it ~1.5x faster, which already hides
     // most of the tail, and the half-height tiles' lower efficiency dominates (392 tiles: +25 % when split).
-    if (can_split && total >= 2 * SLOTS && total < 8 * SLOTS && !getenv("BCOS_NO_TAIL_SPLIT")) {
+    if (can_split && total >= 2 * SLOTS && total < 8 * SLOTS && bcos_option(BCOS_OPT_TAIL_SPLIT)) {
         const int64_t full = (total / SLOTS) * SLOTS;
         const int64_t rem = total - full;
         if (rem > 0 && rem < (SLOTS * 9) / 10) m_big = (int)(full / p.tiles_n);
@@ -2752,8 +2900,8 @@ int launch_d(const KArgs& base, bool norm, hipStream_t stream) {
     size_t lds = (size_t)D_NSLOT * d_slot_bytes<BM, BN>() + (size_t)BM * 4 + 1024 + (kmajor ? (size_t)ntaps * BM * 4 : 0);    // (the half-height body needs less)
     const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
     if (lds_epi > lds) lds = lds_epi;
-    if (const char* one = getenv("BCOS_D_ONE_WG")) {      // development switch: LDS request that leaves room for `one` workgroups per CU only
-        const size_t want = (size_t)160 * 1024 / (atoi(one) > 0 ? atoi(one) : 1) - 512;
+    if (const int64_t one = bcos_option(BCOS_OPT_D_ONE_WG)) {      // development switch: LDS request that leaves room for `one` workgroups per CU only
+        const size_t want = (size_t)160 * 1024 / (size_t)one - 512;
         if (want > lds) lds = want;
     }
     const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
@@ -2791,6 +2939,9 @@ int launch_p(const KArgs& base, bool norm, hipStream_t stream) {
     size_t lds = p_lds_bytes<BM, BN, PXL>();
     const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
     if (lds_epi > lds) lds = lds_epi;
+    lds = (lds + 15) & ~(size_t)15;
+    p.lvl_off = (int)lds;              // row levels + level mask of a tile (tile_body_p), kept across the tile's epilogues
+    lds += BM + 16;
     const dim3 grid((unsigned)p.n_big), block(NTHREADS);
     static std::atomic<size_t> lds_hw[2];
     auto launch = [&](auto k, int which) -> hipError_t {
@@ -3078,11 +3229,14 @@ __global__ __launch_bounds__(256) void rows_absmax_kernel(const float* __restric
 }  // namespace
 
 namespace {
-__global__ __launch_bounds__(1024) void image_absmax_kernel(const unsigned* __restrict__ absmax, unsigned* __restrict__ out, int hw) {
-    // one workgroup of 16 waves per image, four independent loads in flight per thread: the kernel is one load latency long
-    __shared__ unsigned s_max[16];
+__global__ __launch_bounds__(1024) void image_absmax_kernel(const unsigned* __restrict__ absmax, unsigned* __restrict__ out,
+                                                            unsigned* __restrict__ out_min, int hw) {
+    // one workgroup of 16 waves per image, four independent loads in flight per thread: the kernel is one load latency long.
+    // out_min (optional): the smallest NONZERO per-pixel maximum of the image (0xffffffff: every pixel is zero) -- with the
+    // image maximum, the dynamic range of the pixels inside the image (bcos_operands.a_imgmin)
+    __shared__ unsigned s_max[16], s_min[16];
     const unsigned* src = absmax + (size_t)blockIdx.x * hw;
-    unsigned v = 0u;
+    unsigned v = 0u, w = 0xffffffffu;
     for (int i0 = 0; i0 < hw; i0 += 4096) {
         unsigned u[4];
 #pragma unroll
@@ -3091,24 +3245,41 @@ __global__ __launch_bounds__(1024) void image_absmax_kernel(const unsigned* __re
             u[q] = i < hw ? src[i] : 0u;
         }
         v = max(max(v, u[0]), max(max(u[1], u[2]), u[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w = min(w, u[q] - 1u);      // (0 - 1 wraps to the top: zero pixels never win)
     }
 #pragma unroll
-    for (int o = 32; o; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
+    for (int o = 32; o; o >>= 1) {
+        v = max(v, (unsigned)__shfl_xor((int)v, o));
+        w = min(w, (unsigned)__shfl_xor((int)w, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = v; s_min[threadIdx.x >> 6] = w; }
     __syncthreads();
     if (threadIdx.x < 16) {
-        unsigned m = s_max[threadIdx.x];
+        unsigned m = s_max[threadIdx.x], mn = s_min[threadIdx.x];
 #pragma unroll
-        for (int o = 8; o; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if (threadIdx.x == 0) out[blockIdx.x] = m;
+        for (int o = 8; o; o >>= 1) {
+            m = max(m, (unsigned)__shfl_xor((int)m, o));
+            mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+        }
+        if (threadIdx.x == 0) {
+            out[blockIdx.x] = m;
+            if (out_min) out_min[blockIdx.x] = mn == 0xffffffffu ? mn : mn + 1u;
+        }
     }
 }
 }  // namespace
 
 extern "C" int bcos_image_absmax(const uint32_t* absmax, uint32_t* out, int n_images, int pixels_per_image, void* stream) {
+    return bcos_image_absrange(absmax, out, nullptr, n_images, pixels_per_image, stream);
+}
+
+extern "C" int bcos_image_absrange(const uint32_t* absmax, uint32_t* out_max, uint32_t* out_min, int n_images, int pixels_per_image,
+                                   void* stream) {
+    uint32_t* out = out_max;
     if (!absmax || !out || n_images <= 0 || pixels_per_image <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_image_absmax: bad argument");
     hipLaunchKernelGGL(image_absmax_kernel, dim3((unsigned)n_images), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), absmax, out,
-                       pixels_per_image);
+                       out_min, pixels_per_image);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("image_absmax launch", err);
     return BCOS_OK;
@@ -3131,13 +3302,13 @@ extern "C" int bcos_rows_absmax(const float* x, uint32_t* out, int64_t rows, int
 
 extern "C" int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                             const bcos_epilogue* epi, void* stream) {
-    bcos_operands o = {a, nullptr, wt, nullptr, nullptr, BCOS_CONTRACT_DEFAULT, nullptr};
+    bcos_operands o = {a, nullptr, wt, nullptr, nullptr, BCOS_CONTRACT_DEFAULT, nullptr, nullptr};
     return bcos_tapconv_ops(&o, geom, epi, stream);
 }
 
 extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void* wt3, const bcos_tapconv_geom* geom,
                                      const bcos_epilogue* epi, void* stream) {
-    bcos_operands o = {a, nullptr, wt, wt3, nullptr, BCOS_CONTRACT_DEFAULT, nullptr};
+    bcos_operands o = {a, nullptr, wt, wt3, nullptr, BCOS_CONTRACT_DEFAULT, nullptr, nullptr};
     return bcos_tapconv_ops(&o, geom, epi, stream);
 }
 
@@ -3222,6 +3393,9 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     p.h2 = 0;
     p.a_absmax = nullptr;
     p.a_imgmax = nullptr;
+    p.a_imgmin = nullptr;
+    p.lvl_off = 0;
+    p.lvl_on = bcos_option(BCOS_OPT_PATCH_LEVELS) != 0;
     p.t2_bw = p.t2_nbx = p.t2_nb = p.t2_rows = 0;
     p.absmax_bytes = 0;
     p.wt2 = nullptr;
@@ -3232,8 +3406,10 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         const int64_t img_bytes = (int64_t)g.H * g.W * p.g.a_pitch * 4;
         const int64_t a_bytes = img_bytes * g.N, wt_bytes = (int64_t)G * g.Cout * p.Ktot * 4;
         const int64_t lim = (int64_t)1 << 31;
-        if (p.x3 && a_bytes >= lim && g.N > 1 && img_bytes < lim && wt_bytes < lim) {
-            const int per = (int)((lim - 1) / img_bytes);
+        // (BCOS_OPT_SPLIT_LIMIT: tests lower the chunking threshold to drive this path with small tensors)
+        const int64_t chunk_lim = bcos_option(BCOS_OPT_SPLIT_LIMIT);
+        if (p.x3 && a_bytes >= chunk_lim && g.N > 1 && img_bytes < chunk_lim && wt_bytes < lim) {
+            const int per = (int)((chunk_lim - 1) / img_bytes);
             for (int n0 = 0; n0 < g.N; n0 += per) {
                 bcos_tapconv_geom g2 = p.g;
                 bcos_epilogue e2 = *epi;
@@ -3254,6 +3430,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 bcos_operands o2 = *ops;
                 o2.a = a + (int64_t)n0 * g.H * g.W * p.g.a_pitch;
                 if (o2.a_absmax) o2.a_absmax += (int64_t)n0 * g.H * g.W;
+                if (o2.a_imgmax) o2.a_imgmax += n0;          // (per-image maxima are indexed by the chunk's local image index)
+                if (o2.a_imgmin) o2.a_imgmin += n0;
                 const int rc = bcos_tapconv_ops(&o2, &g2, &e2, stream);
                 if (rc != BCOS_OK) return rc;
             }
@@ -3277,6 +3455,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             p.h2 = 1;
             p.a_absmax = ops->a_absmax;
             p.a_imgmax = ops->a_imgmax;
+            p.a_imgmin = ops->a_imgmax ? ops->a_imgmin : nullptr;
             p.absmax_bytes = (unsigned)pixb;
             p.wt2 = ops->wt_f16x2;
             p.wt2_bytes = (unsigned)w2b;
@@ -3297,7 +3476,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         const bcos_epilogue& e = *epi;
         const int64_t obytes = (int64_t)g.N * g.OH * g.OW * p.g.out_pitch * 4;
         const bool norm_l = e.bcos_mode != BCOS_NONE;
-        const bool off = getenv("BCOS_EPI_GENERIC") != nullptr;                 // development / test switch (read per call)
+        const bool off = bcos_option(BCOS_OPT_EPI_GENERIC) != 0;                // development / test switch
         bool ok = !off && p.vec_ok && g.Cout % 4 == 0 && obytes < ((int64_t)1 << 31) && e.max_out <= 1 && e.out != nullptr && !e.col_scale && !(e.flags & BCOS_EPI_UNIT_NORM_W) &&
                   !e.gate2 && !e.relu_gate && !(e.flags & (BCOS_EPI_NORM_ONLY | BCOS_EPI_FORCE_POW)) &&
                   ((reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.ch_scale) | reinterpret_cast<uintptr_t>(e.ch_shift)) & 15) == 0;
@@ -3329,23 +3508,21 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     }
     if (p.h2) {
         // staging of the split-f16 loop: LDS-DMA (tile_body_d, default) or registers (tile_body_h2: BCOS_H2_LOOP=regs); same bits
-        const char* loop = getenv("BCOS_H2_LOOP");
-        const bool dma = !(loop && loop[0] == 'r');
+        const bool dma = bcos_option(BCOS_OPT_H2_LOOP) == 0;
         {
             // multi-tap launches over an LDS-resident input patch (tile_body_p).  The choice depends on the layer's geometry alone,
             // never on the batch: the patch loop rounds differently from the per-tap loops (one operand scale per image), and an
-            // image's bits must not depend on how many images share its launch.  BCOS_PATCH=0: development / test switch.
-            const char* pe = getenv("BCOS_PATCH");
-            if (pe && pe[0] == '0') p.a_imgmax = nullptr;      // (per-row scales everywhere: the per-tap loops as they were)
+            // image's bits must not depend on how many images share its launch.  BCOS_OPT_PATCH = 0: development / test switch.
+            const bool patch_on = bcos_option(BCOS_OPT_PATCH) != 0;
+            if (!patch_on) p.a_imgmax = p.a_imgmin = nullptr;      // (per-row scales everywhere: the per-tap loops as they were)
             const int ntaps = g.TH * g.TW;
             const bool geom_ok = ((ntaps == 9 && g.TH == 3) || (ntaps == 16 && g.TH == 4)) && g.C % X3_BK == 0 && g.in_sh == 1 && g.in_sw == 1 &&
                                  g.dstep_h == 1 && g.dstep_w == 1 && p.g.a_pitch >= g.C;
-            if (dma && geom_ok && p.a_imgmax && !(pe && pe[0] == '0')) {
+            if (dma && geom_ok && p.a_imgmax && patch_on) {
                 if (ntaps == 16) {
                     if (g.Cout <= 32 && g.in_sh == 1) return bcos_tc_p2_256x32_t16(&p, norm, s);
                 } else {
-                const char* pw_ = getenv("BCOS_PATCH_WIDE");
-                if (g.Cout > 128 && g.Cout <= 256 && patch_fits(g, 128, 256, 256) && !(pw_ && pw_[0] == '0')) return bcos_tc_p_128x256_a(&p, norm, s);
+                if (g.Cout > 128 && g.Cout <= 256 && patch_fits(g, 128, 256, 256) && bcos_option(BCOS_OPT_PATCH_WIDE)) return bcos_tc_p_128x256_a(&p, norm, s);
                 if (g.Cout > 64 && patch_fits(g, 128, 256, 256)) return bcos_tc_p_128x128_a(&p, norm, s);
                 if (g.Cout > 64 && patch_fits(g, 128, 256, 448)) return bcos_tc_p_128x128_b(&p, norm, s);
                 if (g.Cout > 64 && patch_fits(g, 128, 384, 320)) return bcos_tc_p_128x128_c(&p, norm, s);
@@ -3360,7 +3537,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         if (g.Cout > 64) {
             // 128 x 256 tiles stage half the A bytes per MFMA; they pay when they do not cost an extra round of tiles
             // (measured on the ResNet-50 shapes: M = 50176, N = 256: -3 %; M = 12544, N = 512: +17 % -> stays 128 x 128)
-            const char* force = getenv("BCOS_H2_TILE");      // development switch: "128x128" | "128x256"
+            const int64_t force = bcos_option(BCOS_OPT_H2_TILE);      // development switch: 1 = 128 x 128, 2 = 128 x 256
             const int64_t tm = (M64 + 127) / 128;
             const int64_t t1 = tm * ((g.Cout + 127) / 128), t2 = tm * ((g.Cout + 255) / 256);
             // (a finer cost model -- a wide tile = 1.75 narrow ones, which moves M = 200 704 with N = 256 / 512 and M = 50 176 with
@@ -3368,7 +3545,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // consecutive launches overlap their tails: not adopted)
             const int64_t c1 = (t1 + SLOTS - 1) / SLOTS, c2 = 2 * ((t2 + SLOTS - 1) / SLOTS);
             bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && p.Ktot >= 1024));
-            if (force) wide = g.Cout > 128 && force[4] == '2';
+            if (force) wide = g.Cout > 128 && force == 2;
             // 129 ... 192 columns (the 192-wide linears of the SimpleViTs: to_out, linear2, their gradients): ONE tile of 192 columns
             // (six accumulator tiles per wave) instead of 128 + a half-empty second 128
             if (dma && g.Cout > 128 && g.Cout <= 192 && !force) return bcos_tc_d_128x192(&p, norm, s);
@@ -3381,15 +3558,13 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // A/B on the ResNet-50 step at batch 256 (M = 802 816): 3x3 64 -> 64 gradient 1.03 -> 0.90 ms, 256 -> 64 gradient
             // 1.21 -> 1.13 ms, stem forward 1.05 -> 1.01 ms, the forward launches -1 %.  Results are identical bit for bit (same
             // K walk, same product order per accumulator).
-            const char* tall = getenv("BCOS_H2_TALL");       // development switch: "0" keeps the 128-row tiles
-            const char* tmin = getenv("BCOS_H2_TALL_MIN");
-            const int64_t tall_min = tmin ? atoll(tmin) : 2 * 256 * SLOTS;     // (batch 128, M = 401 408: +0.4 % per step; M = 200 704: neutral)
-            if (M64 >= tall_min && !(tall && tall[0] == '0')) return dma ? bcos_tc_d_256x64(&p, norm, s) : bcos_tc_h2_256x64(&p, norm, s);
+            const bool tall = bcos_option(BCOS_OPT_H2_TALL) != 0;       // development switch: 0 keeps the 128-row tiles
+            const int64_t tall_min = bcos_option(BCOS_OPT_H2_TALL_MIN);     // default 2 * 256 * SLOTS (batch 128, M = 401 408: +0.4 % per step; M = 200 704: neutral)
+            if (M64 >= tall_min && tall) return dma ? bcos_tc_d_256x64(&p, norm, s) : bcos_tc_h2_256x64(&p, norm, s);
             return dma ? bcos_tc_d_128x64(&p, norm, s) : bcos_tc_h2_128x64(&p, norm, s);
         }
         {   // 256 x 32 tiles likewise (the depth-to-space stem gradient, M = 3.2 M: 1.29-1.38 -> 1.17-1.20 ms in a same-node A/B)
-            const char* tall = getenv("BCOS_H2_TALL");
-            if (M64 >= 2 * 256 * SLOTS && !(tall && tall[0] == '0')) return dma ? bcos_tc_d_256x32(&p, norm, s) : bcos_tc_h2_256x32(&p, norm, s);
+            if (M64 >= 2 * 256 * SLOTS && bcos_option(BCOS_OPT_H2_TALL)) return dma ? bcos_tc_d_256x32(&p, norm, s) : bcos_tc_h2_256x32(&p, norm, s);
         }
         return dma ? bcos_tc_d_128x32(&p, norm, s) : bcos_tc_h2_128x32(&p, norm, s);
     }

@@ -927,9 +927,8 @@ extern "C" int bcos_add_rows_bcast(float* x, const float* pe, int64_t total, int
 static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, float* stats_out, const float* stats_in,
                        unsigned* absmax_out, int B, int T, int H, float scale, void* stream) {
     const int Tpad = (T + 31) & ~31;
-    // f16 matrix pipe (default) or the exact-fp32 MFMA form of rounds 1-2 (BCOS_ATTENTION=f32; also what the f32 contraction mode means)
-    const char* sel = getenv("BCOS_ATTENTION");
-    if (!(sel && sel[0] == 'f' && sel[1] == '3')) {
+    // f16 matrix pipe (default) or the exact-fp32 MFMA form of rounds 1-2 (BCOS_OPT_ATTENTION_F32; also what the f32 contraction mode means)
+    if (!bcos_option(BCOS_OPT_ATTENTION_F32)) {
         const size_t hb = 2 * (size_t)Tpad * AH_XROW + 2 * (size_t)DH * (Tpad * 2 + 16) + ((size_t)Tpad + 2 * DH + 2 * (size_t)Tpad) * 4;
         if (hb <= 160 * 1024) {
             const void* fn2 = bwd ? reinterpret_cast<const void*>(attention_h2_kernel<true>)

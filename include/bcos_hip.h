@@ -13,8 +13,9 @@
  *     the caller owns every buffer; the library never allocates or frees device memory.
  *   - all work is enqueued on the hipStream_t passed as `void* stream` (NULL = default
  *     stream); calls are asynchronous and re-entrant; the only global mutable state is the
- *     thread-local last-error string and the process-wide DEFAULT contraction mode, which
- *     a call overrides through bcos_operands.contraction.
+ *     thread-local last-error string, the process-wide DEFAULT contraction mode (which a call
+ *     overrides through bcos_operands.contraction) and the option table of bcos_set_option.
+ *     The library never reads the process environment.
  *   - return value: 0 = ok, negative = error (BCOS_E_*); never throws.
  *   - activations are NHWC ("channels-last": pixel-major, channels contiguous).  The
  *     logical NCHW shape of the reference is kept by the Python layer through
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 6
+#define BCOS_ABI_VERSION 7
 
 enum {
     BCOS_OK = 0,
@@ -214,6 +215,37 @@ int bcos_get_contraction_mode(void);
 
 enum { BCOS_CONTRACT_DEFAULT = 0, BCOS_CONTRACT_F32 = 1, BCOS_CONTRACT_BF16X3 = 2, BCOS_CONTRACT_F16X2 = 3 };
 
+/* Process-wide development / test switches (ABI v7; rounds 1-3 read them from the environment on every launch).  Every
+ * option selects between code paths that compute the SAME operator -- none changes what an entry point means -- and each
+ * has the default a deployment wants; tests and the A/B scripts flip them through bcos_set_option.  Values are plain
+ * integers held in atomics: a launch reads the table once, without locks and without touching the environment. */
+enum bcos_option {
+    BCOS_OPT_TAIL_SPLIT = 0,      /* 1 (default): half-height tiles fill the last round of a launch of 2-8 rounds; 0: off          */
+    BCOS_OPT_D_ONE_WG = 1,        /* 0 (default): off; n > 0: LDS request of the LDS-DMA kernels that leaves room for n workgroups per CU */
+    BCOS_OPT_EPI_GENERIC = 2,     /* 0 (default): specialised epilogues where a launch's feature set has one; 1: general epilogue  */
+    BCOS_OPT_H2_LOOP = 3,         /* 0 (default): LDS-DMA staged split-f16 loop (tile_body_d); 1: register-staged loop (same bits) */
+    BCOS_OPT_PATCH = 4,           /* 1 (default): 3 x 3 / 4 x 4-union launches with per-image maxima run over an LDS-resident input
+                                     patch; 0: per-tap loops with per-row operand scales everywhere                               */
+    BCOS_OPT_PATCH_WIDE = 5,      /* 1 (default): 128 x 256 patch tiles for 129..256 output columns; 0: 128 x 128                 */
+    BCOS_OPT_H2_TILE = 6,         /* 0 (default): tile width by cost model; 1: force 128 x 128; 2: force 128 x 256                */
+    BCOS_OPT_H2_TALL = 7,         /* 1 (default): 256-row tiles for <= 64-column launches of >= H2_TALL_MIN rows; 0: 128-row tiles */
+    BCOS_OPT_H2_TALL_MIN = 8,     /* row count from which the 256 x 64 tiles are used (default 2 * 256 * 512)                      */
+    BCOS_OPT_ATTENTION_F32 = 9,   /* 0 (default): attention on the f16 matrix pipe (exact 2-way splits); 1: fp32 MFMA kernel       */
+    BCOS_OPT_SPLIT_LIMIT = 10,    /* bytes of A from which a split-operand launch is cut into batch chunks (default and maximum
+                                     2^31: the 32-bit buffer offsets); tests lower it to exercise the chunked path                */
+    BCOS_OPT_BALANCE = 11,        /* 1 (default): launches of less than two rounds of tiles run on the balanced wave-block schedule;
+                                     0: one workgroup per tile                                                                     */
+    BCOS_OPT_SPLIT_K = 12,        /* 1 (default): geometry-keyed 2-way split of K with a fixed-order reduction where a launch has
+                                     fewer tiles than CUs and K >= 2048; 0: off                                                   */
+    BCOS_OPT_PATCH_LEVELS = 13,   /* 1 (default): the input-patch loop runs one pass per operand-scale level present in a tile
+                                     (bcos_operands.a_imgmax); 0: level 0 only, the single per-image scale of ABI v6 -- kept so that
+                                     tests can show what the ladder is for (rows far darker than their image lose accuracy)      */
+    BCOS_OPT_COUNT = 14
+};
+/* 0, or BCOS_E_INVAL for an unknown option or a value outside its range. */
+int bcos_set_option(int option, int64_t value);
+int bcos_get_option(int option, int64_t* value);
+
 /* Operands of one bcos_tapconv launch. */
 typedef struct bcos_operands {
     const float* a;             /* A: activations (forward) or gradients (dgrad), NHWC fp32                          */
@@ -223,11 +255,25 @@ typedef struct bcos_operands {
     const void* wt_bf16x3;      /* NULL or the image made by bcos_split_weights                                    */
     const void* wt_f16x2;       /* NULL or the image made by bcos_split_weights_f16x2                              */
     int32_t contraction;        /* BCOS_CONTRACT_*                                                                  */
-    const uint32_t* a_imgmax;   /* NULL or [N]: max over the pixels of image n of a_absmax (bcos_image_absmax; ABI v6).  With
-                                   it, stride-1 3 x 3 launches (and the 4 x 4 tap union of a depth-to-space gradient) of the f16x2 contraction run over an LDS-resident input patch (every input
-                                   element loaded and split once per 16 channels instead of once per tap) with ONE operand scale
-                                   per image: elements within 2^-17 of their image's max keep 22 bits, smaller ones an absolute
-                                   error <= 2^-40 of that max.  An image's results do not depend on its batch neighbours.      */
+    const uint32_t* a_imgmax;   /* NULL or [N]: max over the pixels of image n of a_absmax (bcos_image_absrange; ABI v6).  With it,
+                                   stride-1 3 x 3 launches (and the 4 x 4 tap union of a depth-to-space gradient) of the f16x2
+                                   contraction run over an LDS-resident input patch: every input element is loaded and split once
+                                   per 16 channels instead of once per tap.  A pixel then serves rows with different tap windows,
+                                   so the operand scales are per IMAGE, on a ladder (ABI v7): row r of image n is contracted with
+                                   the scale 2^(12 l) above the image's, l = floor((E_n - E_r) / 12) for the exponents E of the image
+                                   maximum and of the row's maximum over its taps; a tile whose rows span several levels is
+                                   contracted once per level, each pass writing its own rows.  Every row is therefore computed
+                                   with a scale within 2^12 of its own window's maximum and keeps the full 22 bits of every
+                                   element within 2^-5 of it: |lin - exact| <= 2e-6 ||patch|| ||w|| per output row, as with the
+                                   per-row scales of the other f16x2 loops, whatever the dynamic range inside the image
+                                   (tests/test_gpu_parity.py::test_patch_loop_dynamic_range_inside_an_image).  Level, scale and
+                                   result of a row are functions of its image alone: an image's bits do not depend on its batch
+                                   neighbours or position.                                                                   */
+    const uint32_t* a_imgmin;   /* NULL or [N]: min over the NONZERO pixels of image n of a_absmax (0xffffffff: all zero;
+                                   bcos_image_absrange; ABI v7).  Images whose [a_imgmin, a_imgmax] span at most 2^12 have level 0
+                                   everywhere and skip the level bookkeeping; launches with >= 25 taps (7 x 7 stem) take the image
+                                   maximum as the scale of such an image's rows instead of scanning every row's taps.  NULL: the
+                                   range is unknown -- every tile derives its rows' levels, >= 25-tap launches scan.          */
 } bcos_operands;
 
 /* -- contraction kernels (LDS-tiled implicit GEMM on the matrix cores) ---------------------------------------- */
@@ -254,6 +300,9 @@ int bcos_split_weights_f16x2_conv(const float* wt, void* image, int rows, int ta
 int bcos_rows_absmax(const float* x, uint32_t* out, int64_t rows, int C, int pitch, void* stream);
 /* out[n] = max over p < pixels_per_image of absmax[n * pixels_per_image + p]: bcos_operands.a_imgmax from a_absmax (ABI v6). */
 int bcos_image_absmax(const uint32_t* absmax, uint32_t* out, int n_images, int pixels_per_image, void* stream);
+/* ... and out_min[n] = the smallest NONZERO absmax of image n, 0xffffffff if every pixel is zero (bcos_operands.a_imgmin; ABI v7;
+ * out_min may be NULL). */
+int bcos_image_absrange(const uint32_t* absmax, uint32_t* out_max, uint32_t* out_min, int n_images, int pixels_per_image, void* stream);
 
 /* Pre-split weights for the bf16x3 contraction.  Weights are constant at inference (NormedConv2d / BcosifyConv2d
  * weights only change in training, bcosconv2d.py:26-35), so their exact 3-way bf16 split is done once:

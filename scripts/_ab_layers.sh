@@ -1,5 +1,5 @@
 timeout 300 python scripts/layer_report.py > gpurun_out/r03_layers_dma4.txt 2>&1
-BCOS_H2_LOOP=regs timeout 300 python scripts/layer_report.py > gpurun_out/r03_layers_regs4.txt 2>&1
+BCOS_OPT_H2_LOOP=1 timeout 300 python scripts/layer_report.py > gpurun_out/r03_layers_regs4.txt 2>&1
 tail -n 1 gpurun_out/r03_layers_dma4.txt gpurun_out/r03_layers_regs4.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/r50stats

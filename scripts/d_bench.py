@@ -1,10 +1,11 @@
 """A/B of the split-f16 loops on the ResNet-50 batch-256 layer shapes (development aid): LDS-DMA staging (default) against the
-register-staged loop (BCOS_H2_LOOP=regs), same process, interleaved rounds.  Columns: us per launch, TFLOP/s (algorithmic)."""
+register-staged loop (option h2_loop = 1), same process, interleaved rounds.  Columns: us per launch, TFLOP/s (algorithmic)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "b-cosification_amd")); sys.path.insert(0, ROOT)
 import torch
 from bcos_hip import ops
+from bcos_hip import lib as blib
 dev = "cuda"
 B = int(os.environ.get("B", "256"))
 # (H, Cin, Cout, k, stride)
@@ -34,19 +35,20 @@ for (H, Cin, Cout, k, st) in SHAPES:
     res = {}
     for rnd in range(3):
         for mode in ("dma", "regs"):
-            if mode == "regs" and not os.environ.get("AB_ENV"): os.environ["BCOS_H2_LOOP"] = "regs"
-            else: os.environ.pop("BCOS_H2_LOOP", None)
-            if os.environ.get("AB_ENV"):         # AB_ENV="NAME=value": the second arm sets that variable instead of the register loop
-                k_, v_ = os.environ["AB_ENV"].split("=")
-                if mode == "regs": os.environ[k_] = v_
-                else: os.environ.pop(k_, None)
+            # second arm: the register-staged loop, or AB_OPT="name=value" (a bcos_set_option switch, e.g. patch=0)
+            if os.environ.get("AB_OPT"):
+                k_, v_ = os.environ["AB_OPT"].split("=")
+                if mode == "regs": blib.set_option(k_, int(v_))
+                else: blib.reset_options()
+            else:
+                blib.set_option("h2_loop", 1 if mode == "regs" else 0)
             f(); f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5): f()
             e1.record(); torch.cuda.synchronize()
             res.setdefault(mode, []).append(e0.elapsed_time(e1) / 5 * 1e3)
-    os.environ.pop("BCOS_H2_LOOP", None)
+    blib.reset_options()
     d, r = min(res["dma"]), min(res["regs"])
     print(f"fwd {B}x{H}x{H} {Cin:5d}->{Cout:5d} k{k} s{st}   dma {d:8.1f} us {fl / d / 1e6:6.1f} TF   regs {r:8.1f} us {fl / r / 1e6:6.1f} TF   dma/regs {d / r:.3f}", flush=True)
     del x, w

@@ -93,7 +93,7 @@ if "time" in sys.argv:
         blib.set_contraction_mode("f16x2")
         ops.ensure_absmax(x)
         for t in tiles:
-            os.environ["BCOS_H2_TILE"] = t
+            blib.set_option("h2_tile", 2 if t == "128x256" else 1)
             ms = timeit(lambda: ops.conv2d_fwd(x, w, stride=(1, 1), padding=(k // 2, k // 2), out=out, scale_out=sc, want_scale=True))
             res.append(f"h2 {t} {ms:6.3f} ms {fl/ms/1e9:6.1f} TF")
         print((N * H * H, Cin * k * k, Cout, k), " | ".join(res), flush=True)

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "b-cosification_amd")); sys.path.insert(0,
 import torch
 from bcos_hip import ops
 dev = "cuda"
-os.environ["BCOS_H2_TILE"] = os.environ.get("TILE", "128x128")
+from bcos_hip import lib as blib
+blib.set_option("h2_tile", 2 if os.environ.get("TILE", "128x128") == "128x256" else 1)
 for (N, H, Cin, Cout, k) in [(256, 14, 256, 256, 3), (256, 14, 1024, 256, 1)]:
     x = torch.randn(N, H, H, Cin, device=dev); ops.ensure_absmax(x)
     w = ops.mark_static(torch.randn(Cout, k, k, Cin, device=dev) / math.sqrt(Cin * k * k))

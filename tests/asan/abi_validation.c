@@ -48,6 +48,24 @@ int main(void) {
     EXPECT(bcos_tapconv_presplit(buf, NULL, NULL, &g, &e, NULL), BCOS_E_INVAL);
     EXPECT(bcos_tapconv_group(buf, NULL, &g, &e, 1, NULL), BCOS_E_INVAL);
     EXPECT(bcos_set_contraction_mode(5), BCOS_E_INVAL);
+    /* option table (ABI v7): unknown option, value outside its range, round trip, no environment involved */
+    { int64_t v = -1;
+      EXPECT(bcos_set_option(-1, 0), BCOS_E_INVAL);
+      EXPECT(bcos_set_option(BCOS_OPT_COUNT, 0), BCOS_E_INVAL);
+      EXPECT(bcos_set_option(BCOS_OPT_PATCH, 2), BCOS_E_INVAL);
+      EXPECT(bcos_set_option(BCOS_OPT_SPLIT_LIMIT, 16), BCOS_E_INVAL);
+      EXPECT(bcos_get_option(BCOS_OPT_PATCH, NULL), BCOS_E_INVAL);
+      EXPECT(bcos_get_option(BCOS_OPT_COUNT, &v), BCOS_E_INVAL);
+      setenv("BCOS_PATCH", "0", 1);                         /* rounds 1-3 read this on every launch */
+      EXPECT(bcos_get_option(BCOS_OPT_PATCH, &v), BCOS_OK);
+      if (v != 1) { printf("FAIL default of BCOS_OPT_PATCH %lld\n", (long long)v); ++failures; }
+      EXPECT(bcos_set_option(BCOS_OPT_PATCH, 0), BCOS_OK);
+      EXPECT(bcos_get_option(BCOS_OPT_PATCH, &v), BCOS_OK);
+      if (v != 0) { printf("FAIL BCOS_OPT_PATCH round trip %lld\n", (long long)v); ++failures; }
+      EXPECT(bcos_set_option(BCOS_OPT_PATCH, 1), BCOS_OK); }
+    EXPECT(bcos_image_absrange(NULL, am, am, 1, 4, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_image_absrange(am, NULL, am, 1, 4, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_image_absrange(am, am, NULL, 0, 4, NULL), BCOS_E_INVAL);
     { int64_t nb = 0;
       EXPECT(bcos_split_weights_bytes(0, 16, &nb), BCOS_E_INVAL);
       EXPECT(bcos_split_weights_bytes(64, 64, &nb), BCOS_OK);

@@ -39,3 +39,13 @@ def hip_lib():
     from bcos_hip import lib
     lib.build()
     return lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _library_options_restored():
+    """Tests flip the library's development switches through bcos_set_option (include/bcos_hip.h); whatever a test left
+    set -- also when it failed half way -- is put back to the values the library was loaded with."""
+    yield
+    mod = sys.modules.get("bcos_hip.lib")
+    if mod is not None and getattr(mod, "_lib", None) is not None:
+        mod.reset_options()
