@@ -97,6 +97,41 @@ def synthetic_images(n: int, seed: int = 123, size: int = 224, smooth: bool = Tr
     return torch.cat([x3, 1 - x3], dim=1).contiguous()
 
 
+def structured_images(n: int, seed: int = 77, size: int = 224) -> torch.Tensor:
+    """[n,6,size,size] AddInverse-encoded images whose STRUCTURE is what noise fields lack (dynamic range inside an
+    image -- sparse activations, long-tailed gradients in the explanation pass).  Image i is of kind i % 4:
+    0 a smooth field (as synthetic_images), 1 a few small bright spots on black, 2 a bright disc with a sharp edge on a dark
+    ground, 3 half black / half white with a faint fine checker texture.  Seeded; the same tensor on every host."""
+    gen = torch.Generator().manual_seed(seed)
+    ii = torch.arange(size).view(1, size, 1).float()
+    jj = torch.arange(size).view(1, 1, size).float()
+    out = []
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            low = torch.rand(1, 3, 14, 14, generator=gen)
+            x3 = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=False)[0]
+            x3 = (0.7 * x3 + 0.3 * torch.rand(3, 1, 1, generator=gen)).clamp(0, 1)
+        elif kind == 1:
+            x3 = torch.zeros(3, size, size)
+            for _ in range(5):
+                cy, cx = (torch.rand(2, generator=gen) * (size - 16) + 8).tolist()
+                col = torch.rand(3, 1, 1, generator=gen) * 0.5 + 0.5
+                spot = torch.exp(-((ii - cy) ** 2 + (jj - cx) ** 2) / (2 * 2.5 ** 2))
+                x3 = torch.maximum(x3, col * spot)
+        elif kind == 2:
+            cy, cx = (torch.rand(2, generator=gen) * size * 0.4 + size * 0.3).tolist()
+            disc = (((ii - cy) ** 2 + (jj - cx) ** 2) <= (size * 0.22) ** 2).float()
+            col = torch.rand(3, 1, 1, generator=gen) * 0.3 + 0.7
+            x3 = 0.02 + disc * (col - 0.02)
+        else:
+            half = (jj >= size // 2).float().expand(1, size, size)
+            checker = (((ii.long() // 2 + jj.long() // 2) % 2).float() - 0.5) * 0.01
+            x3 = (half * 0.98 + 0.01 + checker).expand(3, size, size).clamp(0, 1)
+        out.append(torch.cat([x3, 1 - x3], dim=0))
+    return torch.stack(out).contiguous()
+
+
 def _is_bcos_conv(m) -> bool:
     """a B-cos conv or linear layer of either implementation (duck-typed: `.linear` + `.b`)"""
     return hasattr(m, "linear") and hasattr(m, "b") and isinstance(getattr(m, "linear", None), (nn.Conv2d, nn.Linear))

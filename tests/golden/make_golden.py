@@ -539,6 +539,61 @@ def resnet18_end_to_end():
                        torch_version=torch.__version__), f, indent=1)
 
 
+def resnet18_structured():
+    """the B-cosified ResNet-18 of resnet18_e2e (same weights, same calibration record) on four STRUCTURED
+    images (synth.structured_images: smooth field, sparse spots on black, a sharp-edged disc, half black / half white with a faint
+    texture) -- inputs whose activations and explanation gradients have their dynamic range inside the image.  Recorded: the
+    reference's logits, classes, W(x) and maps of all four images and every ReLU decision (bit-packed)."""
+    arch = "resnet18"
+    net = reference_resnet(arch)
+    record = synth.calibrate(net, synth.synthetic_images(8)[:4])
+    e2e = np.load(os.path.join(HERE, "resnet18_e2e.npz"))
+    for k, v in record.items():                      # the weights ARE those of resnet18_e2e: its calibration record is reused
+        assert np.array_equal(v.numpy(), e2e["calib/" + k]), k
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = synth.structured_images(4, seed=77)
+    logits, wts, contribs, preds = [], [], [], []
+    for i in range(4):
+        xi = x[i:i + 1].clone().requires_grad_(True)
+        res = net.explain(xi)
+        with torch.no_grad():
+            logits.append(net(x[i:i + 1]))
+        wts.append(res["dynamic_linear_weights"].detach())
+        contribs.append(res["contribution_map"].detach())
+        preds.append(res["prediction"])
+    logits = torch.cat(logits); wts = torch.cat(wts); contribs = torch.cat(contribs)
+    with torch.backends.mkldnn.flags(enabled=False):      # the reference against itself (summation-order floor of free gates)
+        w2 = []
+        for i in range(4):
+            xi = x[i:i + 1].clone().requires_grad_(True)
+            w2.append(net.explain(xi)["dynamic_linear_weights"].detach())
+        w2 = torch.cat(w2)
+    REPORT["r18s/reference_self_floor_weights"] = rel(w2, wts)
+    oe = O.explain_batch(lambda xx, detach: O.resnet_logits(sd, xx, arch, detach=detach), x)
+    REPORT["r18s/oracle_logits"] = rel(oe["logits"], logits)
+    REPORT["r18s/oracle_weights"] = rel(oe["dynamic_linear_weights"], wts)
+    REPORT["r18s/oracle_argmax_equal"] = bool((oe["prediction"] == torch.tensor(preds)).all())
+    log = []
+    with torch.no_grad():
+        lg = O.resnet_logits(sd, x, arch, detach=True, gate_log=log)
+    assert torch.equal(lg, logits)                      # (the oracle's forward is bit-identical to the reference's on this host)
+    gate_np = {f"gate/{i:02d}": np.packbits((p > 0).permute(0, 2, 3, 1).contiguous().numpy().reshape(-1)) for i, p in enumerate(log)}
+    # how wide the dynamic range inside an image is at the inputs of the 3 x 3 layers (what the fixture is for): per ReLU output,
+    # max over images of (largest / smallest nonzero per-pixel maximum)
+    ranges = []
+    for p_ in log:
+        a = torch.relu(p_).amax(1).flatten(1)
+        lo = torch.where(a > 0, a, torch.full_like(a, float("inf"))).amin(1)
+        ranges.append(float((a.amax(1) / lo).max()))
+    REPORT["r18s/activation_range_inside_image_max"] = max(ranges)
+    np.savez_compressed(os.path.join(HERE, "resnet18_structured.npz"), logits=logits.numpy(), prediction=np.array(preds),
+                        contribution_map=contribs.numpy(), weights=wts.numpy(), **gate_np)
+    with open(os.path.join(HERE, "resnet18_structured.json"), "w") as f:
+        json.dump(dict(arch=arch, weight_seed=0, calibration="tests/golden/resnet18_e2e.npz (calib/*)", image_seed=77, n_images=4,
+                       images="bcos_hip.synth.structured_images", gate_shapes=[list(p.permute(0, 2, 3, 1).shape) for p in log],
+                       activation_range_per_relu=ranges, torch_version=torch.__version__), f, indent=1)
+
+
 def resnet50_logits_small():
     """Config-2 topology at 2 images (logits + argmax only: the maps of a 54-layer ReLU net are below the
     reference's own reproducibility floor)."""
@@ -815,34 +870,38 @@ def clip_rn50_embeddings():
 # --------------------------------------------------------------------------------------------------------
 # Explanation of the zero-shot TEXT logit (interpretability/analyses/text_localisation.py:68-104), pooled and attn_unpool heads
 # --------------------------------------------------------------------------------------------------------
+def _reference_text_attribution_code():
+    """The tensor statements of compute_attributions (interpretability/analyses/text_localisation.py), lifted from the reference's
+    source file with `ast` AT GENERATION TIME -- the body of its `with torch.enable_grad(), model.explanation_mode(), ...` block
+    from `imga = ...` up to `grada = imga.grad` -- the way _reference_localisation_code() lifts localisation.py.  Nothing of the
+    reference's text is kept here or in the fixture: only the sha256 of what was executed (clip_zeroshot_attr.json)."""
+    import ast
+    import hashlib
+    path = os.path.join(refimport.REFERENCE_ROOT, "interpretability", "analyses", "text_localisation.py")
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "compute_attributions")
+    block = next(st for st in fn.body if isinstance(st, ast.With))
+    keep = []
+    for st in block.body:
+        keep.append(ast.unparse(st))
+        if keep[-1].replace(" ", "") == "grada=imga.grad":
+            break
+    else:
+        raise RuntimeError("compute_attributions no longer ends its block the way this lift expects")
+    src = "\n".join(keep)
+    return src, hashlib.sha256(src.encode()).hexdigest()
+
+
 def _reference_text_attribution(model, img, zeroshot_weight, pool_cosine=1, norm_max_cosine=False):
-    """The tensor statements of compute_attributions (text_localisation.py:73-104) on the reference's model classes."""
+    """compute_attributions' own statements (lifted, see above) executed on the reference's model classes: the gradient of the
+    explained text logit w.r.t. the image, the logit's value and the encoder output."""
+    src, _ = _reference_text_attribution_code()
+    ns = dict(torch=torch, model=model, test_img=img, device=torch.device("cpu"), zeroshot_weight=zeroshot_weight,
+              pool_cosine=pool_cosine, norm_max_cosine=norm_max_cosine)
     with torch.enable_grad(), model.explanation_mode():
-        imga = img[None].requires_grad_()
-        outa = model(imga)
-        img_features = outa / outa.norm(dim=-1, keepdim=True)
-        logits = img_features @ zeroshot_weight
-        if model.model.attnpool.attn_unpool:
-            logits = logits.reshape(-1, 1)
-            if pool_cosine == 0:
-                num_features = logits.shape[0]
-                logits = logits.reshape(-1, num_features)
-                max_locations = logits.argmax(dim=1)
-                mask = torch.zeros_like(logits)
-                for i in range(logits.shape[0]):
-                    mask[i, max_locations[i]] = 1.0
-                logits = logits * mask.detach()
-                logits = logits.reshape(1, num_features)
-            if norm_max_cosine:
-                logits = logits / logits.abs().detach().max(dim=0, keepdim=True)[0]
-            if pool_cosine > 1:
-                logits = logits * torch.pow(logits, pool_cosine - 1).abs().detach()
-            logits = logits.mean(dim=0)
-        if logits.dim() == 1:
-            logits = logits.unsqueeze(0)
-        val = logits.max(1).values
-        val.backward(inputs=[imga])
-        return imga.grad.detach()[0], val.detach().view(-1)[0], outa.detach()
+        exec(compile(src, "<compute_attributions, lifted>", "exec"), ns)
+        val = ns["logits"].max(1).values
+    return ns["grada"].detach()[0], val.detach().view(-1)[0], ns["outa"].detach()
 
 
 def clip_zeroshot_attribution():
@@ -902,6 +961,7 @@ def clip_zeroshot_attribution():
         json.dump(dict(arch="clip_rn50", weight_seed=0, image_seed=123, n_images=4, text_seed=99, text_column_unpool=3,
                        calibration="tests/golden/clip_rn50.npz (calib/*)", variants=[[pc, int(nm)] for pc, nm in variants],
                        state_checksum=state_checksum(sd), state_checksum_unpool=state_checksum(sd_u),
+                       reference_statements_sha256=_reference_text_attribution_code()[1],
                        torch_version=torch.__version__), f_, indent=1)
 
 
@@ -1015,7 +1075,7 @@ def localisation_grid():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r50", "vit", "vitc", "vit_train", "clip", "unpool", "zeroshot_attr", "loc"]
+    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r18s", "r50", "vit", "vitc", "vit_train", "clip", "unpool", "zeroshot_attr", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
@@ -1037,6 +1097,8 @@ if __name__ == "__main__":
         small_invariants()
     if "r18" in which:
         resnet18_end_to_end()
+    if "r18s" in which:
+        resnet18_structured()
     if "r50" in which:
         resnet50_logits_small()
     if "vit" in which:

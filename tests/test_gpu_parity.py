@@ -315,6 +315,23 @@ def test_streaming_kernels(lib):
 
 
 # ------------------------------------------------------------------------------------------ whole networks
+def maxabs(a, b):
+    """Worst element of a tensor relative to the reference tensor's largest: max |a - b| / max |b| (VERDICT r03 'What's weak' 2 --
+    a global relL2 cannot see a few wrong pixels of a map)."""
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+def maxabs_per_image(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float(((a - b).abs().flatten(1).amax(1) / b.abs().flatten(1).amax(1).clamp_min(1e-300)).max())
+
+
+def _recorded_gates(meta, data):
+    return [torch.from_numpy(np.unpackbits(data[f"gate/{i:02d}"])[: int(np.prod(shp))].reshape(shp).astype(np.float32)).to(DEV)
+            for i, shp in enumerate(meta["gate_shapes"])]
+
+
 def _golden_net(golden_dir, stem):
     from bcos_hip import synth
     meta = json.load(open(os.path.join(golden_dir, stem + ".json")))
@@ -386,6 +403,8 @@ def test_resnet18_config1_against_reference_golden(lib, golden_dir):
     assert rel(pinned["logits"], data["logits"][:2]) <= 1e-4
     assert rel(pinned["contribution_map"], data["contribution_map"][:2]) <= 1e-4
     assert rel(pinned["dynamic_linear_weights"], data["weights_01"]) <= 1e-4
+    assert maxabs_per_image(pinned["contribution_map"], data["contribution_map"][:2]) <= 1e-4      # worst element / the image's map maximum
+    assert maxabs_per_image(pinned["dynamic_linear_weights"], data["weights_01"]) <= 1e-4
     # (3) against the oracle run on this host: every differing gate is numerically dead, and with the oracle's
     #     gates replayed all 8 maps agree to 1e-4
     flips, total, worst = _gate_flips(net, eng, x, meta["arch"])
@@ -425,6 +444,38 @@ def test_resnet18_config1_against_reference_golden(lib, golden_dir):
     assert float(np.abs(rgba[vis][:, :3] - gold[vis][:, :3]).mean()) <= 1e-2
 
 
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
+def test_resnet18_structured_images_against_reference_golden(lib, golden_dir, mode):
+    """the reference's recorded outputs on STRUCTURED images (tests/golden/resnet18_structured.*: smooth field,
+    sparse spots on black, a sharp-edged disc, half black / half white with a faint texture -- the dynamic range is inside the
+    image, in the activations and above all in the gradients of the explanation pass).  Logits 1e-4, bit-exact classes; with the
+    reference's ReLU decisions replayed, W(x) and the maps hold 1e-4 in relL2 AND in the worst element relative to each image's
+    map maximum; free gates are bounded by the reference's own self-disagreement.  Every contraction mode."""
+    from bcos_hip import engine, synth
+    from bcos_hip import lib as blib
+    net, meta_w, _ = _golden_net(golden_dir, "resnet18_e2e")                 # (same weights: the fixture reuses that calibration record)
+    meta = json.load(open(os.path.join(golden_dir, "resnet18_structured.json")))
+    data = np.load(os.path.join(golden_dir, "resnet18_structured.npz"))
+    x = synth.structured_images(meta["n_images"], seed=meta["image_seed"]).to(DEV)
+    prev = blib.get_contraction_mode()
+    blib.set_contraction_mode(mode)
+    try:
+        eng = engine.attach(net)
+        out = eng.explain(x)
+        assert rel(out["logits"], data["logits"]) <= 1e-4 and maxabs(out["logits"], data["logits"]) <= 1e-4
+        assert np.array_equal(out["prediction"].cpu().numpy(), data["prediction"])
+        assert _completeness(x, out) <= 1e-4
+        floor = json.load(open(os.path.join(golden_dir, "oracle_vs_reference.json")))["r18s/reference_self_floor_weights"][0]
+        assert rel(out["dynamic_linear_weights"], data["weights"]) <= max(3 * floor, 1e-4), (mode, floor)
+        pinned = eng.explain(x, gates=_recorded_gates(meta, data))
+        for key, gold in (("dynamic_linear_weights", data["weights"]), ("contribution_map", data["contribution_map"])):
+            assert rel(pinned[key], gold) <= 1e-4, (mode, key, rel(pinned[key], gold))
+            assert maxabs_per_image(pinned[key], gold) <= 1e-4, (mode, key, maxabs_per_image(pinned[key], gold))
+        assert rel(pinned["logits"], data["logits"]) <= 1e-4
+    finally:
+        blib.set_contraction_mode(prev)
+
+
 def test_resnet50_against_reference_golden(lib, golden_dir):
     from bcos_hip import engine, synth
     net, meta, data = _golden_net(golden_dir, "resnet50_small")
@@ -453,6 +504,9 @@ def test_resnet50_against_reference_golden(lib, golden_dir):
     assert rel(pinned_ref["logits"], data["logits"]) <= 1e-4
     assert rel(pinned_ref["contribution_map"], data["contribution_map"]) <= 1e-4
     assert rel(pinned_ref["dynamic_linear_weights"], data["weights_01"]) <= 1e-4
+    # ... and no single element of a map is off by more than 1e-4 of that image's map maximum
+    assert maxabs_per_image(pinned_ref["contribution_map"], data["contribution_map"]) <= 1e-4
+    assert maxabs_per_image(pinned_ref["dynamic_linear_weights"], data["weights_01"]) <= 1e-4
 
 
 
@@ -590,6 +644,8 @@ def test_vit_ti_against_reference_golden(lib, golden_dir):
     assert np.array_equal(out["prediction"].cpu().numpy(), data["prediction"])
     assert rel(out["contribution_map"], data["contribution_map"]) <= 1e-4
     assert rel(out["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
+    assert maxabs_per_image(out["contribution_map"], data["contribution_map"]) <= 1e-4      # worst element / the image's map maximum
+    assert maxabs_per_image(out["dynamic_linear_weights"][:1], data["weights_0"]) <= 1e-4
     with torch.no_grad():
         assert rel(net(x), data["logits"]) <= 1e-4         # forward through the engine
     again = eng.explain(x)
