@@ -171,43 +171,6 @@ def gradient_to_image(image, linear_mapping, smooth=15, alpha_percentile=99.5, r
     return rgba
 
 
-def plot_contribution_map(contribution_map, ax=None, vrange=None, vshift=0, hide_ticks=True, cmap="bwr",
-                              percentile=99.5):
-        return plot_contribution_map(contribution_map, ax, vrange, vshift, hide_ticks, cmap, percentile)
-
-
-def gradient_to_image(image, linear_mapping, smooth=15, alpha_percentile=99.5, return_contribs=False):
-    """RGBA rendering [H,W,4] of the dynamic linear mapping of one image (reference :387-436): colour = the
-    per-pixel weight direction over the (r,g,b,1-r,1-g,1-b) channels, alpha = its L2 norm, zeroed where the
-    contribution is negative, box-smoothed and clipped at the `alpha_percentile` quantile.
-
-    Tensors on a HIP device are rendered by the batched device kernel (bcos_hip.ops.render_explanations: per-pixel
-    colour/alpha, LDS box filter, exact quantile by radix select -- SURVEY.md section 8(f) N1); CPU tensors take the
-    reference's torch formulation below."""
-    if image.is_cuda and linear_mapping.is_cuda and image.dim() == 3 and image.shape[0] == 6 and (not smooth or smooth % 2):
-        from bcos_hip import ops
-        rgba_t = ops.render_explanations(image.detach()[None].float().contiguous(),
-                                         linear_mapping.detach()[None].float().contiguous(), smooth=smooth,
-                                         alpha_percentile=alpha_percentile)[0]
-        rgba = rgba_t.cpu().numpy()
-        if return_contribs:
-            return rgba, (image * linear_mapping).sum(0, keepdim=True).detach().cpu().numpy()
-        return rgba
-    contribs = (image * linear_mapping).sum(0, keepdim=True)
-    direction = linear_mapping / (linear_mapping.abs().max(0, keepdim=True).values + 1e-12)
-    direction = direction.clamp(min=0)
-    rgb = direction[:3] / (direction[:3] + direction[3:] + 1e-12)
-    alpha = linear_mapping.norm(p=2, dim=0, keepdim=True)
-    alpha = torch.where(contribs < 0, 1e-12, alpha)
-    if smooth:
-        alpha = F.avg_pool2d(alpha, smooth, stride=1, padding=(smooth - 1) // 2)
-    alpha = (alpha / torch.quantile(alpha, q=alpha_percentile / 100)).clip(0, 1)
-    rgba = torch.concatenate([rgb, alpha], dim=0).permute(1, 2, 0).detach().cpu().numpy()
-    if return_contribs:
-        return rgba, contribs.detach().cpu().numpy()
-    return rgba
-
-
 def plot_contribution_map(contribution_map: TensorLike, ax=None, vrange: Optional[float] = None, vshift: float = 0,
                           hide_ticks: bool = True, cmap: str = "bwr", percentile: float = 99.5):
     """Host-side matplotlib helper (reference :439-516); out of the hot path, kept for API completeness."""

@@ -338,6 +338,7 @@ class ResNetEngine:
         if key not in self._dev_consts:
             self._dev_consts[key] = (torch.tensor(self._mean, dtype=torch.float32, device=device),
                                      torch.tensor(self._std, dtype=torch.float32, device=device))
+            ops.publish_cached(self._dev_consts[key][1])
         return self._dev_consts[key]
 
     # ------------------------------------------------------------------------------------------------
@@ -541,9 +542,7 @@ class ResNetEngine:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         S = self._n_subbatches(x) if self.head_kind != "attn_unpool" else 1
         if S > 1:                                  # sub-batches on side streams (see _SUBBATCH_STREAMS)
-            if self._side is None or len(self._side[0]) < S:
-                self._side = ([torch.cuda.Stream() for _ in range(S)], [ops.AbsmaxArena() for _ in range(S)])
-            streams, arenas = self._side
+            streams, arenas = self._side_for(x, S)
             cur = torch.cuda.current_stream()
             x = x.detach()
             x = x if x.is_contiguous() else x.contiguous()
@@ -577,6 +576,19 @@ class ResNetEngine:
             return self._explain_subbatches(x, targets, want_weights, S)
         return self._explain_one(x, targets, want_weights, gates, cotangent, self._absmax_arena)
 
+    def _side_for(self, x, S):
+        """(streams, arenas) of the sub-batch passes on x's device, created on first use.  Everything the passes cache lazily --
+        refreshed layer plans, the attention-pool copies, the mean / std constants -- is brought up to date HERE, on the caller's
+        stream, which every side stream then waits for: no sub-batch reads a cache another one is still producing."""
+        self._ensure_fresh()
+        self._consts(x.device)
+        key = str(x.device)
+        if self._side is None:
+            self._side = {}
+        if key not in self._side or len(self._side[key][0]) < S:
+            self._side[key] = ([torch.cuda.Stream(device=x.device) for _ in range(S)], [ops.AbsmaxArena() for _ in range(S)])
+        return self._side[key]
+
     def _n_subbatches(self, x) -> int:
         S = int(self.subbatch_streams)
         if S <= 1 or not x.is_cuda or x.shape[0] < S * _SUBBATCH_MIN or torch.cuda.is_current_stream_capturing():
@@ -586,9 +598,7 @@ class ResNetEngine:
     def _explain_subbatches(self, x, targets, want_weights, S):
         """explain() of S contiguous sub-batches on S side streams, written into ONE set of output tensors (see
         _SUBBATCH_STREAMS).  The side streams start behind the caller's stream and the caller's stream waits for them."""
-        if self._side is None or len(self._side[0]) < S:
-            self._side = ([torch.cuda.Stream() for _ in range(S)], [ops.AbsmaxArena() for _ in range(S)])
-        streams, arenas = self._side
+        streams, arenas = self._side_for(x, S)
         cur = torch.cuda.current_stream()
         N, _, H, W = x.shape
         x = x.detach()

@@ -221,6 +221,7 @@ class ViTEngine:
         if key not in self._pe:
             pe = self.net.model.positional_embedding(torch.empty((1, gh, gw, self.dim), device=device))
             self._pe[key] = pe.contiguous()
+            ops.publish_cached(self._pe[key])      # (made on whichever stream asked first; read by every later pass)
         return self._pe[key]
 
     # --------------------------------------------------------------------------------------------------------
@@ -294,9 +295,18 @@ class ViTEngine:
         N = x.shape[0]
         if S <= 1 or not x.is_cuda or N < S * _SUBBATCH_MIN or torch.cuda.is_current_stream_capturing():
             return [fn(0, N, self._absmax_arena)]
-        if self._side is None or len(self._side[0]) < S:
-            self._side = ([torch.cuda.Stream() for _ in range(S)], [ops.AbsmaxArena() for _ in range(S)])
-        streams, arenas = self._side
+        # everything the passes cache lazily (refreshed plans, constants, the positional-embedding table) is brought up to date here,
+        # on the caller's stream, which every side stream then waits for; streams are per device
+        self._ensure_fresh()
+        self._consts(x.device)
+        if not self.stem and x.dim() == 4:
+            self._posemb(x.shape[2] // self.patch, x.shape[3] // self.patch, x.device)
+        key = str(x.device)
+        if self._side is None:
+            self._side = {}
+        if key not in self._side or len(self._side[key][0]) < S:
+            self._side[key] = ([torch.cuda.Stream(device=x.device) for _ in range(S)], [ops.AbsmaxArena() for _ in range(S)])
+        streams, arenas = self._side[key]
         cur = torch.cuda.current_stream()
         outs = []
         for i in range(S):

@@ -49,7 +49,7 @@ DTYPES = {
     "f32": "f32",
     "bf16x3": "f32 (contraction: exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products, fp32 accumulate)",
     "f16x2": "f32 (contraction: row-scaled 2-way fp16 split of the fp32 operands, 3 f16 MFMA products, fp32 accumulate; "
-             "launches without operand maxima or with K < 256 use the exact 3-way bf16 split)",
+             "launches without operand maxima or with K < {min_k} use the exact 3-way bf16 split)",
 }
 
 
@@ -101,7 +101,7 @@ def _physical_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(net, arch, n_images, budget_s=30.0):
+def cpu_baseline(net, arch, n_images, budget_s=60.0):
     """The oracle (kind 'port': PyTorch-CPU restatement of the reference path, pinned by tests/golden) on the host cores,
     following BASELINE.md section 4: fp32, warm-up before timing, forward + explanation AND forward-only, the thread count
     stated.  Thread count: BASELINE.md says "all host threads", but torch's intra-op pool collapses on the 2 x 64-core
@@ -150,15 +150,16 @@ def cpu_baseline(net, arch, n_images, budget_s=30.0):
     cores = max(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     rate = sweep[cores]
-    # passes: 1 warm-up + 2 timed of forward+explanation, 1 + 2 of forward-only (~1/3 of the cost each)
-    n = max(8, min(n_images, int(budget_s * rate / 4.0) // 8 * 8))
+    # passes: 2 timed of forward+explanation + 2 of forward-only (~1/6 of the cost each), one-chunk warm-ups: ~2.5 n / rate seconds
+    n = max(8, min(n_images, int(budget_s * rate / 2.5) // 8 * 8))
     x = synth.synthetic_images(n, seed=321)
     run(x[:CH])
     t_fe = sorted(run(x) for _ in range(2))
     run(x[:CH], explain=False)
     t_f = sorted(run(x, explain=False) for _ in range(2))
-    return dict(value=round(n / t_fe[0], 3), unit="images/s", cores=cores, kind="port",
-                forward_only=dict(value=round(n / t_f[0], 3), unit="images/s"),
+    return dict(value=round(n / t_fe[0], 3), unit="images/s", cores=cores, kind="port", images=n,
+                passes_images_per_s=[round(n / t, 3) for t in t_fe],
+                forward_only=dict(value=round(n / t_f[0], 3), unit="images/s", passes_images_per_s=[round(n / t, 3) for t in t_f]),
                 thread_sweep_images_per_s={str(k): v for k, v in sweep.items()},
                 sample=f"forward+explanation (and, separately, forward-only) of one batch of {n} images in chunks of {CH}, best of 2 timed "
                        f"passes after a warm-up (the other pass: {n / t_fe[1]:.1f} images/s), torch {torch.__version__} CPU fp32 with "
@@ -273,7 +274,11 @@ def main():
     EVENT_STRIDE = 10
     event_steps = [] if args.no_kernel_events else [i for i in range(args.steps) if i % EVENT_STRIDE == 0]
     events = []
+    # one HIP event per step boundary on the caller's stream (the engine's side streams are joined into it at the end of every
+    # pass): per-step times -> median / min, and the two execution modes of the timed region reported apart
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         if i in event_steps:
             # the steps that carry the per-launch HIP events run their launches on ONE stream: with the engine's two sub-batch
@@ -287,6 +292,7 @@ def main():
             ops.KERNEL_TIMING = None
         else:
             step()
+        marks[i + 1].record()
     if pipe is not None:
         gathered = pipe.flush()             # the last exchanges complete inside the timed region
     torch.cuda.synchronize()
@@ -300,6 +306,18 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = 1e3 * elapsed / args.steps
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    plain = sorted(t for i, t in enumerate(step_ms) if i not in event_steps)
+    evs = sorted(t for i, t in enumerate(step_ms) if i in event_steps)
+    med = lambda v: (round(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), 3) if v else None)  # noqa: E731
+    n_streams = int(getattr(eng, "subbatch_streams", 1))
+    step_times = dict(
+        unit="ms", source="HIP events on the caller's stream at every step boundary (this rank)",
+        all_steps=dict(median=med(sorted(step_ms)), min=round(min(step_ms), 3), max=round(max(step_ms), 3)),
+        # the steps as deployed: the batch as `n_streams` contiguous sub-batches on that many HIP streams
+        sub_batch_stream_steps=dict(streams=n_streams, steps=len(plain), median=med(plain), min=round(plain[0], 3) if plain else None),
+        # the steps that carry the per-launch events: every launch on ONE stream over the whole batch (+ ~14 us of event records per launch)
+        single_stream_event_steps=dict(steps=len(evs), median=med(evs), min=round(evs[0], 3) if evs else None))
     images = args.batch * world * args.steps
     value = images / elapsed
 
@@ -347,6 +365,13 @@ def main():
                     kernel="tapconv_kernel (all instantiations) + skinny_kernel", launches_per_step=launches // n_ev,
                     avg_launch_us=round(1e3 * kernel_ms / max(launches, 1), 2),
                     kernel_ms_per_step=round(kernel_ms / n_ev, 3), steps_with_events=len(event_steps),
+                    single_stream_kernel_ms_per_step=round(kernel_ms / n_ev, 3),
+                    two_stream_ms_per_step=(step_times["sub_batch_stream_steps"]["median"] if n_streams > 1 else None),
+                    execution_modes=("kernel_ms_per_step / avg_launch_us / by_bound: the event-carrying steps, every launch on ONE stream over the "
+                                     "whole batch (sum of the contraction launches only); ms_per_step / value: all timed steps, of which the "
+                                     f"others run as {n_streams} sub-batches on {n_streams} streams whose launches overlap -- a whole step "
+                                     "(two_stream_ms_per_step, incl. the non-contraction kernels) can therefore be shorter than the "
+                                     "single-stream sum of its contraction launches"),
                     algorithmic_gflop_per_step=round(gflop_step, 1), algorithmic_tflops=round(achieved, 2),
                     vs_fp32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     two_sided=dict(roofline_ms_per_step=round(ideal_ms / n_ev, 3), frac=round(ideal_ms / kernel_ms, 4) if kernel_ms > 0 else None,
@@ -375,10 +400,11 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
+        "step_times": step_times,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": DTYPES[contraction],
+        "dtype": DTYPES[contraction].format(min_k=ops.F16X2_MIN_K),
         "data": "synthetic",
         "config": {"workload": f"B-cosified {args.arch} {'forward' if args.forward_only else 'forward+explanation'}, "
                                f"batch {args.batch} per GPU, 224x224x6 (AddInverse), calibrated random-init weights",

@@ -67,6 +67,22 @@ def test_abi_argument_validation_under_address_sanitizer():
     assert proc.returncode == 0 and "abi_validation: ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
 
 
+def test_gradient_to_image_has_no_cpu_formulation():
+    """bcos.common.gradient_to_image is ONE definition, device-only -- CPU tensors raise (the torch restatement of the
+    reference's statements lives in oracle/), an even `smooth` raises instead of silently taking another path."""
+    import inspect
+    from bcos import common
+    from bcos_hip.lib import BcosHipError
+    src = inspect.getsource(common)
+    assert src.count("\ndef gradient_to_image(") == 1 and src.count("\ndef plot_contribution_map(") == 1
+    with pytest.raises(BcosHipError):
+        common.gradient_to_image(torch.rand(6, 8, 8), torch.rand(6, 8, 8))
+    with pytest.raises(BcosHipError, match="odd"):
+        common.gradient_to_image(torch.rand(6, 8, 8), torch.rand(6, 8, 8), smooth=4)
+    with pytest.raises(ValueError):
+        common.gradient_to_image(torch.rand(3, 8, 8), torch.rand(3, 8, 8))
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from bcos_hip import lib
     monkeypatch.setattr(lib, "_lib", None)
