@@ -88,6 +88,7 @@ SIGNATURES = {
     "bcos_patch_norm_bwd": (C.c_int, [_P, _P, _P] + [_I] * 15 + [_P]),
     "bcos_conv2d_wgrad": (C.c_int, [_P, _P, _P] + [_I] * 18 + [_P]),
     "bcos_colsum": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
+    "bcos_colsum_ordered": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_channel_axpby": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),

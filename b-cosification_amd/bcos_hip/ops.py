@@ -838,6 +838,35 @@ def colsum(a2d, b2d=None, shift_a=None, shift_b=None):
     return out
 
 
+def colsum_ordered(a2d, b2d=None, shift_a=None, shift_b=None):
+    """colsum in a fixed summation order (include/bcos_hip.h: bcos_colsum_ordered): bit-identical across runs and processes."""
+    lib = _l.load()
+    rows, Cc = a2d.shape
+    out = torch.empty((Cc,), device=a2d.device, dtype=torch.float32)
+    _l.check(lib.bcos_colsum_ordered(_dev(a2d, "a"), _dev(b2d, "b"), _dev(shift_a, "shift_a"), _dev(shift_b, "shift_b"), _dev(out, "out"),
+                                     rows, Cc, _stream()), "bcos_colsum_ordered")
+    return out
+
+
+def channel_moments_ordered(x_nchw: torch.Tensor):
+    """(mean [C], biased variance [C], mean of squares over everything) of a HIP tensor [N, C, H, W] (channels-last or not) / [R, C],
+    every sum in a fixed order (colsum_ordered): what torch's x.var((0, 2, 3), unbiased=False) and x.pow(2).mean() give, reproducibly."""
+    if x_nchw.dim() == 4:
+        x2 = x_nchw.permute(0, 2, 3, 1).contiguous()
+        x2 = x2.view(-1, x2.shape[-1])
+    else:
+        x2 = x_nchw.contiguous().view(-1, x_nchw.shape[-1])
+    Cc = x2.shape[1]
+    if Cc % 4:
+        x2 = torch.nn.functional.pad(x2, (0, 4 - Cc % 4))
+    rows = x2.shape[0]
+    mean = colsum_ordered(x2) / rows
+    var = colsum_ordered(x2, x2, mean, mean) / rows
+    sq = colsum_ordered(x2, x2)[:Cc]
+    msq = sq.double().cpu().sum() / (rows * Cc)              # (C <= a few thousand values: summed on the host, in order)
+    return mean[:Cc], var[:Cc], float(msq)
+
+
 def channel_axpby(a, sa, b=None, mb=None, sb=None, out=None):
     """out = a * sa[c] + (b - mb[c]) * sb[c] over the last (channel) dimension."""
     lib = _l.load()

@@ -148,14 +148,29 @@ def calibrate(net: nn.Module, x: torch.Tensor) -> "OrderedDict[str, torch.Tensor
     names = {m: n for n, m in net.named_modules()}
     hooks = []
 
+    # On a HIP device every statistic is summed in a FIXED order by this repo's own kernel (ops.channel_moments_ordered): replicas
+    # that calibrate independently must end bit-identical, and torch's multi-block reductions were measured not to be reproducible
+    # when several processes time-slice one device -- on a settled tensor, behind a device synchronisation, with nothing of this
+    # repo in flight (profiles/r04_var_triage.txt).  CPU tensors (the fixture generator, the oracle) keep torch.
+    def _moments(t):
+        if t.is_cuda and t.dim() >= 2 and t.dtype == torch.float32:
+            from . import ops
+            return ops.channel_moments_ordered(t)
+        return None
+
     def conv_pre(mod, args):
         y = mod(*args)          # re-entrancy guarded below
-        gain = y.pow(2).mean().sqrt().clamp_min(1e-30).pow(-0.5)
+        mom = _moments(y)
+        if mom is not None:
+            gain = torch.tensor(max(mom[2], 0.0) ** 0.5, dtype=torch.float32).clamp_min(1e-30).pow(-0.5).to(y.device)
+        else:
+            gain = y.pow(2).mean().sqrt().clamp_min(1e-30).pow(-0.5)
         mod.linear.weight.mul_(gain)    # in place on the Parameter (bumps its version: kernel-layout caches refresh)
         record[names[mod]] = gain.detach().cpu()
 
     def bn_pre(mod, args):
-        var = args[0].var(dim=(0, 2, 3), unbiased=False)
+        mom = _moments(args[0])
+        var = mom[1] if mom is not None else args[0].var(dim=(0, 2, 3), unbiased=False)
         mod.running_var.copy_(var)
         record[names[mod]] = var.detach().cpu()
 

@@ -324,6 +324,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
     }
 }
 
+// the same sums in a fixed order: workgroup = 16 float4 column groups (64 channels) x 16 row lanes over ALL rows; no atomics
+__global__ __launch_bounds__(256) void colsum_ordered_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ sa, const float* __restrict__ sb,
+                                                             float* __restrict__ out, int64_t rows, int C) {
+    __shared__ float red[256 * 4];
+    const int c4 = C / 4;
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int cg = blockIdx.x * 16 + tc;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (cg < c4) {
+        f32x4 sa4 = {0.f, 0.f, 0.f, 0.f}, sb4 = {0.f, 0.f, 0.f, 0.f};
+        if (sa) sa4 = *reinterpret_cast<const f32x4*>(sa + cg * 4);
+        if (sb) sb4 = *reinterpret_cast<const f32x4*>(sb + cg * 4);
+        for (int64_t r = tr; r < rows; r += 16) {
+            f32x4 va = *reinterpret_cast<const f32x4*>(a + r * C + cg * 4) - sa4;
+            if (b) va *= *reinterpret_cast<const f32x4*>(b + r * C + cg * 4) - sb4;
+            acc += va;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[threadIdx.x * 4 + q] = acc[q];
+    __syncthreads();
+    if (tr == 0 && cg < c4) {
+        for (int k = 1; k < 16; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += red[(k * 16 + tc) * 4 + q];
+        *reinterpret_cast<f32x4*>(out + cg * 4) = acc;
+    }
+}
+
 // out[r,c] = a[r,c] * sa[c] + (b[r,c] - mb[c]) * sb[c]        (b, mb, sb optional as a group)
 __global__ __launch_bounds__(256) void channel_axpby_kernel(const float* __restrict__ a, const float* __restrict__ sa,
                                                             const float* __restrict__ b, const float* __restrict__ mb,
@@ -446,6 +476,17 @@ extern "C" int bcos_colsum(const float* a, const float* b, const float* shift_a,
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, shift_a,
                        shift_b, out, rows, C, rpb);
     return check_launch("colsum launch");
+}
+
+extern "C" int bcos_colsum_ordered(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out,
+                                   int64_t rows, int C, void* stream) {
+    if (!a || !out || rows <= 0 || C <= 0 || C % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_colsum_ordered: bad argument");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) |
+         reinterpret_cast<uintptr_t>(shift_a) | reinterpret_cast<uintptr_t>(shift_b)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_colsum_ordered: tensors must be 16-byte aligned");
+    hipLaunchKernelGGL(colsum_ordered_kernel, dim3((unsigned)((C / 4 + 15) / 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b,
+                       shift_a, shift_b, out, rows, C);
+    return check_launch("colsum_ordered launch");
 }
 
 extern "C" int bcos_channel_axpby(const float* a, const float* sa, const float* b, const float* mb, const float* sb, float* out,

@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=256, help="images in the CPU-baseline sample (BASELINE.md section 4 asks "
                     "for 256; cut down to ~30 s of CPU work and flagged when the host is slower)")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time the forward pass only")
+    ap.add_argument("--train", action="store_true",
+                    help="diagnostic (NOT the BASELINE.json metric): one TRAINING step per step -- train-mode forward (batch statistics in "
+                         "every BatchNormUncentered2d, dynamic scales differentiated), BCE-with-logits loss, backward to every parameter, "
+                         "(N > 1) bucketed gradient all-reduce, SGD-momentum update -- the reference trainer's step "
+                         "(bcos/training/trainer.py:666-784) at its ImageNet batch of 64 per GPU unless --batch is given")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (engine.CapturedPass) instead of launching eagerly; "
                          "measured 1 %% SLOWER than eager launches on ROCm 7.2 (6 667 vs 6 745 images/s), hence off")
@@ -194,10 +199,114 @@ def self_launch(args):
     return proc.returncode if (proc.returncode != 0 or lines) else 1
 
 
+def train_main(args):
+    """`--train`: images/s of whole training steps of the B-cosified network on the per-layer HIP kernels (nn.Module path; the fused
+    inference plans are bypassed in train() mode).  One JSON line of the same shape as the metric's; the roofline prices the
+    algorithmic work of a step -- forward + input-gradient + weight-gradient contractions = 3 x the forward FLOPs -- against the whole
+    step time (no per-kernel events: the weight-gradient kernel runs on the fp32 matrix pipe, the others on the 16-bit one)."""
+    import torch.nn.functional as F
+    from bcos_hip import dist as bdist, lib, synth
+    lib.load()
+    if args.contraction:
+        lib.set_contraction_mode(args.contraction)
+    rank, local_rank, world = bdist.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("BCOS_SINGLE_DEVICE"):
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    spec = ARCHS[args.arch]
+    if spec["family"] == "vit":
+        net = synth.build_bcosified_vit(seed=0).to(dev)
+    elif spec["family"] == "clip":
+        raise SystemExit("--train: resnet18 / resnet50 / vit_ti")
+    else:
+        net = synth.build_bcosified_resnet(args.arch, seed=0).to(dev)
+    with torch.no_grad():
+        synth.calibrate(net, synth.synthetic_images(8, seed=123).to(dev))
+        replica_diff = bdist.replicate_parameters(net) if world > 1 else []
+    if replica_diff:
+        raise SystemExit(f"bench.py: replicas differ after the broadcast of rank 0's parameters: {replica_diff[:5]}")
+    net.train()
+    B = args.batch
+    x = synth.synthetic_images(B, seed=1000 + rank).to(dev)
+    target = F.one_hot(torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(rank)), 1000).float().to(dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = F.binary_cross_entropy_with_logits(net(x), target)
+        loss.backward()
+        if world > 1:
+            bdist.allreduce_gradients(params)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        loss = step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    gflop_step = 3.0 * spec["gflop_fwd"] * B
+    ms = 1e3 * elapsed / args.steps
+    contraction = lib.get_contraction_mode()
+    result = {
+        "metric": f"images/sec (training step: fwd + bwd + update) B-cos {args.arch} @224, batch {B} per GPU -- diagnostic, not the BASELINE.json metric",
+        "value": round(B * world * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3),
+        "step_times": dict(unit="ms", median=round(step_ms[len(step_ms) // 2], 3), min=round(step_ms[0], 3), max=round(step_ms[-1], 3)),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (parameters, activations, gradients, accumulation; forward / input-gradient contractions: " + DTYPES[contraction].format(min_k=0)
+                 + "; weight-gradient contraction: fp32 MFMA)",
+        "data": "synthetic",
+        "config": {"workload": f"B-cosified {args.arch} TRAINING step (train-mode forward with batch statistics, BCE-with-logits, backward, "
+                               f"SGD-momentum update), batch {B} per GPU, 224x224x6, calibrated random-init weights",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "contraction": contraction,
+                   "path": "nn.Module path: one HIP launch sequence per layer under autograd (the fused inference plan is bypassed in train())",
+                   "collective": "bucketed asynchronous all_reduce of the gradients (bcos_hip.dist.allreduce_gradients)" if world > 1 else "none",
+                   "final_loss": round(float(loss), 6)},
+        "roofline": dict(bound="mfma", achieved=round(gflop_step / ms, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s (algorithmic fp32 FLOP of "
+                         "the B-cos contractions: forward + input gradient + weight gradient = 3 x forward; fp32 matrix peak as the common "
+                         "denominator)", frac=round(gflop_step / ms / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                         algorithmic_gflop_per_step=round(gflop_step, 1),
+                         note="whole training step (every kernel, the optimizer update and the Python / autograd dispatch included), not a "
+                              "per-kernel time: the per-layer path is launch- and elementwise-bound at this batch size"),
+        "cpu_baseline": None,
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.train and args.batch == 256 and "--batch" not in " ".join(sys.argv):
+        args.batch = 64          # the reference's ImageNet training batch per GPU (bcosification/experiment_parameters.py:29)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    if args.train:
+        return train_main(args)
     from bcos_hip import dist as bdist, engine, lib, ops, synth
     lib.load()      # fails loudly if the HIP library was not built
     if args.contraction:

@@ -506,6 +506,12 @@ int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, int N, int H
  * (batchnorm_uncentered.py:36-44: var = x.var((0,2,3), unbiased=False), two passes: mean, then centred squares). */
 int bcos_colsum(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out, int64_t rows, int C,
                 void* stream);
+/* The same sums in a FIXED order (no atomics: one workgroup owns 64 channels over all rows, every thread walks its rows in order,
+ * the partial sums meet in a fixed tree) written -- not added -- to `out`: bit-identical from run to run and from process to
+ * process, at a fraction of bcos_colsum's bandwidth.  What replicas that must agree bit for bit derive their statistics with
+ * (bcos_hip/synth.py: calibrate).  (ABI v7) */
+int bcos_colsum_ordered(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out, int64_t rows, int C,
+                        void* stream);
 
 /* out[r,c] = a[r,c] * sa[c] + (b[r,c] - mb[c]) * sb[c]   (b / mb / sb may be NULL: out = a * sa): the input gradient of the
  * training-mode uncentered batch norm, gx = gy * w / std + (x - mean) * coef. */

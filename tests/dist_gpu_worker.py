@@ -177,9 +177,10 @@ def run_unpool(rank, world, n_global):
 
 
 def run_percalib(rank, world, n_global):
-    """Every rank builds AND calibrates its own replica (no broadcast): do the replicas agree?  (They must in deployment; under
-    8-process time-slicing of one device about one process in a hundred was seen to end with different BatchNorm statistics,
-    DESIGN.md section 6 -- kept as a non-strict xfail so that a recurrence is recorded, not hidden by the broadcast.)"""
+    """Every rank builds AND calibrates its own replica (no broadcast): the replicas agree bit for bit.  (Rounds 2-3: under
+    8-process time-slicing of one device about one process in a hundred ended with different BatchNorm statistics -- torch's
+    multi-block variance reduction, DESIGN.md section 6 / profiles/r04_var_triage.txt; calibrate now sums in a fixed order with
+    this repo's own kernel.)"""
     net = synth.build_bcosified_resnet("resnet50").to(DEV)
     with torch.no_grad():
         for _ in range(max(1, n_global)):
@@ -191,12 +192,33 @@ def run_percalib(rank, world, n_global):
     return dict(config="percalib", world=world, shard=[0, 0], replicas_identical=not diff, replica_diff=diff[:8])
 
 
+def run_percalib_stress(rank, world, n_global):
+    """`n_global` ROUNDS of: every rank builds the network from its seed, calibrates it by itself and the ranks compare digests of
+    every state-dict entry.  Since round 4 every statistic of synth.calibrate is summed in a fixed order by this repo's own kernel
+    (bcos_colsum_ordered), so every round must be clean; with torch's multi-block reductions about one process-calibration in a
+    hundred differed under this contention (profiles/r04_var_triage.txt)."""
+    bad = []
+    for rnd in range(max(1, n_global)):
+        net = synth.build_bcosified_resnet("resnet50").to(DEV)
+        with torch.no_grad():
+            synth.calibrate(net, synth.synthetic_images(8).to(DEV))
+        digest = {k: (float(v.double().abs().sum()), float(v.double().sum())) for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+        all_d = [None] * world
+        dist.all_gather_object(all_d, digest)
+        diff = [f"round {rnd} rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]
+        if diff:
+            bad.append(diff[:4])
+        del net
+    return dict(config="percalib_stress", world=world, shard=[0, 0], rounds=max(1, n_global), clean_rounds=max(1, n_global) - len(bad),
+                replicas_identical=not bad, replica_diff=bad[:8])
+
+
 def main():
     config, n_global, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     rank, _, world = bdist.init(backend="gloo")
     torch.cuda.set_device(0)
     t0 = time.time()
-    verdict = {"r50": run_resnet50, "clip": run_clip, "unpool": run_unpool, "percalib": run_percalib}[config](rank, world, n_global)
+    verdict = {"r50": run_resnet50, "clip": run_clip, "unpool": run_unpool, "percalib": run_percalib, "percalib_stress": run_percalib_stress}[config](rank, world, n_global)
     verdict["seconds"] = round(time.time() - t0, 1)
     all_v = [None] * world
     dist.all_gather_object(all_v, verdict)

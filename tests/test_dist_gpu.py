@@ -68,11 +68,13 @@ def test_attn_unpool_outputs_gather_along_batch_dim(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="8 processes time-slicing ONE device: independently calibrated replicas were seen to differ "
-                                        "about once in a hundred processes (DESIGN.md section 6); not reproduced with torch alone "
-                                        "(scripts/probe/var_stress_torch_only.py: 0 of 960 000 reductions), so a stray write of this "
-                                        "repo's kernels is not excluded -- this test records recurrences instead of hiding them")
 def test_independently_calibrated_replicas_agree(tmp_path):
+    """8 ranks time-slicing ONE device, each building and calibrating its own replica (3 passes, no parameter broadcast): bit-identical
+    state dicts.  Rounds 2-3 carried this as a non-strict xfail: about one process in a hundred ended with different BatchNorm
+    statistics.  Round 4 traced it to torch's multi-block `var` reduction under GPU time-slicing -- 26 grossly wrong results
+    (16 channels each, 12-85 % off) in 425 600 reductions of bit-identical, settled inputs behind a device synchronisation, against
+    0 of 212 800 for this repo's fixed-order kernel (profiles/r04_var_triage.txt) -- and synth.calibrate now derives every statistic
+    with that kernel (bcos_colsum_ordered): the test is strict."""
     v = _launch("percalib", 3, tmp_path)          # 8 ranks x 3 calibration passes each, no parameter broadcast
     assert v["replicas_identical"], json.dumps(v)
 
