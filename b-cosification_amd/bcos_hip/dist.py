@@ -31,6 +31,19 @@ def init(backend: Optional[str] = None):
     return rank, local_rank, world
 
 
+def state_digest(module) -> dict:
+    """{state-dict key: hash of the entry's exact bytes}, taken on the HOST.  (Not a device-side checksum: torch's multi-block
+    reductions were measured to return wrong sums now and then when several processes time-slice one GPU -- DESIGN.md section 6 --
+    and a digest that can be wrong by itself proves nothing about the replicas.)"""
+    import hashlib
+    out = {}
+    for k, v in module.state_dict().items():
+        t = v.detach().cpu().contiguous()
+        out[k] = hashlib.blake2b(t.numpy().tobytes() if t.dtype != torch.bfloat16 else t.view(torch.int16).numpy().tobytes(),
+                                 digest_size=16).hexdigest()
+    return out
+
+
 def replicate_parameters(module) -> list:
     """Give every rank rank 0's parameters and buffers (one broadcast per state-dict entry -- what loading one checkpoint
     on every rank gives in deployment), then prove the replicas identical: each rank's digest of every entry is exchanged
@@ -48,8 +61,7 @@ def replicate_parameters(module) -> list:
         dist.broadcast(t, src=0)
         if t.device != v.device or t.data_ptr() != v.data_ptr():
             v.copy_(t.to(v.device))
-    digest = {k: (float(v.double().abs().sum()), float(v.double().sum())) for k, v in module.state_dict().items()
-              if v.dtype.is_floating_point}
+    digest = state_digest(module)
     all_d = [None] * world
     dist.all_gather_object(all_d, digest)
     return [f"rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]

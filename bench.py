@@ -13,7 +13,7 @@ Besides the contract fields the JSON line carries
   roofline      fp32-MFMA roofline of the dominant kernel family (tapconv_kernel): algorithmic FLOP of the B-cos
                 contractions of one step (17.22 GFLOP/image) / the time spent in those launches,
                 measured live with HIP events on the launch stream inside the timed region (around every contraction
-                launch of every 10th timed step, which runs on ONE stream so that an event pair times its own launch only);
+                launch of every 20th timed step, which runs on ONE stream so that an event pair times its own launch only);
   cpu_baseline  the CPU oracle (the PyTorch-CPU restatement of the reference's path) timed on this host's cores on
                 a bounded sample (rank 0, N = 1 only).
 """
@@ -370,17 +370,25 @@ def main():
             pipe.submit({k: out[k] for k in keys}, copy_out=False)      # (overlaps the next step's compute; drained inside the timed region)
         return out
 
-    for _ in range(args.warmup):
-        step()
+    for w in range(args.warmup):
+        if w == 0 and not args.no_kernel_events and args.warmup > 1:
+            # the first warm-up step runs the way the event-carrying timed steps do (every launch on the caller's stream, over the whole
+            # batch): the kernel instantiations, LDS / scratch reservations and arenas of THAT path are first-use costs too
+            sub = getattr(eng, "subbatch_streams", 1)
+            eng.subbatch_streams = 1
+            step(eager=True)
+            eng.subbatch_streams = sub
+        else:
+            step()
     if pipe is not None:
         pipe.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP events on the launch stream around every contraction launch of a SAMPLE of the timed steps (every 10th: the
+    # HIP events on the launch stream around every contraction launch of a SAMPLE of the timed steps (every 20th: the
     # two events per launch cost ~7 us of stream time each, 0.9 ms per step if taken on every step)
-    EVENT_STRIDE = 10
+    EVENT_STRIDE = 20
     event_steps = [] if args.no_kernel_events else [i for i in range(args.steps) if i % EVENT_STRIDE == 0]
     events = []
     # one HIP event per step boundary on the caller's stream (the engine's side streams are joined into it at the end of every

@@ -260,17 +260,18 @@ typedef struct bcos_operands {
                                    contraction run over an LDS-resident input patch: every input element is loaded and split once
                                    per 16 channels instead of once per tap.  A pixel then serves rows with different tap windows,
                                    so the operand scales are per IMAGE, on a ladder (ABI v7): row r of image n is contracted with
-                                   the scale 2^(12 l) above the image's, l = floor((E_n - E_r) / 12) for the exponents E of the image
-                                   maximum and of the row's maximum over its taps; a tile whose rows span several levels is
-                                   contracted once per level, each pass writing its own rows.  Every row is therefore computed
-                                   with a scale within 2^12 of its own window's maximum and keeps the full 22 bits of every
-                                   element within 2^-5 of it: |lin - exact| <= 2e-6 ||patch|| ||w|| per output row, as with the
-                                   per-row scales of the other f16x2 loops, whatever the dynamic range inside the image
-                                   (tests/test_gpu_parity.py::test_patch_loop_dynamic_range_inside_an_image).  Level, scale and
-                                   result of a row are functions of its image alone: an image's bits do not depend on its batch
-                                   neighbours or position.                                                                   */
+                                   the scale 2^(16 l) above the image's, l = floor((E_n - E_r) / 16) for the exponents E of the image
+                                   maximum and of the row's maximum over its taps (from a_absmax; exact maxima as the epilogues and
+                                   bcos_rows_absmax emit them); a tile whose rows span several levels is contracted once per level,
+                                   each pass writing its own rows.  Every row is therefore computed with a scale within 2^16 of its
+                                   own window's maximum: no element of it is off by more than 2^-23 of that maximum, and
+                                   |lin - exact| <= 2e-6 ||patch|| ||w|| per output row -- as with the per-row scales of the other
+                                   f16x2 loops -- whatever the dynamic range inside the image
+                                   (tests/test_gpu_parity.py::test_patch_loop_dynamic_range_inside_an_image: measured ~2e-7).  Level,
+                                   scale and result of a row are functions of its image alone: an image's bits do not depend on its
+                                   batch neighbours or position.                                                              */
     const uint32_t* a_imgmin;   /* NULL or [N]: min over the NONZERO pixels of image n of a_absmax (0xffffffff: all zero;
-                                   bcos_image_absrange; ABI v7).  Images whose [a_imgmin, a_imgmax] span at most 2^12 have level 0
+                                   bcos_image_absrange; ABI v7).  Images whose [a_imgmin, a_imgmax] span at most 2^16 have level 0
                                    everywhere and skip the level bookkeeping; launches with >= 25 taps (7 x 7 stem) take the image
                                    maximum as the scale of such an image's rows instead of scanning every row's taps.  NULL: the
                                    range is unknown -- every tile derives its rows' levels, >= 25-tap launches scan.          */

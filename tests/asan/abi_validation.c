@@ -64,6 +64,9 @@ int main(void) {
       if (v != 0) { printf("FAIL BCOS_OPT_PATCH round trip %lld\n", (long long)v); ++failures; }
       EXPECT(bcos_set_option(BCOS_OPT_PATCH, 1), BCOS_OK); }
     EXPECT(bcos_image_absrange(NULL, am, am, 1, 4, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_colsum_ordered(NULL, NULL, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_colsum_ordered(buf, NULL, NULL, NULL, buf, 4, 6, NULL), BCOS_E_INVAL);            /* C % 4 */
+    EXPECT(bcos_colsum_ordered(buf + 1, NULL, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);        /* misaligned */
     EXPECT(bcos_image_absrange(am, NULL, am, 1, 4, NULL), BCOS_E_INVAL);
     EXPECT(bcos_image_absrange(am, am, NULL, 0, 4, NULL), BCOS_E_INVAL);
     { int64_t nb = 0;

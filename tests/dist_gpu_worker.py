@@ -185,7 +185,7 @@ def run_percalib(rank, world, n_global):
     with torch.no_grad():
         for _ in range(max(1, n_global)):
             synth.calibrate(net, synth.synthetic_images(8).to(DEV))
-    digest = {k: (float(v.double().abs().sum()), float(v.double().sum())) for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    digest = bdist.state_digest(net)
     all_d = [None] * world
     dist.all_gather_object(all_d, digest)
     diff = [f"rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]
@@ -202,12 +202,17 @@ def run_percalib_stress(rank, world, n_global):
         net = synth.build_bcosified_resnet("resnet50").to(DEV)
         with torch.no_grad():
             synth.calibrate(net, synth.synthetic_images(8).to(DEV))
-        digest = {k: (float(v.double().abs().sum()), float(v.double().sum())) for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+        digest = bdist.state_digest(net)
         all_d = [None] * world
         dist.all_gather_object(all_d, digest)
         diff = [f"round {rnd} rank {r}: {k}" for r in range(world) for k in digest if all_d[r][k] != all_d[0][k]]
         if diff:
-            bad.append(diff[:4])
+            # the first entry (state-dict order) on which the ranks disagree, and how they group on it
+            first = next(k for k in digest if any(all_d[r][k] != all_d[0][k] for r in range(world)))
+            groups = {}
+            for r in range(world):
+                groups.setdefault(repr(all_d[r][first]), []).append(r)
+            bad.append(dict(round=rnd, first_key=first, groups=sorted(groups.values()), n_keys=len({d_.split(": ")[1] for d_ in diff})))
         del net
     return dict(config="percalib_stress", world=world, shard=[0, 0], rounds=max(1, n_global), clean_rounds=max(1, n_global) - len(bad),
                 replicas_identical=not bad, replica_diff=bad[:8])

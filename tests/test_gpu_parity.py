@@ -1719,6 +1719,30 @@ def test_batch_chunks_carry_their_image_maxima(lib):
         blib.reset_options()
 
 
+def test_colsum_ordered_is_exact_enough_and_reproducible(lib):
+    """bcos_colsum_ordered (ABI v7): the column sums of bcos_colsum in a FIXED order, no atomics -- against fp64, bit-identical
+    from call to call, and the moments synth.calibrate derives with it against torch's (replicas that
+    calibrate independently must agree bit for bit, which torch's multi-block reductions do not guarantee under time-slicing)."""
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(77)
+    for (rows, Cc) in [(1, 4), (1000, 64), (25088, 256), (1568, 1024), (333, 2048), (77, 12)]:
+        a = torch.randn(rows, Cc, generator=g).to(DEV)
+        b = (torch.randn(rows, Cc, generator=g) + 0.3).to(DEV)
+        sa, sb = torch.randn(Cc, generator=g).to(DEV), torch.randn(Cc, generator=g).to(DEV)
+        for args, ref in (((a,), a.double().sum(0)), ((a, b), (a.double() * b.double()).sum(0)),
+                          ((a, b, sa, sb), ((a.double() - sa.double()) * (b.double() - sb.double())).sum(0))):
+            o1, o2 = ops.colsum_ordered(*args), ops.colsum_ordered(*args)
+            assert torch.equal(o1, o2), (rows, Cc, len(args))
+            scale = (args[0].double().abs() * (args[1].double().abs() if len(args) > 1 else 1)).sum(0) + 1e-30
+            assert float(((o1.double() - ref).abs() / scale).max()) <= 2e-6, (rows, Cc, len(args))
+            assert rel(ops.colsum(*args), ref) <= 1e-5
+    x = (torch.randn(8, 64, 14, 14, generator=g) * 3 + 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    mean, var, msq = ops.channel_moments_ordered(x)
+    assert rel(mean, x.double().mean((0, 2, 3))) <= 1e-6 and rel(var, x.double().var((0, 2, 3), unbiased=False)) <= 1e-6
+    assert abs(msq - float(x.double().pow(2).mean())) <= 1e-6 * msq
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(ops.channel_moments_ordered(x)[:2], (mean, var)))
+
+
 def test_c_abi_image_absmax(lib):
     """bcos_image_absmax (ABI v6) through the C ABI: per-image maxima of per-pixel maxima, image sizes on either side of the
     kernel's 4096-pixel stride, bit-exact (integer maxima of fp32 bit patterns)."""
