@@ -48,6 +48,7 @@ _REBUILD_MAX_SHIFT = float(os.environ.get("BCOS_REBUILD_MAX_SHIFT", "0.5"))
 # results bit-identical (an image's result does not depend on what else is in its batch: test_determinism_and_batch_independence).
 _SUBBATCH_STREAMS = int(os.environ.get("BCOS_SUBBATCH_STREAMS", "2"))
 _SUBBATCH_MIN = int(os.environ.get("BCOS_SUBBATCH_MIN", "32"))
+_CAPTURE_STREAMS = bool(os.environ.get("BCOS_CAPTURE_STREAMS"))      # experiment: keep the sub-batch streams inside a hipGraph capture (fork / join captured)
 
 
 def _pair(v):
@@ -591,7 +592,7 @@ class ResNetEngine:
 
     def _n_subbatches(self, x) -> int:
         S = int(self.subbatch_streams)
-        if S <= 1 or not x.is_cuda or x.shape[0] < S * _SUBBATCH_MIN or torch.cuda.is_current_stream_capturing():
+        if S <= 1 or not x.is_cuda or x.shape[0] < S * _SUBBATCH_MIN or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_STREAMS):
             return 1
         return S
 

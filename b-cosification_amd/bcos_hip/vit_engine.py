@@ -290,10 +290,10 @@ class ViTEngine:
     def _sub_batches(self, x, fn):
         """Run fn(sub_batch_index, lo, hi, arena) for contiguous sub-batches on side streams (bcos_hip/engine.py: _SUBBATCH_STREAMS:
         images are independent, the sub-batches fill each other's launch tails) or once on the caller's stream."""
-        from .engine import _SUBBATCH_MIN
+        from .engine import _SUBBATCH_MIN, _CAPTURE_STREAMS
         S = int(self.subbatch_streams)
         N = x.shape[0]
-        if S <= 1 or not x.is_cuda or N < S * _SUBBATCH_MIN or torch.cuda.is_current_stream_capturing():
+        if S <= 1 or not x.is_cuda or N < S * _SUBBATCH_MIN or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_STREAMS):
             return [fn(0, N, self._absmax_arena)]
         # everything the passes cache lazily (refreshed plans, constants, the positional-embedding table) is brought up to date here,
         # on the caller's stream, which every side stream then waits for (ADVICE r03); streams are per device

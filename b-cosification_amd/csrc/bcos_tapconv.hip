@@ -1765,6 +1765,9 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
 #ifndef D_DEAL_DMA
 #define D_DEAL_DMA 0              // 1 = issue the DMA pieces one by one behind the step's matrix instructions instead of together behind the barrier
 #endif
+#ifndef D_EARLY
+#define D_EARLY 1                 // 1 = the prologue's DMA pieces go out ahead of the loads of the operand maxima (every walk but the channel-chunk-major one); 0 = behind the scales (round 3)
+#endif
 #ifndef D_SCHED
 #define D_SCHED 1                 // 1 = pin the issue order of a step's fragment reads / matrix / vector instructions (sched_group_barrier)
 #endif
@@ -1812,69 +1815,29 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     float* s_scale = reinterpret_cast<float*>(lds + D_NSLOT * SLOT);                          // [BM] row scales
     char* s_dummy = lds + D_NSLOT * SLOT + BM * 4;                                           // 1 KB: target of the dummy B DMAs
     unsigned* s_tapoff = reinterpret_cast<unsigned*>(lds + D_NSLOT * SLOT + BM * 4 + 1024);    // [tap][BM] byte offsets (without the lane's chunk)
-    {
-        // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 lanes of a row share the taps.
-        // Launches with 25 or more taps that were given the per-image range of those maxima (the 7 x 7 stem: 49 taps = 13
-        // dependent-latency loads per lane and tile before the first DMA) take the row's IMAGE maximum instead -- for the rows of
-        // images whose nonzero pixels all lie within 2^LVL_STEP of that maximum (then it is within 2^LVL_STEP of every row's own
-        // maximum too, and every row keeps the full 22 bits: the B-cos network input [x, 1 - x] always qualifies); the rows of
-        // other images scan their taps.  Either way the scale of a row is a function of its image alone.
-        const bool img_scale = p.a_imgmax != nullptr && p.a_imgmin != nullptr && g.TH * g.TW >= 25;
-        bool scan = !img_scale;
-        unsigned rmax[A_LD];
-        int pix0[A_LD];
+    // rows of the tile this lane's DMA pieces cover: image base, first tap position (rows beyond M fail every bounds check)
+    int pix0[A_LD], row_img[A_LD];
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            const int m = m0 + r0 + 16 * j;
-            rmax[j] = 0u;
-            if (m < p.M) {
-                const int n = m / p.PQ;
-                const int rem = m - n * p.PQ;
-                const int i = rem / g.Q;
-                const int jj = rem - i * g.Q;
-                a_nbase[j] = ((unsigned)n * H * W * a_pitch + chunk * 4) * 4u;
-                pix0[j] = n * H * W;
-                if (img_scale) {
-                    const unsigned mx = p.a_imgmax[n], mn = p.a_imgmin[n];
-                    const unsigned Ei = max(mx >> 23, 15u);
-                    if (Ei - min(mn >> 23, Ei) <= (unsigned)LVL_STEP) rmax[j] = mx; else scan = true;
-                }
-                a_ih0[j] = i * g.in_sh + g.dh0;
-                a_iw0[j] = jj * g.in_sw + g.dw0;
-            } else {
-                a_nbase[j] = 0;
-                pix0[j] = 0;
-                a_ih0[j] = -(1 << 28);
-                a_iw0[j] = -(1 << 28);
-            }
-        }
-        const int ntaps = g.TH * g.TW;
-        // (the four lanes of a row take the same decision; a pixel maximum never exceeds its image's, so a row that already holds
-        //  its image maximum is not changed by lanes of the same wave that scan)
-        if (scan) {
-            for (int t = chunk; t < ntaps; t += 4) {
-                const int th = t / g.TW, tw = t - th * g.TW;
-                const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
-#pragma unroll
-                for (int j = 0; j < A_LD; ++j) {
-                    const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
-                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                    const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)(pix0[j] + ih * W + iw) * 4u : OOB, 0, 0);
-                    rmax[j] = max(rmax[j], v);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            unsigned v = rmax[j];
-            v = max(v, (unsigned)__shfl_xor((int)v, 1));
-            v = max(v, (unsigned)__shfl_xor((int)v, 2));
-            unsigned E = v >> 23;                  // biased exponent of the row max (the bit patterns carry no sign)
-            E = E < 15u ? 15u : E;
-            if ((lane & 3) == 0) s_scale[r0 + 16 * j] = __uint_as_float((268u - E) << 23);     // max * scale in [2^14, 2^15)
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = m0 + r0 + 16 * j;
+        if (m < p.M) {
+            const int n = m / p.PQ;
+            const int rem = m - n * p.PQ;
+            const int i = rem / g.Q;
+            const int jj = rem - i * g.Q;
+            a_nbase[j] = ((unsigned)n * H * W * a_pitch + chunk * 4) * 4u;
+            pix0[j] = n * H * W;
+            row_img[j] = n;
+            a_ih0[j] = i * g.in_sh + g.dh0;
+            a_iw0[j] = jj * g.in_sw + g.dw0;
+        } else {
+            a_nbase[j] = 0;
+            pix0[j] = 0;
+            row_img[j] = -1;
+            a_ih0[j] = -(1 << 28);
+            a_iw0[j] = -(1 << 28);
         }
     }
-
     const int nk = (p.nchunks + 3) / 4;
     const bool uniform = (g.C % X3_BK) == 0;
     const bool small_c = g.C == 4 || g.C == 8;      // see tile_body_h2
@@ -1987,6 +1950,74 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
         for (int j = 0; j < B_LD; ++j) piece_b(j, ks, slot_off);
     };
     constexpr int LA = A_LD, LB = B_LD;      // DMA instructions per wave and step: A pieces, then B blocks
+    // The DMA of the first steps needs addresses only -- the row scales are applied when a fragment is converted -- so for every K walk
+    // that derives its addresses from registers (1 x 1 layers, the small-channel stem, the general walk: everything but the
+    // channel-chunk-major multi-tap walk, whose (tap, row) table lives in LDS) the prologue's pieces go out HERE, ahead of the loads of
+    // the operand maxima, and land under their latency instead of behind it (round 4: the K <= 256 layers run a dozen tiles per
+    // workgroup slot, each paying that latency).  Same pieces, same order, same arithmetic: bit-identical results.
+    auto prologue_issue = [&](auto walk_c) {
+        if constexpr (PRIV) {
+            issue_a(walk_c, 0, 0);
+            if (nk > 1) issue_a(walk_c, 1, SLOT);
+            issue_b(0, 0);
+            if (nk > 2) issue_a(walk_c, 2, 2 * SLOT);
+            if (nk > 1) issue_b(1, SLOT);
+        } else {
+            issue_a(walk_c, 0, 0); issue_b(0, 0);
+            if (nk > 1) { issue_a(walk_c, 1, SLOT); issue_b(1, SLOT); }
+        }
+    };
+#if D_EARLY
+    if (walk == 1) prologue_issue(std::integral_constant<int, 1>{});
+    else if (walk == 2) prologue_issue(std::integral_constant<int, 2>{});
+    else if (walk == 3) prologue_issue(std::integral_constant<int, 3>{});
+#endif
+    {
+        // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 lanes of a row share the taps.
+        // Launches with 25 or more taps that were given the per-image range of those maxima (the 7 x 7 stem: 49 taps = 13
+        // dependent-latency loads per lane and tile before the first DMA) take the row's IMAGE maximum instead -- for the rows of
+        // images whose nonzero pixels all lie within 2^LVL_STEP of that maximum (then it is within 2^LVL_STEP of every row's own
+        // maximum too, and every row keeps the full 22 bits: the B-cos network input [x, 1 - x] always qualifies); the rows of
+        // other images scan their taps.  Either way the scale of a row is a function of its image alone.
+        const bool img_scale = p.a_imgmax != nullptr && p.a_imgmin != nullptr && g.TH * g.TW >= 25;
+        bool scan = !img_scale;
+        unsigned rmax[A_LD];
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            rmax[j] = 0u;
+            if (img_scale && row_img[j] >= 0) {
+                const unsigned mx = p.a_imgmax[row_img[j]], mn = p.a_imgmin[row_img[j]];
+                const unsigned Ei = max(mx >> 23, 15u);
+                if (Ei - min(mn >> 23, Ei) <= (unsigned)LVL_STEP) rmax[j] = mx; else scan = true;
+            }
+        }
+        const int ntaps = g.TH * g.TW;
+        // (the four lanes of a row take the same decision; a pixel maximum never exceeds its image's, so a row that already holds
+        //  its image maximum is not changed by lanes of the same wave that scan)
+        if (scan) {
+            for (int t = chunk; t < ntaps; t += 4) {
+                const int th = t / g.TW, tw = t - th * g.TW;
+                const int dh = th * g.dstep_h, dw = tw * g.dstep_w;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) {
+                    const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)(pix0[j] + ih * W + iw) * 4u : OOB, 0, 0);
+                    rmax[j] = max(rmax[j], v);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            unsigned v = rmax[j];
+            v = max(v, (unsigned)__shfl_xor((int)v, 1));
+            v = max(v, (unsigned)__shfl_xor((int)v, 2));
+            unsigned E = v >> 23;                  // biased exponent of the row max (the bit patterns carry no sign)
+            E = E < 15u ? 15u : E;
+            if ((lane & 3) == 0) s_scale[r0 + 16 * j] = __uint_as_float((268u - E) << 23);     // max * scale in [2^14, 2^15)
+        }
+    }
+
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -2145,11 +2176,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             //   A(ks+1) B(ks) | A(ks+2) B(ks+1)            (A(ks+3) B(ks+2) are issued behind the barrier)
             // and ONE counted wait (everything but the last pair) covers what step ks needs: B(ks) for its matrix instructions,
             // A(ks+1) for the split that runs in their shadow.  Every piece has two steps to land.
-            issue_a(walk_c, 0, 0);
-            if (nk > 1) issue_a(walk_c, 1, SLOT);
-            issue_b(0, 0);
-            if (nk > 2) issue_a(walk_c, 2, 2 * SLOT);
-            if (nk > 1) issue_b(1, SLOT);
+            if constexpr (decltype(walk_c)::value == 0 || !D_EARLY) prologue_issue(walk_c);      // (the other walks: issued ahead of the scales, above)
             if (nk > 2) wait_vmcnt<2 * LA + 2 * LB>(); else if (nk > 1) wait_vmcnt<LA + 2 * LB>(); else wait_vmcnt<LB>();
             {
                 f32x4 x0[TM], x1[TM];
@@ -2191,8 +2218,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
         } else {
             // A rows shared by the waves of a row group (half-height tiles): A and B of step ks + 2 are issued together at the top of
             // step ks, the split happens at the top of the step behind the barrier
-            issue_a(walk_c, 0, 0); issue_b(0, 0);
-            if (nk > 1) { issue_a(walk_c, 1, SLOT); issue_b(1, SLOT); }
+            if constexpr (decltype(walk_c)::value == 0 || !D_EARLY) prologue_issue(walk_c);
             int off = 0, off_in = (2 * SLOT) % (D_NSLOT * SLOT);
             for (int ks = 0; ks < nk; ++ks) {
                 if (ks + 1 < nk) wait_vmcnt<LA + LB>(); else wait_vmcnt<0>();
@@ -2396,6 +2422,23 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
     // The first chunk's loads and the first B blocks go out BEFORE the rest of the prologue (image scales, row table: two barriers
     // and a few hundred integer instructions), which then runs under their latency instead of ahead of it.
     constexpr int AHEAD = P_NSLOT - 1;               // the DMA of step ks + AHEAD is issued in step ks
+    // (first pass, ladder enabled: the per-pixel maxima of the patch go out FIRST -- NI 4-byte loads per even thread, L2 hits -- so
+    //  that a tile of a wide-range image can derive its rows' levels behind a counted wait instead of draining the chunk loads and
+    //  DMAs issued right behind them; tiles of narrow images never look at them)
+    unsigned pmx[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) pmx[it] = 0u;
+    if constexpr (!MORE) {
+        if (p.lvl_on && !(tid & 1)) {
+            const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.a_absmax), 0, p.absmax_bytes, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                int jr, cc, n, ih, iw;
+                const bool ok = item_pixel(it, jr, cc, n, ih, iw);
+                pmx[it] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)((n * H + ih) * W + iw) * 4u : OOB, 0, 0);
+            }
+        }
+    }
     load_items(0);
     issue_b(0, 0);
     if constexpr (AHEAD == 2) issue_b(1, BSLOT);
@@ -2427,18 +2470,13 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
     }
     const unsigned char* lvl_rows = wide ? s_lvl : nullptr;
     if (!MORE && wide) {
-        const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.a_absmax), 0, p.absmax_bytes, 0x00020000);
         if (tid == 0) *s_lvlmask = 0u;
         if (!(tid & 1)) {
 #pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                int jr, cc, n, ih, iw;
-                const bool ok = item_pixel(it, jr, cc, n, ih, iw);
-                const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, ok ? (unsigned)((n * H + ih) * W + iw) * 4u : OOB, 0, 0);
-                if (idst[it] >= 0) s_pixmax[idst[it] >> 4] = v;
-            }
+            for (int it = 0; it < NI; ++it)
+                if (idst[it] >= 0) s_pixmax[idst[it] >> 4] = pmx[it];
         }
-        __syncthreads();
+        lds_barrier();
         for (int r = tid; r < BM; r += NT) {
             int n = n_first, jr = -1, jc = 0;
             if constexpr (T2D) {
@@ -2470,7 +2508,7 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
             }
             s_lvl[r] = (unsigned char)level;
         }
-        __syncthreads();
+        lds_barrier();
         lvl_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)*s_lvlmask);
         if (lvl_mask == 0u) lvl_mask = 1u;
         pass = __builtin_ctz(lvl_mask);

@@ -172,6 +172,11 @@ struct WgradArgs {
     int tiles_ci;
     int64_t M;                     // N*P*Q
     int64_t chunk;                 // pixels per workgroup (multiple of 32)
+    int fuse;                      // 1: narrow inputs (C < 128, several taps): the tile's "ci" columns run over (tap, channel) pairs --
+                                   // column c = tap c / C, channel c % C -- instead of one tap per workgroup with most of the tile empty
+                                   // (the 7 x 7 stem over 8 channels: 4 column tiles instead of 49 nearly empty ones)
+    int cf;                        // ... channel stride of a tap among the fused columns: C rounded up to 4 (<= x_pitch; columns >= C are skipped)
+    int ctot;                      // kh * kw * cf
 };
 
 constexpr int WG_T = 128;          // tile edge (channels)
@@ -187,7 +192,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int tile = blockIdx.x;
     const int tile_co = tile / p.tiles_ci, tile_ci = tile - tile_co * p.tiles_ci;
     const int co0 = tile_co * WG_T, ci0 = tile_ci * WG_T;
-    const int tap = blockIdx.y;
+    // this thread's 16-byte column chunk of the x operand: (tap, first channel); fused launches derive the tap from the column
+    const int cq_ = threadIdx.x & 31;
+    const int bcol = ci0 + cq_ * 4;
+    const int tap = p.fuse ? (bcol < p.ctot ? bcol / p.cf : 0) : (int)blockIdx.y;
+    const int bci = p.fuse ? bcol - tap * p.cf : bcol;
+    const bool bcol_ok = p.fuse ? bcol < p.ctot : true;
     const int th = tap / p.kw, tw = tap - th * p.kw;
     const int64_t m_lo = (int64_t)blockIdx.z * p.chunk;
     const int64_t m_hi = m_lo + p.chunk < p.M ? m_lo + p.chunk : p.M;
@@ -212,10 +222,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                     for (int q = 0; q < 4; ++q) if (co + q < p.Cout) a[q] = p.glin[m * p.g_pitch + co + q];
                 }
                 const int ih = i * p.sh - p.ph + th * p.dh, iw = jj * p.sw - p.pw + tw * p.dw;
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+                if (bcol_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
                     const float* src = p.x + (((int64_t)n * p.H + ih) * p.W + iw) * p.x_pitch;
-                    const int ci = ci0 + cq * 4;
-                    if (ci + 3 < p.C) b = *reinterpret_cast<const f32x4*>(src + ci);
+                    const int ci = bci;
+                    if (p.fuse || ci + 3 < p.C) b = *reinterpret_cast<const f32x4*>(src + ci);      // (fused: the chunk lies inside [0, cf) <= x_pitch)
                     else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) if (ci + q < p.C) b[q] = src[ci + q];
@@ -275,12 +285,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ci = ci0 + wave_n * 64 + j * 32 + (lane & 31);
+            const int col = ci0 + wave_n * 64 + j * 32 + (lane & 31);
+            const int otap = p.fuse ? (col < p.ctot ? col / p.cf : 0) : tap;      // (fused: this lane's column names its own tap)
+            const int ci = p.fuse ? col - otap * p.cf : col;
+            const bool col_ok = p.fuse ? (col < p.ctot && ci < p.C) : ci < p.C;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < p.Cout && ci < p.C)
-                    atomicAdd(p.gw + ((int64_t)co * p.kh * p.kw + tap) * p.gw_cin + ci, acc[i][j][r]);
+                if (co < p.Cout && col_ok)
+                    atomicAdd(p.gw + ((int64_t)co * p.kh * p.kw + otap) * p.gw_cin + ci, acc[i][j][r]);
             }
         }
 }
@@ -447,8 +460,12 @@ extern "C" int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, i
     p.gw_cin = gw_cin;
     p.M = (int64_t)N * P * Q;
     const int tiles_co = (Cout + WG_T - 1) / WG_T;
-    p.tiles_ci = (C + WG_T - 1) / WG_T;
-    const int64_t tiles = (int64_t)tiles_co * p.tiles_ci * kh * kw;
+    p.cf = (C + 3) & ~3;
+    p.ctot = kh * kw * p.cf;
+    p.fuse = (p.cf < WG_T && kh * kw > 1 && x_pitch >= p.cf) ? 1 : 0;
+    p.tiles_ci = ((p.fuse ? p.ctot : C) + WG_T - 1) / WG_T;
+    const int grid_y = p.fuse ? 1 : kh * kw;
+    const int64_t tiles = (int64_t)tiles_co * p.tiles_ci * grid_y;
     // split the pixels so that ~4 workgroups per CU are in flight, chunks of at least 256 pixels
     int64_t split = (1024 + tiles - 1) / tiles;
     const int64_t max_split = (p.M + 255) / 256;
@@ -461,7 +478,7 @@ extern "C" int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, i
     static std::atomic<size_t> lds_hw{0};
     hipError_t e = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_kernel), lds, lds_hw);
     if (e != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", e);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(tiles_co * p.tiles_ci), (unsigned)(kh * kw), (unsigned)split), dim3(256), lds,
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(tiles_co * p.tiles_ci), (unsigned)grid_y, (unsigned)split), dim3(256), lds,
                        reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("wgrad launch");
 }

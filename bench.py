@@ -349,7 +349,7 @@ def main():
     # --graph: the step is recorded once into a hipGraph (engine.CapturedPass) and replayed; the steps that carry the
     # per-launch HIP events for the roofline run the very same launches eagerly (events cannot be read back from a graph).
     captured = None
-    if args.graph and spec["family"] == "resnet":
+    if args.graph:
         try:
             captured = engine.CapturedPass(eng, x, explain=not args.forward_only, want_weights=True)
         except Exception as exc:        # capture is an optimisation: fall back to eager launches, say so

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash scripts/collect_profiles.sh r03'
+#   gpurun --timeout 2700 -- 'bash scripts/collect_profiles.sh r04'
 # Writes gpurun_out/prof_<tag>/{stats,fetch,write,...}/ and gpurun_out/profiles_<tag>/ (the summaries to copy into profiles/).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -36,6 +36,15 @@ for spec in "resnet50 --forward-only" "resnet18" "vit_ti --batch 512" "vit_ti --
   cd "$ROOT"
   f=$(find "$OUT/stats_${name}" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$SUM/${TAG}_kernel_stats_${name}.csv"
+done
+# 4b. the training-step diagnostic (bench.py --train: nn.Module path, reference batch 64 per GPU) and its kernel stats
+for spec in "resnet50" "vit_ti"; do
+  python3 bench.py --train --arch $spec --steps 10 --warmup 3 > "$SUM/${TAG}_bench_train_${spec}.json" 2> "$OUT/bench_train_${spec}.err"
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train_${spec}" -- python3 "$ROOT/bench.py" --train --arch $spec --steps 3 --warmup 2 > /dev/null 2> "$OUT/stats_train_${spec}.err"
+  cd "$ROOT"
+  f=$(find "$OUT/stats_train_${spec}" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$SUM/${TAG}_kernel_stats_train_${spec}.csv"
 done
 # 5. SQ counters of four representative contraction launches (one counter group per pass): A = GEMM-shaped 3x3-class launch
 #    M = 50176, K = 2304, N = 256; B = forward 64 -> 256 @56^2 (residual + ReLU + stored multiplier); C = forward 256 -> 1024 @14^2
