@@ -89,6 +89,8 @@ SIGNATURES = {
     "bcos_conv2d_wgrad": (C.c_int, [_P, _P, _P] + [_I] * 18 + [_P]),
     "bcos_colsum": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_colsum_ordered": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
+    "bcos_colsum_ws_floats": (C.c_int, [_L, _I, C.POINTER(C.c_int64)]),
+    "bcos_colsum_ws": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "bcos_channel_axpby": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),

@@ -829,7 +829,22 @@ def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation):
 
 
 def colsum(a2d, b2d=None, shift_a=None, shift_b=None):
-    """out[c] = sum_r (a[r,c] - shift_a[c]) * (b[r,c] - shift_b[c])   (b None: plain column sums); C % 4 == 0."""
+    """out[c] = sum_r (a[r,c] - shift_a[c]) * (b[r,c] - shift_b[c])   (b None: plain column sums); C % 4 == 0.
+    Two launches over a torch-owned workspace (include/bcos_hip.h: bcos_colsum_ws): full bandwidth, no atomics, one fixed summation
+    order per (rows, C) -- bit-identical from run to run."""
+    lib = _l.load()
+    rows, Cc = a2d.shape
+    n = C.c_int64(0)
+    _l.check(lib.bcos_colsum_ws_floats(rows, Cc, C.byref(n)), "bcos_colsum_ws_floats")
+    ws = torch.empty((n.value,), device=a2d.device, dtype=torch.float32)
+    out = torch.empty((Cc,), device=a2d.device, dtype=torch.float32)
+    _l.check(lib.bcos_colsum_ws(_dev(a2d, "a"), _dev(b2d, "b"), _dev(shift_a, "shift_a"), _dev(shift_b, "shift_b"), _dev(out, "out"),
+                                _dev(ws, "workspace"), n.value, rows, Cc, _stream()), "bcos_colsum_ws")
+    return out
+
+
+def colsum_atomic(a2d, b2d=None, shift_a=None, shift_b=None):
+    """The single-launch form (bcos_colsum: partial sums combined with fp32 atomics, order not fixed); kept for A/B timing."""
     lib = _l.load()
     rows, Cc = a2d.shape
     out = torch.zeros((Cc,), device=a2d.device, dtype=torch.float32)
@@ -850,7 +865,7 @@ def colsum_ordered(a2d, b2d=None, shift_a=None, shift_b=None):
 
 def channel_moments_ordered(x_nchw: torch.Tensor):
     """(mean [C], biased variance [C], mean of squares over everything) of a HIP tensor [N, C, H, W] (channels-last or not) / [R, C],
-    every sum in a fixed order (colsum_ordered): what torch's x.var((0, 2, 3), unbiased=False) and x.pow(2).mean() give, reproducibly."""
+    every sum in a fixed order (colsum: bcos_colsum_ws): what torch's x.var((0, 2, 3), unbiased=False) and x.pow(2).mean() give, reproducibly."""
     if x_nchw.dim() == 4:
         x2 = x_nchw.permute(0, 2, 3, 1).contiguous()
         x2 = x2.view(-1, x2.shape[-1])
@@ -860,9 +875,9 @@ def channel_moments_ordered(x_nchw: torch.Tensor):
     if Cc % 4:
         x2 = torch.nn.functional.pad(x2, (0, 4 - Cc % 4))
     rows = x2.shape[0]
-    mean = colsum_ordered(x2) / rows
-    var = colsum_ordered(x2, x2, mean, mean) / rows
-    sq = colsum_ordered(x2, x2)[:Cc]
+    mean = colsum(x2) / rows
+    var = colsum(x2, x2, mean, mean) / rows
+    sq = colsum(x2, x2)[:Cc]
     msq = sq.double().cpu().sum() / (rows * Cc)              # (C <= a few thousand values: summed on the host, in order)
     return mean[:Cc], var[:Cc], float(msq)
 

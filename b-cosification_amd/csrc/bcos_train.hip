@@ -299,9 +299,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 }
 
 // ---- per-channel sums over rows: out[c] += sum_r (a[r,c] - sa[c]) * (b ? b[r,c] - sb[c] : 1) -----------------------------------
+// `partial` != NULL: the workgroup's sums go to partial[blockIdx.x][C] instead (no atomics; colsum_finish_kernel adds the rows of
+// `partial` in order: every sum of the launch then has ONE fixed order -- bcos_colsum_ws)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                      const float* __restrict__ sa, const float* __restrict__ sb,
-                                                     float* __restrict__ out, int64_t rows, int C, int64_t rows_per_block) {
+                                                     float* __restrict__ out, int64_t rows, int C, int64_t rows_per_block,
+                                                     float* __restrict__ partial) {
     __shared__ float red[256 * 4];
     const int c4 = C / 4;                                  // float4 columns
     const int tpc = c4 < 256 ? c4 : 256;                   // threads along the channel dimension
@@ -331,9 +334,39 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
             for (int k = 1; k < rstride; ++k)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] += red[(k * tpc + tc) * 4 + q];
+            if (partial) {
+                *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.x * C + cg * 4) = acc;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) atomicAdd(out + cg * 4 + q, acc[q]);
+                for (int q = 0; q < 4; ++q) atomicAdd(out + cg * 4 + q, acc[q]);
+            }
         }
+    }
+}
+
+// out[c] = sum_b partial[b][c] in ONE fixed order: workgroup = 16 channels x 16 lanes; lane t adds rows t, t + 16, ... in four
+// interleaved chains (independent loads in flight), the 64 partial sums of a channel meet in a fixed tree
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
+    __shared__ float red[256];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        int b = tr;
+        for (; b + 48 < nblk; b += 64) {
+            a0 += partial[(int64_t)b * C + c];
+            a1 += partial[(int64_t)(b + 16) * C + c];
+            a2 += partial[(int64_t)(b + 32) * C + c];
+            a3 += partial[(int64_t)(b + 48) * C + c];
+        }
+        for (; b < nblk; b += 16) a0 += partial[(int64_t)b * C + c];
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        float acc = red[tc];
+        for (int k = 1; k < 16; ++k) acc += red[k * 16 + tc];
+        out[c] = acc;
     }
 }
 
@@ -491,8 +524,36 @@ extern "C" int bcos_colsum(const float* a, const float* b, const float* shift_a,
     const int64_t rpb = (rows + blocks - 1) / blocks;
     blocks = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, shift_a,
-                       shift_b, out, rows, C, rpb);
+                       shift_b, out, rows, C, rpb, static_cast<float*>(nullptr));
     return check_launch("colsum launch");
+}
+
+static void colsum_ws_plan(int64_t rows, int64_t* blocks, int64_t* rpb) {
+    int64_t nb = (rows + 255) / 256;        // >= 256 rows per workgroup, <= 1024 workgroups (the second launch reads them all)
+    if (nb > 1024) nb = 1024;
+    *rpb = (rows + nb - 1) / nb;
+    *blocks = (rows + *rpb - 1) / *rpb;
+}
+
+extern "C" int bcos_colsum_ws_floats(int64_t rows, int C, int64_t* floats) {
+    if (rows <= 0 || C <= 0 || C % 4 != 0 || !floats) return bcos_set_error(BCOS_E_INVAL, "bcos_colsum_ws_floats: bad argument");
+    int64_t blocks, rpb;
+    colsum_ws_plan(rows, &blocks, &rpb);
+    *floats = blocks * C;
+    return BCOS_OK;
+}
+
+extern "C" int bcos_colsum_ws(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out, float* workspace,
+                              int64_t workspace_floats, int64_t rows, int C, void* stream) {
+    if (!a || !out || !workspace || rows <= 0 || C <= 0 || C % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_colsum_ws: bad argument");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15)) return bcos_set_error(BCOS_E_INVAL, "bcos_colsum_ws: workspace must be 16-byte aligned");
+    int64_t blocks, rpb;
+    colsum_ws_plan(rows, &blocks, &rpb);
+    if (workspace_floats < blocks * C) return bcos_set_error(BCOS_E_INVAL, "bcos_colsum_ws: workspace smaller than bcos_colsum_ws_floats");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, shift_a, shift_b, out, rows, C, rpb, workspace);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, workspace, out, (int)blocks, C);
+    return check_launch("colsum_ws launch");
 }
 
 extern "C" int bcos_colsum_ordered(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out,

@@ -507,6 +507,14 @@ int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, int N, int H
  * (batchnorm_uncentered.py:36-44: var = x.var((0,2,3), unbiased=False), two passes: mean, then centred squares). */
 int bcos_colsum(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out, int64_t rows, int C,
                 void* stream);
+/* The same sums at full bandwidth AND in a fixed order, given a caller-owned workspace of bcos_colsum_ws_floats(rows, C) floats
+ * (16-byte aligned): every workgroup writes its partial sums there, a second launch adds them in workgroup order and WRITES `out`
+ * (no zeroing by the caller, no atomics).  The order depends on (rows, C) alone: results are bit-identical from run to run and from
+ * process to process.  What the training path (BatchNormUncentered2d batch statistics, bias gradients) and synth.calibrate use.
+ * (ABI v7) */
+int bcos_colsum_ws_floats(int64_t rows, int C, int64_t* floats);
+int bcos_colsum_ws(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out, float* workspace,
+                   int64_t workspace_floats, int64_t rows, int C, void* stream);
 /* The same sums in a FIXED order (no atomics: one workgroup owns 64 channels over all rows, every thread walks its rows in order,
  * the partial sums meet in a fixed tree) written -- not added -- to `out`: bit-identical from run to run and from process to
  * process, at a fraction of bcos_colsum's bandwidth.  What replicas that must agree bit for bit derive their statistics with

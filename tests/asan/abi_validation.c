@@ -65,6 +65,14 @@ int main(void) {
       EXPECT(bcos_set_option(BCOS_OPT_PATCH, 1), BCOS_OK); }
     EXPECT(bcos_image_absrange(NULL, am, am, 1, 4, NULL), BCOS_E_INVAL);
     EXPECT(bcos_colsum_ordered(NULL, NULL, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);
+    { int64_t nf = 0;
+      EXPECT(bcos_colsum_ws_floats(0, 8, &nf), BCOS_E_INVAL);
+      EXPECT(bcos_colsum_ws_floats(1000, 8, NULL), BCOS_E_INVAL);
+      EXPECT(bcos_colsum_ws_floats(1000, 8, &nf), BCOS_OK);
+      if (nf != 4 * 8) { printf("FAIL colsum workspace %lld\n", (long long)nf); ++failures; }
+      EXPECT(bcos_colsum_ws(buf, NULL, NULL, NULL, buf, NULL, nf, 1000, 8, NULL), BCOS_E_INVAL);          /* no workspace */
+      EXPECT(bcos_colsum_ws(buf, NULL, NULL, NULL, buf, buf, nf - 1, 1000, 8, NULL), BCOS_E_INVAL);       /* workspace too small */
+      EXPECT(bcos_colsum_ws(buf, NULL, NULL, NULL, buf, buf + 1, nf, 1000, 8, NULL), BCOS_E_INVAL); }     /* misaligned workspace */
     EXPECT(bcos_colsum_ordered(buf, NULL, NULL, NULL, buf, 4, 6, NULL), BCOS_E_INVAL);            /* C % 4 */
     EXPECT(bcos_colsum_ordered(buf + 1, NULL, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);        /* misaligned */
     EXPECT(bcos_image_absrange(am, NULL, am, 1, 4, NULL), BCOS_E_INVAL);

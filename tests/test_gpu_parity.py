@@ -1733,9 +1733,15 @@ def test_colsum_ordered_is_exact_enough_and_reproducible(lib):
                           ((a, b, sa, sb), ((a.double() - sa.double()) * (b.double() - sb.double())).sum(0))):
             o1, o2 = ops.colsum_ordered(*args), ops.colsum_ordered(*args)
             assert torch.equal(o1, o2), (rows, Cc, len(args))
-            scale = (args[0].double().abs() * (args[1].double().abs() if len(args) > 1 else 1)).sum(0) + 1e-30
+            fa = (args[0].double() - (args[2].double() if len(args) > 2 else 0)).abs()
+            fb = (args[1].double() - (args[3].double() if len(args) > 3 else 0)).abs() if len(args) > 1 else 1
+            scale = (fa * fb).sum(0) + 1e-30
             assert float(((o1.double() - ref).abs() / scale).max()) <= 2e-6, (rows, Cc, len(args))
-            assert rel(ops.colsum(*args), ref) <= 1e-5
+            # the product's column sums (bcos_colsum_ws: full bandwidth, fixed order) and the single-launch atomic form
+            w1, w2 = ops.colsum(*args), ops.colsum(*args)
+            assert torch.equal(w1, w2), (rows, Cc, len(args))
+            assert float(((w1.double() - ref).abs() / scale).max()) <= 2e-6, (rows, Cc, len(args))
+            assert rel(ops.colsum_atomic(*args), ref) <= 1e-5
     x = (torch.randn(8, 64, 14, 14, generator=g) * 3 + 1).to(DEV).contiguous(memory_format=torch.channels_last)
     mean, var, msq = ops.channel_moments_ordered(x)
     assert rel(mean, x.double().mean((0, 2, 3))) <= 1e-6 and rel(var, x.double().var((0, 2, 3), unbiased=False)) <= 1e-6
