@@ -1749,6 +1749,56 @@ def test_colsum_ordered_is_exact_enough_and_reproducible(lib):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(ops.channel_moments_ordered(x)[:2], (mean, var)))
 
 
+def test_option_table_switches_code_paths_not_results(lib):
+    """bcos_set_option (ABI v7) through ctypes: defaults, range checks, and that an option selects between code paths of the SAME
+    operator -- a 3 x 3 launch under every setting of the loop / tile / epilogue switches agrees with the default to fp32 rounding
+    (bit for bit where the paths promise it).  The library ignores the process environment (rounds 1-3 read it per launch)."""
+    import ctypes as C
+    from bcos_hip import lib as blib
+    from bcos_hip import ops
+    v = C.c_int64(-1)
+    assert lib.bcos_get_option(blib.OPTIONS["patch"], C.byref(v)) == 0 and v.value == 1
+    assert lib.bcos_set_option(99, 1) != 0 and lib.bcos_set_option(blib.OPTIONS["h2_tile"], 3) != 0
+    assert lib.bcos_get_option(blib.OPTIONS["h2_tile"], C.byref(v)) == 0 and v.value == 0
+    if blib.get_contraction_mode() != "f16x2":
+        return
+    g = torch.Generator().manual_seed(5)
+    x = ops.ensure_absmax(torch.randn(4, 28, 28, 128, generator=g).to(DEV))
+    w = ops.mark_static((torch.randn(256, 3, 3, 128, generator=g) / 34).to(DEV))
+
+    def run():
+        return ops.conv2d_fwd(x, w, stride=(1, 1), padding=(1, 1), relu=True, want_scale=True, want_norm=True)
+    base = run()
+    os.environ["BCOS_PATCH"] = "0"                 # what rounds 1-3 would have obeyed
+    try:
+        again = run()
+    finally:
+        os.environ.pop("BCOS_PATCH", None)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(base, again))
+    for name, val, exact in (("epi_generic", 1, True), ("patch_levels", 0, True), ("patch_wide", 0, True), ("patch", 0, False),
+                             ("h2_loop", 1, False), ("h2_tile", 1, False), ("h2_tile", 2, False), ("tail_split", 0, False)):
+        with blib.option(name, val):
+            other = run()
+        for a_, b_ in zip(base, other):
+            assert (torch.equal(a_, b_) if exact else rel(b_, a_) <= 2e-6), (name, val, rel(b_, a_))
+        assert blib.get_option(name) == blib._loaded_options[name]
+
+
+def test_bench_train_diagnostic_line(lib):
+    """`bench.py --train` (a driver-visible training number): one JSON line of the contract's shape for a small
+    configuration -- train-mode forward, BCE loss, backward, SGD update on the per-layer HIP kernels; finite loss, positive rate."""
+    import subprocess
+    import sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([_sys.executable, os.path.join(repo, "bench.py"), "--train", "--arch", "resnet18", "--batch", "8", "--steps", "2",
+                           "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    res = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["unit"] == "images/s" and res["value"] > 0 and res["steps"] == 2 and res["n_gpus"] == 1
+    assert "TRAINING step" in res["config"]["workload"] and res["config"]["global_batch"] == 8
+    assert math.isfinite(res["config"]["final_loss"]) and res["roofline"]["achieved"] > 0 and res["step_times"]["min"] > 0
+
+
 def test_c_abi_image_absmax(lib):
     """bcos_image_absmax (ABI v6) through the C ABI: per-image maxima of per-pixel maxima, image sizes on either side of the
     kernel's 4096-pixel stride, bit-exact (integer maxima of fp32 bit patterns)."""
