@@ -1,0 +1,291 @@
+"""Training step of a B-cosified ResNet as ONE launch plan.
+
+The reference's training step (bcos/training/trainer.py:666-784: forward in train() mode, criterion, backward; DDP at :916-918)
+runs the same modules as inference.  Here `net.train(); net(x)` on a network with an attached ResNetEngine no longer falls back
+to one autograd node per layer: the whole network is ONE autograd.Function (`_TrainStepFn`) whose forward and backward walk the
+engine's layer list and issue the HIP launches directly, on NHWC tensors, keeping exactly what the backward needs.
+
+Per convolution unit (BcosifyConv2d -> BatchNormUncentered2d [-> + shortcut] [-> ReLU], bcosifyconv2d.py:50-102,
+batchnorm_uncentered.py:36-44):
+  forward    contraction + B-cos scale with the scale NOT detached (one bcos_tapconv launch: y, s, patch norms), batch statistics of
+             y in a fixed summation order (bcos_colsum_ws: mean, centred variance), running_var update, then ONE elementwise launch
+             for normalisation + affine + ReLU (bcos_channel_affine; blocks: + the shortcut through torch's add)
+  backward   ReLU gate, the two column sums of the BatchNorm gradient, its input gradient (bcos_channel_axpby), the derivative
+             of the dynamic scale (bcos_train_scale_bwd), the patch-norm term (bcos_patch_norm_bwd, added by the input-gradient
+             launch's epilogue), the input gradient (ops.DgradPlan) and the weight gradient (bcos_conv2d_wgrad).
+The arithmetic is the per-layer path's (bcos/modules/_hipfn.py: BcosConv2dFn, batchnorm_uncentered.py: _BatchStatsFn) launch for
+launch, so both are held to the same reference-recorded fixtures (tests/golden/resnet18_train_step.npz).
+
+Scope: torchvision-topology ResNets with the GAP + 1x1 `fc` head (BASELINE configs), groups == 1, max_out == 1, fixed B.  Anything
+else -- CLIP's attention-pool head, grouped / MaxOut layers, a learnable exponent, native unit-norm layers -- is refused by
+`supported()` and keeps the per-layer path.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .lib import BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_NONE, BcosHipError
+
+
+def _pad4(t: torch.Tensor) -> torch.Tensor:
+    r = (-t.shape[-1]) % 4
+    return F.pad(t, (0, r)) if r else t
+
+
+class _UnitState:
+    __slots__ = ("x", "y", "scale", "norm", "w", "bias", "b", "force_pow", "mean", "rstd", "g", "act", "relu", "bn", "conv",
+                 "has_addend", "in_hw")
+
+
+class ResNetTrainPlan:
+    def __init__(self, eng):
+        self.eng = eng
+        self.net = eng.net
+        ok, why = self.supported(eng)
+        if not ok:
+            raise BcosHipError(f"train plan: {why}")
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def supported(eng):
+        from bcos.modules.bcosconv2d import NormedConv2d
+        if getattr(eng, "head_kind", None) != "gap_fc":
+            return False, "only the global-average-pool + fc head"
+        if any(b.hybrid or b.pool or b.shortcut_pool or not b.relu for b in eng.blocks):
+            return False, "grouped / MaxOut / anti-aliased / ReLU-free blocks keep the per-layer path"
+        if len(eng.stem) != 1 or not eng.stem[0][1]:
+            return False, "single-conv stem with ReLU"
+        for c in eng._all_convs():
+            m = c.module
+            if isinstance(getattr(m, "b", None), torch.Tensor) and m.b.requires_grad:
+                return False, "learnable exponent"
+            if isinstance(m.linear, NormedConv2d):
+                return False, "native unit-norm layers"
+        return True, ""
+
+    def parameters(self) -> List[nn.Parameter]:
+        """every parameter the plan reads, in a fixed order (the autograd Function's inputs)"""
+        ps, seen = [], set()
+        for c in self.eng._all_convs():
+            for p in (c.module.linear.weight, c.module.linear.bias, getattr(c.bn, "weight", None), getattr(c.bn, "bias", None)):
+                if isinstance(p, nn.Parameter) and id(p) not in seen:
+                    seen.add(id(p))
+                    ps.append(p)
+        return ps
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _unit_fwd(self, c, x, addend=None, relu=True, batch_stats=True) -> (torch.Tensor, _UnitState):
+        """one conv (+ BatchNorm with batch statistics) (+ shortcut) (+ ReLU) on NHWC tensors"""
+        conv, bn = c.module, c.bn
+        w, bias = conv._effective_weight_and_bias()
+        wd = w.detach()
+        wk = ops.mark_static(_pad4(wd.permute(0, 2, 3, 1)).contiguous())
+        N, H, W, Cp = x.shape
+        Cout = wd.shape[0]
+        kh, kw = c.k
+        Ho, Wo = c.out_hw(H, W)
+        b = float(conv._b_value())
+        force_pow = bool(conv._scaling()[1]) if hasattr(conv, "_scaling") else False
+        y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        scale = torch.empty_like(y) if b != 1.0 else None
+        norm = torch.empty((N, Ho, Wo, 1), device=x.device, dtype=torch.float32) if b != 1.0 else None
+        geom = ops.fwd_geom(N, H, W, Cp, Cout, kh, kw, c.stride[0], c.stride[1], c.padding[0], c.padding[1], c.dilation[0], c.dilation[1])
+        ops.tapconv(x, wk, geom, out=y, scale_out=scale, norm_out=norm, bias=bias.detach() if bias is not None else None,
+                    bcos_mode=BCOS_NONE if b == 1.0 else BCOS_CONV_EPS, b=b, flags=BCOS_EPI_FORCE_POW if force_pow else 0,
+                    track_absmax=False)
+        st = _UnitState()
+        st.conv, st.bn, st.x, st.y, st.scale, st.norm, st.w, st.bias, st.b, st.force_pow = c, bn, x, y, scale, norm, wd, bias, b, force_pow
+        st.relu, st.has_addend, st.in_hw = relu, addend is not None, (H, W)
+        st.mean = st.rstd = st.g = None
+        if bn is None:
+            out = y
+            if addend is not None:
+                out = out + addend
+            if relu:
+                out = torch.relu(out)
+            st.act = out if relu else None
+            return out, st
+        y2 = y.view(-1, Cout)
+        m = y2.shape[0]
+        if batch_stats:
+            momentum = 0.0 if bn.momentum is None else bn.momentum
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+                if bn.momentum is None:
+                    momentum = 1.0 / float(bn.num_batches_tracked)
+            mean = ops.colsum(y2) / m
+            var = ops.colsum(y2, y2, mean, mean) / m             # x.var(unbiased=False), batchnorm_uncentered.py:36-44
+            if bn.track_running_stats and bn.running_var is not None:
+                bn.running_var.copy_((1 - momentum) * bn.running_var + momentum * var)
+        else:
+            mean = torch.zeros(Cout, device=x.device)
+            var = bn.running_var.detach()
+        rstd = torch.rsqrt(var + bn.eps)
+        g = (rstd if bn.weight is None else bn.weight.detach() * rstd).contiguous()
+        shift = bn.bias.detach().contiguous() if isinstance(bn.bias, torch.Tensor) else None
+        if addend is None:
+            out = ops.channel_affine(y, g, shift, relu=relu)
+        else:
+            out = ops.channel_affine(y, g, shift, relu=False)
+            out.add_(addend)
+            if relu:
+                out.relu_()
+        st.mean, st.rstd, st.g, st.act = mean, rstd, g, (out if relu else None)
+        return out, st
+
+    def _unit_bwd(self, st: _UnitState, ga: torch.Tensor, grads: Dict, need_x: bool = True):
+        """-> (gradient w.r.t. the unit's input or None, gradient w.r.t. the shortcut addend or None)"""
+        c, bn = st.conv, st.bn
+        conv = c.module
+        if st.relu:
+            ga = ga * (st.act > 0)                                # ReLU gate (also the gradient that reaches the shortcut)
+        g_addend = ga if st.has_addend else None
+        N, Ho, Wo, Cout = st.y.shape
+        y2 = st.y.view(-1, Cout)
+        g2 = ga.reshape(-1, Cout)
+        m = y2.shape[0]
+        if bn is not None:
+            has_w, has_b = isinstance(bn.weight, nn.Parameter), isinstance(bn.bias, nn.Parameter)
+            sgx = ops.colsum(g2, y2)                              # batchnorm_uncentered.py: _BatchStatsFn.backward, same launches
+            if has_w and bn.weight.requires_grad:
+                grads[bn.weight] = sgx * st.rstd
+            if has_b and bn.bias.requires_grad:
+                grads[bn.bias] = ops.colsum(g2)
+            if bn.detach:
+                gy = ops.channel_affine(ga.contiguous(), st.g, None)
+            else:
+                coef = (-(st.g * sgx) * st.rstd * st.rstd / m).contiguous()
+                gy = ops.channel_axpby(ga.contiguous(), st.g, st.y, st.mean.contiguous(), coef)
+        else:
+            gy = ga.contiguous()
+        # the convolution: scale derivative, patch-norm term, weight / bias / input gradients (_hipfn.BcosConv2dFn.backward)
+        x = st.x
+        H, W = st.in_hw
+        cin = c.cin
+        addend = None
+        if st.b != 1.0 and not conv.detach:
+            from bcos.modules._hipfn import _scale_bwd_cols
+            glin, rnorm, _ = _scale_bwd_cols(gy.reshape(-1, Cout), y2, st.scale.view(-1, Cout), st.norm.view(-1), BCOS_CONV_EPS,
+                                             dict(b=st.b, force_pow=st.force_pow), False)
+            glin = glin.view(N, Ho, Wo, Cout)
+            if need_x:
+                addend = ops.patch_norm_bwd(x, rnorm.view(N, Ho, Wo), cin, c.k, c.stride, c.padding, c.dilation)
+        elif st.b != 1.0:
+            glin = ops.mul(gy, st.scale)
+        else:
+            glin = gy
+        lin = conv.linear
+        gl4 = _pad4(glin).contiguous()
+        if lin.weight.requires_grad:
+            gwk = ops.conv2d_wgrad(gl4, x, cin, Cout, c.k, c.stride, c.padding, c.dilation)
+            grads[lin.weight] = gwk.permute(0, 3, 1, 2).contiguous()          # [Cout,kh,kw,Cin] -> OIHW
+        if lin.bias is not None and lin.bias.requires_grad:
+            grads[lin.bias] = ops.colsum(gl4.view(-1, gl4.shape[3]))[:Cout].contiguous()
+        gx = None
+        if need_x:
+            wq = st.w
+            r = (-wq.shape[0]) % 4                                # the dgrad K dimension (Cout) padded with zero filters
+            if r:
+                wq = torch.cat([wq, wq.new_zeros((r,) + tuple(wq.shape[1:]))], 0)
+            plan = ops.DgradPlan(wq, c.stride, c.padding, c.dilation)
+            gx = plan.run(gl4 if (r or Cout % 4) else glin.contiguous(), H, W, addend=addend)
+        return gx, g_addend
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor):
+        eng = self.eng
+        if x.dim() != 4 or x.shape[1] not in (3, 6):
+            raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
+        ops.require_device(x, "bcos_hip.train_plan")
+        xd = x.detach()
+        xd = xd if xd.is_contiguous() else xd.contiguous()
+        mean, std = eng._consts(x.device)
+        st = dict(x=xd, add_inverse=xd.shape[1] == 3, H=xd.shape[2], W=xd.shape[3])
+        xn = ops.prep_input(xd, mean, std, cpad=8, add_inverse=st["add_inverse"], want_absmax=False)
+        a0, st["stem"] = self._unit_fwd(eng.stem[0][0], xn, relu=True)
+        st["a0_hw"] = (a0.shape[1], a0.shape[2])
+        k, s, p = eng.pool
+        cur = ops.avgpool2d_fwd(a0, k, s, p)
+        blocks = []
+        for blk in eng.blocks:
+            inp = cur
+            rec = dict(units=[], shortcut=None)
+            h = inp
+            for c in blk.convs[:-1]:
+                h, u = self._unit_fwd(c, h, relu=True)
+                rec["units"].append(u)
+            if blk.shortcut is not None:
+                idn, rec["shortcut"] = self._unit_fwd(blk.shortcut, inp, relu=False)
+            else:
+                idn = inp
+            out, u = self._unit_fwd(blk.convs[-1], h, addend=idn, relu=True)
+            rec["units"].append(u)
+            blocks.append(rec)
+            cur = out
+        st["blocks"] = blocks
+        f, st["head"] = self._unit_fwd(eng.head, cur, relu=False)
+        st["feat_hw"] = (f.shape[1], f.shape[2])
+        logits = ops.global_avgpool_logits(f, eng.logit_temperature, eng.logit_bias)
+        return logits, st
+
+    def backward(self, st, g_logits: torch.Tensor, need_x: bool = True):
+        eng = self.eng
+        grads: Dict = {}
+        fh, fw = st["feat_hw"]
+        N = g_logits.shape[0]
+        inv_t = 1.0 if eng.logit_temperature is None else 1.0 / float(eng.logit_temperature)
+        gf = (g_logits.to(torch.float32) * (inv_t / float(fh * fw))).view(N, 1, 1, -1).expand(N, fh, fw, g_logits.shape[1]).contiguous()
+        g, _ = self._unit_bwd(st["head"], gf, grads)
+        for bi in range(len(eng.blocks) - 1, -1, -1):
+            blk, rec = eng.blocks[bi], st["blocks"][bi]
+            units = rec["units"]
+            gh, g_idn = self._unit_bwd(units[-1], g, grads)
+            for u in reversed(units[:-1]):
+                gh, _ = self._unit_bwd(u, gh, grads)
+            if rec["shortcut"] is not None:
+                g_sc, _ = self._unit_bwd(rec["shortcut"], g_idn, grads)
+                g = gh + g_sc
+            else:
+                g = gh + g_idn
+        k, s, p = eng.pool
+        a_h, a_w = st["a0_hw"]
+        ga0 = ops.avgpool2d_bwd(g.contiguous(), a_h, a_w, k, s, p)
+        gxn, _ = self._unit_bwd(st["stem"], ga0, grads, need_x=need_x)       # [N,H,W,6]: w.r.t. the normalised, AddInverse-encoded input
+        gx = None
+        if need_x:
+            _, std = eng._consts(g_logits.device)
+            g6 = gxn.permute(0, 3, 1, 2) / std.view(1, 6, 1, 1)            # d/dx of (x - mean) / std (bcosify.py:43)
+            gx = (g6[:, :3] - g6[:, 3:]).contiguous() if st["add_inverse"] else g6.contiguous()      # AddInverse: [x, 1 - x]
+        return gx, grads
+
+
+class _TrainStepFn(torch.autograd.Function):
+    """logits = plan(x) with the whole backward pass as ONE autograd node: d/dx and d/d(every parameter) from the plan's own launches"""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        logits, st = plan.forward(x)
+        ctx.plan, ctx.st, ctx.params = plan, st, params
+        ctx.need_x = ctx.needs_input_grad[1]
+        return logits
+
+    @staticmethod
+    def backward(ctx, g_logits):
+        gx, grads = ctx.plan.backward(ctx.st, g_logits.contiguous(), need_x=ctx.need_x)
+        ctx.st = None
+        return (None, gx) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
+
+
+def train_forward(eng, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """`net(x)` in train() mode through the plan, or None when the network is outside the plan's scope (per-layer path then)."""
+    plan = getattr(eng, "_train_plan", None)
+    if plan is None:
+        ok, _ = ResNetTrainPlan.supported(eng)
+        plan = ResNetTrainPlan(eng) if ok else False
+        eng._train_plan = plan
+    if plan is False:
+        return None
+    return _TrainStepFn.apply(plan, x, *plan.parameters())

@@ -83,6 +83,13 @@ class BcosifyNetwork(BcosUtilMixin, nn.Module):
         engine = getattr(self, "_bcos_engine", None)
         if engine is not None and not torch.is_grad_enabled() and not self.training:
             return engine.forward(x)          # eval + no_grad: the fused plan (it re-reads parameters that changed)
+        if engine is not None and self.training and torch.is_grad_enabled():
+            # train() + autograd: the whole network as ONE autograd node over the engine's layer list (bcos_hip/train_plan.py);
+            # networks outside that plan's scope (attention-pool heads, grouped / MaxOut layers, learnable B) return None here
+            from bcos_hip import train_plan
+            out = train_plan.train_forward(engine, x)
+            if out is not None:
+                return out
         out = self.model(self.bcosifynormalize(x))
         return self.logit_layer(out) if self.logit_layer else out
 

@@ -200,8 +200,8 @@ def self_launch(args):
 
 
 def train_main(args):
-    """`--train`: images/s of whole training steps of the B-cosified network on the per-layer HIP kernels (nn.Module path; the fused
-    inference plans are bypassed in train() mode).  One JSON line of the same shape as the metric's; the roofline prices the
+    """`--train`: images/s of whole training steps of the B-cosified network on the HIP kernels -- ResNets through the engine's training
+    plan (bcos_hip/train_plan.py), other topologies per layer on the nn.Module path.  One JSON line of the same shape as the metric's; the roofline prices the
     algorithmic work of a step -- forward + input-gradient + weight-gradient contractions = 3 x the forward FLOPs -- against the whole
     step time (no per-kernel events: the weight-gradient kernel runs on the fp32 matrix pipe, the others on the 16-bit one)."""
     import torch.nn.functional as F
@@ -229,6 +229,9 @@ def train_main(args):
         replica_diff = bdist.replicate_parameters(net) if world > 1 else []
     if replica_diff:
         raise SystemExit(f"bench.py: replicas differ after the broadcast of rank 0's parameters: {replica_diff[:5]}")
+    if spec["family"] == "resnet":
+        from bcos_hip import engine
+        engine.attach(net)               # (in eval mode: the inference plan; its layer list also drives the training plan)
     net.train()
     B = args.batch
     x = synth.synthetic_images(B, seed=1000 + rank).to(dev)
@@ -236,9 +239,13 @@ def train_main(args):
     params = [p for p in net.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9)
 
+    path = {}
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = F.binary_cross_entropy_with_logits(net(x), target)
+        logits = net(x)
+        path["node"] = type(logits.grad_fn).__name__
+        loss = F.binary_cross_entropy_with_logits(logits, target)
         loss.backward()
         if world > 1:
             bdist.allreduce_gradients(params)
@@ -282,7 +289,9 @@ def train_main(args):
         "config": {"workload": f"B-cosified {args.arch} TRAINING step (train-mode forward with batch statistics, BCE-with-logits, backward, "
                                f"SGD-momentum update), batch {B} per GPU, 224x224x6, calibrated random-init weights",
                    "global_batch": B * world, "parallelism": f"dp{world}", "contraction": contraction,
-                   "path": "nn.Module path: one HIP launch sequence per layer under autograd (the fused inference plan is bypassed in train())",
+                   "path": ("training plan (bcos_hip/train_plan.py): the whole network ONE autograd node whose forward / backward walk the engine's "
+                            "layer list" if path.get("node") == "_TrainStepFnBackward" else
+                            "nn.Module path: one HIP launch sequence per layer under autograd (no training plan for this topology)"),
                    "collective": "bucketed asynchronous all_reduce of the gradients (bcos_hip.dist.allreduce_gradients)" if world > 1 else "none",
                    "final_loss": round(float(loss), 6)},
         "roofline": dict(bound="mfma", achieved=round(gflop_step / ms, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s (algorithmic fp32 FLOP of "

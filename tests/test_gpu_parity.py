@@ -104,18 +104,24 @@ def test_training_mode_gradients_against_reference_golden(lib, golden_dir):
     run_training_goldens2(golden_dir, DEV, 1e-5)
 
 
-def test_resnet18_training_step_against_reference_golden(lib, golden_dir):
+@pytest.mark.parametrize("path", ["plan", "layers"])
+def test_resnet18_training_step_against_reference_golden(lib, golden_dir, path):
     """N4 end to end: B-cosified ResNet-18 in train() mode -- batch statistics in all 20 BatchNormUncentered2d, every
-    dynamic scale differentiated, BCE-with-logits loss -- forward and backward through the per-layer HIP kernels against
-    the loss, input gradient and parameter gradients recorded from the reference's training-mode step."""
-    from bcos_hip import synth
+    dynamic scale differentiated, BCE-with-logits loss -- against the loss, input gradient and parameter gradients recorded from
+    the reference's training-mode step, through BOTH training paths: `plan` = the engine's training plan (bcos_hip/train_plan.py:
+    the whole network one autograd node whose forward / backward walk the engine's layer list), `layers` =
+    one autograd node per layer on the nn.Module path (no engine attached)."""
+    from bcos_hip import engine, synth
     net, _, _ = _golden_net(golden_dir, "resnet18_e2e")                     # the fixture's calibrated weights
     meta = json.load(open(os.path.join(golden_dir, "resnet18_train_step.json")))
     data = np.load(os.path.join(golden_dir, "resnet18_train_step.npz"))
     x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV).requires_grad_(True)
     target = F.one_hot(torch.tensor(meta["labels"]), 1000).float().to(DEV)
+    if path == "plan":
+        engine.attach(net)                                                   # (attached in eval mode: the inference plan folds BatchNorm)
     net.train()
-    logits = net(x)                                                          # training: the fused engine is bypassed
+    logits = net(x)
+    assert (type(logits.grad_fn).__name__ == "_TrainStepFnBackward") == (path == "plan"), type(logits.grad_fn).__name__
     assert rel(logits, data["logits"]) <= 1e-4
     loss = F.binary_cross_entropy_with_logits(logits, target)
     assert abs(float(loss) - float(data["loss"])) <= 1e-5 * abs(float(data["loss"]))
@@ -133,6 +139,15 @@ def test_resnet18_training_step_against_reference_golden(lib, golden_dir):
     bufs = dict(net.named_buffers())
     for key in [k for k in data.files if k.startswith("running_var/")]:
         assert rel(bufs[key[12:] + ".running_var"], data[key]) <= 1e-4, key
+    if path == "plan":
+        # back in eval mode the inference plan re-reads the parameters and statistics the training step left behind
+        net.eval()
+        with torch.no_grad():
+            le = net(x.detach())
+        engine.detach(net)
+        with torch.no_grad():
+            lm = net(x.detach())
+        assert rel(le, lm) <= 1e-5
 
 
 def test_wgrad_kernel_on_resnet_shapes(lib):
