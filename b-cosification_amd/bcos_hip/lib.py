@@ -108,6 +108,8 @@ SIGNATURES = {
     "bcos_head_onehot_grad": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "bcos_argmax_rows": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "bcos_channel_affine": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "bcos_channel_affine_add": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "bcos_relu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "bcos_layernorm_bwd_detached": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_gelu_gate": (C.c_int, [_P, _P, _P, _L, _P]),

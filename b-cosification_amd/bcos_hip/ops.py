@@ -763,6 +763,26 @@ def channel_affine(x, scale, shift=None, relu=False, out=None):
     return out
 
 
+def channel_affine_add(x, scale, shift, addend, relu=False, out=None):
+    """out = [relu](x * scale[c] + shift[c] + addend) (include/bcos_hip.h: bcos_channel_affine_add)."""
+    lib = _l.load()
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _l.check(lib.bcos_channel_affine_add(_dev(x, "x"), _dev(scale, "scale"), _dev(shift, "shift"), _dev(addend, "addend"), _dev(out, "y"),
+                                         x.numel() // Cc, Cc, int(bool(relu)), _stream()), "bcos_channel_affine_add")
+    return out
+
+
+def relu_bwd(g, act, out=None):
+    """out = act > 0 ? g : 0 (include/bcos_hip.h: bcos_relu_bwd)."""
+    lib = _l.load()
+    if out is None:
+        out = torch.empty_like(g)
+    _l.check(lib.bcos_relu_bwd(_dev(g, "g"), _dev(act, "act"), _dev(out, "out"), g.numel(), _stream()), "bcos_relu_bwd")
+    return out
+
+
 # ---- training-mode backward (csrc/bcos_train.hip, SURVEY.md section 8(f) N4) --------------------------------------------
 def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False):
     """(gy * dy/dlin [rows,C], dL/dnorm / norm-denominator [rows], dL/dB_eff [1] or None) of y = s(lin, norm) * lin with s not

@@ -9,7 +9,7 @@ Per convolution unit (BcosifyConv2d -> BatchNormUncentered2d [-> + shortcut] [->
 batchnorm_uncentered.py:36-44):
   forward    contraction + B-cos scale with the scale NOT detached (one bcos_tapconv launch: y, s, patch norms), batch statistics of
              y in a fixed summation order (bcos_colsum_ws: mean, centred variance), running_var update, then ONE elementwise launch
-             for normalisation + affine + ReLU (bcos_channel_affine; blocks: + the shortcut through torch's add)
+             for normalisation + affine [+ shortcut] + ReLU (bcos_channel_affine / bcos_channel_affine_add)
   backward   ReLU gate, the two column sums of the BatchNorm gradient, its input gradient (bcos_channel_axpby), the derivative
              of the dynamic scale (bcos_train_scale_bwd), the patch-norm term (bcos_patch_norm_bwd, added by the input-gradient
              launch's epilogue), the input gradient (ops.DgradPlan) and the weight gradient (bcos_conv2d_wgrad).
@@ -129,10 +129,7 @@ class ResNetTrainPlan:
         if addend is None:
             out = ops.channel_affine(y, g, shift, relu=relu)
         else:
-            out = ops.channel_affine(y, g, shift, relu=False)
-            out.add_(addend)
-            if relu:
-                out.relu_()
+            out = ops.channel_affine_add(y, g, shift, addend if addend.is_contiguous() else addend.contiguous(), relu=relu)
         st.mean, st.rstd, st.g, st.act = mean, rstd, g, (out if relu else None)
         return out, st
 
@@ -141,7 +138,7 @@ class ResNetTrainPlan:
         c, bn = st.conv, st.bn
         conv = c.module
         if st.relu:
-            ga = ga * (st.act > 0)                                # ReLU gate (also the gradient that reaches the shortcut)
+            ga = ops.relu_bwd(ga if ga.is_contiguous() else ga.contiguous(), st.act)      # ReLU gate (also the gradient that reaches the shortcut)
         g_addend = ga if st.has_addend else None
         N, Ho, Wo, Cout = st.y.shape
         y2 = st.y.view(-1, Cout)

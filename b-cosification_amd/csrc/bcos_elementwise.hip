@@ -338,6 +338,37 @@ __global__ __launch_bounds__(TPB) void channel_affine_kernel(const float* __rest
     }
 }
 
+// y = [relu](x * scale[c] + shift[c] + addend): the normalisation, affine map, residual add and ReLU of a training-mode unit in one pass
+__global__ __launch_bounds__(TPB) void channel_affine_add_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ addend,
+                                                                 float* __restrict__ y, int64_t total4, int C4, int relu) {
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total4; i += stride) {
+        const int c4 = (int)(i % C4);
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * reinterpret_cast<const f32x4*>(scale)[c4];
+        if (shift) v += reinterpret_cast<const f32x4*>(shift)[c4];
+        v += reinterpret_cast<const f32x4*>(addend)[i];
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// out = act > 0 ? g : 0   (the ReLU gate of a gradient, from the kept activation)
+__global__ __launch_bounds__(TPB) void relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ act, float* __restrict__ out,
+                                                       int64_t total4) {
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total4; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
+        f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] : 0.f;
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -537,6 +568,22 @@ extern "C" int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N,
     if (!x || (!idx && !val) || N <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_argmax_rows: bad argument");
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(grid_for((int64_t)N * 64)), dim3(TPB), 0, STREAM(stream), x, idx, val, N, C);
     return check_launch("argmax_rows_kernel");
+}
+
+extern "C" int bcos_channel_affine_add(const float* x, const float* scale, const float* shift, const float* addend, float* y,
+                                       int64_t pixels, int C, int relu, void* stream) {
+    if (!x || !scale || !addend || !y || pixels <= 0 || C <= 0 || C % 4 != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_channel_affine_add: bad argument (C % 4)");
+    const int64_t total4 = pixels * (C / 4);
+    hipLaunchKernelGGL(channel_affine_add_kernel, dim3(grid_for(total4)), dim3(TPB), 0, STREAM(stream), x, scale, shift, addend, y,
+                       total4, C / 4, relu);
+    return check_launch("channel_affine_add_kernel");
+}
+
+extern "C" int bcos_relu_bwd(const float* g, const float* act, float* out, int64_t n, void* stream) {
+    if (!g || !act || !out || n <= 0 || n % 4 != 0) return bcos_set_error(BCOS_E_INVAL, "bcos_relu_bwd: bad argument (n % 4)");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, STREAM(stream), g, act, out, n / 4);
+    return check_launch("relu_bwd_kernel");
 }
 
 extern "C" int bcos_channel_affine(const float* x, const float* scale, const float* shift, float* y, int64_t pixels,

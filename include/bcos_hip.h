@@ -459,6 +459,12 @@ int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N, int C, voi
  * y = x * scale[c] + shift[c] (shift may be NULL) (batchnorm_uncentered.py:46-60). */
 int bcos_channel_affine(const float* x, const float* scale, const float* shift, float* y,
                         int64_t pixels, int C, int relu, void* stream);
+/* y = [relu](x * scale[c] + shift[c] + addend): normalisation + affine + residual add + ReLU of a training-mode unit in one pass
+ * (BatchNormUncentered2d with batch statistics followed by `out += identity; relu`, torchvision BasicBlock / Bottleneck.forward);
+ * out = act > 0 ? g : 0, the gate of that ReLU on the way back.  (ABI v7; bcos_hip/train_plan.py) */
+int bcos_channel_affine_add(const float* x, const float* scale, const float* shift, const float* addend, float* y, int64_t pixels,
+                            int C, int relu, void* stream);
+int bcos_relu_bwd(const float* g, const float* act, float* out, int64_t n, void* stream);
 
 /* -- training-mode backward (bcos_train.hip) ------------------------------------------ */
 /* Outside explanation mode the dynamic scale is not detached (bcosconv2d.py:176-194), so with lin = conv(x, W) (+ bias),

@@ -64,6 +64,10 @@ int main(void) {
       if (v != 0) { printf("FAIL BCOS_OPT_PATCH round trip %lld\n", (long long)v); ++failures; }
       EXPECT(bcos_set_option(BCOS_OPT_PATCH, 1), BCOS_OK); }
     EXPECT(bcos_image_absrange(NULL, am, am, 1, 4, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_channel_affine_add(buf, buf, NULL, NULL, buf, 4, 8, 1, NULL), BCOS_E_INVAL);      /* no addend */
+    EXPECT(bcos_channel_affine_add(buf, buf, NULL, buf, buf, 4, 6, 1, NULL), BCOS_E_INVAL);       /* C % 4 */
+    EXPECT(bcos_relu_bwd(buf, NULL, buf, 16, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_relu_bwd(buf, buf, buf, 6, NULL), BCOS_E_INVAL);
     EXPECT(bcos_colsum_ordered(NULL, NULL, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);
     { int64_t nf = 0;
       EXPECT(bcos_colsum_ws_floats(0, 8, &nf), BCOS_E_INVAL);

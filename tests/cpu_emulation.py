@@ -245,6 +245,27 @@ def channel_affine(x, scale, shift=None, relu=False, out=None):
     return y
 
 
+def channel_affine_add(x, scale, shift, addend, relu=False, out=None):
+    y = x * scale
+    if shift is not None:
+        y = y + shift
+    y = y + addend
+    if relu:
+        y = y.clamp_min(0)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def relu_bwd(g, act, out=None):
+    r = torch.where(act > 0, g, torch.zeros_like(g))
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def weight_rownorm_scale(w2d, gain=None):
     flat = w2d.reshape(w2d.shape[0], -1)
     out = flat / flat.norm(dim=1, keepdim=True)
@@ -444,7 +465,7 @@ def install(monkeypatch):
     """Patch bcos_hip.ops with the emulators (pytest monkeypatch fixture) and lift the HIP-device checks."""
     from bcos_hip import ops
     for name in ("tapconv", "prep_input", "finalize_explanation", "avgpool2d_fwd", "avgpool2d_bwd",
-                 "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine",
+                 "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine", "channel_affine_add", "relu_bwd",
                  "weight_rownorm_scale", "rows_normalize", "cosine_grad", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",

@@ -613,6 +613,60 @@ def test_fused_engine_plan_against_oracle(monkeypatch, arch):
     assert rel(eng.forward(x), ref["logits"]) <= 1e-5
 
 
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_training_plan_equals_per_layer_path_and_oracle_autograd(monkeypatch, arch):
+    """bcos_hip/train_plan.py: `net.train(); net(x)` with an engine attached runs the whole network as ONE
+    autograd node whose forward / backward walk the engine's layer list.  On emulated kernels: same logits, input gradient, every
+    parameter gradient and BatchNorm running statistics as the per-layer nn.Module path; 3-channel (AddInverse) input; back in eval mode the inference plan re-reads what the step left behind."""
+    import copy
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import engine, synth, train_plan
+    torch.manual_seed(0)
+    net = synth.build_bcosified_resnet(arch)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "linear") and isinstance(m.linear, nn.Conv2d):
+                m.linear.weight.mul_(3.0)
+    net_ref = copy.deepcopy(net)
+    x = synth.synthetic_images(2, size=64)
+    target = torch.nn.functional.one_hot(torch.tensor([3, 500]), 1000).float()
+
+    def step(n, xin):
+        xr = xin.clone().requires_grad_(True)
+        logits = n(xr)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, target)
+        ps = [p for p in n.parameters() if p.requires_grad]
+        gs = torch.autograd.grad(loss, [xr] + ps)
+        return logits, gs
+
+    engine.attach(net)
+    net.train(); net_ref.train()
+    lp, gp = step(net, x)
+    assert type(lp.grad_fn).__name__ == "_TrainStepFnBackward"
+    lr, gr = step(net_ref, x)
+    assert type(lr.grad_fn).__name__ != "_TrainStepFnBackward"
+    assert rel(lp, lr) <= 1e-5
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    for name, a, b in zip(["x"] + names, gp, gr):
+        assert rel(a, b) <= 1e-4, (name, rel(a, b))
+    for (k, a), (_, b) in zip(net.named_buffers(), net_ref.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert rel(a, b) <= 1e-5, k
+        else:
+            assert torch.equal(a, b), k
+    # AddInverse entry: 3-channel input, gradient w.r.t. the 3 channels -- again both paths
+    l3, g3 = step(net, x[:, :3].contiguous())
+    x3 = x[:, :3].clone().requires_grad_(True)                      # (the module path takes the encoded image: encode under autograd)
+    l3r = net_ref(torch.cat([x3, 1 - x3], 1))
+    (g3r,) = torch.autograd.grad(torch.nn.functional.binary_cross_entropy_with_logits(l3r, target), [x3])
+    assert g3[0].shape == (2, 3, 64, 64) and rel(l3, l3r) <= 1e-5 and rel(g3[0], g3r) <= 1e-4
+    # parameters outside autograd's reach stay untouched; eval mode: the inference plan sees the updated statistics
+    net.eval(); net_ref.eval()
+    with torch.no_grad():
+        assert rel(net(x), net_ref(x)) <= 1e-5
+    assert train_plan.ResNetTrainPlan.supported(net._bcos_engine)[0]
+
+
 def test_fused_engine_plan_with_grouped_and_maxout_blocks(monkeypatch):
     """Round 3: networks with grouped or MaxOut B-cos convolutions (bcosconv2d.py:84-140, 166-170) attach to the
     fused plan too -- such a block is a hybrid node that runs layer by layer on the nn.Module path inside the plan (bcos_hip/engine.py:
