@@ -293,7 +293,7 @@ def train_main(args):
                             "layer list" if path.get("node") == "_TrainStepFnBackward" else
                             "nn.Module path: one HIP launch sequence per layer under autograd (no training plan for this topology)"),
                    "collective": "bucketed asynchronous all_reduce of the gradients (bcos_hip.dist.allreduce_gradients)" if world > 1 else "none",
-                   "final_loss": round(float(loss), 6)},
+                   "final_loss": round(float(loss.detach()), 6)},
         "roofline": dict(bound="mfma", achieved=round(gflop_step / ms, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s (algorithmic fp32 FLOP of "
                          "the B-cos contractions: forward + input gradient + weight gradient = 3 x forward; fp32 matrix peak as the common "
                          "denominator)", frac=round(gflop_step / ms / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
