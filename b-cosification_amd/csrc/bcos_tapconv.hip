@@ -1766,10 +1766,19 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
 #define D_DEAL_DMA 0              // 1 = issue the DMA pieces one by one behind the step's matrix instructions instead of together behind the barrier
 #endif
 #ifndef D_EARLY
-#define D_EARLY 1                 // 1 = the prologue's DMA pieces go out ahead of the loads of the operand maxima (every walk but the channel-chunk-major one); 0 = behind the scales (round 3)
+#define D_EARLY 1                 // 1 = the prologue's DMA pieces go out between the loads of the operand maxima and their use, no workgroup barrier ahead of the loop (every walk but the channel-chunk-major one); 0 = behind the scales and a barrier (round 3)
 #endif
 #ifndef D_SCHED
 #define D_SCHED 1                 // 1 = pin the issue order of a step's fragment reads / matrix / vector instructions (sched_group_barrier)
+#endif
+#ifndef BCOS_PHASE_TIMING
+#define BCOS_PHASE_TIMING 0       // development builds: per-workgroup clock of prologue / K loop / epilogue of tile_body_d, summed in g_phase
+#endif
+#if BCOS_PHASE_TIMING
+__device__ unsigned long long g_phase[8];          // [0..2] clock sums of prologue, loop, epilogue; [3] workgroups; [4] launch-wide first / [5] last clock
+#define BCOS_PHASE_MARK(var) const unsigned long long var = wall_clock64()
+#else
+#define BCOS_PHASE_MARK(var)
 #endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define BCOS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -1793,6 +1802,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     constexpr bool PRIV = WAVES_N == 1;             // a wave's fragment rows are loaded by that wave alone: it converts them a step ahead
     char* lds = reinterpret_cast<char*>(smem);
 
+    BCOS_PHASE_MARK(ph_t0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1952,9 +1962,9 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     constexpr int LA = A_LD, LB = B_LD;      // DMA instructions per wave and step: A pieces, then B blocks
     // The DMA of the first steps needs addresses only -- the row scales are applied when a fragment is converted -- so for every K walk
     // that derives its addresses from registers (1 x 1 layers, the small-channel stem, the general walk: everything but the
-    // channel-chunk-major multi-tap walk, whose (tap, row) table lives in LDS) the prologue's pieces go out HERE, ahead of the loads of
-    // the operand maxima, and land under their latency instead of behind it (round 4: the K <= 256 layers run a dozen tiles per
-    // workgroup slot, each paying that latency).  Same pieces, same order, same arithmetic: bit-identical results.
+    // channel-chunk-major multi-tap walk, whose (tap, row) table lives in LDS) the prologue's pieces go out right behind the loads of
+    // the operand maxima and ahead of their use (D_EARLY), and the tile enters its loop without a workgroup barrier (see no_barrier
+    // below).  Same pieces, same order, same arithmetic: bit-identical results.
     auto prologue_issue = [&](auto walk_c) {
         if constexpr (PRIV) {
             issue_a(walk_c, 0, 0);
@@ -1967,11 +1977,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             if (nk > 1) { issue_a(walk_c, 1, SLOT); issue_b(1, SLOT); }
         }
     };
-#if D_EARLY
-    if (walk == 1) prologue_issue(std::integral_constant<int, 1>{});
-    else if (walk == 2) prologue_issue(std::integral_constant<int, 2>{});
-    else if (walk == 3) prologue_issue(std::integral_constant<int, 3>{});
-#endif
+    float rsc[A_LD];                 // this lane's rows' operand scales (the four lanes of a row agree)
     {
         // per-row operand scale: max over the row's taps of the per-pixel max |A|; the 4 lanes of a row share the taps.
         // Launches with 25 or more taps that were given the per-image range of those maxima (the 7 x 7 stem: 49 taps = 13
@@ -2007,6 +2013,12 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
                 }
             }
         }
+        // (round 4) the prologue's DMA pieces go out behind the loads of the maxima and ahead of their use: both latencies overlap
+#if D_EARLY
+        if (walk == 1) prologue_issue(std::integral_constant<int, 1>{});
+        else if (walk == 2) prologue_issue(std::integral_constant<int, 2>{});
+        else if (walk == 3) prologue_issue(std::integral_constant<int, 3>{});
+#endif
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             unsigned v = rmax[j];
@@ -2014,7 +2026,8 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             v = max(v, (unsigned)__shfl_xor((int)v, 2));
             unsigned E = v >> 23;                  // biased exponent of the row max (the bit patterns carry no sign)
             E = E < 15u ? 15u : E;
-            if ((lane & 3) == 0) s_scale[r0 + 16 * j] = __uint_as_float((268u - E) << 23);     // max * scale in [2^14, 2^15)
+            rsc[j] = __uint_as_float((268u - E) << 23);                                          // max * scale in [2^14, 2^15)
+            if ((lane & 3) == 0) s_scale[r0 + 16 * j] = rsc[j];
         }
     }
 
@@ -2035,17 +2048,26 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     float f_scale[TM];
     const int b_frag = A_BYTES + (wave_n * TN) * 2048 + lane * 16;
 
-    __syncthreads();                 // scales and the (tap, row) offset table are complete
+    // A wave whose fragment rows are the rows of its own DMA pieces (PRIV) already HOLDS their scales -- lane l has the rows
+    // (l >> 2) + 16 j -- so for every walk without the LDS tap table the scales travel by lane permutation and the tile starts its
+    // loop without a workgroup barrier (and without the drain of the prologue's DMA that barrier implies): the K <= 256 layers run a
+    // dozen short tiles per slot and paid that barrier in each.  The LDS copy of the scales is still written: the epilogue's staging
+    // layout reads other waves' rows, behind the loop's barriers.
+    const bool no_barrier = D_EARLY && PRIV && walk != 0;
+    if (!no_barrier) __syncthreads();                 // scales and the (tap, row) offset table are complete
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int R = wave_m * WM + i * 32 + frag_row;
         a_frag[i] = R * 64 + (((2 * frag_half) ^ ((R >> 2) & 3)) << 4);
-        f_scale[i] = s_scale[R];
+        if constexpr (PRIV) {
+            // local row i * 32 + frag_row = 16 j + (lane >> 2) of lane 4 (frag_row & 15), j = 2 i + (frag_row >> 4)
+            const float v0 = __shfl(rsc[(2 * i) % A_LD], 4 * (frag_row & 15));
+            const float v1 = __shfl(rsc[(2 * i + 1) % A_LD], 4 * (frag_row & 15));
+            f_scale[i] = no_barrier ? ((frag_row & 16) ? v1 : v0) : s_scale[R];
+        } else {
+            f_scale[i] = s_scale[R];
+        }
     }
-    float a_inv[BM / (NT / 4)];      // inverse row scales in staging layout (what tile_epilogue takes): 2^-e from the row's 2^e
-#pragma unroll
-    for (int j = 0; j < BM / (NT / 4); ++j)
-        a_inv[j] = __uint_as_float((254u - (__float_as_uint(s_scale[(tid >> 2) + (NT / 4) * j]) >> 23)) << 23);
 
     f16x8 af[2][TM];                 // the A fragments of the step about to be multiplied: [h | l][row tile]
     // fp32 fragment rows of the slot at byte offset `off` -> registers (two 16-byte pieces per 32 x 16 fragment) ...
@@ -2232,15 +2254,34 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             }
         }
     };
+    BCOS_PHASE_MARK(ph_t1);
     if (walk == 0) run(std::integral_constant<int, 0>{});
     else if (walk == 1) run(std::integral_constant<int, 1>{});
     else if (walk == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 3>{});
     __syncthreads();                           // the ring is free: the epilogue reuses it
+    float a_inv[BM / (NT / 4)];      // inverse row scales in staging layout (what tile_epilogue takes): 2^-e from the row's 2^e
+#pragma unroll
+    for (int j = 0; j < BM / (NT / 4); ++j)
+        a_inv[j] = __uint_as_float((254u - (__float_as_uint(s_scale[(tid >> 2) + (NT / 4) * j]) >> 23)) << 23);
+    __syncthreads();                           // (the epilogue's row records may overlap the scale table)
     float ss[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) ss[i] = pa[i] + pb[i];
+    BCOS_PHASE_MARK(ph_t2);
     tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, NORM ? ss : nullptr, nullptr, a_inv, m0, n0, tile_n);
+#if BCOS_PHASE_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ph_t3 = wall_clock64();
+        atomicAdd(&g_phase[0], ph_t1 - ph_t0);
+        atomicAdd(&g_phase[1], ph_t2 - ph_t1);
+        atomicAdd(&g_phase[2], ph_t3 - ph_t2);
+        atomicAdd(&g_phase[3], 1ull);
+        atomicMin(&g_phase[4], ph_t0);
+        atomicMax(&g_phase[5], ph_t3);
+    }
+#endif
 }
 
 // ---- split-f16 contraction over an LDS-RESIDENT INPUT PATCH (round 3, multi-tap launches) --------------------------------------
@@ -3016,6 +3057,25 @@ inline bool patch_fits(const bcos_tapconv_geom& g, int BM, int items_px, int lds
 
 }  // namespace
 
+#if BCOS_PHASE_TIMING
+// development builds: fetch and reset the phase clocks of tile_body_d (100 MHz wall-clock ticks); every slice of the file owns a copy
+// of g_phase, so every slice exports its own bcos_debug_phase_p<slice>
+#ifndef BCOS_TAPCONV_PART
+#define BCOS_TAPCONV_PART -1
+#endif
+#define BCOS_PH_CAT(a, b) a##b
+#define BCOS_PH_NAME(n) BCOS_PH_CAT(bcos_debug_phase_p, n)
+#if BCOS_TAPCONV_PART >= 0
+extern "C" int BCOS_PH_NAME(BCOS_TAPCONV_PART)(unsigned long long* out) {
+    unsigned long long z[8] = {0, 0, 0, 0, ~0ull, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    return 0;
+}
+#endif
+#endif
+
 // The file is compiled either whole or in slices (-DBCOS_TAPCONV_PART=k, bcos_hip/lib.py: build): slice 0 carries the C ABI
 // and the small tile configurations, slices 1.. the kernel instantiations of one or two tile configurations each.  The
 // launchers cross slices as plain functions taking the launch descriptor by address (every slice compiles the same KArgs).
@@ -3104,6 +3164,7 @@ extern "C" int bcos_set_contraction_mode(int mode) {
 }
 
 extern "C" int bcos_get_contraction_mode(void) { return g_contraction_mode; }
+
 
 namespace {
 
