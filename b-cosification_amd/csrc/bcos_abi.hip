@@ -41,14 +41,15 @@ constexpr OptSpec OPT_SPECS[BCOS_OPT_COUNT] = {
     {2 * 256 * 512, 0, TWO31},       // H2_TALL_MIN
     {0, 0, 1},                       // ATTENTION_F32
     {TWO31, 1 << 16, TWO31},         // SPLIT_LIMIT
-    {1, 0, 1},                       // BALANCE
-    {1, 0, 1},                       // SPLIT_K
+    {0, 0, 0},                       // reserved
+    {0, 0, 0},                       // reserved
     {1, 0, 1},                       // PATCH_LEVELS
+    {7, 4, 8},                       // H2_WIDE_COST
 };
 std::atomic<int64_t> g_opts[BCOS_OPT_COUNT] = {
     OPT_SPECS[0].def, OPT_SPECS[1].def, OPT_SPECS[2].def, OPT_SPECS[3].def, OPT_SPECS[4].def, OPT_SPECS[5].def, OPT_SPECS[6].def,
-    OPT_SPECS[7].def, OPT_SPECS[8].def, OPT_SPECS[9].def, OPT_SPECS[10].def, OPT_SPECS[11].def, OPT_SPECS[12].def, OPT_SPECS[13].def};
-static_assert(BCOS_OPT_COUNT == 14, "one OPT_SPECS row and one initialiser per option");
+    OPT_SPECS[7].def, OPT_SPECS[8].def, OPT_SPECS[9].def, OPT_SPECS[10].def, OPT_SPECS[11].def, OPT_SPECS[12].def, OPT_SPECS[13].def, OPT_SPECS[14].def};
+static_assert(BCOS_OPT_COUNT == 15, "one OPT_SPECS row and one initialiser per option");
 }  // namespace
 
 int64_t bcos_option(int option) { return g_opts[option].load(std::memory_order_relaxed); }

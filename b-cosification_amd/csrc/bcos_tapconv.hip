@@ -41,6 +41,16 @@ namespace {
 // where the call provides what that needs (a_absmax + wt_f16x2), else 1
 std::atomic<int> g_contraction_mode{2};
 
+#ifndef BCOS_PHASE_TIMING
+#define BCOS_PHASE_TIMING 0       // development builds: per-workgroup clock of prologue / K loop / epilogue of tile_body_d, summed in g_phase
+#endif
+#if BCOS_PHASE_TIMING
+__device__ unsigned long long g_phase[8];          // [0..2] clock sums of prologue, loop, epilogue; [3] workgroups; [4] launch-wide first / [5] last clock;
+                                                   // [6] / [7] inside the epilogue: row records + accumulators -> LDS of part 0, the stores of part 0
+#define BCOS_PHASE_MARK(var) const unsigned long long var = wall_clock64()
+#else
+#define BCOS_PHASE_MARK(var)
+#endif
 constexpr int BK = 32;            // K floats per step
 constexpr int LDS_LD = BK + 4;    // padded LDS row (floats): 144 B, 16 rows hit 16 distinct 16-B slots
 constexpr int NTHREADS = 256;
@@ -783,15 +793,34 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
             if (SCALE_OUT) stq_sc(r_sc, voff[u], s);
         }
         if (want_max1 || want_max2) {
+            // Per-pixel maxima of what the tile wrote.  A row's maximum over the tile's column PARTS is carried in LDS (the same lane
+            // leads the same row in every part), so a tile contributes ONE update per row and tensor; a launch with a single column
+            // tile (Cout <= BN) owns its pixels and writes them with a plain store -- round 3 issued one fp-order-free but L2-serialised
+            // atomicMax per row, part and tensor: 72 us of the 444 us of the 64 -> 256 @56^2 forward launch (scripts/probe/epi_knock.py).
+            unsigned* sMax = reinterpret_cast<unsigned*>(epi_col_table<BM, BN, WAVES_M>(smem) + BN);      // [2][BM]
+            const bool own = p.tiles_n == 1 && g.out_pitch == g.Cout;      // (a launch that writes a column slice of wider pixels shares them)
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 // lanes outside the tensor hold zeros or values whose stores were dropped: keep them out of the maxima
                 const bool live = (int)voff[u] >= 0;
-                const unsigned a1 = want_max1 ? group_max_u32<CPR>(live ? mx1[u] : 0u) : 0u;
-                const unsigned a2 = want_max2 ? group_max_u32<CPR>(live ? mx2[u] : 0u) : 0u;
+                unsigned a1 = want_max1 ? group_max_u32<CPR>(live ? mx1[u] : 0u) : 0u;
+                unsigned a2 = want_max2 ? group_max_u32<CPR>(live ? mx2[u] : 0u) : 0u;
                 if (cq == group_max_lane<CPR>() && rw[u].pix >= 0) {
-                    if (want_max1 && a1) atomicMax(e.out_absmax + rw[u].pix, a1);
-                    if (want_max2 && a2) atomicMax(e.out2_absmax + rw[u].pix, a2);
+                    const int lrow = rbase + (p0 + u) * RPP;
+                    const int trow = (lrow / HM) * WM + pm * HM + lrow % HM;
+                    if constexpr (PN > 1) {
+                        if (pn > 0) { a1 = max(a1, sMax[trow]); a2 = max(a2, sMax[BM + trow]); }
+                        if (pn + 1 < PN) { sMax[trow] = a1; sMax[BM + trow] = a2; }
+                    }
+                    if (pn + 1 == PN) {
+                        if (own) {
+                            if (want_max1) e.out_absmax[rw[u].pix] = a1;
+                            if (want_max2) e.out2_absmax[rw[u].pix] = a2;
+                        } else {
+                            if (want_max1 && a1) atomicMax(e.out_absmax + rw[u].pix, a1);
+                            if (want_max2 && a2) atomicMax(e.out2_absmax + rw[u].pix, a2);
+                        }
+                    }
                 }
             }
         }
@@ -810,6 +839,7 @@ __device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16
                                               const int tile_n, const unsigned char* lvl = nullptr, const int pass = 0) {
     BCOS_EPI_SHAPE
     const int kind = p.epi_kind;
+    BCOS_PHASE_MARK(pe_t0);
     KArgsSegPtr kpin = nullptr;          // (see BCOS_EPI_KARGS)
     if constexpr (!std::is_same_v<std::remove_cvref_t<decltype(p)>, KArgs>) kpin = &p;
     // (all waves are past the last barrier of the main loop: the staging buffers are free)
@@ -832,6 +862,10 @@ __device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16
                     sC[row * LDC + colt] = acc[pm * TMP + ii][pn * TNP + jj][r];
                 }
         __syncthreads();                         // (part 0: also publishes the row metadata written above)
+#if BCOS_PHASE_TIMING
+        unsigned long long pe_t1 = 0;
+        if constexpr (part == 0) pe_t1 = wall_clock64();
+#endif
 #define BCOS_EPI_CASE(I)                                                                                                     \
     case I + 1:                                                                                                              \
         epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, (NORM ? EPI_KINDS_FWD[I] : EPI_KINDS_BWD[I])>(smem, pm, pn, part, \
@@ -849,6 +883,14 @@ __device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16
         }
 #undef BCOS_EPI_CASE
 #undef BCOS_EPI_CASE_FWD
+#if BCOS_PHASE_TIMING
+        if constexpr (part == 0) {
+            if (threadIdx.x == 0) {
+                atomicAdd(&g_phase[6], pe_t1 - pe_t0);
+                atomicAdd(&g_phase[7], wall_clock64() - pe_t1);
+            }
+        }
+#endif
     };
     static_assert(PM * PN <= 4, "parts");
     drain(std::integral_constant<int, 0>{});
@@ -1770,15 +1812,6 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
 #endif
 #ifndef D_SCHED
 #define D_SCHED 1                 // 1 = pin the issue order of a step's fragment reads / matrix / vector instructions (sched_group_barrier)
-#endif
-#ifndef BCOS_PHASE_TIMING
-#define BCOS_PHASE_TIMING 0       // development builds: per-workgroup clock of prologue / K loop / epilogue of tile_body_d, summed in g_phase
-#endif
-#if BCOS_PHASE_TIMING
-__device__ unsigned long long g_phase[8];          // [0..2] clock sums of prologue, loop, epilogue; [3] workgroups; [4] launch-wide first / [5] last clock
-#define BCOS_PHASE_MARK(var) const unsigned long long var = wall_clock64()
-#else
-#define BCOS_PHASE_MARK(var)
 #endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define BCOS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -2906,7 +2939,7 @@ template <int BM, int BN, int WAVES_M>
 constexpr size_t epilogue_lds() {
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
     constexpr int SBM = BM / PM, SBN = BN / epi_pn<BN>();
-    return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20 + (size_t)BN * 4;
+    return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20 + (size_t)BN * 4 + (size_t)BM * 8;      // (+ the row maxima of the column parts)
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -3646,8 +3679,14 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // (a finer cost model -- a wide tile = 1.75 narrow ones, which moves M = 200 704 with N = 256 / 512 and M = 50 176 with
             // N = 1024, K = 512 to wide tiles -- wins 11-18 % on those launches timed one by one and loses 0.1 ms on the step, where
             // consecutive launches overlap their tails: not adopted)
-            const int64_t c1 = (t1 + SLOTS - 1) / SLOTS, c2 = 2 * ((t2 + SLOTS - 1) / SLOTS);
-            bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && p.Ktot >= 1024));
+            // rounds of tiles, a wide tile priced at BCOS_OPT_H2_WIDE_COST / 4 narrow ones (8 = two, the model of rounds 2-3; the wide
+            // tile shares the A operand's DMA and split between its halves, so 7 is nearer what the layers measure)
+            const int64_t wc = bcos_option(BCOS_OPT_H2_WIDE_COST);
+            const int64_t c1 = 4 * ((t1 + SLOTS - 1) / SLOTS), c2 = wc * ((t2 + SLOTS - 1) / SLOTS);
+#ifndef H2_WIDE_MIN_K
+#define H2_WIDE_MIN_K 0           // development switch: launches with K below this keep the 128 x 128 tiles
+#endif
+            bool wide = g.Cout > 128 && p.Ktot >= H2_WIDE_MIN_K && (c2 < c1 || (c2 == c1 && (wc < 8 || p.Ktot >= 1024)));
             if (force) wide = g.Cout > 128 && force == 2;
             // 129 ... 192 columns (the 192-wide linears of the SimpleViTs: to_out, linear2, their gradients): ONE tile of 192 columns
             // (six accumulator tiles per wave) instead of 128 + a half-empty second 128

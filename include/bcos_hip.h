@@ -233,14 +233,14 @@ enum bcos_option {
     BCOS_OPT_ATTENTION_F32 = 9,   /* 0 (default): attention on the f16 matrix pipe (exact 2-way splits); 1: fp32 MFMA kernel       */
     BCOS_OPT_SPLIT_LIMIT = 10,    /* bytes of A from which a split-operand launch is cut into batch chunks (default and maximum
                                      2^31: the 32-bit buffer offsets); tests lower it to exercise the chunked path                */
-    BCOS_OPT_BALANCE = 11,        /* 1 (default): launches of less than two rounds of tiles run on the balanced wave-block schedule;
-                                     0: one workgroup per tile                                                                     */
-    BCOS_OPT_SPLIT_K = 12,        /* 1 (default): geometry-keyed 2-way split of K with a fixed-order reduction where a launch has
-                                     fewer tiles than CUs and K >= 2048; 0: off                                                   */
+    BCOS_OPT_RESERVED_11 = 11,    /* reserved (value fixed at 0; any other value is BCOS_E_INVAL): numbers of the balanced wave-block      */
+    BCOS_OPT_RESERVED_12 = 12,    /* schedule and the 2-way split of K, both measured in round 4 and not adopted          */
     BCOS_OPT_PATCH_LEVELS = 13,   /* 1 (default): the input-patch loop runs one pass per operand-scale level present in a tile
                                      (bcos_operands.a_imgmax); 0: level 0 only, the single per-image scale of ABI v6 -- kept so that
                                      tests can show what the ladder is for (rows far darker than their image lose accuracy)      */
-    BCOS_OPT_COUNT = 14
+    BCOS_OPT_H2_WIDE_COST = 14,   /* cost of a 128 x 256 tile in quarters of a 128 x 128 tile in the tile-width choice of the f16x2 loop
+                                     (rounds of tiles on 512 slots are compared): 8 = two narrow tiles (rounds 2-3), default 7            */
+    BCOS_OPT_COUNT = 15
 };
 /* 0, or BCOS_E_INVAL for an unknown option or a value outside its range. */
 int bcos_set_option(int option, int64_t value);

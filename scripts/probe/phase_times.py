@@ -22,7 +22,7 @@ def phases():
         buf = (C.c_ulonglong * 8)()
         f(buf)
         if buf[3]:
-            for i in (0, 1, 2, 3):
+            for i in (0, 1, 2, 3, 6, 7):
                 tot[i] += buf[i]
             tot[4] = min(tot[4], buf[4]); tot[5] = max(tot[5], buf[5])
     return tot
@@ -42,5 +42,5 @@ for (H, Cin, Cout, name) in shapes:
     t = phases()
     n = max(t[3], 1)
     pro, loop, epi = (t[0] / n / 100.0, t[1] / n / 100.0, t[2] / n / 100.0)
-    print(f"{name:24s} {t[3]:6d} {e0.elapsed_time(e1) * 1e3:10.1f} | {pro:23.2f} {loop:8.2f} {epi:9.2f} {pro + loop + epi:7.2f}    | {epi / (pro + loop + epi):.2f}   (span {(t[5] - t[4]) / 100.0:.1f} us)", flush=True)
+    print(f"{name:24s} {t[3]:6d} {e0.elapsed_time(e1) * 1e3:10.1f} | {pro:23.2f} {loop:8.2f} {epi:9.2f} {pro + loop + epi:7.2f}    | {epi / (pro + loop + epi):.2f}   (span {(t[5] - t[4]) / 100.0:.1f} us; epilogue part 0: rows + transpose {t[6] / n / 100.0:.2f}, math + stores (issue) {t[7] / n / 100.0:.2f})", flush=True)
     del x, w
