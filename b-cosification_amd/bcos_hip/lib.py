@@ -46,7 +46,7 @@ class TapconvGeom(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2", "relu_gate",
-        "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax", "mul_norm", "mul_csc", "mul_csh", "col_scale")] + [
+        "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax", "mul_norm", "mul_csc", "mul_csh", "col_scale", "row_scale", "a_sumsq")] + [
         ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32), ("max_out", C.c_int32), ("addend_sub", C.c_int32)]
 
 
@@ -111,6 +111,7 @@ SIGNATURES = {
     "bcos_channel_affine_add": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "bcos_relu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "bcos_layernorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "bcos_layernorm_bwd_detached": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_gelu_gate": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_groupnorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

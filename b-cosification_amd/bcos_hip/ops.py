@@ -259,12 +259,14 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
             gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0, contraction=None,
             track_absmax=None, track_absmax2=None, max_out=1, mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0,
-            col_scale=None):
+            col_scale=None, row_scale=None, a_sumsq=None):
     """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv_ops).
     `addend_sub` = s > 1: `addend` is the dense [N, ceil(OH/s), ceil(OW/s), pitch] tensor of the output pixels on the s-grid.
     `contraction`: None = the library default, or 'f32' / 'bf16x3' / 'f16x2' for this call.
     `track_absmax` / `track_absmax2`: emit the per-pixel maxima of out / out2 (default: whenever the f16x2 contraction is
-    selected; a caller that knows the reader of a tensor will not use them -- K < F16X2_MIN_K -- passes False)."""
+    selected; a caller that knows the reader of a tensor will not use them -- K < F16X2_MIN_K -- passes False).
+    `row_scale` [rows] / `a_sumsq` [rows]: a factor of every accumulator row / the squared operand norm of a B-cos launch given
+    from outside (a LayerNorm folded into the contraction, include/bcos_hip.h: bcos_epilogue.row_scale)."""
     lib = _l.load()
     g = TapconvGeom()
     for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup", "groups"):
@@ -274,7 +276,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     e = Epilogue()
     tensors = dict(bias=bias, ch_scale=ch_scale, ch_shift=ch_shift, addend=addend, mul=mul, mul2=mul2,
                    gate2=gate2, relu_gate=relu_gate, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out,
-                   mul_norm=mul_norm, mul_csc=mul_csc, mul_csh=mul_csh, col_scale=col_scale)
+                   mul_norm=mul_norm, mul_csc=mul_csc, mul_csh=mul_csh, col_scale=col_scale, row_scale=row_scale, a_sumsq=a_sumsq)
     for k, t in tensors.items():
         p = _dev(t, f"tapconv.{k}", contiguous=False)
         setattr(e, k, p.value if p is not None else None)
@@ -420,15 +422,18 @@ def linear_fwd(x2d, w, *, bias=None, b=2.0, want_scale=False, want_norm=False, m
     return out, scale, norm
 
 
-def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None, track_absmax=None):
-    """Plain fp32 GEMM on the same kernel: out[rows,N] = a2d[rows,K] @ bt[N,K]^T (no B-cos scaling)."""
+def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None, track_absmax=None, bias=None, row_scale=None, out2=None, mul2=None,
+              track_absmax2=None):
+    """Plain fp32 GEMM on the same kernel: out[rows,N] = a2d[rows,K] @ bt[N,K]^T (no B-cos scaling).  With v = row_scale * acc + bias
+    + addend:  out = v * mul, out2 = v * mul2 (the gradient epilogue of bcos_tapconv)."""
     rows, K = a2d.shape
     Nn = bt.shape[0]
     g = dict(N=1, H=1, W=rows, C=K, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
              TH=1, TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Nn)
     if out is None:
         out = torch.empty((rows, Nn), device=a2d.device, dtype=torch.float32)
-    tapconv(a2d, bt, g, out=out, addend=addend, mul=mul, track_absmax=track_absmax)
+    tapconv(a2d, bt, g, out=out, addend=addend, mul=mul, track_absmax=track_absmax, bias=bias, row_scale=row_scale, out2=out2, mul2=mul2,
+            track_absmax2=track_absmax2)
     return out
 
 
@@ -928,6 +933,19 @@ def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None, want_absmax
     _l.check(lib.bcos_layernorm_fwd(_dev(x2d, "x"), _dev(weight, "w"), _dev(bias, "b"), _dev(y, "y"), _dev(rstd, "rstd"), _am_ptr(am),
                                     rows, D, float(eps), _stream()), "bcos_layernorm_fwd")
     return y, rstd
+
+
+def layernorm_stats(x2d, weight, bias, eps, want_zsumsq=False, want_absmax=False):
+    """Row statistics of a LayerNorm whose output is never written (include/bcos_hip.h: bcos_layernorm_stats): (rstd, |y|^2 or None);
+    `want_absmax`: x2d gets its operand maxima attached (the contraction that follows reads x2d itself)."""
+    lib = _l.load()
+    rows, D = x2d.shape
+    rstd = torch.empty((rows,), device=x2d.device, dtype=torch.float32)
+    zss = torch.empty((rows,), device=x2d.device, dtype=torch.float32) if want_zsumsq else None
+    am = _fused_absmax(x2d, want_absmax and absmax_of(x2d) is None)
+    _l.check(lib.bcos_layernorm_stats(_dev(x2d, "x"), _dev(weight, "w"), _dev(bias, "b"), _dev(rstd, "rstd"), _dev(zss, "zss"), _am_ptr(am),
+                                      rows, D, float(eps), _stream()), "bcos_layernorm_stats")
+    return rstd, zss
 
 
 def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None, want_absmax2=False):

@@ -43,20 +43,57 @@ class _Lin:
         self.bias = bias.detach().contiguous() if bias is not None else None
         self.cin, self.cout = w.shape[1], w.shape[0]
 
-    def fwd(self, x2d, *, addend=None, act=0, want_scale=False, track=False):
-        """`track`: emit the row maxima of y (its reader is another contraction)"""
+    def fold(self, ln):
+        """The LayerNorm in front of this layer folded into its weights (`_fold_ln`): fwd(..., ln=stats) / dgrad_ln read the
+        LayerNorm's INPUT."""
+        wc, c = _fold_ln(self.w, ln)
+        self.w_ln = ops.mark_static(wc)
+        self.wt_ln = ops.mark_static(wc.t().contiguous())
+        self.bias_ln = c if self.bias is None else (self.bias + c if c is not None else self.bias)
+
+    def fwd(self, x2d, *, addend=None, act=0, want_scale=False, track=False, ln=None):
+        """`track`: emit the row maxima of y (its reader is another contraction).  `ln` = (rstd, |LN(x)|^2) of ops.layernorm_stats:
+        x2d is the input of the folded LayerNorm"""
         rows = x2d.shape[0]
         g = dict(N=1, H=1, W=rows, C=self.cin, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1, TH=1,
                  TW=1, OH=1, OW=rows, out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=self.cout)
         y = torch.empty((rows, self.cout), device=x2d.device, dtype=torch.float32)
         t = torch.empty_like(y) if want_scale else None
-        ops.tapconv(x2d, self.w, g, out=y, scale_out=t, bias=self.bias, addend=addend,
-                    bcos_mode=BCOS_LINEAR_EPS if self.b != 1.0 else 0, b=self.b, relu=act,
-                    flags=BCOS_EPI_FORCE_POW if self.force_pow else 0, track_absmax=track and _F16X2)
+        bcos = self.b != 1.0
+        ops.tapconv(x2d, self.w if ln is None else self.w_ln, g, out=y, scale_out=t, bias=self.bias if ln is None else self.bias_ln,
+                    addend=addend, bcos_mode=BCOS_LINEAR_EPS if bcos else 0, b=self.b, relu=act,
+                    flags=BCOS_EPI_FORCE_POW if self.force_pow else 0, track_absmax=track and _F16X2,
+                    row_scale=None if ln is None else ln[0], a_sumsq=None if ln is None or not bcos else ln[1])
         return y, t
 
     def dgrad(self, glin, *, mul=None, track=False):
         return ops.matmul_nt(glin, self.wt, mul=mul, track_absmax=track and _F16X2)
+
+    def dgrad_ln(self, glin, rstd, *, addend=None, mul=None):
+        """Input gradient through this layer AND the folded LayerNorm (variance held constant): (g * mul, g) with
+        g = rstd (W'^T glin) + addend -- the first feeds the next input-gradient launch, the second is the residual-stream gradient."""
+        return _dgrad_ln(glin, self.wt_ln, rstd, addend, mul)
+
+
+def _fold_ln(w, ln):
+    """W [Cout, D] behind a LayerNorm with affine (gamma, beta):  W LN(x) = rstd (W' x) + W beta  with
+    W'[j, k] = gamma[k] W[j, k] - mean_k'(gamma[k'] W[j, k'])  (the mean subtraction of the LayerNorm moved into the weight rows;
+    include/bcos_hip.h: bcos_epilogue.row_scale).  Returns (W' fp32, W beta or None); built in fp64, once per refresh."""
+    w64 = w.double()
+    wg = w64 * ln.w.double() if ln.w is not None else w64
+    wc = (wg - wg.mean(dim=1, keepdim=True)).float().contiguous()
+    c = (w64 @ ln.bias.double()).float().contiguous() if ln.bias is not None else None
+    return wc, c
+
+
+def _dgrad_ln(glin, wt_ln, rstd, addend, mul):
+    g = torch.empty((glin.shape[0], wt_ln.shape[0]), device=glin.device, dtype=torch.float32)
+    if mul is None:
+        ops.matmul_nt(glin, wt_ln, out=g, addend=addend, row_scale=rstd, track_absmax=False)
+        return g, g
+    gm = torch.empty_like(g)
+    ops.matmul_nt(glin, wt_ln, out=gm, out2=g, addend=addend, mul=mul, row_scale=rstd, track_absmax=_F16X2, track_absmax2=False)
+    return gm, g
 
 
 class _LN:
@@ -76,6 +113,10 @@ class _LN:
     def fwd(self, x2d, keep):
         return ops.layernorm_fwd(x2d, self.w, self.bias, self.eps, want_rstd=keep, want_absmax=_F16X2)      # y feeds a contraction
 
+    def stats(self, x2d, want_norm):
+        """(rstd, |LN(x)|^2): what the contraction with the folded weights needs to read x2d itself (x2d gets its operand maxima)"""
+        return ops.layernorm_stats(x2d, self.w, self.bias, self.eps, want_zsumsq=want_norm, want_absmax=_F16X2)
+
     def bwd(self, gy, rstd, *, addend=None, mul2=None, want_out=True, want_out2=False):
         return ops.layernorm_bwd_detached(gy, self.w, rstd, addend=addend, mul2=mul2, want_out=want_out, want_out2=want_out2,
                                           want_absmax2=_F16X2 and want_out2)                                # out2 = g_lin feeds one
@@ -86,6 +127,12 @@ import os
 
 
 _F16X2 = os.environ.get("BCOS_VIT_F16X2", "1") != "0"
+# Round 4: every LayerNorm of the plan is folded into the contraction that reads it -- forward: row statistics (one read of x, two
+# floats per row out) + the GEMM over x with mean-centred, gamma-scaled weight rows, rstd as a row factor of the accumulator and
+# W beta as bias; explanation pass: the detached-variance input gradient IS the input-gradient GEMM over the same weights, with
+# the residual add and the next layer's stored scale in its epilogue.  No LayerNorm output or gradient tensor is written or
+# read.  BCOS_VIT_LN_FUSED=0: the round-3 plan (layernorm_fwd / layernorm_bwd_detached kernels between the GEMMs).
+_LN_FUSED = os.environ.get("BCOS_VIT_LN_FUSED", "1") != "0"
 
 
 def _absmax_policy():
@@ -205,8 +252,13 @@ class ViTEngine:
             blk["wqkv"] = ops.mark_static(wq.clone().contiguous())                   # [3*inner, dim]
             blk["wv_t"] = ops.mark_static(wq[2 * inner:].t().contiguous())           # [dim, inner]: gx = gv @ Wv
             blk["inner"] = inner
+            wc, c = _fold_ln(wq, blk["ln1"])                                          # LN1 folded into to_qkv, LN2 into linear1
+            blk["wqkv_ln"], blk["cqkv"] = ops.mark_static(wc), c
+            blk["wv_t_ln"] = ops.mark_static(wc[2 * inner:].t().contiguous())
+            blk["l1"].fold(blk["ln2"])
         self.head_ln.refresh()
         self.head.refresh()
+        self.head.fold(self.head_ln)
         self._pe = {}
 
     def _consts(self, device):
@@ -260,17 +312,31 @@ class ViTEngine:
         st = dict(x=x, add_inverse=add_inverse, N=N, T=T, t_embed=t_embed, blocks=[], stem=stem_st, tok_hw=(H, W)) if keep else None
         cur = tok
         for blk in self.blocks:
-            h, rstd1 = blk["ln1"].fwd(cur, keep)
-            qkv = ops.matmul_nt(_mx(h), blk["wqkv"], track_absmax=False)
+            if _LN_FUSED:
+                rstd1, _ = blk["ln1"].stats(cur, False)
+                qkv = ops.matmul_nt(cur, blk["wqkv_ln"], bias=blk["cqkv"], row_scale=rstd1, track_absmax=False)
+            else:
+                h, rstd1 = blk["ln1"].fwd(cur, keep)
+                qkv = ops.matmul_nt(_mx(h), blk["wqkv"], track_absmax=False)
             a, stats = ops.attention_fwd(qkv.view(N, T, -1), blk["heads"], blk["scale"], want_stats=keep, want_absmax=_F16X2)
             x1, t_out = blk["out"].fwd(_mx(a.view(N * T, -1), a), addend=cur, want_scale=keep)
-            h2, rstd2 = blk["ln2"].fwd(x1, keep)
-            z, t1 = blk["l1"].fwd(_mx(h2), act=blk["act"], want_scale=keep, track=True)          # z feeds linear2
+            if _LN_FUSED:
+                st2 = blk["ln2"].stats(x1, True)
+                rstd2 = st2[0]
+                z, t1 = blk["l1"].fwd(x1, act=blk["act"], want_scale=keep, track=True, ln=st2)
+            else:
+                h2, rstd2 = blk["ln2"].fwd(x1, keep)
+                z, t1 = blk["l1"].fwd(_mx(h2), act=blk["act"], want_scale=keep, track=True)      # z feeds linear2
             x2, t2 = blk["l2"].fwd(z, addend=x1, want_scale=keep)
             if keep:
                 st["blocks"].append(dict(rstd1=rstd1, qkv=qkv, stats=stats, t_out=t_out, rstd2=rstd2, t1=t1, t2=t2))
             cur = x2
-        if self.gap_reorder:
+        if self.gap_reorder and _LN_FUSED:
+            st_h = self.head_ln.stats(cur, True)
+            rstd_h = st_h[0]
+            f, t_head = self.head.fwd(cur, want_scale=keep, ln=st_h)
+            logits = ops.global_avgpool_logits(f.view(N, T, 1, -1), self.logit_temperature, self.logit_bias)
+        elif self.gap_reorder:
             hN, rstd_h = self.head_ln.fwd(cur, keep)
             f, t_head = self.head.fwd(_mx(hN), want_scale=keep)
             logits = ops.global_avgpool_logits(f.view(N, T, 1, -1), self.logit_temperature, self.logit_bias)
@@ -355,8 +421,11 @@ class ViTEngine:
         t_last = st["blocks"][-1]["t2"] if nb else st["t_embed"]
         if self.gap_reorder:
             g_head = ops.head_onehot_grad(cls, st["t_head"].view(N, T, 1, -1), self.logit_temperature)     # [N,T,1,K]
-            g_hN = self.head.dgrad(_mx(g_head.view(N * T, -1)))
-            g_x, g_lin = self.head_ln.bwd(g_hN, st["rstd_h"], mul2=t_last, want_out=True, want_out2=True)
+            if _LN_FUSED:
+                g_lin, g_x = self.head.dgrad_ln(_mx(g_head.view(N * T, -1)), st["rstd_h"], mul=t_last)
+            else:
+                g_hN = self.head.dgrad(_mx(g_head.view(N * T, -1)))
+                g_x, g_lin = self.head_ln.bwd(g_hN, st["rstd_h"], mul2=t_last, want_out=True, want_out2=True)
         else:
             g_head = ops.head_onehot_grad(cls, st["t_head"].view(N, 1, 1, -1), self.logit_temperature)     # [N,1,1,K]
             g_hN = self.head.dgrad(g_head.view(N, -1))
@@ -367,14 +436,20 @@ class ViTEngine:
         for bi in range(nb - 1, -1, -1):
             blk, rec = self.blocks[bi], st["blocks"][bi]
             g_z = blk["l2"].dgrad(_mx(g_lin), mul=rec["t1"], track=True)        # = g_lin of linear1 (GELU gate inside t1)
-            g_h2 = blk["l1"].dgrad(g_z)
-            g_x1, g_lin_out = blk["ln2"].bwd(g_h2, rec["rstd2"], addend=g_x, mul2=rec["t_out"], want_out2=True)
+            if _LN_FUSED:
+                g_lin_out, g_x1 = blk["l1"].dgrad_ln(g_z, rec["rstd2"], addend=g_x, mul=rec["t_out"])
+            else:
+                g_h2 = blk["l1"].dgrad(g_z)
+                g_x1, g_lin_out = blk["ln2"].bwd(g_h2, rec["rstd2"], addend=g_x, mul2=rec["t_out"], want_out2=True)
             g_a = blk["out"].dgrad(_mx(g_lin_out))
             g_v = ops.attention_bwd_v(rec["qkv"].view(N, T, -1), rec["stats"], g_a.view(N, T, -1), blk["heads"], blk["scale"],
                                       want_absmax=_F16X2)
-            g_h = ops.matmul_nt(_mx(g_v.view(N * T, -1), g_v), blk["wv_t"], track_absmax=False)
             t_prev = st["blocks"][bi - 1]["t2"] if bi > 0 else st["t_embed"]
-            g_x, g_lin = blk["ln1"].bwd(g_h, rec["rstd1"], addend=g_x1, mul2=t_prev, want_out=bi > 0, want_out2=True)
+            if _LN_FUSED:
+                g_lin, g_x = _dgrad_ln(_mx(g_v.view(N * T, -1), g_v), blk["wv_t_ln"], rec["rstd1"], g_x1, t_prev)
+            else:
+                g_h = ops.matmul_nt(_mx(g_v.view(N * T, -1), g_v), blk["wv_t"], track_absmax=False)
+                g_x, g_lin = blk["ln1"].bwd(g_h, rec["rstd1"], addend=g_x1, mul2=t_prev, want_out=bi > 0, want_out2=True)
             st["blocks"][bi] = None
         gp = ops.matmul_nt(_mx(g_lin), self.embed_wt, track_absmax=False)      # [N*T, p*p*cpad] patch-major input gradient
         _, std = self._consts(x.device)

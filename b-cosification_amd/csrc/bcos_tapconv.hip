@@ -215,15 +215,23 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
         }
         sPix[r] = pix;
         if (!NORM && e.addend_sub > 1) reinterpret_cast<int64_t*>(sNorm)[r] = apix;
+        if (!SCALED && e.row_scale) sAinv[r] = pix >= 0 ? e.row_scale[pix] : 0.f;      // (bcos_epilogue.row_scale: rides in the row factor)
     }
+    // output pixel of tile row r (bcos_epilogue.row_scale / a_sumsq are indexed by it), or -1
+    auto row_pix = [&](int r) -> int64_t {
+        int n, i, jj;
+        if (!tile_row_nij(p, m0, r, n, i, jj)) return -1;
+        return ((int64_t)n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+    };
     if (NORM && ROWSS == nullptr) {
         // row sums of squares in MFMA fragment layout (fp32 kernel): lane (row, k-half), two halves per row
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float t = ss[i] + __shfl_xor(ss[i], 32);
             if (wave_n == 0 && lane < 32) {
-                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 const int row = wave_m * WM + i * 32 + lane;
+                if (e.a_sumsq) { const int64_t px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRinv[row] = 1.0f / nrm;
             }
@@ -237,8 +245,9 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
             t += __shfl_xor(t, 1);
             t += __shfl_xor(t, 2);
             if ((tid & 3) == 0) {
-                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 const int row = (tid >> 2) + RP * j;
+                if (e.a_sumsq) { const int64_t px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRinv[row] = 1.0f / nrm;
             }
@@ -247,7 +256,12 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
     if (SCALED) {
 #pragma unroll
         for (int j = 0; j < BM / (NT / 4); ++j)
-            if ((tid & 3) == 0) sAinv[(tid >> 2) + (NT / 4) * j] = AINV[j];
+            if ((tid & 3) == 0) {
+                const int row = (tid >> 2) + (NT / 4) * j;
+                float ai = AINV[j];
+                if (e.row_scale) { const int64_t px = row_pix(row); ai *= px >= 0 ? e.row_scale[px] : 0.f; }
+                sAinv[row] = ai;
+            }
     }
 
 }
@@ -298,6 +312,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
     // col_scale (the unit-norm projection 1 / ||w_c|| of NormedConv2d / NormedLinear, folded into the contraction) multiplies
     // the accumulator ahead of everything else: it rides in the column factor the scaled loop applies anyway
     const bool col_pre = SCALED || e.col_scale != nullptr || (e.flags & BCOS_EPI_UNIT_NORM_W);
+    const bool row_pre = !SCALED && e.row_scale != nullptr;      // (SCALED: the row factor is folded into sAinv)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = col + q < Cout ? col + q : 0;
@@ -379,7 +394,10 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                 if (pix < 0 || col >= Cout) continue;
                 f32x4 val = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
                 if (SCALED) val = val * sAinv[row] * cinv4;
-                else if (col_pre) val = val * cinv4;
+                else {
+                    if (row_pre) val = val * sAinv[row];
+                    if (col_pre) val = val * cinv4;
+                }
                 val += bias4;
                 f32x4 tf = {0.f, 0.f, 0.f, 0.f};
                 for (int u0 = 0; u0 < 4; u0 += M_) {
@@ -408,7 +426,10 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                 idx[u] = (ok[u] ? pix : 0) * g.out_pitch + coladd;
                 v[u] = *reinterpret_cast<const f32x4*>(sC + lrow * LDC + cq * 4);
                 if (SCALED) v[u] = v[u] * sAinv[row] * cinv4;
-                else if (col_pre) v[u] = v[u] * cinv4;
+                else {
+                    if (row_pre) v[u] = v[u] * sAinv[row];
+                    if (col_pre) v[u] = v[u] * cinv4;
+                }
                 rinv[u] = NORM ? sRinv[row] : 1.f;
                 nrm[u] = NORM ? sNorm[row] : 1.f;
                 ad[u] = in.ad[u];
@@ -485,7 +506,10 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                     const int64_t idx = pix * g.out_pitch + col + q;
                     float v = sC[lrow * LDC + cq * 4 + q];
                     if (SCALED) v = v * sAinv[row] * cinv4[q];
-                    else if (col_pre) v = v * cinv4[q];
+                    else {
+                        if (row_pre) v = v * sAinv[row];
+                        if (col_pre) v = v * cinv4[q];
+                    }
                     v += bias4[q];
                     float s = 1.f;
                     if (NORM && !norm_only) {
@@ -600,13 +624,20 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
             sRow[r].rinv = __uint_as_float(aoff);
         }
     }
+    // output pixel of tile row r (bcos_epilogue.row_scale / a_sumsq are indexed by it), or -1
+    auto row_pix = [&](int r) -> int {
+        int n, i, jj;
+        if (!tile_row_nij(p, m0, r, n, i, jj)) return -1;
+        return (n * g.OH + (i * g.out_sh + g.out_h0)) * g.OW + (jj * g.out_sw + g.out_w0);
+    };
     if (NORM && ROWSS == nullptr) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float t = ss[i] + __shfl_xor(ss[i], 32);
             if (wave_n == 0 && lane < 32) {
-                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 const int row = wave_m * WM + i * 32 + lane;
+                if (e.a_sumsq) { const int px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRow[row].rinv = 1.0f / nrm;
             }
@@ -619,17 +650,25 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
             t += __shfl_xor(t, 1);
             t += __shfl_xor(t, 2);
             if ((tid & 3) == 0) {
-                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 const int row = (tid >> 2) + RP * j;
+                if (e.a_sumsq) { const int px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRow[row].rinv = 1.0f / nrm;
             }
         }
     }
     if (SCALED) {
+        // (bcos_epilogue.row_scale rides in the inverse operand scale of the row: launches that carry one and are not SCALED take the
+        //  general epilogue)
 #pragma unroll
         for (int j = 0; j < BM / (NT / 4); ++j)
-            if ((tid & 3) == 0) sRow[(tid >> 2) + (NT / 4) * j].ainv = AINV[j];
+            if ((tid & 3) == 0) {
+                const int row = (tid >> 2) + (NT / 4) * j;
+                float ai = AINV[j];
+                if (e.row_scale) { const int px = row_pix(row); ai *= px >= 0 ? e.row_scale[px] : 0.f; }
+                sRow[row].ainv = ai;
+            }
     }
 
 }
@@ -706,7 +745,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, csc4 = {1.f, 1.f, 1.f, 1.f}, csh4 = {0.f, 0.f, 0.f, 0.f}, cinv4 = {1.f, 1.f, 1.f, 1.f};
     if (col_ok) {
-        if (NORM && e.bias) bias4 = *reinterpret_cast<const f32x4*>(e.bias + col);
+        if (e.bias) bias4 = *reinterpret_cast<const f32x4*>(e.bias + col);
         if (NORM && e.ch_scale) csc4 = *reinterpret_cast<const f32x4*>(e.ch_scale + col);
         if (NORM && e.ch_shift) csh4 = *reinterpret_cast<const f32x4*>(e.ch_shift + col);
     }
@@ -3481,6 +3520,10 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         if ((reinterpret_cast<uintptr_t>(epi->scale_out) & 15))
             return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: scale_out must be 16-byte aligned");
     }
+    if (epi->a_sumsq && epi->bcos_mode == BCOS_NONE)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: a_sumsq belongs to a B-cos launch (bcos_mode != BCOS_NONE)");
+    if ((epi->row_scale || epi->a_sumsq) && (g.groups > 1 || g.out_cgroup != 0))
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: row_scale / a_sumsq exclude grouped and depth-to-space launches");
     if (epi->addend_sub < 0 || (epi->addend_sub > 1 && (!epi->addend || g.out_cgroup != 0 || g.groups > 1 || epi->bcos_mode != BCOS_NONE)))
         return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: addend_sub > 1 needs an addend and a plain gradient launch (bcos_mode BCOS_NONE, "
                                             "no out_cgroup, no groups)");
@@ -3561,6 +3604,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 for (float** q : cout) if (*q) *q += opix * p.g.out_pitch;
                 if (e2.norm_out) e2.norm_out += opix * p.g.norm_pitch;
                 if (e2.mul_norm) e2.mul_norm += opix;
+                if (e2.row_scale) e2.row_scale += opix;
+                if (e2.a_sumsq) e2.a_sumsq += opix;
                 if (e2.out_absmax) e2.out_absmax += opix;
                 if (e2.out2_absmax) e2.out2_absmax += opix;
                 bcos_operands o2 = *ops;
@@ -3613,7 +3658,9 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         const int64_t obytes = (int64_t)g.N * g.OH * g.OW * p.g.out_pitch * 4;
         const bool norm_l = e.bcos_mode != BCOS_NONE;
         const bool off = bcos_option(BCOS_OPT_EPI_GENERIC) != 0;                // development / test switch
+        // (a row_scale rides in the inverse operand scale of the split-f16 loops; the other loops carry it through the general epilogue)
         bool ok = !off && p.vec_ok && g.Cout % 4 == 0 && obytes < ((int64_t)1 << 31) && e.max_out <= 1 && e.out != nullptr && !e.col_scale && !(e.flags & BCOS_EPI_UNIT_NORM_W) &&
+                  (!e.row_scale || p.h2) &&
                   !e.gate2 && !e.relu_gate && !(e.flags & (BCOS_EPI_NORM_ONLY | BCOS_EPI_FORCE_POW)) &&
                   ((reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.ch_scale) | reinterpret_cast<uintptr_t>(e.ch_shift)) & 15) == 0;
         int ef = 0;
@@ -3622,7 +3669,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                  !(e.flags & BCOS_EPI_MUL_FROM_ACT);
             ef = (e.addend ? EF_ADDEND : 0) | (e.relu == 1 ? EF_RELU : 0) | (e.relu == 2 ? EF_GELU : 0) | (e.scale_out ? EF_SCALE_OUT : 0);
         } else {
-            ok = ok && e.relu == 0 && !e.bias && !e.ch_scale && !e.ch_shift && !e.scale_out && (!e.mul2 || e.out2) &&
+            ok = ok && e.relu == 0 && !e.ch_scale && !e.ch_shift && !e.scale_out && (!e.mul2 || e.out2) &&
                  (!e.out2 || e.mul) && (!e.out2_absmax || e.out2);
             // out2 is either ungated or gated by the low bit of mul (BCOS_EPI_GATE2_FROM_MUL): both are what the kinds compute
             ef = (e.addend ? EF_ADDEND : 0) | (e.mul ? EF_MUL : 0) | (e.out2 ? EF_OUT2 : 0) | (e.mul2 ? EF_MUL2 : 0) |
@@ -3638,7 +3685,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1 && epi->addend_sub <= 1) {
+    if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1 && epi->addend_sub <= 1 && !epi->row_scale && !epi->a_sumsq) {
         const int handled = bcos_try_skinny(a, wt, p.g, p.e, p.M, s);
         if (handled != 0) return handled < 0 ? handled : BCOS_OK;
     }
@@ -3683,10 +3730,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // tile shares the A operand's DMA and split between its halves, so 7 is nearer what the layers measure)
             const int64_t wc = bcos_option(BCOS_OPT_H2_WIDE_COST);
             const int64_t c1 = 4 * ((t1 + SLOTS - 1) / SLOTS), c2 = wc * ((t2 + SLOTS - 1) / SLOTS);
-#ifndef H2_WIDE_MIN_K
-#define H2_WIDE_MIN_K 0           // development switch: launches with K below this keep the 128 x 128 tiles
-#endif
-            bool wide = g.Cout > 128 && p.Ktot >= H2_WIDE_MIN_K && (c2 < c1 || (c2 == c1 && (wc < 8 || p.Ktot >= 1024)));
+            bool wide = g.Cout > 128 && (c2 < c1 || (c2 == c1 && (wc < 8 || p.Ktot >= 1024)));
             if (force) wide = g.Cout > 128 && force == 2;
             // 129 ... 192 columns (the 192-wide linears of the SimpleViTs: to_out, linear2, their gradients): ONE tile of 192 columns
             // (six accumulator tiles per wave) instead of 128 + a half-empty second 128

@@ -104,6 +104,110 @@ __global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// Row statistics of the LayerNorm for a contraction that reads x itself (bcos_epilogue.row_scale / a_sumsq): same reductions as
+// layernorm_fwd_kernel (mean, then the centered second moment), plus |gamma xhat + beta|^2 and max |x|; nothing row-sized is written.
+__global__ __launch_bounds__(TPB) void layernorm_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float* __restrict__ rstd_out,
+                                                              float* __restrict__ zss_out, unsigned* __restrict__ absmax_out,
+                                                              int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float* src = x + r * D;
+        float s = 0.f;
+        unsigned m = 0u;
+        for (int c = lane; c < D; c += 64) { s += src[c]; m = max(m, __float_as_uint(src[c]) & 0x7fffffffu); }
+        const float mean = wave_sum(s) / (float)D;
+        float v = 0.f;
+        for (int c = lane; c < D; c += 64) { const float d = src[c] - mean; v = fmaf(d, d, v); }
+        const float var = wave_sum(v) / (float)D;
+        const float sd = sqrtf(var + eps);
+        if (lane == 0) rstd_out[r] = 1.0f / sd;
+        if (zss_out) {
+            float zs = 0.f;
+            for (int c = lane; c < D; c += 64) {
+                float o = (src[c] - mean) / sd;
+                if (w) o *= w[c];
+                if (b) o += b[c];
+                zs = fmaf(o, o, zs);
+            }
+            zs = wave_sum(zs);
+            if (lane == 0) zss_out[r] = zs;
+        }
+        if (absmax_out) {
+            m = wave_max_u32(m);
+            if (lane == 0) absmax_out[r] = m;
+        }
+    }
+}
+
+// The same statistics for rows of up to 256 floats (D % 4 == 0), SIXTEEN lanes per row: a wavefront holds four rows at once (NV
+// 16-byte pieces per lane, four-step reductions), so a workgroup keeps 16 rows of loads in flight where the one-row-per-wavefront
+// form above keeps four -- the kernel is one dependent chain per row (load, mean, centred moment, output norm) and nothing else.
+__device__ inline float sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int NV>
+__global__ __launch_bounds__(TPB) void layernorm_stats16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float* __restrict__ rstd_out,
+                                                                float* __restrict__ zss_out, unsigned* __restrict__ absmax_out,
+                                                                int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    f32x4 wv[NV], bv[NV];
+    bool on[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (sub + 16 * i) * 4;
+        on[i] = c < D;
+        wv[i] = (on[i] && w) ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        bv[i] = (on[i] && b) ? *reinterpret_cast<const f32x4*>(b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t r0 = wave * 4; r0 < rows; r0 += nwaves * 4) {
+        const int64_t r = r0 + grp;
+        const bool live = r < rows;
+        f32x4 v[NV];
+        float s = 0.f;
+        unsigned m = 0u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = (live && on[i]) ? *reinterpret_cast<const f32x4*>(x + r * D + (sub + 16 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            m = max(m, abs_bits4(v[i]));
+        }
+        const float mean = sum16(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = on[i] ? v[i] - mean : f32x4{0.f, 0.f, 0.f, 0.f};
+            q += fmaf(v[i][0], v[i][0], v[i][1] * v[i][1]) + fmaf(v[i][2], v[i][2], v[i][3] * v[i][3]);
+        }
+        const float sd = sqrtf(sum16(q) / (float)D + eps);
+        if (sub == 0 && live) rstd_out[r] = 1.0f / sd;
+        if (zss_out) {
+            float zs = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f32x4 o = {v[i][0] / sd, v[i][1] / sd, v[i][2] / sd, v[i][3] / sd};       // (the value layernorm_fwd_kernel writes)
+                o = o * wv[i] + bv[i];
+                if (!on[i]) o = f32x4{0.f, 0.f, 0.f, 0.f};
+                zs += fmaf(o[0], o[0], o[1] * o[1]) + fmaf(o[2], o[2], o[3] * o[3]);
+            }
+            zs = sum16(zs);
+            if (sub == 0 && live) zss_out[r] = zs;
+        }
+        if (absmax_out) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            if (sub == 0 && live) absmax_out[r] = m;
+        }
+    }
+}
+
 // explanation mode: the variance is a constant, the mean is not (centered_norms.py:204-215):
 //   y = w * (x - mean(x)) / std   =>   gx = h - mean(h),  h = gy * w / std
 // out = gx (+ addend); out2 = out * mul2 (the scale of the B-cos layer that produced x), both optional extras.
@@ -894,6 +998,26 @@ extern "C" int bcos_layernorm_fwd(const float* x, const float* weight, const flo
         hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), x, weight, bias, y,
                            rstd_out, y_absmax, rows, D, eps);
     return check_launch("layernorm_fwd_kernel");
+}
+
+extern "C" int bcos_layernorm_stats(const float* x, const float* weight, const float* bias, float* rstd_out, float* zsumsq_out,
+                                    uint32_t* x_absmax, int64_t rows, int D, float eps, void* stream) {
+    if (!x || !rstd_out || rows <= 0 || D <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_layernorm_stats: bad argument");
+    if (ln_vec_ok(D, {x, weight, bias})) {
+        int64_t nb = (rows + 15) / 16;           // 16 rows per workgroup and pass
+        if (nb > 256 * 32) nb = 256 * 32;
+        const dim3 grid((unsigned)nb), block(TPB);
+        hipStream_t st = STREAM(stream);
+        switch ((D + 63) / 64) {
+            case 1: hipLaunchKernelGGL(layernorm_stats16_kernel<1>, grid, block, 0, st, x, weight, bias, rstd_out, zsumsq_out, x_absmax, rows, D, eps); break;
+            case 2: hipLaunchKernelGGL(layernorm_stats16_kernel<2>, grid, block, 0, st, x, weight, bias, rstd_out, zsumsq_out, x_absmax, rows, D, eps); break;
+            case 3: hipLaunchKernelGGL(layernorm_stats16_kernel<3>, grid, block, 0, st, x, weight, bias, rstd_out, zsumsq_out, x_absmax, rows, D, eps); break;
+            default: hipLaunchKernelGGL(layernorm_stats16_kernel<4>, grid, block, 0, st, x, weight, bias, rstd_out, zsumsq_out, x_absmax, rows, D, eps); break;
+        }
+    } else
+        hipLaunchKernelGGL(layernorm_stats_kernel, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), x, weight, bias, rstd_out,
+                           zsumsq_out, x_absmax, rows, D, eps);
+    return check_launch("layernorm_stats_kernel");
 }
 
 extern "C" int bcos_layernorm_bwd_detached(const float* gy, const float* weight, const float* rstd, const float* addend,

@@ -141,6 +141,14 @@ typedef struct bcos_epilogue {
     const float* mul_csc;   /* ... its ch_scale [Cout] (NULL = 1) */
     const float* mul_csh;   /* ... its ch_shift [Cout] (NULL = 0) */
     const float* col_scale; /* NULL or [Cout] (grouped launches: [G Cout]): factor of every accumulator column, applied first (ABI v5) */
+    const float* row_scale; /* NULL or [N*OH*OW]: factor of every accumulator ROW, applied with col_scale ahead of the bias (ABI v7)         */
+    const float* a_sumsq;   /* NULL or [N*OH*OW] (B-cos launches): sum of squares of the row's EFFECTIVE operand, taken in place of the sum
+                               the loop collects from A.  The two fields fold a LayerNorm into the contraction that reads it
+                               (centered_norms.py:197-224 in front of a linear layer): with z = gamma (x - mean(x)) r + beta,
+                                   W z = r (W' x) + W beta,   W'[j,k] = gamma[k] W[j,k] - mean_k'(gamma[k'] W[j,k'])
+                               -- A = x, wt = W' (built once per weight), row_scale = r = 1 / sqrt(var + eps), bias = W beta,
+                               a_sumsq = |z|^2 (both per row from bcos_layernorm_stats) -- and the gradient of the detached-variance
+                               form, gx = r (gamma gz - mean(gamma gz)), is the input-gradient launch over W'^T with the same row_scale. */
     int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
     int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */
@@ -541,6 +549,14 @@ int bcos_channel_axpby(const float* a, const float* sa, const float* b, const fl
  * the operand scale source of the split-f16 contraction that reads y (bcos_operands.a_absmax). */
 int bcos_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_out, uint32_t* y_absmax,
                        int64_t rows, int D, float eps, void* stream);
+
+/* Row statistics of the same LayerNorm WITHOUT writing y: what a contraction needs to read x in place of y (bcos_epilogue.row_scale /
+ * a_sumsq).  rstd_out [rows] = 1 / sqrt(var + eps); zsumsq_out (NULL or [rows]) = sum_c (weight[c] (x[r,c] - mean) rstd + bias[c])^2,
+ * the squared norm of the LayerNorm output the B-cos scale of the reading layer divides by; x_absmax (NULL or [rows]): bit
+ * pattern of max_c |x[r,c]| (the operand maxima of x for the split-f16 contraction).  One read of x, nothing output-sized
+ * written.  (ABI v7) */
+int bcos_layernorm_stats(const float* x, const float* weight, const float* bias, float* rstd_out, float* zsumsq_out,
+                         uint32_t* x_absmax, int64_t rows, int D, float eps, void* stream);
 
 /* Input gradient of DetachableLayerNorm in explanation mode (variance constant, mean differentiable,
  * centered_norms.py:204-215):  g = gy * weight * rstd - mean_D(gy * weight * rstd)  (+ addend);

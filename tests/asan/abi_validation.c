@@ -107,6 +107,7 @@ int main(void) {
     EXPECT(bcos_weight_rownorm_bwd(NULL, buf, NULL, buf, NULL, 4, 8, NULL), BCOS_E_INVAL);
     EXPECT(bcos_weight_rownorm_bwd(buf, buf, NULL, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);                                /* no output */
     EXPECT(bcos_maxout_scatter(buf, NULL, buf, 4, 8, 2, NULL), BCOS_E_INVAL);
+    e.a_sumsq = buf; EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); e.a_sumsq = NULL;                          /* a_sumsq without a B-cos mode */
     g.out_cgroup = 4; EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_INVAL); g.out_cgroup = 0;                         /* Cout != out_sh*out_sw*G */
     EXPECT(bcos_patch_norm_bwd(buf, buf, NULL, 1, 4, 4, 8, 0, 4, 4, 1, 1, 1, 1, 0, 0, 1, 1, NULL), BCOS_E_INVAL);
     EXPECT(bcos_conv2d_wgrad(buf, buf, buf, 1, 4, 4, 8, 6, 4, 4, 8, 0, 1, 1, 1, 1, 0, 0, 1, 1, 0, NULL), BCOS_E_INVAL);
@@ -119,6 +120,8 @@ int main(void) {
     EXPECT(bcos_weight_row_invnorm(buf, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);
     EXPECT(bcos_weight_row_invnorm(buf, NULL, buf, 0, 8, NULL), BCOS_E_INVAL);
     EXPECT(bcos_layernorm_fwd(NULL, NULL, NULL, buf, NULL, am, 4, 8, 1e-5f, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_layernorm_stats(buf, NULL, NULL, NULL, buf, am, 4, 8, 1e-5f, NULL), BCOS_E_INVAL);               /* rstd_out is required */
+    EXPECT(bcos_layernorm_stats(NULL, NULL, NULL, buf, NULL, NULL, 4, 8, 1e-5f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_layernorm_bwd_detached(buf, NULL, buf, NULL, NULL, buf, NULL, am, 4, 8, NULL), BCOS_E_INVAL);   /* maxima of an absent out2 */
     EXPECT(bcos_attention_fwd(buf, NULL, NULL, am, 1, 4, 1, 64, 1.0f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_attention_bwd_v(buf, buf, buf, buf, am, 1, 4, 1, 32, 1.0f, NULL), BCOS_E_NOSUP);               /* head dimension */

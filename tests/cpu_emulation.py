@@ -15,7 +15,7 @@ from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
             ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
             b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None, max_out=1,
-            mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0, col_scale=None):
+            mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0, col_scale=None, row_scale=None, a_sumsq=None):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
     g = dict(a_pitch=0, out_pitch=0, norm_pitch=0, out_cgroup=0, groups=0)
@@ -59,6 +59,10 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
         v = v / w.reshape(Cout, -1).double().norm(dim=1)
     if col_scale is not None:
         v = v * col_scale.double()
+    if row_scale is not None:     # bcos_epilogue.row_scale / a_sumsq: indexed by output pixel (these launches map rows to pixels one to one)
+        v = v * row_scale.double().view(N, P, Q, 1)
+    if a_sumsq is not None:
+        ss = a_sumsq.double().view(N, P, Q)
     if bias is not None:
         v = v + bias.double()
     if max_out > 1:       # fused MaxOut (include/bcos_hip.h: bcos_epilogue.max_out): out narrow, scale_out at the winner
@@ -466,7 +470,7 @@ def install(monkeypatch):
     from bcos_hip import ops
     for name in ("tapconv", "prep_input", "finalize_explanation", "avgpool2d_fwd", "avgpool2d_bwd",
                  "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine", "channel_affine_add", "relu_bwd",
-                 "weight_rownorm_scale", "rows_normalize", "cosine_grad", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_bwd_detached",
+                 "weight_rownorm_scale", "rows_normalize", "cosine_grad", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_stats", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
                  "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand",
@@ -502,6 +506,11 @@ def layernorm_fwd(x2d, weight, bias, eps, want_rstd=False, out=None, want_absmax
     if bias is not None:
         y = y + bias.double()
     return y.float(), ((1 / sd).float().view(-1) if want_rstd else None)
+
+
+def layernorm_stats(x2d, weight, bias, eps, want_zsumsq=False, want_absmax=False):
+    y, rstd = layernorm_fwd(x2d, weight, bias, eps, want_rstd=True)
+    return rstd, ((y.double() ** 2).sum(-1).float() if want_zsumsq else None)
 
 
 def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=True, want_out2=False, out=None, want_absmax2=False):

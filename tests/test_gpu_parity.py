@@ -632,6 +632,69 @@ def test_vit_kernels(lib):
         assert rel(gv, gv_ref.transpose(1, 2).reshape(B, T, inner)) <= 1e-5, (B, T, H)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+def test_layernorm_folded_into_the_contraction(lib, mode):
+    """bcos_epilogue.row_scale / a_sumsq + bcos_layernorm_stats: a DetachableLayerNorm (centered_norms.py:197-224) in front of a
+    B-cos linear layer (bcosifylinear.py:61-94) or a plain one, computed WITHOUT writing the LayerNorm's output -- rows with means
+    far from zero, affine with bias -- against the fp64 composition, forward (value, stored scale) and the detached-variance
+    input gradient with residual addend and next-layer multiplier; every contraction mode; through the C ABI."""
+    from bcos_hip import ops, vit_engine
+    from bcos_hip import lib as blib
+    g = torch.Generator().manual_seed(23)
+    rows, D, Cout = 333, 192, 256
+    x = torch.randn(rows, D, generator=g) * (torch.rand(rows, 1, generator=g) * 3 + 0.1) + torch.randn(rows, 1, generator=g) * 2
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.2
+    W = torch.randn(Cout, D, generator=g) / D ** 0.5
+    eps = 1e-5
+    x64 = x.double()
+    mean = x64.mean(-1, keepdim=True)
+    rstd64 = 1 / (x64.var(-1, unbiased=False, keepdim=True) + eps).sqrt()
+    z64 = (x64 - mean) * rstd64 * gamma.double() + beta.double()
+    lin64 = z64 @ W.double().t()
+    nrm64 = z64.norm(dim=-1, keepdim=True) + 1e-12
+    s64 = lin64.abs() / nrm64
+
+    class _LNv:
+        w, bias = gamma, beta
+    wc, c = vit_engine._fold_ln(W, _LNv)
+    prev = blib.get_contraction_mode()
+    blib.set_contraction_mode(mode)
+    try:
+        xd = x.to(DEV)
+        rstd, zss = ops.layernorm_stats(xd, gamma.to(DEV), beta.to(DEV), eps, want_zsumsq=True, want_absmax=True)
+        assert rel(rstd, rstd64.view(-1)) <= 1e-6 and rel(zss, (z64 ** 2).sum(-1)) <= 1e-6
+        if mode == "f16x2":
+            assert torch.equal(ops.absmax_of(xd).cpu().view(torch.float32), x.abs().amax(-1))
+        for D2, affine in ((64, True), (200, True), (256, False), (50, True), (384, True)):      # every row width of the two kernels
+            x2 = torch.randn(77, D2, generator=g) * 3 + 1.5
+            g2, b2 = (torch.rand(D2, generator=g) + 0.5, torch.randn(D2, generator=g)) if affine else (None, None)
+            r2, z2 = ops.layernorm_stats(x2.to(DEV), None if g2 is None else g2.to(DEV), None if b2 is None else b2.to(DEV), eps, want_zsumsq=True)
+            v2, m2 = torch.var_mean(x2.double(), dim=-1, unbiased=False, keepdim=True)
+            zz = (x2.double() - m2) / (v2 + eps).sqrt() * (g2.double() if affine else 1.0) + (b2.double() if affine else 0.0)
+            assert rel(r2, 1 / (v2 + eps).sqrt().view(-1)) <= 1e-6 and rel(z2, (zz ** 2).sum(-1)) <= 1e-6, D2
+        wcd, cd = ops.mark_static(wc.to(DEV)), c.to(DEV)
+        # B-cos linear over the LayerNorm output, with the stored scale
+        geom = dict(N=1, H=1, W=rows, C=D, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1, TH=1, TW=1, OH=1, OW=rows,
+                    out_sh=1, out_sw=1, out_h0=0, out_w0=0, Cout=Cout)
+        y, t = torch.empty(rows, Cout, device=DEV), torch.empty(rows, Cout, device=DEV)
+        ops.tapconv(xd, wcd, geom, out=y, scale_out=t, bias=cd, bcos_mode=blib.BCOS_LINEAR_EPS, b=2.0, row_scale=rstd, a_sumsq=zss,
+                    contraction=mode)
+        assert rel(y, lin64 * s64) <= 3e-6 and rel(t, s64) <= 3e-6, (mode, rel(y, lin64 * s64), rel(t, s64))
+        # plain linear (to_qkv): value only
+        q = ops.matmul_nt(xd, wcd, bias=cd, row_scale=rstd)
+        assert rel(q, lin64) <= 3e-6, (mode, rel(q, lin64))
+        # detached-variance input gradient: gx = rstd (gamma gz - mean(gamma gz)), gz = W^T a; + addend; second output * multiplier
+        a = torch.randn(rows, Cout, generator=g)
+        add, mul = torch.randn(rows, D, generator=g), torch.rand(rows, D, generator=g)
+        gz = a.double() @ W.double()
+        h = gz * gamma.double() * rstd64
+        gx64 = h - h.mean(-1, keepdim=True) + add.double()
+        gm, gx = vit_engine._dgrad_ln(ops.ensure_absmax(a.to(DEV)), ops.mark_static(wc.t().contiguous().to(DEV)), rstd, add.to(DEV), mul.to(DEV))
+        assert rel(gx, gx64) <= 3e-6 and rel(gm, gx64 * mul.double()) <= 3e-6, (mode, rel(gx, gx64))
+    finally:
+        blib.set_contraction_mode(prev)
+
+
 def _golden_vit(golden_dir):
     from bcos_hip import synth
     meta = json.load(open(os.path.join(golden_dir, "vit_ti_e2e.json")))
