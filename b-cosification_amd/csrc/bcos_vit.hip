@@ -466,6 +466,14 @@ __global__ __launch_bounds__(ATPB) void attention_mfma_kernel(const float* __res
 typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 af16x4 __attribute__((ext_vector_type(4)));
 constexpr int AH_XROW = 144;        // bytes per X row and plane: 64 f16 + 16 (16 rows at distinct 16-byte bank groups)
+constexpr float AH_LOG2E = 1.4426950408889634f, AH_LN2 = 0.6931471805599453f;
+#ifndef AH_KO
+#define AH_KO 0
+#endif
+#ifndef AH_TWO_CHAINS
+#define AH_TWO_CHAINS 0
+#endif
+constexpr int AH_MAXIT = 9;         // 32-row blocks of the walked operand a workgroup holds at most (288 tokens: what the LDS planes allow)
 
 __device__ __forceinline__ void split_scale_exp(unsigned maxbits, float& sc, float& inv) {
     unsigned E = maxbits >> 23;
@@ -502,34 +510,50 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
 
     if (tid < DH) sZmax[tid] = 0u;
     __syncthreads();
-    // pass 1: X rows -> scaled (h | l) planes; per-d maxima of Z.  A thread keeps its 16-byte column c4 = tid % 16 throughout.
+    // pass 1: X rows -> scaled (h | l) planes; per-d maxima of Z.  A thread keeps its 16-byte column c4 = tid % 16 throughout and
+    // owns the rows (tid >> 4) + 32 it.  ALL of its X and Z pieces are requested up front (AH_MAXIT x 2 loads in flight, one
+    // exposed memory latency per workgroup) and the Z pieces stay in registers for pass 2 -- round 3 walked the rows in a loop of
+    // dependent (load, reduce, store) iterations and read Z a second time: with one workgroup per CU (the planes fill the LDS)
+    // nothing else covered those latencies.
     const int c4 = tid & 15;
     const int xpos = (16 * (c4 >> 2) + 4 * (((c4 & 3) == 1) ? 2 : ((c4 & 3) == 2) ? 1 : (c4 & 3))) * 2;     // byte offset of d block c4
+    const int nit = Tpad / 32;                     // <= AH_MAXIT (host: the planes must fit the LDS)
+    f32x4 zreg[AH_MAXIT];
     {
+        f32x4 xreg[AH_MAXIT];
+#pragma unroll
+        for (int it = 0; it < AH_MAXIT; ++it) {
+            const int t = (tid >> 4) + 32 * it;
+            xreg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            zreg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (it < nit && t < T) {
+                xreg[it] = *reinterpret_cast<const f32x4*>(xsrc + (int64_t)t * 3 * inner + c4 * 4);
+                zreg[it] = *reinterpret_cast<const f32x4*>(zrow0 + (int64_t)t * zstride + c4 * 4);
+            }
+        }
         unsigned zm[4] = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < Tpad * (DH / 4); i += ATPB) {
-            const int t = i >> 4;
-            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
-            if (t < T) {
-                xv = *reinterpret_cast<const f32x4*>(xsrc + (int64_t)t * 3 * inner + c4 * 4);
-                zv = *reinterpret_cast<const f32x4*>(zrow0 + (int64_t)t * zstride + c4 * 4);
-            }
-            unsigned m = abs_bits4(xv);
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-            float sc, inv;
-            split_scale_exp(m, sc, inv);
-            af16x4 hh, ll;
+        for (int it = 0; it < AH_MAXIT; ++it) {
+            if (it < nit) {
+                const int t = (tid >> 4) + 32 * it;
+                const f32x4 xv = xreg[it], zv = zreg[it];
+                unsigned m = abs_bits4(xv);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v = xv[q] * sc;
-                hh[q] = (_Float16)v;
-                ll[q] = (_Float16)(v - (float)hh[q]);
-                zm[q] = max(zm[q], __float_as_uint(zv[q]) & 0x7fffffffu);
+                for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+                float sc, inv;
+                split_scale_exp(m, sc, inv);
+                af16x4 hh, ll;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = xv[q] * sc;
+                    hh[q] = (_Float16)v;
+                    ll[q] = (_Float16)(v - (float)hh[q]);
+                    zm[q] = max(zm[q], __float_as_uint(zv[q]) & 0x7fffffffu);
+                }
+                *reinterpret_cast<af16x4*>(sXh + t * AH_XROW + xpos) = hh;
+                *reinterpret_cast<af16x4*>(sXl + t * AH_XROW + xpos) = ll;
+                if (c4 == 0) sXinv[t] = inv;
             }
-            *reinterpret_cast<af16x4*>(sXh + t * AH_XROW + xpos) = hh;
-            *reinterpret_cast<af16x4*>(sXl + t * AH_XROW + xpos) = ll;
-            if (c4 == 0) sXinv[t] = inv;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) atomicMax(&sZmax[c4 * 4 + q], zm[q]);
@@ -542,7 +566,7 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
         }
     }
     __syncthreads();
-    // pass 2: Z -> scaled, split, transposed planes (token index permuted like d above)
+    // pass 2: Z -> scaled, split, transposed planes (token index permuted like d above), from the registers of pass 1
     {
         float zsc[4];
 #pragma unroll
@@ -551,25 +575,27 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
             split_scale_exp(sZmax[c4 * 4 + q], zsc[q], inv);
             if (tid < 16) sZinv[c4 * 4 + q] = inv;
         }
-        for (int i = tid; i < Tpad * (DH / 4); i += ATPB) {
-            const int t = i >> 4;
-            f32x4 zv = {0.f, 0.f, 0.f, 0.f};
-            if (t < T) zv = *reinterpret_cast<const f32x4*>(zrow0 + (int64_t)t * zstride + c4 * 4);
-            const int tb = (t >> 2) & 3;
-            const int tpos = ((t & ~15) + 4 * (tb == 1 ? 2 : tb == 2 ? 1 : tb) + (t & 3)) * 2;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v = zv[q] * zsc[q];
-                const _Float16 hh = (_Float16)v;
-                *reinterpret_cast<_Float16*>(sZh + (c4 * 4 + q) * zrow + tpos) = hh;
-                *reinterpret_cast<_Float16*>(sZl + (c4 * 4 + q) * zrow + tpos) = (_Float16)(v - (float)hh);
+        for (int it = 0; it < AH_MAXIT; ++it) {
+            if (it < nit && !(AH_KO & 2)) {
+                const int t = (tid >> 4) + 32 * it;
+                const f32x4 zv = zreg[it];
+                const int tb = (t >> 2) & 3;
+                const int tpos = ((t & ~15) + 4 * (tb == 1 ? 2 : tb == 2 ? 1 : tb) + (t & 3)) * 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = zv[q] * zsc[q];
+                    const _Float16 hh = (_Float16)v;
+                    *reinterpret_cast<_Float16*>(sZh + (c4 * 4 + q) * zrow + tpos) = hh;
+                    *reinterpret_cast<_Float16*>(sZl + (c4 * 4 + q) * zrow + tpos) = (_Float16)(v - (float)hh);
+                }
             }
         }
     }
     __syncthreads();
 
     const int col = lane & 31, hf = lane >> 5;
-    const int ntiles = Tpad / 32;
+    const int ntiles = (AH_KO & 1) ? 0 : Tpad / 32;      // (AH_KO: development knock-outs, timing only)
     for (int tile = wave; tile < ntiles; tile += ATPB / 64) {
         const int y = tile * 32 + col;                 // the Y row (query fwd / key bwd) of this lane
         f32x4 yf[8];
@@ -592,7 +618,9 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
                 yh[j][q] = (_Float16)v;
                 yl[j][q] = (_Float16)(v - (float)yh[j][q]);
             }
-        const float sfac = scale * yinv;
+        // forward: scores in the base-2 domain (the softmax runs on v_exp_f32 directly); backward: natural scores against the recorded
+        // natural maxima, the difference converted
+        const float sfac = BWD ? scale * yinv : scale * yinv * AH_LOG2E;
         f32x16 o0, o1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -603,6 +631,30 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
             const char* xh = sXh + (chunk * 32 + col) * AH_XROW + 16 * hf;
             const char* xl = sXl + (chunk * 32 + col) * AH_XROW + 16 * hf;
+#if AH_TWO_CHAINS
+            // two accumulation chains (k blocks 0-1 and 2-3), added at the end: a v_mfma directly behind the one it depends on waits
+            // for its result, and with one workgroup per CU there are at most two waves per SIMD to fill that wait
+            f32x16 sacc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc2[r] = 0.f;
+            af16x8 ah4[4], al4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ah4[j] = *reinterpret_cast<const af16x8*>(xh + 32 * j);
+                al4[j] = *reinterpret_cast<const af16x8*>(xl + 32 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al4[j], yh[j], sacc, 0, 0, 0);
+                sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al4[j + 2], yh[j + 2], sacc2, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah4[j], yl[j], sacc, 0, 0, 0);
+                sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah4[j + 2], yl[j + 2], sacc2, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah4[j], yh[j], sacc, 0, 0, 0);
+                sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah4[j + 2], yh[j + 2], sacc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] += sacc2[r];
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const af16x8 ah = *reinterpret_cast<const af16x8*>(xh + 32 * j);
@@ -611,6 +663,7 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, yl[j], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, yh[j], sacc, 0, 0, 0);
             }
+#endif
             // register r <-> X row  chunk*32 + 8(r>>2) + 4hf + (r&3); undo the X row's power of two
             float pr[16];
 #pragma unroll
@@ -619,34 +672,42 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
 #pragma unroll
                 for (int c = 0; c < 4; ++c) pr[4 * g + c] = sacc[4 * g + c] * sfac * xi[c];
             }
+            // (round 4) the step was bound by its ~530 vector instructions per 24 matrix instructions: the exponentials are the
+            // hardware's base-2 ones (1 ulp; the scores already carry the log2 e), keys beyond T exist in the last chunk only, and the
+            // running output is rescaled only when some row's maximum moved
             if (!BWD) {
-                float mx = -INFINITY;
+                if (chunk + 1 == ntiles) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int x = chunk * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
-                    pr[r] = x < T ? pr[r] : -INFINITY;
-                    mx = fmaxf(mx, pr[r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int x = chunk * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                        pr[r] = x < T ? pr[r] : -INFINITY;
+                    }
                 }
+                float mx = fmaxf(fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3])), fmaxf(fmaxf(pr[4], pr[5]), fmaxf(pr[6], pr[7])));
+                mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pr[8], pr[9]), fmaxf(pr[10], pr[11])), fmaxf(fmaxf(pr[12], pr[13]), fmaxf(pr[14], pr[15]))));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float m_new = fmaxf(m_run, mx);          // finite: every chunk holds at least one valid key
-                const float alpha = expf(m_run - m_new);
                 float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { pr[r] = expf(pr[r] - m_new); sum += pr[r]; }
+                for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(pr[r] - m_new); sum += pr[r]; }
                 sum += __shfl_xor(sum, 32);
-                l_run = l_run * alpha + sum;
-                m_run = m_new;
+                if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // (exactly 1 for the rows whose maximum stayed)
+                    l_run *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                    m_run = m_new;
+                }
+                l_run += sum;
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float* st = sS + 2 * (chunk * 32 + 8 * g + 4 * hf);
                     const f32x4 s01 = *reinterpret_cast<const f32x4*>(st), s23 = *reinterpret_cast<const f32x4*>(st + 4);
-                    pr[4 * g + 0] = expf(pr[4 * g + 0] - s01[0]) * s01[1];
-                    pr[4 * g + 1] = expf(pr[4 * g + 1] - s01[2]) * s01[3];
-                    pr[4 * g + 2] = expf(pr[4 * g + 2] - s23[0]) * s23[1];
-                    pr[4 * g + 3] = expf(pr[4 * g + 3] - s23[2]) * s23[3];
+                    pr[4 * g + 0] = __builtin_amdgcn_exp2f((pr[4 * g + 0] - s01[0]) * AH_LOG2E) * s01[1];
+                    pr[4 * g + 1] = __builtin_amdgcn_exp2f((pr[4 * g + 1] - s01[2]) * AH_LOG2E) * s01[3];
+                    pr[4 * g + 2] = __builtin_amdgcn_exp2f((pr[4 * g + 2] - s23[0]) * AH_LOG2E) * s23[1];
+                    pr[4 * g + 3] = __builtin_amdgcn_exp2f((pr[4 * g + 3] - s23[2]) * AH_LOG2E) * s23[3];
                 }
             }
             const char* zh = sZh + col * zrow + (chunk * 32 + 8 * hf) * 2;
@@ -691,7 +752,7 @@ __global__ __launch_bounds__(ATPB) void attention_h2_kernel(const float* __restr
             }
             if (!BWD && stats_out && hf == 0) {
                 float* st = stats_out + (((int64_t)b * H + h) * T + y) * 2;
-                st[0] = m_run;
+                st[0] = m_run * AH_LN2;          // (the statistics tensor keeps the natural-log maximum of rounds 1-3)
                 st[1] = 1.0f / l_run;
             }
         }
@@ -1054,7 +1115,7 @@ static int attn_launch(bool bwd, const float* qkv, const float* z, float* out, f
     // f16 matrix pipe (default) or the exact-fp32 MFMA form of rounds 1-2 (BCOS_OPT_ATTENTION_F32; also what the f32 contraction mode means)
     if (!bcos_option(BCOS_OPT_ATTENTION_F32)) {
         const size_t hb = 2 * (size_t)Tpad * AH_XROW + 2 * (size_t)DH * (Tpad * 2 + 16) + ((size_t)Tpad + 2 * DH + 2 * (size_t)Tpad) * 4;
-        if (hb <= 160 * 1024) {
+        if (hb <= 160 * 1024 && Tpad <= 32 * AH_MAXIT) {
             const void* fn2 = bwd ? reinterpret_cast<const void*>(attention_h2_kernel<true>)
                                   : reinterpret_cast<const void*>(attention_h2_kernel<false>);
             static std::atomic<size_t> lds_hw2[2];
