@@ -127,6 +127,7 @@ import os
 
 
 _F16X2 = os.environ.get("BCOS_VIT_F16X2", "1") != "0"
+_VIT_SUBBATCH_STREAMS = int(os.environ.get("BCOS_VIT_SUBBATCH_STREAMS", os.environ.get("BCOS_SUBBATCH_STREAMS", "3")))
 # Round 4: every LayerNorm of the plan is folded into the contraction that reads it -- forward: row statistics (one read of x, two
 # floats per row out) + the GEMM over x with mean-centred, gamma-scaled weight rows, rstd as a row factor of the accumulator and
 # W beta as bias; explanation pass: the detached-variance input gradient IS the input-gradient GEMM over the same weights, with
@@ -205,8 +206,10 @@ class ViTEngine:
         self.logit_bias = ll.logit_bias if ll is not None else None
         self.logit_temperature = ll.logit_temperature if ll is not None else None
         self._absmax_arena = ops.AbsmaxArena()      # row maxima of one pass: one zero fill instead of one per tensor
-        from .engine import _SUBBATCH_STREAMS
-        self.subbatch_streams, self._side = _SUBBATCH_STREAMS, None
+        # three sub-batch streams for the token path (ResNets: two): its launches are shorter -- 394 tiles per half-batch GEMM at batch
+        # 512 -- and a third stream fills more of their tails: same-node A/B at ViT-Ti batch 512, three pairs: 18.76 / 18.86 / 18.77 ms
+        # against 19.23 / 19.29 / 19.14 with two (ResNet-50: no difference).  Fewer streams for batches under 3 x _SUBBATCH_MIN.
+        self.subbatch_streams, self._side = _VIT_SUBBATCH_STREAMS, None
         self.refresh()
 
     def _fingerprint(self):
@@ -357,8 +360,8 @@ class ViTEngine:
         """Run fn(sub_batch_index, lo, hi, arena) for contiguous sub-batches on side streams (bcos_hip/engine.py: _SUBBATCH_STREAMS:
         images are independent, the sub-batches fill each other's launch tails) or once on the caller's stream."""
         from .engine import _SUBBATCH_MIN, _CAPTURE_STREAMS
-        S = int(self.subbatch_streams)
         N = x.shape[0]
+        S = min(int(self.subbatch_streams), N // _SUBBATCH_MIN)
         if S <= 1 or not x.is_cuda or N < S * _SUBBATCH_MIN or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_STREAMS):
             return [fn(0, N, self._absmax_arena)]
         # everything the passes cache lazily (refreshed plans, constants, the positional-embedding table) is brought up to date here,
