@@ -192,7 +192,7 @@ __device__ __forceinline__ float* epi_col_table(float* smem) {
 //   epi_part_generic: one part of the tile, LDS transpose buffer -> epilogue math -> tensors.
 // `lvl` (input-patch loop on images of wide dynamic range, tile_body_p): NULL, or one byte per tile row -- only the rows whose byte
 // equals `pass` belong to this pass of the tile; the others are dropped like rows beyond M
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT, bool ROWX = true>
 __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0,
                                                  const unsigned char* lvl, const int pass, KArgsSegPtr kpin) {
     BCOS_EPI_SHAPE
@@ -215,7 +215,7 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
         }
         sPix[r] = pix;
         if (!NORM && e.addend_sub > 1) reinterpret_cast<int64_t*>(sNorm)[r] = apix;
-        if (!SCALED && e.row_scale) sAinv[r] = pix >= 0 ? e.row_scale[pix] : 0.f;      // (bcos_epilogue.row_scale: rides in the row factor)
+        if (ROWX && !SCALED && e.row_scale) sAinv[r] = pix >= 0 ? e.row_scale[pix] : 0.f;      // (bcos_epilogue.row_scale: rides in the row factor)
     }
     // output pixel of tile row r (bcos_epilogue.row_scale / a_sumsq are indexed by it), or -1
     auto row_pix = [&](int r) -> int64_t {
@@ -230,7 +230,7 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
             float t = ss[i] + __shfl_xor(ss[i], 32);
             if (wave_n == 0 && lane < 32) {
                 const int row = wave_m * WM + i * 32 + lane;
-                if (e.a_sumsq) { const int64_t px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                if (ROWX && e.a_sumsq) { const int64_t px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
                 float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRinv[row] = 1.0f / nrm;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
             t += __shfl_xor(t, 2);
             if ((tid & 3) == 0) {
                 const int row = (tid >> 2) + RP * j;
-                if (e.a_sumsq) { const int64_t px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                if (ROWX && e.a_sumsq) { const int64_t px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
                 float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRinv[row] = 1.0f / nrm;
@@ -259,7 +259,7 @@ __device__ __forceinline__ void epi_rows_generic(float* smem, const float* ss, c
             if ((tid & 3) == 0) {
                 const int row = (tid >> 2) + (NT / 4) * j;
                 float ai = AINV[j];
-                if (e.row_scale) { const int64_t px = row_pix(row); ai *= px >= 0 ? e.row_scale[px] : 0.f; }
+                if (ROWX && e.row_scale) { const int64_t px = row_pix(row); ai *= px >= 0 ? e.row_scale[px] : 0.f; }
                 sAinv[row] = ai;
             }
     }
@@ -594,7 +594,7 @@ struct __attribute__((aligned(16))) EpiRow { unsigned off; float rinv; float ain
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT, bool ROWX = true>
 __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, const float* ROWSS, const float* AINV, const int m0,
                                               const unsigned char* lvl, const int pass, KArgsSegPtr kpin) {
     BCOS_EPI_SHAPE
@@ -636,7 +636,7 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
             float t = ss[i] + __shfl_xor(ss[i], 32);
             if (wave_n == 0 && lane < 32) {
                 const int row = wave_m * WM + i * 32 + lane;
-                if (e.a_sumsq) { const int px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                if (ROWX && e.a_sumsq) { const int px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
                 float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRow[row].rinv = 1.0f / nrm;
@@ -651,7 +651,7 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
             t += __shfl_xor(t, 2);
             if ((tid & 3) == 0) {
                 const int row = (tid >> 2) + RP * j;
-                if (e.a_sumsq) { const int px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
+                if (ROWX && e.a_sumsq) { const int px = row_pix(row); t = px >= 0 ? e.a_sumsq[px] : 0.f; }
                 float nrm = e.bcos_mode == BCOS_LINEAR_EPS ? sqrtf(t) + 1e-12f : sqrtf(t + 1e-6f);
                 sNorm[row] = nrm;
                 sRow[row].rinv = 1.0f / nrm;
@@ -666,7 +666,7 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
             if ((tid & 3) == 0) {
                 const int row = (tid >> 2) + (NT / 4) * j;
                 float ai = AINV[j];
-                if (e.row_scale) { const int px = row_pix(row); ai *= px >= 0 ? e.row_scale[px] : 0.f; }
+                if (ROWX && e.row_scale) { const int px = row_pix(row); ai *= px >= 0 ? e.row_scale[px] : 0.f; }
                 sRow[row].ainv = ai;
             }
     }
@@ -872,7 +872,9 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
 // parts still waiting stay put while one part is drained.
 // Tiles larger than 128 x 128 are drained in 128 x 128 parts (one part = half the accumulators of every wave) so that the
 // LDS transpose buffer stays at 66 KB and two workgroups fit a CU.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT = NTHREADS>
+// ROWX = false (the input-patch loop): bcos_epilogue.row_scale / a_sumsq are compiled out -- they belong to launches that read a LayerNorm's
+// input (1 x 1 geometries), and their row lookups cost the patch kernels registers they do not have (248 -> 256 VGPRs, +0.16 ms per step)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, bool SCALED, int NT = NTHREADS, bool ROWX = true>
 __device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16 (&acc)[(BM / WAVES_M) / 32][(BN / WAVES_N) / 32],
                                               const float* ss, const float* ROWSS, const float* AINV, const int m0, const int n0,
                                               const int tile_n, const unsigned char* lvl = nullptr, const int pass = 0) {
@@ -882,8 +884,8 @@ __device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16
     KArgsSegPtr kpin = nullptr;          // (see BCOS_EPI_KARGS)
     if constexpr (!std::is_same_v<std::remove_cvref_t<decltype(p)>, KArgs>) kpin = &p;
     // (all waves are past the last barrier of the main loop: the staging buffers are free)
-    if (kind) epi_rows_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0, lvl, pass, kpin);
-    else epi_rows_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, ss, ROWSS, AINV, m0, lvl, pass, kpin);
+    if (kind) epi_rows_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, ROWX>(smem, ss, ROWSS, AINV, m0, lvl, pass, kpin);
+    else epi_rows_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, ROWX>(smem, ss, ROWSS, AINV, m0, lvl, pass, kpin);
     float* sC = smem;
     // (the parts are expanded at compile time: a loop the optimiser declines to unroll would index the accumulators at run time)
     auto drain = [&](auto part_c) {
@@ -2844,7 +2846,7 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
 #pragma unroll
     for (int j = 0; j < BM / (NT / 4); ++j) a_inv[j] = s_rowinv[(tid >> 2) + (NT / 4) * j];
     __syncthreads();                   // the epilogue reuses all of it
-    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n, lvl_rows, pass);
+    tile_epilogue<BM, BN, WAVES_M, WAVES_N, NORM, true, NT, false>(p, smem, acc, nullptr, NORM ? rowss : nullptr, a_inv, m0, n0, tile_n, lvl_rows, pass);
     if constexpr (!MORE) {      // the other levels present, if any
         lvl_mask >>= 1;
         if (lvl_mask)
@@ -3701,7 +3703,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             const int ntaps = g.TH * g.TW;
             const bool geom_ok = ((ntaps == 9 && g.TH == 3) || (ntaps == 16 && g.TH == 4)) && g.C % X3_BK == 0 && g.in_sh == 1 && g.in_sw == 1 &&
                                  g.dstep_h == 1 && g.dstep_w == 1 && p.g.a_pitch >= g.C;
-            if (dma && geom_ok && p.a_imgmax && patch_on) {
+            if (dma && geom_ok && p.a_imgmax && patch_on && !epi->row_scale && !epi->a_sumsq) {      // (the patch kernels compile those two out)
                 if (ntaps == 16) {
                     if (g.Cout <= 32 && g.in_sh == 1) return bcos_tc_p2_256x32_t16(&p, norm, s);
                 } else {
