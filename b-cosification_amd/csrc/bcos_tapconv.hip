@@ -2213,7 +2213,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
                 [&]<int... As>(std::integer_sequence<int, As...>) { (act(std::integral_constant<int, a0 + As>{}), ...); }(std::make_integer_sequence<int, PER>{});
             }
         };
-        constexpr bool ACC_MAJOR = H2_MFMA_ORDER == 1 || (H2_MFMA_ORDER == 0 && TM * TN >= 8);
+        constexpr bool ACC_MAJOR = TM == 1 && (H2_MFMA_ORDER == 1 || (H2_MFMA_ORDER == 0 && TM * TN >= 8));
         if constexpr (!ACC_MAJOR) {
             f16x8 bf[2][TN];
 #pragma unroll
@@ -3199,7 +3199,11 @@ BCOS_TC_DEFINE(bcos_tc_h2_256x64, (launch_h2<256, 64, 4, 1>))
 BCOS_TC_DEFINE(bcos_tc_h2_256x32, (launch_h2<256, 32, 4, 1>))
 #endif
 #if BCOS_TC_IN(5)
-BCOS_TC_DEFINE(bcos_tc_d_128x256, (launch_d<128, 256, 4, 1>))
+#ifndef D_WIDE_WM
+#define D_WIDE_WM 4                // development switch: wave layout of the 128 x 256 LDS-DMA configuration (4 x 1; 2 x 2 measured in round 4)
+#define D_WIDE_WN 1
+#endif
+BCOS_TC_DEFINE(bcos_tc_d_128x256, (launch_d<128, 256, D_WIDE_WM, D_WIDE_WN>))
 #endif
 #if BCOS_TC_IN(6)
 BCOS_TC_DEFINE(bcos_tc_d_128x128, (launch_d<128, 128, 4, 1>))
