@@ -14,6 +14,15 @@ namespace {
 constexpr int TPB = 256;
 constexpr int64_t MAX_BLOCKS = 256 * 8;
 
+// one-pixel-per-thread kernels whose passes are chains of dependent loads and stores (prep_input, finalize_explanation): more, shorter
+// threads keep more independent memory operations in flight than MAX_BLOCKS workgroups walking 25 passes each
+inline unsigned grid_pixels(int64_t pixels) {
+    int64_t b = (pixels + TPB - 1) / TPB;
+    if (b < 1) b = 1;
+    if (b > 256 * 64) b = 256 * 64;
+    return (unsigned)b;
+}
+
 inline unsigned grid_for(int64_t work_items) {
     int64_t b = (work_items + TPB - 1) / TPB;
     if (b < 1) b = 1;
@@ -499,7 +508,7 @@ extern "C" int bcos_prep_input(const float* x, float* out, const float* mean6, c
     if (!x || !out || !mean6 || !std6 || N <= 0 || H <= 0 || W <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: bad argument");
     if (Cx != (add_inverse ? 3 : 6)) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: Cx must be 3 (add_inverse) or 6");
     if (Cpad < 6) return bcos_set_error(BCOS_E_INVAL, "bcos_prep_input: Cpad < 6");
-    hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), x, out,
+    hipLaunchKernelGGL(prep_input_kernel, dim3(grid_pixels((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), x, out,
                        mean6, std6, absmax_out, N, Cx, H * W, Cpad, add_inverse);
     return check_launch("prep_input_kernel");
 }
@@ -510,7 +519,7 @@ extern "C" int bcos_finalize_explanation(const float* gxn, const float* x, const
     if (!gxn || !x || !std6 || (!weights_out && !contrib_out) || N <= 0 || H <= 0 || W <= 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_finalize_explanation: bad argument");
     if (Cx != (add_inverse ? 3 : 6) || Cpad < 6) return bcos_set_error(BCOS_E_INVAL, "bcos_finalize_explanation: bad channels");
-    hipLaunchKernelGGL(finalize_expl_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), gxn, x,
+    hipLaunchKernelGGL(finalize_expl_kernel, dim3(grid_pixels((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), gxn, x,
                        std6, weights_out, contrib_out, N, Cx, H * W, Cpad, add_inverse);
     return check_launch("finalize_expl_kernel");
 }

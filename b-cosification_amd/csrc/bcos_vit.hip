@@ -773,6 +773,7 @@ __global__ __launch_bounds__(TPB) void finalize_patches_kernel(const float* __re
     float sd[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) sd[c] = std6[c];
+    const bool vec = Cpad == 8 && (reinterpret_cast<uintptr_t>(gp) & 15) == 0;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
         const int64_t n = i / HW;
         const int64_t hw = i - n * HW;
@@ -780,10 +781,18 @@ __global__ __launch_bounds__(TPB) void finalize_patches_kernel(const float* __re
         const int pi = hh / ps, r = hh - pi * ps, pj = ww / ps, s = ww - pj * ps;
         const float* g = gp + ((((n * (H / ps) + pi) * gw + pj) * ps + r) * ps + s) * Cpad;
         const float* src = x + n * (int64_t)Cx * HW + hw;
+        float gv[6];
+        if (vec) {                                         // the usual padded pixel record: two 16-byte loads
+            const f32x4 a = reinterpret_cast<const f32x4*>(g)[0], b = reinterpret_cast<const f32x4*>(g)[1];
+            gv[0] = a[0]; gv[1] = a[1]; gv[2] = a[2]; gv[3] = a[3]; gv[4] = b[0]; gv[5] = b[1];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) gv[c] = g[c];
+        }
         float contrib = 0.f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const float wv = g[c] / sd[c];
+            const float wv = gv[c] / sd[c];
             float xv;
             if (add_inverse) xv = c < 3 ? src[(int64_t)c * HW] : 1.0f - src[(int64_t)(c - 3) * HW];
             else xv = src[(int64_t)c * HW];
@@ -1168,7 +1177,11 @@ extern "C" int bcos_finalize_explanation_patches(const float* gp, const float* x
         return bcos_set_error(BCOS_E_INVAL, "bcos_finalize_explanation_patches: bad argument");
     if (H % patch || W % patch || Cx != (add_inverse ? 3 : 6) || Cpad < 6)
         return bcos_set_error(BCOS_E_INVAL, "bcos_finalize_explanation_patches: bad geometry");
-    hipLaunchKernelGGL(finalize_patches_kernel, dim3(grid_elems((int64_t)N * H * W)), dim3(TPB), 0, STREAM(stream), gp, x,
+    // (one pixel per thread and pass: a grid of 16 workgroups per CU keeps enough independent loads in flight -- the 2 048 of
+    //  grid_elems ran 25 dependent passes per thread at ViT-Ti batch 256)
+    int64_t fb = ((int64_t)N * H * W + TPB - 1) / TPB;
+    if (fb > 256 * 64) fb = 256 * 64;
+    hipLaunchKernelGGL(finalize_patches_kernel, dim3((unsigned)fb), dim3(TPB), 0, STREAM(stream), gp, x,
                        std6, weights_out, contrib_out, N, Cx, H, W, patch, Cpad, add_inverse);
     return check_launch("finalize_patches_kernel");
 }
