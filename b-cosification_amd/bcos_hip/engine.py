@@ -58,19 +58,29 @@ def _pair(v):
 class _Conv:
     """Kernel-side view of one BcosifyConv2d (+ the BatchNormUncentered2d that follows it)."""
 
-    def __init__(self, conv, bn, cin_pad_to=4):
+    def __init__(self, conv, bn, cin_pad_to=4, main_path=False):
         from bcos.modules.bcosconv2d import BcosConv2d
         if not isinstance(conv, BcosConv2d):
             raise BcosHipError(f"engine: expected a B-cos conv, got {type(conv).__name__}")
         lin = conv.linear
-        if lin.groups != 1 or conv.max_out != 1:
-            raise BcosHipError("engine: groups > 1 / max_out > 1 layers run through the module path only")
+        if not _fusable(conv) or (conv.max_out != 1 and not main_path):      # (only a block's main path walks MaxOut layers)
+            raise BcosHipError("engine: this grouped / MaxOut layer runs through the module path only")
         if lin.padding_mode != "zeros":
             raise BcosHipError("engine: only zero padding")
         self.module, self.bn = conv, bn
         self.stride, self.padding, self.dilation = tuple(lin.stride), tuple(lin.padding), tuple(lin.dilation)
         self.k = tuple(lin.kernel_size)
-        self.cin, self.cout = lin.in_channels, lin.out_channels
+        # MaxOut (bcosconv2d.py:166-170; round 4): the contraction is max_out times as wide as the layer's output -- the launch takes
+        # the max over each unit's adjacent filters before the B-cos scale and keeps the scale at the winning filter (d out / d lin)
+        self.max_out = int(conv.max_out)
+        self.cin, self.cout_all = lin.in_channels, lin.out_channels
+        self.cout = lin.out_channels // self.max_out
+        self._wide = None
+        # grouped layers (ResNeXt-style `groups`, bcosconv2d.py:84-140; round 4): one grouped launch forward, one per parity class
+        # backward (bcos_tapconv_geom.groups) -- every group with its own patch norm, B-cos scale and transposed filters
+        self.groups = int(lin.groups)
+        if self.groups > 1 and not _grouped_ok(lin):
+            raise BcosHipError("engine: grouped layers need in_channels / groups and out_channels / groups to be multiples of 4")
         self.refresh()
 
     def fingerprint(self):
@@ -93,13 +103,13 @@ class _Conv:
         self.b = conv._b_value()
         # learnable-B variants take the general pow form even at B = 2 (bcosifyconv2d.py:91-98)
         self.force_pow = bool(conv._scaling()[1]) if hasattr(conv, "_scaling") else False
-        cin_pad = (-self.cin) % 4
+        cin_pad = (-self.cin) % 4 if self.groups == 1 else 0
         wk = w.permute(0, 2, 3, 1)
         if cin_pad:
             wk = torch.nn.functional.pad(wk, (0, cin_pad))
         self.w_fwd = ops.mark_static(wk.contiguous())     # rebuilt by refresh() when parameters change
         self.bias = bias.detach().contiguous() if bias is not None else None
-        self.dgrad = ops.DgradPlan(w, self.stride, self.padding, self.dilation)
+        self.dgrad = ops.DgradPlan(w, self.stride, self.padding, self.dilation, groups=self.groups)
         if bn is not None:
             if bn.training:
                 raise BcosHipError("engine: BatchNormUncentered2d must be in eval mode (call model.eval())")
@@ -107,8 +117,8 @@ class _Conv:
         else:
             self.ch_scale = self.ch_shift = None
         # may the multiplier of this layer be rebuilt from its activation (see _REBUILD_MAX_SHIFT)?  Decided once per refresh.
-        self.rebuild_ok = True
-        if self.ch_shift is not None and self.ch_scale is not None:
+        self.rebuild_ok = self.groups == 1          # (the rebuild takes ONE patch norm per pixel: a grouped layer has one per group)
+        if self.rebuild_ok and self.ch_shift is not None and self.ch_scale is not None:
             self.rebuild_ok = bool(float(self.ch_shift.abs().max()) <= _REBUILD_MAX_SHIFT * float(self.ch_scale.abs().median()))
         ops.publish_cached(self.w_fwd)      # (a refresh inside a sub-batch pass runs on that pass's side stream; the other one reads the result)
 
@@ -119,12 +129,12 @@ class _Conv:
     @property
     def k_fwd(self):
         """K of the forward contraction (its A operand is the layer input)."""
-        return self.cin * self.k[0] * self.k[1]
+        return (self.cin // self.groups) * self.k[0] * self.k[1]
 
     @property
     def k_dgrad(self):
         """largest K of the input-gradient launches (their A operand is the gradient w.r.t. this layer's `lin`)."""
-        return self.cout * self.k[0] * self.k[1]
+        return (self.cout_all // self.groups) * self.k[0] * self.k[1]
 
     def fwd(self, x, *, addend=None, relu=False, want_scale=False, gates=None, flags=0, track=None, keep_act=False):
         """-> (y, t).  `keep_act` (explanation state of a layer whose output stays alive anyway is cheaper to REBUILD than to
@@ -132,17 +142,96 @@ class _Conv:
         is not written; the returned `t` is then an _ActScale record (activation, patch norms, BN scale / shift) from which
         the consuming input-gradient launch rebuilds the multiplier (BCOS_EPI_MUL_FROM_ACT)."""
         gate = gates.pop(0) if (relu and gates is not None) else None
+        if self.max_out > 1:
+            return self._fwd_maxout(x, addend, relu, want_scale, gate, flags, track)
         rebuild = (keep_act and want_scale and relu and gate is None and addend is None and self.b == 2.0 and not self.force_pow
                    and self.rebuild_ok)
         y, t, nrm = ops.conv2d_fwd(x, self.w_fwd, stride=self.stride, padding=self.padding, dilation=self.dilation,
                                    bias=self.bias, b=self.b, mode=BCOS_CONV_EPS, ch_scale=self.ch_scale,
                                    ch_shift=self.ch_shift, addend=addend, relu=relu, relu_gate=gate,
                                    want_scale=want_scale and not rebuild, want_norm=rebuild,
-                                   flags=flags | (BCOS_EPI_FORCE_POW if self.force_pow else 0), track_absmax=track)
+                                   flags=flags | (BCOS_EPI_FORCE_POW if self.force_pow else 0), track_absmax=track,
+                                   groups=self.groups)
         self.last_gate = gate       # the replayed gate tensor, if any (else the output itself encodes the gate)
         if rebuild:
             t = _ActScale(y, nrm, self.ch_scale, self.ch_shift)
         return y, t
+
+
+    def _fwd_maxout(self, x, addend, relu, want_scale, gate, flags, track):
+        """MaxOut layer: one launch for contraction + unit maximum + B-cos scale (include/bcos_hip.h: bcos_epilogue.max_out), then the
+        BatchNorm fold, shortcut and ReLU as one elementwise launch (the fused MaxOut epilogue carries none of them).  -> (activation,
+        narrow multiplier = BN scale x ReLU gate, the gate in its low mantissa bit where the consumer reads it there); the WIDE
+        multiplier -- the scale at each unit's winning filter -- is left in `take_wide()` for the layer's own input-gradient launch."""
+        N, H, W, _ = x.shape
+        Ho, Wo = self.out_hw(H, W)
+        g = ops.fwd_geom(N, H, W, self.w_fwd.shape[3], self.cout_all, self.k[0], self.k[1], self.stride[0], self.stride[1],
+                         self.padding[0], self.padding[1], self.dilation[0], self.dilation[1])
+        y = torch.empty((N, Ho, Wo, self.cout), device=x.device, dtype=torch.float32)
+        t_wide = torch.empty((N, Ho, Wo, self.cout_all), device=x.device, dtype=torch.float32) if want_scale else None
+        ops.tapconv(x, self.w_fwd, g, out=y, scale_out=t_wide, bias=self.bias, bcos_mode=BCOS_NONE if self.b == 1.0 else BCOS_CONV_EPS,
+                    b=self.b, flags=BCOS_EPI_FORCE_POW if self.force_pow else 0, max_out=self.max_out)
+        csc = self.ch_scale if self.ch_scale is not None else torch.ones(self.cout, device=x.device)
+        own_relu = relu and gate is None
+        if addend is not None:
+            act = ops.channel_affine_add(y, csc, self.ch_shift if self.ch_shift is not None else torch.zeros_like(csc), addend,
+                                         relu=own_relu)
+        elif self.ch_scale is not None or own_relu:
+            act = ops.channel_affine(y, csc, self.ch_shift, relu=own_relu)
+        else:
+            act = y
+        open_ = None
+        if relu:
+            open_ = (gate > 0) if gate is not None else (act > 0)
+            if gate is not None:
+                act = act * open_
+        self.last_gate = gate
+        t = None
+        if want_scale:
+            t = csc.expand_as(act)
+            if open_ is not None and (flags & BCOS_EPI_SCALE_GATE_LSB):       # gate in the low mantissa bit, a closed gate stores exactly 0
+                t = torch.where(open_, (t.contiguous().view(torch.int32) | 1).view(torch.float32), torch.zeros((), device=x.device))
+            elif open_ is not None:
+                t = t * open_
+            t = t.contiguous()
+        self._wide = t_wide
+        if track and ops.DEFAULT_TRACK_ABSMAX and _l_mode() == "f16x2":
+            ops.ensure_absmax(act)
+        return act, t
+
+    def take_wide(self):
+        """the wide multiplier the last fwd() of a MaxOut layer left behind (None for every other layer)"""
+        w, self._wide = self._wide, None
+        return w
+
+    def expand(self, gl, wide):
+        """gradient w.r.t. the layer's (narrow) output, already times its narrow multiplier -> gradient w.r.t. the contraction's
+        columns: every unit's value at its winning filter, times the B-cos scale there (bcos_maxout_expand)"""
+        if self.max_out == 1:
+            return gl
+        N, H, W, Cn = gl.shape
+        out = ops.maxout_expand(gl.reshape(-1, Cn), wide.view(-1, Cn * self.max_out), self.max_out).view(N, H, W, Cn * self.max_out)
+        return ops.ensure_absmax(out) if (self.k_dgrad >= ops.F16X2_MIN_K and ops.DEFAULT_TRACK_ABSMAX and _l_mode() == "f16x2") else out
+
+
+def _grouped_ok(lin) -> bool:
+    """can a grouped convolution be a fused node of the plan?  (the grouped launches move 16-byte pieces of every group's channels)"""
+    return lin.groups == 1 or ((lin.in_channels // lin.groups) % 4 == 0 and (lin.out_channels // lin.groups) % 4 == 0)
+
+
+def _l_mode() -> str:
+    from . import lib as _lib
+    return _lib.get_contraction_mode()
+
+
+def _fusable(conv) -> bool:
+    """can this B-cos convolution be a fused node of the plan?  Grouped: group widths multiples of four; MaxOut: 2 or 4 filters per
+    unit (what the fused epilogue takes), ungrouped."""
+    lin = conv.linear
+    mo = getattr(conv, "max_out", 1)
+    if mo == 1:
+        return _grouped_ok(lin)
+    return mo in (2, 4) and lin.groups == 1 and lin.out_channels % 4 == 0
 
 
 class _ActScale:
@@ -167,21 +256,25 @@ class _Block:
 
     def __init__(self, block):
         names = [n for n in ("conv1", "conv2", "conv3") if hasattr(block, n)]
-        # Blocks with grouped or MaxOut convolutions (ResNeXt-style `groups`, bcosconv2d.py:84-140, 166-170) are HYBRID nodes of the plan:
-        # the block runs layer by layer on the nn.Module path (one fused HIP launch per layer: bcos/modules/_hipfn.py) and its input
+        # Grouped convolutions (ResNeXt-style `groups`, bcosconv2d.py:84-140) and MaxOut ones (:166-170, 2 or 4 filters per unit) on the
+        # main path are fused nodes like any other since round 4 (_Conv.groups, _Conv._fwd_maxout).  What the fused launches do not
+        # take -- group widths that are not multiples of four, other unit sizes, grouped MaxOut, a MaxOut shortcut -- makes the block a
+        # HYBRID node: it runs layer by layer on the nn.Module path (one fused HIP launch per layer: bcos/modules/_hipfn.py) and its input
         # gradient comes from that path's own backward; the blocks around it stay fused.
-        self.hybrid = any(getattr(getattr(block, n), "linear", None) is not None and
-                          (getattr(block, n).linear.groups != 1 or getattr(getattr(block, n), "max_out", 1) != 1) for n in names)
+        def needs_module_path(m, main):
+            if getattr(m, "linear", None) is None:
+                return False
+            return not _fusable(m) or (not main and getattr(m, "max_out", 1) != 1)       # (MaxOut shortcuts: module path)
+        self.hybrid = any(needs_module_path(getattr(block, n), True) for n in names)
         ds0 = getattr(block, "downsample", None)
         if ds0 is not None:
-            self.hybrid = self.hybrid or any(getattr(m, "linear", None) is not None and (m.linear.groups != 1 or getattr(m, "max_out", 1) != 1)
-                                             for m in ds0.children())
+            self.hybrid = self.hybrid or any(needs_module_path(m, False) for m in ds0.children())
         self.module = block
         self.k_first = 0
         if self.hybrid:
             self.convs, self.shortcut, self.pool, self.shortcut_pool, self.relu = [], None, 0, 0, True
             return
-        self.convs = [_Conv(getattr(block, n), getattr(block, n.replace("conv", "bn"))) for n in names]
+        self.convs = [_Conv(getattr(block, n), getattr(block, n.replace("conv", "bn")), main_path=True) for n in names]
         self.k_first = self.convs[0].k_fwd
         relus = [getattr(block, r) for r in ("relu", "relu1", "relu2", "relu3") if hasattr(block, r)]
         self.relu = all(isinstance(r, nn.ReLU) for r in relus)
@@ -355,7 +448,7 @@ class ResNetEngine:
         xn = ops.prep_input(x, mean, std, cpad=8, add_inverse=add_inverse, want_absmax=True)
         gates = list(gates) if gates is not None else None
         if gates is not None and any(b.hybrid for b in self.blocks):
-            raise BcosHipError("engine: replayed ReLU gates are not available for networks with grouped / MaxOut blocks")
+            raise BcosHipError("engine: replayed ReLU gates are not available for networks with a block on the nn.Module path (hybrid node)")
         st = dict(x=x, add_inverse=add_inverse, H=x.shape[2], W=x.shape[3], stem_ts=[], stem_hws=[], blocks=[]) if keep else None
         a = xn
         need = lambda k: k >= ops.F16X2_MIN_K      # noqa: E731  will the reader of a tensor use its per-pixel maxima?
@@ -384,13 +477,14 @@ class ResNetEngine:
                     st["blocks"].append(rec)
                 continue
             h = inp
-            ts, hws = [], []
+            ts, hws, tw = [], [], []
             for ci, c in enumerate(blk.convs[:-1]):
                 hws.append((h.shape[1], h.shape[2]))
                 pooled_next = blk.pool and ci == len(blk.convs) - 2              # a pool sits between this conv and the next
                 h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates, keep_act=not pooled_next and not _STORE_T,
                              track=need(blk.convs[ci + 1].k_fwd) and not pooled_next)
                 ts.append(t)
+                tw.append(c.take_wide())
             pre_pool_hw = (h.shape[1], h.shape[2])
             if blk.pool:
                 h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0)
@@ -413,12 +507,13 @@ class ResNetEngine:
             out, t = blk.convs[-1].fwd(h, addend=idn, relu=blk.relu, want_scale=keep, gates=gates, track=need(k_next),
                                        flags=BCOS_EPI_SCALE_GATE_LSB if (keep and blk.relu and not _GATE_TENSOR) else 0)
             ts.append(t)
+            tw.append(blk.convs[-1].take_wide())
             if keep:
                 gate_t = None
                 if _GATE_TENSOR and blk.relu:       # development switch: separate gate tensor instead of the bit
                     pinned = blk.convs[-1].last_gate
                     gate_t = pinned if pinned is not None else out
-                rec.update(ts=ts, td=td, gated=bool(blk.relu), gate_t=gate_t, hws=hws, pre_pool_hw=pre_pool_hw)
+                rec.update(ts=ts, tw=tw, td=td, gated=bool(blk.relu), gate_t=gate_t, hws=hws, pre_pool_hw=pre_pool_hw)
                 st["blocks"].append(rec)
             cur = out
         if self.head_kind in ("attnpool", "attn_unpool"):
@@ -713,6 +808,9 @@ class ResNetEngine:
             convs = blk.convs
             for ci in range(len(convs) - 1, 0, -1):
                 h, w = rec["hws"][ci]
+                gl = convs[ci].expand(gl, rec["tw"][ci])          # (MaxOut layers: to the contraction's width; anything else: as is)
+                if consume:
+                    rec["tw"][ci] = None
                 if blk.pool and ci == len(convs) - 1:
                     # anti-aliasing pool between conv(ci-1) and conv(ci): gradient w.r.t. the pooled tensor, then
                     # the pool's input gradient times the scale of conv(ci-1)
@@ -725,6 +823,9 @@ class ResNetEngine:
                                              **_mul_kwargs(rec["ts"][ci - 1]))
                 if consume:
                     rec["ts"][ci - 1] = None
+            gl = convs[0].expand(gl, rec["tw"][0])
+            if consume:
+                rec["tw"][0] = None
             consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc, blk.shortcut_pool)
         # block 0 reads the stem pool output: raw gradient, pool backward (* t of the last stem conv), then the stem
         H0, W0 = st["blocks"][0]["in_hw"]
@@ -779,7 +880,7 @@ class _Consumer:
             if self.sc_pool:
                 pooled = self.shortcut_conv.dgrad.run(self.g_sc, H // self.sc_pool, W // self.sc_pool, track_absmax=False)
                 addend = ops.avgpool2d_bwd(pooled, H, W, self.sc_pool, self.sc_pool, 0)
-            elif _SUB_ADDEND and self.shortcut_conv.dgrad.subsampled and not self.conv.dgrad.has_empty:
+            elif _SUB_ADDEND and self.shortcut_conv.dgrad.subsampled and not self.conv.dgrad.has_empty and self.conv.dgrad.groups == 1:
                 # 1x1 / stride-s shortcut: its input gradient is zero off the s-grid -- hand the grid pixels alone to the main
                 # branch's launch (bcos_epilogue.addend_sub) instead of scattering them into a zero-filled full-size tensor
                 # (ResNet-50: 1.44 GB of zero fill per step and as much again read back as an addend)

@@ -384,23 +384,32 @@ def fwd_geom(N, H, W, Cin, Cout, kh, kw, sh, sw, ph, pw, dh=1, dw=1):
 
 def conv2d_fwd(x, w, *, stride=(1, 1), padding=(0, 0), dilation=(1, 1), bias=None, b=2.0, mode=BCOS_CONV_EPS,
                ch_scale=None, ch_shift=None, addend=None, relu=False, relu_gate=None, want_scale=False,
-               want_norm=False, out=None, scale_out=None, flags=0, track_absmax=None):
-    """Fused B-cos convolution.  x [N,H,W,Cin], w [Cout,kh,kw,Cin] -> y [N,Ho,Wo,Cout] (+ scale, norm)."""
+               want_norm=False, out=None, scale_out=None, flags=0, track_absmax=None, groups=1):
+    """Fused B-cos convolution.  x [N,H,W,Cin], w [Cout,kh,kw,Cin / groups] -> y [N,Ho,Wo,Cout] (+ scale, norm; grouped layers
+    (bcosconv2d.py:84-140): every group has its own patch norm -- norm [N,Ho,Wo,groups] -- and the launch emits no operand
+    maxima: `track_absmax` then costs one extra pass)."""
     N, H, W, Cin = x.shape
     Cout, kh, kw, Cin_w = w.shape
-    if Cin_w != Cin:
-        raise BcosHipError(f"conv2d_fwd: weight has {Cin_w} input channels, activation has {Cin}")
-    g = fwd_geom(N, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1])
+    G = int(groups)
+    if Cin_w * G != Cin or Cout % G:
+        raise BcosHipError(f"conv2d_fwd: weight has {Cin_w} input channels per group ({G} groups), activation has {Cin}")
+    g = fwd_geom(N, H, W, Cin_w, Cout // G, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1])
+    want_track = track_absmax
+    if G > 1:
+        g.update(groups=G, a_pitch=Cin, out_pitch=Cout, norm_pitch=G)
+        track_absmax = False
     if out is None:
         out = torch.empty((N, g["P"], g["Q"], Cout), device=x.device, dtype=torch.float32)
     if want_scale and scale_out is None:
         scale_out = torch.empty_like(out)
-    norm = torch.empty((N, g["P"], g["Q"]), device=x.device, dtype=torch.float32) if want_norm else None
+    norm = torch.empty((N, g["P"], g["Q"]) + ((G,) if G > 1 else ()), device=x.device, dtype=torch.float32) if want_norm else None
     if float(b) == 1.0:
         mode = BCOS_NONE
     tapconv(x, w, g, out=out, scale_out=scale_out, norm_out=norm, bias=bias, ch_scale=ch_scale,
             ch_shift=ch_shift, addend=addend, bcos_mode=mode, b=b, relu=relu, relu_gate=relu_gate, flags=flags,
             track_absmax=track_absmax)
+    if G > 1 and (DEFAULT_TRACK_ABSMAX if want_track is None else want_track) and _l.get_contraction_mode() == "f16x2":
+        ensure_absmax(out)
     return out, scale_out, norm
 
 
@@ -445,14 +454,23 @@ class DgradPlan:
     r0 = (rho + p) % s; with th = U-1-u the gathered g coordinate is i + dh0 + th, dh0 = (rho+p-r0)/s - U + 1.
     """
 
-    def __init__(self, w_oihw: torch.Tensor, stride, padding, dilation=(1, 1)):
-        Cout, Cin, kh, kw = w_oihw.shape
+    def __init__(self, w_oihw: torch.Tensor, stride, padding, dilation=(1, 1), groups: int = 1):
+        """`groups` > 1 (w_oihw [Cout, Cin / groups, kh, kw], the layout of nn.Conv2d): every class is ONE grouped launch
+        (bcos_tapconv_geom.groups) -- group g contracts its Cout / groups gradient channels with its own transposed filters and
+        writes its Cin / groups columns; Cin below is the layer's total input width."""
+        Cout, Cin_g, kh, kw = w_oihw.shape
+        G = int(groups)
+        if G < 1 or Cout % G:
+            raise BcosHipError("dgrad: out_channels must be divisible by groups")
+        if G > 1 and ((Cout // G) % 4 or Cin_g % 4):
+            raise BcosHipError("dgrad: grouped layers need in_channels / groups and out_channels / groups to be multiples of 4")
+        Cin = Cin_g * G
         sh, sw = stride
         ph, pw = padding
         if (dilation[0] != 1 or dilation[1] != 1) and (sh != 1 or sw != 1):
             raise BcosHipError("dgrad with dilation > 1 and stride > 1 is not supported")
         self.stride, self.padding, self.dilation = (sh, sw), (ph, pw), tuple(dilation)
-        self.Cin, self.Cout, self.k = Cin, Cout, (kh, kw)
+        self.Cin, self.Cout, self.k, self.groups = Cin, Cout, (kh, kw), G
         self.classes = []     # (rho_h, rho_w, TH, TW, dh0, dw0, weight [Cin,TH,TW,Cout] or None)
         for rh in range(sh):
             rs_h, dh0, step_h = self._taps(rh, sh, ph, kh, dilation[0])
@@ -461,8 +479,12 @@ class DgradPlan:
                 if len(rs_h) == 0 or len(rs_w) == 0:
                     self.classes.append((rh, rw, 0, 0, 0, 0, 1, 1, None))
                     continue
-                sub = w_oihw[:, :, rs_h][:, :, :, rs_w]                    # [Cout,Cin,TH,TW]
-                wt = sub.permute(1, 2, 3, 0).contiguous()                   # [Cin,TH,TW,Cout]
+                sub = w_oihw[:, :, rs_h][:, :, :, rs_w]                    # [Cout,Cin/G,TH,TW]
+                if G == 1:
+                    wt = sub.permute(1, 2, 3, 0).contiguous()               # [Cin,TH,TW,Cout]
+                else:                                                       # [G Cin/G, TH, TW, Cout/G]: the groups' transposed filters, stacked
+                    cg = Cout // G
+                    wt = torch.cat([sub[k * cg:(k + 1) * cg].permute(1, 2, 3, 0) for k in range(G)], 0).contiguous()
                 mark_static(wt)     # a DgradPlan is built once per weight version (engine plan / WeightCache)
                 self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
         self.has_empty = any(c[8] is None for c in self.classes)
@@ -511,7 +533,7 @@ class DgradPlan:
         """s when this is the gradient of a 1x1 / stride-s / unpadded convolution (a ResNet shortcut): gx is zero off the
         s-grid and `run_compact` returns the grid pixels alone; 0 otherwise."""
         sh, sw = self.stride
-        return sh if (self.k == (1, 1) and sh == sw and sh > 1 and self.padding == (0, 0)) else 0
+        return sh if (self.k == (1, 1) and sh == sw and sh > 1 and self.padding == (0, 0) and self.groups == 1) else 0
 
     def run_compact(self, glin, **track):
         """glin [N,Ho,Wo,Cout] -> the non-zero pixels of gx as a dense [N,Ho,Wo,Cin] tensor (gx[:, ::s, ::s] of `run`), for
@@ -541,7 +563,15 @@ class DgradPlan:
         pitch = out.shape[-1]
         sh, sw = self.stride
         narrow = (self.Cin <= 8 and len(self.classes) > 1 and not self.has_empty and set(epi) <= {"addend", "mul"}
-                  and self.dilation == (1, 1))
+                  and self.dilation == (1, 1) and self.groups == 1)
+        G = self.groups
+        grouped = {}
+        if G > 1:       # one launch per class for all groups; grouped launches emit no operand maxima (one extra pass where asked for)
+            if Cout != self.Cout or pitch < self.Cin:
+                raise BcosHipError("dgrad: gradient / output width does not match the grouped layer")
+            grouped = dict(groups=G, a_pitch=Cout)
+            want_track = bool(track.get("track_absmax")) or bool(track.get("track_absmax2"))
+            track = dict(track_absmax=False, track_absmax2=False)
         if narrow and not _NO_D2S and pitch % 4 == 0 and pitch <= 16 and H % sh == 0 and W % sw == 0:
             # one launch for all parity classes: columns = (class, channel), depth-to-space output mapping
             wc, TH, TW, dh0, dw0 = self._depth_to_space(pitch)
@@ -574,10 +604,14 @@ class DgradPlan:
                 if not zero_filled:
                     self._empty_class(out, N, H, W, rh, rw, P, Q, epi)
                 continue
-            g = dict(N=N, H=Ho, W=Wo, C=Cout, P=P, Q=Q, in_sh=1, in_sw=1, dh0=dh0, dw0=dw0, dstep_h=step_h,
+            g = dict(N=N, H=Ho, W=Wo, C=Cout // G, P=P, Q=Q, in_sh=1, in_sw=1, dh0=dh0, dw0=dw0, dstep_h=step_h,
                      dstep_w=step_w, TH=TH, TW=TW, OH=H, OW=W, out_sh=sh, out_sw=sw, out_h0=rh, out_w0=rw,
-                     Cout=self.Cin, out_pitch=pitch)
+                     Cout=self.Cin // G, out_pitch=pitch, **grouped)
             tapconv(glin, wt, g, out=out, **epi, **track)
+        if G > 1 and want_track:
+            ensure_absmax(out)
+            if epi.get("out2") is not None:
+                ensure_absmax(epi["out2"])
         return out
 
     def _empty_class(self, out, N, H, W, rh, rw, P, Q, epi):

@@ -64,6 +64,8 @@ class ResNetTrainPlan:
                 return False, "learnable exponent"
             if isinstance(m.linear, NormedConv2d):
                 return False, "native unit-norm layers"
+            if getattr(c, "groups", 1) != 1:
+                return False, "grouped layers keep the per-layer path"
         return True, ""
 
     def parameters(self) -> List[nn.Parameter]:

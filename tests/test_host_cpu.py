@@ -691,7 +691,8 @@ def test_fused_engine_plan_with_grouped_and_maxout_blocks(monkeypatch):
     x = synth.synthetic_images(2, size=64)
     ref = net.explain_batch(x)                                      # no engine attached: autograd over the modules
     eng = engine.ResNetEngine(net)
-    assert [b.hybrid for b in eng.blocks] == [False, False, False, True, False, True, False, False]
+    assert not any(b.hybrid for b in eng.blocks)          # grouped and MaxOut convolutions: fused nodes since round 4
+    assert eng.blocks[3].convs[0].groups == 2 and eng.blocks[5].convs[1].max_out == 2
     out = eng.explain(x)
     assert rel(out["logits"], ref["logits"]) <= 1e-5
     assert torch.equal(out["prediction"], ref["prediction"])
@@ -702,8 +703,21 @@ def test_fused_engine_plan_with_grouped_and_maxout_blocks(monkeypatch):
     assert rel(eng.explain(x, targets=tgt)["contribution_map"], net.explain_batch(x, targets=tgt)["contribution_map"]) <= 1e-4
     multi = eng.explain_targets(x, torch.tensor([[1, 2], [3, 4]]))  # the kept forward is walked twice (retain_graph)
     assert rel(multi["contribution_maps"][:, 1], eng.explain(x, targets=torch.tensor([2, 4]))["contribution_map"]) <= 1e-5
+    # what the fused launches do not take stays a hybrid node on the nn.Module path (here: three filters per unit); replayed gates
+    # are refused for such a network
+    with torch.no_grad():
+        blk = net.model.layer4[1]
+        blk.conv1 = BcosifyConv2d(512, 512, 3, 1, 1, max_out=3, b=2)
+        blk.conv1.linear.weight.copy_(torch.randn(blk.conv1.linear.weight.shape, generator=g) * (3.0 / (9 * 512) ** 0.5))
+    net = net.eval()
+    net.explanation_mode().find_expl_modules()          # (the context caches its module list on first use, like the reference: common.py:347-384)
+    ref3 = net.explain_batch(x)
+    eng3 = engine.ResNetEngine(net)
+    assert [b.hybrid for b in eng3.blocks] == [False] * 7 + [True]
+    out3 = eng3.explain(x)
+    assert rel(out3["logits"], ref3["logits"]) <= 1e-5 and rel(out3["contribution_map"], ref3["contribution_map"]) <= 1e-4
     with pytest.raises(Exception, match="gates"):
-        eng.explain(x, gates=[torch.ones(1)])
+        eng3.explain(x, gates=[torch.ones(1)])
 
 
 def test_synthetic_recipe_is_deterministic():
