@@ -667,10 +667,20 @@ class ResNetEngine:
         for an `attn_unpool` head -- and returns d(scalar to explain) / d(head output) of the same shape; the input-gradient
         pass then starts from it instead of from a one-hot coordinate (the zero-shot text logit of
         interpretability/analyses/text_localisation.py:68-126: bcos_hip.clip_head.zeroshot_attribution)."""
-        S = self._n_subbatches(x) if (gates is None and cotangent is None and self.head_kind != "attn_unpool") else 1
+        S = self.n_streams(x, cotangent=cotangent)
         if S > 1:
-            return self._explain_subbatches(x, targets, want_weights, S)
+            return self._explain_subbatches(x, targets, want_weights, S, gates)
         return self._explain_one(x, targets, want_weights, gates, cotangent, self._absmax_arena)
+
+    def n_streams(self, x, cotangent=None) -> int:
+        """On how many sub-batch streams does explain(x, ...) run?  `subbatch_streams` (default 2) for a batch of at least that many
+        times _SUBBATCH_MIN images on a device -- replayed `gates` included: they are cut along the batch like the images -- and ONE
+        in exactly three cases: a `cotangent` callable (it is handed the head output of the whole batch at once), the `attn_unpool`
+        head (its output is token-major), and a pass that is being captured into a hipGraph (unless BCOS_CAPTURE_STREAMS).  Results
+        do not depend on the answer: an image's bits are a function of the image alone."""
+        if cotangent is not None or self.head_kind == "attn_unpool":
+            return 1
+        return self._n_subbatches(x)
 
     def _side_for(self, x, S):
         """(streams, arenas) of the sub-batch passes on x's device, created on first use.  Everything the passes cache lazily --
@@ -691,7 +701,7 @@ class ResNetEngine:
             return 1
         return S
 
-    def _explain_subbatches(self, x, targets, want_weights, S):
+    def _explain_subbatches(self, x, targets, want_weights, S, gates=None):
         """explain() of S contiguous sub-batches on S side streams, written into ONE set of output tensors (see
         _SUBBATCH_STREAMS).  The side streams start behind the caller's stream and the caller's stream waits for them."""
         streams, arenas = self._side_for(x, S)
@@ -709,7 +719,8 @@ class ResNetEngine:
             st = streams[i]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                out = self._explain_one(x[lo:hi], None if tg is None else tg[lo:hi], want_weights, None, None, arenas[i],
+                sub_gates = None if gates is None else [gt[lo:hi] for gt in gates]       # (replayed ReLU decisions: [N, ...] like the activations)
+                out = self._explain_one(x[lo:hi], None if tg is None else tg[lo:hi], want_weights, sub_gates, None, arenas[i],
                                         outs=(wts[lo:hi] if want_weights else None, contrib[lo:hi]))
             parts.append(out)
         for st in streams[:S]:

@@ -1967,6 +1967,32 @@ def test_training_gradients_with_ragged_output_widths(lib):
             assert rel(m.linear.bias.grad, bd.grad) <= 1e-5, what
 
 
+def test_replayed_gates_run_on_the_sub_batch_streams_too(lib):
+    """engine.explain(x, gates=...) cuts the replayed ReLU decisions along the batch like the images (round 4: the gate-pinned path
+    used to fall back to one stream silently); n_streams() states on how many streams a call runs; the bits of every output are the
+    same on one stream and on two."""
+    from bcos_hip import engine, synth
+    net = synth.build_bcosified_resnet("resnet18").to(DEV).eval()
+    with torch.no_grad():
+        synth.calibrate(net, synth.synthetic_images(8).to(DEV))
+    eng = engine.attach(net)
+    try:
+        x = synth.synthetic_images(64, seed=3, size=64).to(DEV)
+        gates = _oracle_gates(net, x, "resnet18")
+        assert eng.n_streams(x) == 2 and eng.n_streams(x[:8]) == 1 and eng.n_streams(x, cotangent=lambda e: e) == 1
+        two = eng.explain(x, gates=[g.clone() for g in gates])
+        eng.subbatch_streams = 1
+        assert eng.n_streams(x) == 1
+        one = eng.explain(x, gates=[g.clone() for g in gates])
+        for k in ("logits", "dynamic_linear_weights", "contribution_map"):
+            assert torch.equal(one[k], two[k]), k
+        free = eng.explain(x)
+        assert rel(one["logits"], free["logits"]) <= 1e-6          # (the forward values of open gates are the same; closed ones are zero either way)
+    finally:
+        eng.subbatch_streams = 2
+        engine.detach(net)
+
+
 def test_engine_with_grouped_and_maxout_blocks(lib):
     """Networks with grouped / MaxOut B-cos convolutions in the fused plan -- both as fused nodes since round 4 (grouped launches forward
     and backward; MaxOut inside the contraction's epilogue, its gradient routed to the winning filters by bcos_maxout_expand): same
