@@ -1851,6 +1851,9 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
 #ifndef D_EARLY
 #define D_EARLY 1                 // 1 = the prologue's DMA pieces go out between the loads of the operand maxima and their use, no workgroup barrier ahead of the loop (every walk but the channel-chunk-major one); 0 = behind the scales and a barrier (round 3)
 #endif
+#ifndef D_A_AUX
+#define D_A_AUX 0                 // cache policy bits of the A operand's LDS-DMA loads (2 = non-temporal: measured in round 4)
+#endif
 #ifndef D_SCHED
 #define D_SCHED 1                 // 1 = pin the issue order of a step's fragment reads / matrix / vector instructions (sched_group_barrier)
 #endif
@@ -2014,7 +2017,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
         }
     };
     auto piece_a = [&](int j, int slot_off, unsigned voff, int soff) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, BCOS_LDS_PTR(lds + slot_off + a_dst0 + j * 1024), 16, (int)voff, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, BCOS_LDS_PTR(lds + slot_off + a_dst0 + j * 1024), 16, (int)voff, soff, 0, D_A_AUX);
     };
     auto issue_a = [&](auto walk_c, int ks, int slot_off) {
         walk_a(walk_c, ks, [&](int j, unsigned voff, int soff) { piece_a(j, slot_off, voff, soff); });
