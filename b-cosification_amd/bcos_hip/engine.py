@@ -51,6 +51,41 @@ _SUBBATCH_MIN = int(os.environ.get("BCOS_SUBBATCH_MIN", "32"))
 _CAPTURE_STREAMS = bool(os.environ.get("BCOS_CAPTURE_STREAMS"))      # experiment: keep the sub-batch streams inside a hipGraph capture (fork / join captured)
 
 
+def _drive(gen):
+    """run a pass generator to its end and hand back its return value"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
+def _interleave(gens, streams, arenas, device):
+    """Issue the passes of several sub-batches INTERLEAVED: generator i is resumed under stream i and maxima arena i, one block at a
+    time, round-robin.  Issued one whole pass after the other, the second stream's first launch is queued only when the host is done
+    with the first pass -- 4 ms into a ResNet-50 step that takes 23 (scripts/probe/host_bound_probe.py); back-to-back steps hide that
+    behind the previous step, an isolated call does not.  The launches of a pass and their order on its stream are unchanged."""
+    n = len(gens)
+    results, live = [None] * n, list(range(n))
+    prev = ops._ARENA
+    for i in range(n):
+        with torch.cuda.stream(streams[i]):          # (the zero fill of pass i's maxima is ordered on pass i's stream)
+            arenas[i].reset(device)
+    try:
+        while live:
+            for i in list(live):
+                ops.set_absmax_arena(arenas[i])
+                with torch.cuda.stream(streams[i]):
+                    try:
+                        next(gens[i])
+                    except StopIteration as stop:
+                        results[i] = stop.value
+                        live.remove(i)
+    finally:
+        ops.set_absmax_arena(prev)
+    return results
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
@@ -439,6 +474,11 @@ class ResNetEngine:
 
     # ------------------------------------------------------------------------------------------------
     def _run_forward(self, x: torch.Tensor, keep: bool, gates=None):
+        return _drive(self._run_forward_gen(x, keep, gates))
+
+    def _run_forward_gen(self, x: torch.Tensor, keep: bool, gates=None):
+        """The forward pass as a generator: it yields (nothing) behind the stem and behind every block, so that the passes of several
+        sub-batches can be ISSUED interleaved (see _interleave); its return value is (head output, kept state)."""
         if x.dim() != 4 or x.shape[1] not in (3, 6):
             raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
         ops.require_device(x, "bcos_hip.engine")
@@ -468,6 +508,7 @@ class ResNetEngine:
         if keep:
             st["a0_hw"] = (a.shape[1], a.shape[2])
         del a
+        yield
         for bi, blk in enumerate(self.blocks):
             inp = cur
             rec = dict(in_hw=(inp.shape[1], inp.shape[2])) if keep else None
@@ -477,6 +518,7 @@ class ResNetEngine:
                 cur = self._hybrid_forward(blk, inp, rec, need(k_after))
                 if keep:
                     st["blocks"].append(rec)
+                yield
                 continue
             h = inp
             ts, hws, tw = [], [], []
@@ -518,6 +560,7 @@ class ResNetEngine:
                 rec.update(ts=ts, tw=tw, td=td, gated=bool(blk.relu), gate_t=gate_t, hws=hws, pre_pool_hw=pre_pool_hw)
                 st["blocks"].append(rec)
             cur = out
+            yield
         if self.head_kind in ("attnpool", "attn_unpool"):
             emb = self._attnpool_forward(cur, st) if self.head_kind == "attnpool" else self._attn_unpool_forward(cur, st)
             if keep:
@@ -645,11 +688,10 @@ class ResNetEngine:
             x = x.detach()
             x = x if x.is_contiguous() else x.contiguous()
             N = x.shape[0]
-            parts = []
             for i in range(S):
                 streams[i].wait_stream(cur)
-                with torch.cuda.stream(streams[i]), ops.absmax_arena(arenas[i], x.device):
-                    parts.append(self._run_forward(x[(N * i) // S:(N * (i + 1)) // S], keep=False)[0])
+            parts = [r[0] for r in _interleave([self._run_forward_gen(x[(N * i) // S:(N * (i + 1)) // S], keep=False) for i in range(S)],
+                                               streams, arenas, x.device)]
             for st in streams[:S]:
                 cur.wait_stream(st)
             for t in parts:
@@ -715,16 +757,14 @@ class ResNetEngine:
         contrib = torch.empty((N, H, W), device=x.device, dtype=torch.float32)
         bounds = [(N * i) // S for i in range(S + 1)]
         tg = None if targets is None else targets.to(device=x.device, dtype=torch.int64).contiguous()
-        parts = []
+        gens = []
         for i in range(S):
             lo, hi = bounds[i], bounds[i + 1]
-            st = streams[i]
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                sub_gates = None if gates is None else [gt[lo:hi] for gt in gates]       # (replayed ReLU decisions: [N, ...] like the activations)
-                out = self._explain_one(x[lo:hi], None if tg is None else tg[lo:hi], want_weights, sub_gates, None, arenas[i],
-                                        outs=(wts[lo:hi] if want_weights else None, contrib[lo:hi]))
-            parts.append(out)
+            streams[i].wait_stream(cur)
+            sub_gates = None if gates is None else [gt[lo:hi] for gt in gates]       # (replayed ReLU decisions: [N, ...] like the activations)
+            gens.append(self._explain_one_gen(x[lo:hi], None if tg is None else tg[lo:hi], want_weights, sub_gates, None,
+                                              outs=(wts[lo:hi] if want_weights else None, contrib[lo:hi])))
+        parts = _interleave(gens, streams, arenas, x.device)
         for st in streams[:S]:
             cur.wait_stream(st)
         res = {}
@@ -738,21 +778,26 @@ class ResNetEngine:
 
     def _explain_one(self, x, targets, want_weights, gates, cotangent, arena, outs=None):
         with ops.absmax_arena(arena, x.device):
-            logits, st = self._run_forward(x, keep=True, gates=gates)
-            if cotangent is not None:
-                if self.head_kind not in ("attnpool", "attn_unpool"):
-                    raise BcosHipError("engine: `cotangent` needs an attention-pool head (CLIP image encoder)")
-                g_head = cotangent(logits)
-                if tuple(g_head.shape) != tuple(logits.shape):
-                    raise ValueError(f"cotangent: expected shape {tuple(logits.shape)}, got {tuple(g_head.shape)}")
-                wts, contrib = self._backward(x, st, None, want_weights, consume=True, g_head=g_head, outs=outs)
-                return dict(logits=logits, embedding=logits, dynamic_linear_weights=wts, contribution_map=contrib)
-            if self.head_kind == "attn_unpool":
-                raise BcosHipError("engine: an attn_unpool head has no class logits of its own: pass `cotangent` "
-                                   "(bcos_hip.clip_head.zeroshot_attribution builds it from the text embeddings)")
-            pred, _ = ops.argmax_rows(logits)
-            cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
-            wts, contrib = self._backward(x, st, cls, want_weights, consume=True, outs=outs)
+            return _drive(self._explain_one_gen(x, targets, want_weights, gates, cotangent, outs))
+
+    def _explain_one_gen(self, x, targets, want_weights, gates, cotangent, outs=None):
+        """forward + input-gradient pass of one (sub-)batch as a generator (yields behind every block of either pass); the caller owns
+        the stream and the maxima arena the launches are issued under"""
+        logits, st = yield from self._run_forward_gen(x, keep=True, gates=gates)
+        if cotangent is not None:
+            if self.head_kind not in ("attnpool", "attn_unpool"):
+                raise BcosHipError("engine: `cotangent` needs an attention-pool head (CLIP image encoder)")
+            g_head = cotangent(logits)
+            if tuple(g_head.shape) != tuple(logits.shape):
+                raise ValueError(f"cotangent: expected shape {tuple(logits.shape)}, got {tuple(g_head.shape)}")
+            wts, contrib = yield from self._backward_gen(x, st, None, want_weights, consume=True, g_head=g_head, outs=outs)
+            return dict(logits=logits, embedding=logits, dynamic_linear_weights=wts, contribution_map=contrib)
+        if self.head_kind == "attn_unpool":
+            raise BcosHipError("engine: an attn_unpool head has no class logits of its own: pass `cotangent` "
+                               "(bcos_hip.clip_head.zeroshot_attribution builds it from the text embeddings)")
+        pred, _ = ops.argmax_rows(logits)
+        cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
+        wts, contrib = yield from self._backward_gen(x, st, cls, want_weights, consume=True, outs=outs)
         return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
                     contribution_map=contrib)
 
@@ -782,6 +827,9 @@ class ResNetEngine:
         return out
 
     def _backward(self, x, st, cls, want_weights: bool, consume: bool, g_head=None, outs=None):
+        return _drive(self._backward_gen(x, st, cls, want_weights, consume, g_head, outs))
+
+    def _backward_gen(self, x, st, cls, want_weights: bool, consume: bool, g_head=None, outs=None):
         """Input-gradient pass of logit[cls[n]] for every image n over the state `st` of a kept forward; `consume` frees
         each saved multiplier as soon as it has been used (last / only pass over this state)."""
         # A "consumer" owns the g_lin tensors of the layers that read some activation X and can therefore
@@ -809,6 +857,7 @@ class ResNetEngine:
                     rec["hybrid"] = None
                 gx = gx.permute(0, 2, 3, 1)
                 consumer = _RawConsumer(gx if gx.is_contiguous() else gx.contiguous())
+                yield
                 continue
             # v = d logit / d out_b;  G_main = v * t_last (bn scale, ReLU gate and s of the block's last conv),
             # G_sc = v * gate(out_b) [* t_d]  for the shortcut
@@ -840,6 +889,7 @@ class ResNetEngine:
             if consume:
                 rec["tw"][0] = None
             consumer = _Consumer(convs[0], gl, blk.shortcut, G_sc, blk.shortcut_pool)
+            yield
         # block 0 reads the stem pool output: raw gradient, pool backward (* t of the last stem conv), then the stem
         H0, W0 = st["blocks"][0]["in_hw"]
         g_pool, _ = consumer.run(H0, W0, t_main=None, td=None, gated=False, track=False)

@@ -281,6 +281,11 @@ class ViTEngine:
 
     # --------------------------------------------------------------------------------------------------------
     def _run_forward(self, x, keep):
+        from .engine import _drive
+        return _drive(self._run_forward_gen(x, keep))
+
+    def _run_forward_gen(self, x, keep):
+        """the forward pass as a generator (yields behind the embedding and behind every encoder block: engine._interleave)"""
         if x.dim() != 4 or x.shape[1] not in (3, 6):
             raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
         ops.require_device(x, "bcos_hip.vit_engine")
@@ -314,6 +319,7 @@ class ViTEngine:
         ops.add_rows_bcast(tok, self._posemb(gh, gw, x.device))
         st = dict(x=x, add_inverse=add_inverse, N=N, T=T, t_embed=t_embed, blocks=[], stem=stem_st, tok_hw=(H, W)) if keep else None
         cur = tok
+        yield
         for blk in self.blocks:
             if _LN_FUSED:
                 rstd1, _ = blk["ln1"].stats(cur, False)
@@ -334,6 +340,7 @@ class ViTEngine:
             if keep:
                 st["blocks"].append(dict(rstd1=rstd1, qkv=qkv, stats=stats, t_out=t_out, rstd2=rstd2, t1=t1, t2=t2))
             cur = x2
+            yield
         if self.gap_reorder and _LN_FUSED:
             st_h = self.head_ln.stats(cur, True)
             rstd_h = st_h[0]
@@ -356,14 +363,16 @@ class ViTEngine:
             st.update(rstd_h=rstd_h, t_head=t_head)
         return logits, st
 
-    def _sub_batches(self, x, fn):
-        """Run fn(sub_batch_index, lo, hi, arena) for contiguous sub-batches on side streams (bcos_hip/engine.py: _SUBBATCH_STREAMS:
-        images are independent, the sub-batches fill each other's launch tails) or once on the caller's stream."""
-        from .engine import _SUBBATCH_MIN, _CAPTURE_STREAMS
+    def _sub_batches(self, x, make_gen):
+        """Run the pass generator make_gen(lo, hi) for contiguous sub-batches on side streams, their launches issued interleaved
+        (bcos_hip/engine.py: _SUBBATCH_STREAMS, _interleave: images are independent, the sub-batches fill each other's launch tails)
+        or once on the caller's stream."""
+        from .engine import _SUBBATCH_MIN, _CAPTURE_STREAMS, _drive, _interleave
         N = x.shape[0]
         S = min(int(self.subbatch_streams), N // _SUBBATCH_MIN)
-        if S <= 1 or not x.is_cuda or N < S * _SUBBATCH_MIN or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_STREAMS):
-            return [fn(0, N, self._absmax_arena)]
+        if S <= 1 or not x.is_cuda or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_STREAMS):
+            with _absmax_policy(), ops.absmax_arena(self._absmax_arena, x.device):
+                return [_drive(make_gen(0, N))]
         # everything the passes cache lazily (refreshed plans, constants, the positional-embedding table) is brought up to date here,
         # on the caller's stream, which every side stream then waits for (ADVICE r03); streams are per device
         self._ensure_fresh()
@@ -377,11 +386,10 @@ class ViTEngine:
             self._side[key] = ([torch.cuda.Stream(device=x.device) for _ in range(S)], [ops.AbsmaxArena() for _ in range(S)])
         streams, arenas = self._side[key]
         cur = torch.cuda.current_stream()
-        outs = []
         for i in range(S):
             streams[i].wait_stream(cur)
-            with torch.cuda.stream(streams[i]):
-                outs.append(fn((N * i) // S, (N * (i + 1)) // S, arenas[i]))
+        with _absmax_policy():
+            outs = _interleave([make_gen((N * i) // S, (N * (i + 1)) // S) for i in range(S)], streams, arenas, x.device)
         for st in streams[:S]:
             cur.wait_stream(st)
         for o in outs:
@@ -395,9 +403,9 @@ class ViTEngine:
         x = x.detach()
         x = x if x.is_contiguous() else x.contiguous()
 
-        def one(lo, hi, arena):
-            with _absmax_policy(), ops.absmax_arena(arena, x.device):
-                return self._run_forward(x[lo:hi], keep=False)[0]
+        def one(lo, hi):
+            logits, _ = yield from self._run_forward_gen(x[lo:hi], keep=False)
+            return logits
         outs = self._sub_batches(x, one)
         return outs[0] if len(outs) == 1 else torch.cat(outs)
 
@@ -407,16 +415,19 @@ class ViTEngine:
         x = x if x.is_contiguous() else x.contiguous()
         tg = None if targets is None else targets.to(device=x.device, dtype=torch.int64).contiguous()
 
-        def one(lo, hi, arena):
-            with _absmax_policy(), ops.absmax_arena(arena, x.device):
-                return self._explain(x[lo:hi], None if tg is None else tg[lo:hi], want_weights)
+        def one(lo, hi):
+            return self._explain_gen(x[lo:hi], None if tg is None else tg[lo:hi], want_weights)
         outs = self._sub_batches(x, one)
         if len(outs) == 1:
             return outs[0]
         return {k: (torch.cat([o[k] for o in outs]) if outs[0][k] is not None else None) for k in outs[0]}
 
     def _explain(self, x, targets, want_weights):
-        logits, st = self._run_forward(x, keep=True)
+        from .engine import _drive
+        return _drive(self._explain_gen(x, targets, want_weights))
+
+    def _explain_gen(self, x, targets, want_weights):
+        logits, st = yield from self._run_forward_gen(x, keep=True)
         N, T = st["N"], st["T"]
         pred, _ = ops.argmax_rows(logits)
         cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
@@ -454,6 +465,7 @@ class ViTEngine:
                 g_h = ops.matmul_nt(_mx(g_v.view(N * T, -1), g_v), blk["wv_t"], track_absmax=False)
                 g_x, g_lin = blk["ln1"].bwd(g_h, rec["rstd1"], addend=g_x1, mul2=t_prev, want_out=bi > 0, want_out2=True)
             st["blocks"][bi] = None
+            yield
         gp = ops.matmul_nt(_mx(g_lin), self.embed_wt, track_absmax=False)      # [N*T, p*p*cpad] patch-major input gradient
         _, std = self._consts(x.device)
         if self.stem:
