@@ -732,7 +732,7 @@ class ResNetEngine:
         stream, which every side stream then waits for: no sub-batch reads a cache another one is still producing."""
         self._ensure_fresh()
         self._consts(x.device)
-        key = str(x.device)
+        key = (str(x.device), int(getattr(self, "lane", 0)))     # (`lane`: a second set of streams / arenas for a caller that keeps two batches in flight: scripts/probe/two_in_flight_probe.py)
         if self._side is None:
             self._side = {}
         if key not in self._side or len(self._side[key][0]) < S:
