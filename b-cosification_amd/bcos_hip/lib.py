@@ -219,7 +219,7 @@ def reset_options():
 
 # include/bcos_hip.h: enum bcos_option
 OPTIONS = {"tail_split": 0, "d_one_wg": 1, "epi_generic": 2, "h2_loop": 3, "patch": 4, "patch_wide": 5, "h2_tile": 6, "h2_tall": 7,
-           "h2_tall_min": 8, "attention_f32": 9, "split_limit": 10, "patch_levels": 13, "h2_wide_cost": 14}
+           "h2_tall_min": 8, "attention_f32": 9, "split_limit": 10, "lds_min_kb": 11, "patch_levels": 13, "h2_wide_cost": 14}
 
 
 def set_option(name: str, value: int):

@@ -41,7 +41,7 @@ constexpr OptSpec OPT_SPECS[BCOS_OPT_COUNT] = {
     {2 * 256 * 512, 0, TWO31},       // H2_TALL_MIN
     {0, 0, 1},                       // ATTENTION_F32
     {TWO31, 1 << 16, TWO31},         // SPLIT_LIMIT
-    {0, 0, 0},                       // reserved
+    {0, 0, 160},                     // LDS_MIN_KB
     {0, 0, 0},                       // reserved
     {1, 0, 1},                       // PATCH_LEVELS
     {7, 4, 8},                       // H2_WIDE_COST

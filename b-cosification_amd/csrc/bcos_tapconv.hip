@@ -3064,6 +3064,7 @@ int launch_d(const KArgs& base, bool norm, hipStream_t stream) {
         const size_t want = (size_t)160 * 1024 / (size_t)one - 512;
         if (want > lds) lds = want;
     }
+    if (const int64_t kb = bcos_option(BCOS_OPT_LDS_MIN_KB)) { if ((size_t)kb * 1024 > lds) lds = (size_t)kb * 1024; }
     const dim3 grid((unsigned)(p.n_big + p.n_small)), block(NTHREADS);
     static std::atomic<size_t> lds_hw[2];
     auto launch = [&](auto k, int which) -> hipError_t {
@@ -3102,6 +3103,7 @@ int launch_p(const KArgs& base, bool norm, hipStream_t stream) {
     lds = (lds + 15) & ~(size_t)15;
     p.lvl_off = (int)lds;              // row levels + level mask of a tile (tile_body_p), kept across the tile's epilogues
     lds += BM + 16;
+    if (const int64_t kb = bcos_option(BCOS_OPT_LDS_MIN_KB)) { if ((size_t)kb * 1024 > lds) lds = (size_t)kb * 1024; }
     const dim3 grid((unsigned)p.n_big), block(NTHREADS);
     static std::atomic<size_t> lds_hw[2];
     auto launch = [&](auto k, int which) -> hipError_t {

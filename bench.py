@@ -43,6 +43,7 @@ ARCHS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_16BIT_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (the pipe the split contractions execute on)
+SPEC_SCLK_MHZ = 2400.0             # MI355X_MICROARCH.md: the shader clock the dense MFMA peaks are quoted at
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6 290 GB/s measured with a float4 copy)
 PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3}     # matrix instructions per algorithmic fp32 product, by contraction mode
 DTYPES = {
@@ -74,6 +75,7 @@ def parse():
                          "measured 1 %% SLOWER than eager launches on ROCm 7.2 (6 667 vs 6 745 images/s), hence off")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: do not bracket the contraction launches with HIP events (roofline fields become null)")
+    ap.add_argument("--no-telemetry", action="store_true", help="diagnostic: do not sample shader clock / socket power during the timed region")
     ap.add_argument("--contraction", choices=("f16x2", "bf16x3", "f32"), default=None,
                     help="arithmetic of the contraction kernel (include/bcos_hip.h: bcos_set_contraction_mode); default: "
                          "the library default (f16x2 = row-scaled 2-way fp16 split, 3 products, fp32 accumulation)")
@@ -330,6 +332,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    # shader clock and socket power DURING the timed region (a child process samples every ~10 ms: bcos_hip/telemetry.py) -- the part
+    # is power / clock limited under these kernels, so the roofline is also stated at the clock it actually sustained.  Started ahead
+    # of the model build: the child has found its SMI source long before the timed region begins.
+    sampler = None
+    if rank == 0 and not args.no_telemetry:
+        from bcos_hip import telemetry
+        sampler = telemetry.Sampler(index=local_rank, interval=0.01).start()
+
     # -- model + data, resident in HBM --------------------------------------------------------------------------
     spec = ARCHS[args.arch]
     if not spec["explain"]:
@@ -379,6 +389,9 @@ def main():
             pipe.submit({k: out[k] for k in keys}, copy_out=False)      # (overlaps the next step's compute; drained inside the timed region)
         return out
 
+    if sampler is not None:
+        sampler.wait_ready()
+
     for w in range(args.warmup):
         if w == 0 and not args.no_kernel_events and args.warmup > 1:
             # the first warm-up step runs the way the event-carrying timed steps do (every launch on the caller's stream, over the whole
@@ -403,6 +416,7 @@ def main():
     # one HIP event per step boundary on the caller's stream (the engine's side streams are joined into it at the end of every
     # pass): per-step times -> median / min, and the two execution modes of the timed region reported apart
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    wall0 = time.time()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -426,6 +440,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    wall1 = time.time()
+    clocks = sampler.window(wall0, wall1) if sampler is not None else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -514,6 +530,20 @@ def main():
                           f"{gflop_step:.1f} GFLOP per step, SURVEY.md section 8(d): 17.22 GFLOP/image forward+explanation) / the time of "
                           "the contraction launches measured with HIP events on the launch stream, against that pipe's dense peak; "
                           "vs_fp32_mfma_peak = algorithmic TFLOP/s / 157.3 (the fp32 matrix pipe the contraction does not run on)"))
+
+    # the same fraction at the clock the part sustained during the timed region: the pipe's dense peak scales with the shader
+    # clock (PEAK_16BIT_MFMA_TFLOPS is quoted at SPEC_SCLK_MHZ); `frac` itself stays priced at the specification clock
+    if clocks is not None:
+        sclk = clocks.get("sclk_mhz_mean")
+        roofline.update(sclk_mhz_mean=sclk, sclk_mhz_min=clocks.get("sclk_mhz_min"), sclk_mhz_max=clocks.get("sclk_mhz_max"),
+                        power_w_mean=clocks.get("power_w_mean"), power_w_max=clocks.get("power_w_max"),
+                        spec_sclk_mhz=SPEC_SCLK_MHZ, clock_samples=clocks.get("samples"), clock_source=clocks.get("source"),
+                        frac_at_measured_clock=(round(roofline["frac"] * SPEC_SCLK_MHZ / sclk, 4) if sclk else None),
+                        clock_note=("sclk_mhz_mean / power_w_mean: samples taken every ~10 ms by a child process over the WHOLE timed region "
+                                    "(all steps, both execution modes); frac_at_measured_clock = frac x spec clock / mean sampled clock, i.e. "
+                                    "the matrix pipe's peak re-priced at the clock the part sustained"))
+        if roofline["by_bound"]["mfma"].get("frac_of_executing_pipe") is not None and sclk:
+            roofline["by_bound"]["mfma"]["frac_at_measured_clock"] = round(roofline["by_bound"]["mfma"]["frac_of_executing_pipe"] * SPEC_SCLK_MHZ / sclk, 4)
 
     result = {
         "metric": ("images/sec (fwd+explanation) B-cos ResNet-50 @224, batch 256, 1/2/4/8 MI355X"

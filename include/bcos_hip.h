@@ -241,8 +241,13 @@ enum bcos_option {
     BCOS_OPT_ATTENTION_F32 = 9,   /* 0 (default): attention on the f16 matrix pipe (exact 2-way splits); 1: fp32 MFMA kernel       */
     BCOS_OPT_SPLIT_LIMIT = 10,    /* bytes of A from which a split-operand launch is cut into batch chunks (default and maximum
                                      2^31: the 32-bit buffer offsets); tests lower it to exercise the chunked path                */
-    BCOS_OPT_RESERVED_11 = 11,    /* reserved (value fixed at 0; any other value is BCOS_E_INVAL): numbers of the balanced wave-block      */
-    BCOS_OPT_RESERVED_12 = 12,    /* schedule and the 2-way split of K, both measured in round 4 and not adopted          */
+    BCOS_OPT_LDS_MIN_KB = 11,     /* 0 (default): off; n (<= 160): the split-f16 LDS-DMA / input-patch launches request at least n KiB of
+                                     LDS -- > 80 keeps two workgroups of such a launch off one CU while a launch with a smaller request
+                                     can still sit beside it (round 5 probe of matrix-bound beside bandwidth-bound launches:
+                                     scripts/probe/corun2_probe.py, profiles/r05_corun_probe.txt).  (Number of an option measured in
+                                     round 4 and not adopted.)                                                                            */
+    BCOS_OPT_RESERVED_12 = 12,    /* reserved (value fixed at 0; any other value is BCOS_E_INVAL): number of the 2-way split of K,
+                                     measured in round 4 and not adopted                                                  */
     BCOS_OPT_PATCH_LEVELS = 13,   /* 1 (default): the input-patch loop runs one pass per operand-scale level present in a tile
                                      (bcos_operands.a_imgmax); 0: level 0 only, the single per-image scale of ABI v6 -- kept so that
                                      tests can show what the ladder is for (rows far darker than their image lose accuracy)      */

@@ -54,7 +54,8 @@ int main(void) {
       EXPECT(bcos_set_option(BCOS_OPT_COUNT, 0), BCOS_E_INVAL);
       EXPECT(bcos_set_option(BCOS_OPT_PATCH, 2), BCOS_E_INVAL);
       EXPECT(bcos_set_option(BCOS_OPT_SPLIT_LIMIT, 16), BCOS_E_INVAL);
-      EXPECT(bcos_set_option(BCOS_OPT_RESERVED_11, 1), BCOS_E_INVAL);
+      EXPECT(bcos_set_option(BCOS_OPT_RESERVED_12, 1), BCOS_E_INVAL);
+      EXPECT(bcos_set_option(BCOS_OPT_LDS_MIN_KB, 161), BCOS_E_INVAL);
       EXPECT(bcos_set_option(BCOS_OPT_H2_WIDE_COST, 3), BCOS_E_INVAL);
       EXPECT(bcos_get_option(BCOS_OPT_PATCH, NULL), BCOS_E_INVAL);
       EXPECT(bcos_get_option(BCOS_OPT_COUNT, &v), BCOS_E_INVAL);
