@@ -25,24 +25,37 @@ __all__ = ["BatchNormUncentered2d", "batch_norm_uncentered_2d"]
 
 
 class _ChannelAffineFn(Function):
+    """eval mode: y = x * scale + shift, scale = weight / sqrt(running_var + eps).  `weight` / `bias` are passed along so that they
+    receive their gradients (sum gy x / std, sum gy) when they are trained with the statistics frozen, like the reference's eval
+    branch (:46-60), whose weight and bias stay in the autograd graph."""
+
     @staticmethod
-    def forward(ctx, x, scale, shift):
+    def forward(ctx, x, scale, shift, weight, bias, rstd):
         _hipfn.require_hip(x, "BatchNormUncentered2d")
         xh = _hipfn.to_nhwc(x)
         c = xh.shape[-1]
         if c % 4 != 0:
             raise _hipfn.BcosHipError(f"BatchNormUncentered2d HIP kernel needs C % 4 == 0 (got {c})")
-        ctx.save_for_backward(scale)
+        need_w = weight is not None and ctx.needs_input_grad[3]
+        ctx.save_for_backward(scale, rstd, *((xh,) if need_w else ()))
         y_cl, y = _hipfn.empty_cl(x.shape[0], c, x.shape[2], x.shape[3], x.device)
         ops.channel_affine(xh, scale, shift, out=y)
         return y_cl
 
     @staticmethod
     def backward(ctx, gy):
-        (scale,) = ctx.saved_tensors
-        g_cl, g = _hipfn.empty_cl(gy.shape[0], gy.shape[1], gy.shape[2], gy.shape[3], gy.device)
-        ops.channel_affine(_hipfn.to_nhwc(gy), scale, None, out=g)
-        return g_cl, None, None
+        scale, rstd = ctx.saved_tensors[:2]
+        gh = _hipfn.to_nhwc(gy)
+        c = gh.shape[-1]
+        g_cl = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            g_cl, g = _hipfn.empty_cl(gy.shape[0], gy.shape[1], gy.shape[2], gy.shape[3], gy.device)
+            ops.channel_affine(gh, scale, None, out=g)
+        if ctx.needs_input_grad[3]:
+            gw = ops.colsum(gh.reshape(-1, c), ctx.saved_tensors[2].view(-1, c)) * rstd
+        if ctx.needs_input_grad[4]:
+            gb = ops.colsum(gh.reshape(-1, c))
+        return g_cl, None, None, gw, gb, None
 
 
 class _BatchStatsFn(Function):
@@ -104,11 +117,10 @@ def batch_norm_uncentered_2d(input, running_var, weight=None, bias=None, trainin
                 running_var.copy_((1 - momentum) * running_var + momentum * stats[0])
         return out
     assert running_var is not None, "running_var must be defined in eval mode"
-    scale = 1.0 / (running_var.detach() + eps).sqrt()
-    if weight is not None:
-        scale = weight.detach() * scale
+    rstd = 1.0 / (running_var.detach() + eps).sqrt()
+    scale = rstd if weight is None else weight.detach() * rstd
     shift = bias.detach().contiguous() if bias is not None else None
-    return _ChannelAffineFn.apply(input, scale.contiguous(), shift)
+    return _ChannelAffineFn.apply(input, scale.contiguous(), shift, weight, bias if isinstance(bias, torch.Tensor) else None, rstd)
 
 
 class BatchNormUncentered2d(nn.BatchNorm2d, DetachableModule):

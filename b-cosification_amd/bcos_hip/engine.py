@@ -18,6 +18,7 @@ dynamic scale s = |lin| / ||patch|| held constant -- exactly what `.detach()` do
 """
 import math
 import os
+import threading
 from typing import Dict, List, Optional
 
 import torch
@@ -48,7 +49,6 @@ _REBUILD_MAX_SHIFT = float(os.environ.get("BCOS_REBUILD_MAX_SHIFT", "0.5"))
 # results bit-identical (an image's result does not depend on what else is in its batch: test_determinism_and_batch_independence).
 _SUBBATCH_STREAMS = int(os.environ.get("BCOS_SUBBATCH_STREAMS", "2"))
 _SUBBATCH_MIN = int(os.environ.get("BCOS_SUBBATCH_MIN", "32"))
-_CAPTURE_STREAMS = bool(os.environ.get("BCOS_CAPTURE_STREAMS"))      # experiment: keep the sub-batch streams inside a hipGraph capture (fork / join captured)
 
 
 def _drive(gen):
@@ -60,18 +60,29 @@ def _drive(gen):
         return stop.value
 
 
+_ISSUING = threading.Lock()        # ops._ARENA is a module global switched per generator resume: ONE pass sequence is issued at a time
+
+
 def _interleave(gens, streams, arenas, device):
     """Issue the passes of several sub-batches INTERLEAVED: generator i is resumed under stream i and maxima arena i, one block at a
     time, round-robin.  Issued one whole pass after the other, the second stream's first launch is queued only when the host is done
     with the first pass -- 4 ms into a ResNet-50 step that takes 23 (scripts/probe/host_bound_probe.py); back-to-back steps hide that
-    behind the previous step, an isolated call does not.  The launches of a pass and their order on its stream are unchanged."""
+    behind the previous step, an isolated call does not.  The launches of a pass and their order on its stream are unchanged.
+    Threading: like the reference's `explanation_mode` context (bcos/common.py:347-384 mutates module state) this is single-threaded by
+    design -- the maxima arena is a module global of bcos_hip.ops; a second Python thread entering while a pass sequence is being
+    issued raises instead of corrupting both passes silently.
+    Errors: when one pass generator raises, the others are closed and the caller's stream is ordered behind every side stream BEFORE
+    the exception propagates -- the half-issued launches write into output tensors the caller may free or reuse."""
+    if not _ISSUING.acquire(blocking=False):
+        raise BcosHipError("engine: explain() / forward() re-entered from a second thread while a pass sequence is being issued "
+                           "(the fused plan is single-threaded, like the reference's explanation_mode context)")
     n = len(gens)
     results, live = [None] * n, list(range(n))
     prev = ops._ARENA
-    for i in range(n):
-        with torch.cuda.stream(streams[i]):          # (the zero fill of pass i's maxima is ordered on pass i's stream)
-            arenas[i].reset(device)
     try:
+        for i in range(n):
+            with torch.cuda.stream(streams[i]):          # (the zero fill of pass i's maxima is ordered on pass i's stream)
+                arenas[i].reset(device)
         while live:
             for i in list(live):
                 ops.set_absmax_arena(arenas[i])
@@ -81,8 +92,16 @@ def _interleave(gens, streams, arenas, device):
                     except StopIteration as stop:
                         results[i] = stop.value
                         live.remove(i)
+    except BaseException:
+        for g in gens:
+            g.close()
+        cur = torch.cuda.current_stream()
+        for st in streams[:n]:
+            cur.wait_stream(st)
+        raise
     finally:
         ops.set_absmax_arena(prev)
+        _ISSUING.release()
     return results
 
 
@@ -720,7 +739,7 @@ class ResNetEngine:
         """On how many sub-batch streams does explain(x, ...) run?  `subbatch_streams` (default 2) for a batch of at least that many
         times _SUBBATCH_MIN images on a device -- replayed `gates` included: they are cut along the batch like the images -- and ONE
         in exactly three cases: a `cotangent` callable (it is handed the head output of the whole batch at once), the `attn_unpool`
-        head (its output is token-major), and a pass that is being captured into a hipGraph (unless BCOS_CAPTURE_STREAMS).  Results
+        head (its output is token-major), and a pass that is being captured into a hipGraph.  Results
         do not depend on the answer: an image's bits are a function of the image alone."""
         if cotangent is not None or self.head_kind == "attn_unpool":
             return 1
@@ -732,7 +751,7 @@ class ResNetEngine:
         stream, which every side stream then waits for: no sub-batch reads a cache another one is still producing."""
         self._ensure_fresh()
         self._consts(x.device)
-        key = (str(x.device), int(getattr(self, "lane", 0)))     # (`lane`: a second set of streams / arenas for a caller that keeps two batches in flight: scripts/probe/two_in_flight_probe.py)
+        key = str(x.device)
         if self._side is None:
             self._side = {}
         if key not in self._side or len(self._side[key][0]) < S:
@@ -741,7 +760,7 @@ class ResNetEngine:
 
     def _n_subbatches(self, x) -> int:
         S = min(int(self.subbatch_streams), x.shape[0] // _SUBBATCH_MIN)      # (fewer streams for batches under S x _SUBBATCH_MIN images)
-        if S <= 1 or not x.is_cuda or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_STREAMS):
+        if S <= 1 or not x.is_cuda or torch.cuda.is_current_stream_capturing():
             return 1
         return S
 

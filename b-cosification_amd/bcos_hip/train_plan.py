@@ -37,7 +37,7 @@ def _pad4(t: torch.Tensor) -> torch.Tensor:
 
 class _UnitState:
     __slots__ = ("x", "y", "scale", "norm", "w", "bias", "b", "force_pow", "mean", "rstd", "g", "act", "relu", "bn", "conv",
-                 "has_addend", "in_hw")
+                 "has_addend", "in_hw", "batch_stats")
 
 
 class ResNetTrainPlan:
@@ -66,6 +66,8 @@ class ResNetTrainPlan:
                 return False, "native unit-norm layers"
             if getattr(c, "groups", 1) != 1:
                 return False, "grouped layers keep the per-layer path"
+            if int(getattr(m, "max_out", 1)) != 1:          # (fused MaxOut nodes of the inference plan: the unit below takes cout_all for Cout)
+                return False, "MaxOut layers keep the per-layer path"
         return True, ""
 
     def parameters(self) -> List[nn.Parameter]:
@@ -79,9 +81,12 @@ class ResNetTrainPlan:
         return ps
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _unit_fwd(self, c, x, addend=None, relu=True, batch_stats=True) -> (torch.Tensor, _UnitState):
-        """one conv (+ BatchNorm with batch statistics) (+ shortcut) (+ ReLU) on NHWC tensors"""
+    def _unit_fwd(self, c, x, addend=None, relu=True) -> (torch.Tensor, _UnitState):
+        """one conv (+ BatchNorm) (+ shortcut) (+ ReLU) on NHWC tensors.  Every BatchNormUncentered2d follows ITS OWN train / eval state
+        (batchnorm_uncentered.py:80-99: `self.training or no running statistics`): a layer put in eval() under net.train() -- frozen-BN
+        fine-tuning -- normalises with its running variance, and neither running_var nor num_batches_tracked is touched."""
         conv, bn = c.module, c.bn
+        batch_stats = bn is not None and (bn.training or (bn.running_mean is None and bn.running_var is None))
         w, bias = conv._effective_weight_and_bias()
         wd = w.detach()
         wk = ops.mark_static(_pad4(wd.permute(0, 2, 3, 1)).contiguous())
@@ -100,7 +105,7 @@ class ResNetTrainPlan:
                     track_absmax=False)
         st = _UnitState()
         st.conv, st.bn, st.x, st.y, st.scale, st.norm, st.w, st.bias, st.b, st.force_pow = c, bn, x, y, scale, norm, wd, bias, b, force_pow
-        st.relu, st.has_addend, st.in_hw = relu, addend is not None, (H, W)
+        st.relu, st.has_addend, st.in_hw, st.batch_stats = relu, addend is not None, (H, W), batch_stats
         st.mean = st.rstd = st.g = None
         if bn is None:
             out = y
@@ -123,6 +128,8 @@ class ResNetTrainPlan:
             if bn.track_running_stats and bn.running_var is not None:
                 bn.running_var.copy_((1 - momentum) * bn.running_var + momentum * var)
         else:
+            if bn.running_var is None:
+                raise BcosHipError("train plan: a BatchNormUncentered2d in eval() needs its running_var")
             mean = torch.zeros(Cout, device=x.device)
             var = bn.running_var.detach()
         rstd = torch.rsqrt(var + bn.eps)
@@ -153,7 +160,7 @@ class ResNetTrainPlan:
                 grads[bn.weight] = sgx * st.rstd
             if has_b and bn.bias.requires_grad:
                 grads[bn.bias] = ops.colsum(g2)
-            if bn.detach:
+            if bn.detach or not st.batch_stats:       # the variance is a constant (explanation mode, or a layer in eval()): a per-channel scale
                 gy = ops.channel_affine(ga.contiguous(), st.g, None)
             else:
                 coef = (-(st.g * sgx) * st.rstd * st.rstd / m).contiguous()

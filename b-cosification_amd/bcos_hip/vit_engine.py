@@ -367,10 +367,10 @@ class ViTEngine:
         """Run the pass generator make_gen(lo, hi) for contiguous sub-batches on side streams, their launches issued interleaved
         (bcos_hip/engine.py: _SUBBATCH_STREAMS, _interleave: images are independent, the sub-batches fill each other's launch tails)
         or once on the caller's stream."""
-        from .engine import _SUBBATCH_MIN, _CAPTURE_STREAMS, _drive, _interleave
+        from .engine import _SUBBATCH_MIN, _drive, _interleave
         N = x.shape[0]
         S = min(int(self.subbatch_streams), N // _SUBBATCH_MIN)
-        if S <= 1 or not x.is_cuda or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_STREAMS):
+        if S <= 1 or not x.is_cuda or torch.cuda.is_current_stream_capturing():
             with _absmax_policy(), ops.absmax_arena(self._absmax_arena, x.device):
                 return [_drive(make_gen(0, N))]
         # everything the passes cache lazily (refreshed plans, constants, the positional-embedding table) is brought up to date here,

@@ -195,7 +195,7 @@ def run_percalib(rank, world, n_global):
 def run_percalib_stress(rank, world, n_global):
     """`n_global` ROUNDS of: every rank builds the network from its seed, calibrates it by itself and the ranks compare digests of
     every state-dict entry.  Since round 4 every statistic of synth.calibrate is summed in a fixed order by this repo's own kernel
-    (bcos_colsum_ordered), so every round must be clean; with torch's multi-block reductions about one process-calibration in a
+    (ops.channel_moments_ordered -> bcos_colsum_ws: partials added in workgroup order), so every round must be clean; with torch's multi-block reductions about one process-calibration in a
     hundred differed under this contention (profiles/r04_var_triage.txt)."""
     bad = []
     for rnd in range(max(1, n_global)):

@@ -74,7 +74,9 @@ def test_independently_calibrated_replicas_agree(tmp_path):
     statistics.  Round 4 traced it to torch's multi-block `var` reduction under GPU time-slicing -- 26 grossly wrong results
     (16 channels each, 12-85 % off) in 425 600 reductions of bit-identical, settled inputs behind a device synchronisation, against
     0 of 212 800 for this repo's fixed-order kernel (profiles/r04_var_triage.txt) -- and synth.calibrate now derives every statistic
-    with that kernel (bcos_colsum_ordered): the test is strict."""
+    with this repo's fixed-order reductions -- ops.channel_moments_ordered -> ops.colsum = bcos_colsum_ws: per-workgroup partials added in
+    workgroup order, the kernel the 3 200 process-calibrations of profiles/r04_percalib_stress.json ran (the triage measured its
+    single-pass sibling bcos_colsum_ordered) --: the test is strict."""
     v = _launch("percalib", 3, tmp_path)          # 8 ranks x 3 calibration passes each, no parameter broadcast
     assert v["replicas_identical"], json.dumps(v)
 

@@ -667,6 +667,76 @@ def test_training_plan_equals_per_layer_path_and_oracle_autograd(monkeypatch, ar
     assert train_plan.ResNetTrainPlan.supported(net._bcos_engine)[0]
 
 
+def test_training_plan_follows_each_batchnorms_own_mode_and_refuses_maxout(monkeypatch):
+    """(high) a BatchNormUncentered2d put in eval() under net.train() -- frozen-BN fine-tuning -- must be normalised with its
+    running variance by the training plan too, and its buffers must not move (the plan used batch statistics for every layer:
+    17 % off and 40 corrupted buffers); (medium) a network with a fused MaxOut node is outside the plan and trains per layer."""
+    import copy
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import engine, synth, train_plan
+    from bcos.modules.bcosifyconv2d import BcosifyConv2d
+    from bcos.modules.norms.uncentered_norms.batchnorm_uncentered import BatchNormUncentered2d
+    torch.manual_seed(0)
+    x = synth.synthetic_images(2, size=64)
+    target = torch.nn.functional.one_hot(torch.tensor([3, 500]), 1000).float()
+
+    def step(n):
+        xr = x.clone().requires_grad_(True)
+        logits = n(xr)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, target)
+        ps = [p for p in n.parameters() if p.requires_grad]
+        return logits, torch.autograd.grad(loss, [xr] + ps)
+
+    def boost(n):
+        with torch.no_grad():
+            for m in n.modules():
+                if hasattr(m, "linear") and isinstance(m.linear, nn.Conv2d):
+                    m.linear.weight.mul_(3.0)
+
+    # -- frozen BatchNorm: every BN in eval(), the rest of the network in train(); then a MIXED network (layer3 / layer4 frozen only)
+    for frozen in ("all", "late"):
+        net = synth.build_bcosified_resnet("resnet18")
+        boost(net)
+        ref = copy.deepcopy(net)
+        engine.attach(net)
+        for n in (net, ref):
+            n.train()
+            for name, m in n.named_modules():
+                if isinstance(m, BatchNormUncentered2d) and (frozen == "all" or "layer3" in name or "layer4" in name):
+                    m.eval()
+        before = {k: v.clone() for k, v in net.named_buffers()}
+        lp, gp = step(net)
+        lr, gr = step(ref)
+        assert type(lp.grad_fn).__name__ == "_TrainStepFnBackward" and type(lr.grad_fn).__name__ != "_TrainStepFnBackward"
+        assert rel(lp, lr) <= 1e-5, (frozen, rel(lp, lr))
+        for name, a, b in zip(["x"] + [n for n, p in net.named_parameters() if p.requires_grad], gp, gr):
+            assert rel(a, b) <= 1e-4, (frozen, name, rel(a, b))
+        changed = 0
+        for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+            assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 1e-5, (frozen, k)
+            changed += int(not torch.equal(a, before[k]))
+        assert (changed == 0) if frozen == "all" else (changed > 0)
+
+    # -- a fused MaxOut node (engine._Conv.max_out) is refused by the plan BEFORE any buffer has been touched
+    net = synth.build_bcosified_resnet("resnet18")
+    blk = net.model.layer3[1]
+    blk.conv2 = BcosifyConv2d(256, 256, 3, 1, 1, max_out=2, b=2)
+    boost(net)
+    ref = copy.deepcopy(net)
+    eng = engine.attach(net)
+    ok, why = train_plan.ResNetTrainPlan.supported(eng)
+    assert not ok and "MaxOut" in why
+    net.train(); ref.train()
+    lp, gp = step(net)
+    lr, gr = step(ref)
+    assert type(lp.grad_fn).__name__ != "_TrainStepFnBackward"
+    assert rel(lp, lr) <= 1e-5
+    for a, b in zip(gp, gr):
+        assert rel(a, b) <= 1e-4
+    for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 1e-5, k
+
+
 def test_fused_engine_plan_with_grouped_and_maxout_blocks(monkeypatch):
     """Round 3: networks with grouped or MaxOut B-cos convolutions (bcosconv2d.py:84-140, 166-170) attach to the
     fused plan too -- such a block is a hybrid node that runs layer by layer on the nn.Module path inside the plan (bcos_hip/engine.py:
