@@ -1074,11 +1074,46 @@ def localisation_grid():
                   f, indent=1)
 
 
+# --------------------------------------------------------------------------------------------------------
+# a21: execution trace of the imported reference ResNets (VERDICT r04 housekeeping): which B-cos convolution / norm / pool runs
+# in which order on which shapes.  The torchvision topology is a stand-in shared by reference import, oracle and product
+# (oracle/refimport.py), so a wiring error common to all three would pass every numeric test; what is recorded here comes from
+# running the reference's own ResNetBcos._forward_impl (bcos/models/standard_models.py:37-54) over those blocks with forward hooks,
+# and tests hold the ENGINE's launch list (bcos_hip/engine.py walks the blocks with its own logic) to it.
+# --------------------------------------------------------------------------------------------------------
+def resnet_exec_trace():
+    out = {}
+    for arch in ("resnet18", "resnet50"):
+        net = reference_resnet(arch)
+        names = {m: n for n, m in net.named_modules()}
+        trace, hooks = [], []
+
+        def hook(m, inp, res):
+            trace.append([names[m], type(m).__name__, list(inp[0].shape), list(res.shape)])
+
+        for m in net.modules():
+            if len(list(m.children())) == 0 or type(m).__name__ in ("BcosifyConv2d",):
+                if type(m).__name__ in ("BcosifyConv2d", "BatchNormUncentered2d", "AvgPool2d", "AdaptiveAvgPool2d", "ReLU", "LogitLayer", "Normalize"):
+                    hooks.append(m.register_forward_hook(hook))
+        with torch.no_grad():
+            net(synth.synthetic_images(1, seed=5))
+        for h in hooks:
+            h.remove()
+        out[arch] = trace
+        REPORT[f"trace/{arch}/calls"] = len(trace)
+    with open(os.path.join(HERE, "resnet_exec_trace.json"), "w") as f:
+        json.dump(dict(note="(module name, class, input shape, output shape) of every B-cos conv / norm / pool / ReLU call of ONE forward of the "
+                            "imported reference network on a [1, 6, 224, 224] image, in execution order (make_golden.py: resnet_exec_trace)",
+                       **out), f)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r18s", "r50", "vit", "vitc", "vit_train", "clip", "unpool", "zeroshot_attr", "loc"]
+    which = sys.argv[1:] or ["trace", "layers", "variants", "train", "train2", "train_r18", "inv", "r18", "r18s", "r50", "vit", "vitc", "vit_train", "clip", "unpool", "zeroshot_attr", "loc"]
     rep_path = os.path.join(HERE, "oracle_vs_reference.json")
     if os.path.exists(rep_path):
         REPORT.update(json.load(open(rep_path)))
+    if "trace" in which:
+        resnet_exec_trace()
     if "layers" in which:
         layer_cases()
     if "variants" in which:

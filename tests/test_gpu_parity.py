@@ -559,6 +559,15 @@ def test_rebuilt_multipliers_match_stored_ones(lib, golden_dir, monkeypatch):
     assert rel(rebuilt["contribution_map"], data["contribution_map"]) <= 2e-3
 
 
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_engine_launch_list_matches_reference_execution_trace_on_device(lib, golden_dir, monkeypatch, arch):
+    """a21: what the fused plan launches ON THE DEVICE against the execution trace recorded from the imported reference
+    (tests/golden/resnet_exec_trace.json; the checks are tests/test_host_cpu.py's, here without the emulated kernels)."""
+    import test_host_cpu as H
+    calls, pools = H._engine_exec_trace(arch, monkeypatch, device="cuda")
+    H.check_engine_against_reference_trace(arch, calls, pools, golden_dir)
+
+
 def test_resnet50_batch256_properties(lib):
     """BASELINE.json configs[1] at full size (batch 256): properties that do not need the CPU oracle at size --
     completeness of every explanation, agreement of a small sub-batch with the oracle, batch independence."""

@@ -737,6 +737,72 @@ def test_training_plan_follows_each_batchnorms_own_mode_and_refuses_maxout(monke
         assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 1e-5, k
 
 
+def _engine_exec_trace(arch, monkeypatch, device="cpu"):
+    """(name of the module a launch stands for, input shape NCHW, output shape NCHW) of every forward launch of the fused plan"""
+    from bcos_hip import engine, ops, synth
+    net = synth.build_bcosified_resnet(arch).to(device)
+    eng = engine.attach(net)
+    names = {m: n for n, m in net.named_modules()}
+    calls = []
+    orig = engine._Conv.fwd
+
+    def fwd(self, x, **kw):
+        y, t = orig(self, x, **kw)
+        nchw = lambda t4: [t4.shape[0], t4.shape[3], t4.shape[1], t4.shape[2]]      # noqa: E731
+        calls.append([names[self.module], names.get(self.bn), nchw(x), nchw(y), kw.get("addend") is not None, bool(kw.get("relu"))])
+        return y, t
+
+    monkeypatch.setattr(engine._Conv, "fwd", fwd)
+    pools = []
+    orig_pool = ops.avgpool2d_fwd
+    monkeypatch.setattr(ops, "avgpool2d_fwd", lambda a, k, s_, p_: (pools.append([list(a.shape), k, s_, p_]), orig_pool(a, k, s_, p_))[1])
+    with torch.no_grad():
+        eng.forward(synth.synthetic_images(1, seed=5).to(next(net.parameters()).device))
+    return calls, pools
+
+
+def check_engine_against_reference_trace(arch, calls, pools, golden_dir):
+    """the engine's launch list against tests/golden/resnet_exec_trace.json (recorded from the imported reference, make_golden.py)"""
+    ref = json.load(open(os.path.join(golden_dir, "resnet_exec_trace.json")))[arch]
+    convs = [r for r in ref if r[1] == "BcosifyConv2d"]
+    assert len(calls) == len(convs)
+    by_name = {c[0]: c for c in calls}
+    assert len(by_name) == len(calls)                                   # every B-cos convolution exactly once
+    for name, _, ishape, oshape in convs:
+        c = by_name[name]
+        cin_pad = c[2][1] - ishape[1]
+        assert 0 <= cin_pad < 4 and [c[2][0]] + c[2][2:] == [ishape[0]] + ishape[2:], (name, c[2], ishape)    # (the 6-channel input is padded to 8)
+        assert c[3] == oshape, (name, c[3], oshape)
+    # the norm folded into each launch is the module the reference calls right behind that convolution, on its output
+    for i, r in enumerate(ref):
+        if r[1] == "BcosifyConv2d" and i + 1 < len(ref) and ref[i + 1][1] == "BatchNormUncentered2d":
+            assert by_name[r[0]][1] == ref[i + 1][0] and ref[i + 1][2] == r[3], (r[0], by_name[r[0]][1], ref[i + 1][0])
+        elif r[1] == "BcosifyConv2d":
+            assert by_name[r[0]][1] is None, r[0]
+    # order: the engine launches a block's shortcut between its main-path convolutions; per block the main path keeps the reference's order,
+    # and the blocks follow each other as in the reference
+    main = lambda seq: [n for n in seq if "downsample" not in n]        # noqa: E731
+    assert main([c[0] for c in calls]) == main([r[0] for r in convs])
+    # residual adds and ReLUs: the last convolution of every block takes the shortcut; every main-path launch but the head has a ReLU
+    for c in calls:
+        last = c[0].endswith("conv3") or (arch == "resnet18" and c[0].endswith("conv2"))
+        assert c[4] == (last and "layer" in c[0]), c[0]
+        assert c[5] == ("downsample" not in c[0] and not c[0].endswith(".fc")), c[0]
+    pool_ref = [r for r in ref if r[1] == "AvgPool2d"]
+    assert len(pools) == len(pool_ref) == 1
+    assert [pools[0][0][0], pools[0][0][3], pools[0][0][1], pools[0][0][2]] == pool_ref[0][2]
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_engine_launch_list_matches_reference_execution_trace(monkeypatch, golden_dir, arch):
+    """a21 (VERDICT r04 'What's weak' 1): the torchvision ResNet topology file is shared by reference import, oracle and product.  The
+    reference-recorded execution trace pins what the ENGINE launches: every BcosifyConv2d of the reference exactly once, on the
+    reference's input / output shapes, with the reference's next module as the folded norm, main-path order, shortcut adds and ReLUs."""
+    cpu_emulation.install(monkeypatch)
+    calls, pools = _engine_exec_trace(arch, monkeypatch)
+    check_engine_against_reference_trace(arch, calls, pools, golden_dir)
+
+
 def test_fused_engine_plan_with_grouped_and_maxout_blocks(monkeypatch):
     """Round 3: networks with grouped or MaxOut B-cos convolutions (bcosconv2d.py:84-140, 166-170) attach to the
     fused plan too -- such a block is a hybrid node that runs layer by layer on the nn.Module path inside the plan (bcos_hip/engine.py:
