@@ -28,7 +28,7 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 BCOS_EPI_UNIT_NORM_W = 32
-ABI_VERSION = 7
+ABI_VERSION = 8
 TAPCONV_PARTS = 11
 
 
@@ -92,6 +92,9 @@ SIGNATURES = {
     "bcos_colsum_ws_floats": (C.c_int, [_L, _I, C.POINTER(C.c_int64)]),
     "bcos_colsum_ws": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "bcos_channel_axpby": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "bcos_bn_train_ws_floats": (C.c_int, [_L, _I, C.POINTER(C.c_int64)]),
+    "bcos_bn_batch_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _F, _P]),
+    "bcos_relu_bwd_colsums": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_weight_row_invnorm": (C.c_int, [_P, _P, _P, _I, _L, _P]),

@@ -902,6 +902,40 @@ def colsum(a2d, b2d=None, shift_a=None, shift_b=None):
     return out
 
 
+def _bn_ws(rows, Cc, device):
+    n = C.c_int64(0)
+    _l.check(_l.load().bcos_bn_train_ws_floats(rows, Cc, C.byref(n)), "bcos_bn_train_ws_floats")
+    return torch.empty((n.value,), device=device, dtype=torch.float32), n.value
+
+
+def bn_batch_stats(y2d, weight, eps, running_var=None, momentum=0.0):
+    """-> (mean, var, rstd, g = weight * rstd) of a BatchNormUncentered2d in training mode from ONE pass over y [rows, C]
+    (include/bcos_hip.h: bcos_bn_batch_stats); `running_var` is updated in place with `momentum`."""
+    rows, Cc = y2d.shape
+    ws, n = _bn_ws(rows, Cc, y2d.device)
+    mean, var, rstd, g = (torch.empty((Cc,), device=y2d.device, dtype=torch.float32) for _ in range(4))
+    _l.check(_l.load().bcos_bn_batch_stats(_dev(y2d, "y"), _dev(weight, "weight"), _dev(running_var, "running_var"), _dev(mean, "mean"),
+                                           _dev(var, "var"), _dev(rstd, "rstd"), _dev(g, "g"), _dev(ws, "workspace"), n, rows, Cc, float(eps),
+                                           float(momentum), _stream()), "bcos_bn_batch_stats")
+    if running_var is not None:          # written through its pointer: tell torch (plans keyed on tensor versions re-read it, engine._Conv.fingerprint)
+        torch.autograd.graph.increment_version(running_var)
+    return mean, var, rstd, g
+
+
+def relu_bwd_colsums(g2d, act2d, y2d, rstd=None, gvec=None, want_sg=False, want_gw=False, want_coef=False):
+    """-> (ga, sgx, sg, gw, coef): the ReLU gate of a unit's gradient and the column sums of its BatchNorm backward from one pass
+    (include/bcos_hip.h: bcos_relu_bwd_colsums).  `act2d` None: no gate, ga is g2d itself."""
+    rows, Cc = g2d.shape
+    ws, n = _bn_ws(rows, Cc, g2d.device)
+    new = lambda: torch.empty((Cc,), device=g2d.device, dtype=torch.float32)      # noqa: E731
+    ga = torch.empty_like(g2d) if act2d is not None else None
+    sgx, sg, gw, coef = new(), (new() if want_sg else None), (new() if want_gw else None), (new() if want_coef else None)
+    _l.check(_l.load().bcos_relu_bwd_colsums(_dev(g2d, "g"), _dev(act2d, "act"), _dev(y2d, "y"), _dev(ga, "ga"), _dev(rstd, "rstd"),
+                                             _dev(gvec, "gvec"), _dev(sgx, "sgx"), _dev(sg, "sg"), _dev(gw, "gw"), _dev(coef, "coef"),
+                                             _dev(ws, "workspace"), n, rows, Cc, _stream()), "bcos_relu_bwd_colsums")
+    return (ga if ga is not None else g2d), sgx, sg, gw, coef
+
+
 def colsum_atomic(a2d, b2d=None, shift_a=None, shift_b=None):
     """The single-launch form (bcos_colsum: partial sums combined with fp32 atomics, order not fixed); kept for A/B timing."""
     lib = _l.load()

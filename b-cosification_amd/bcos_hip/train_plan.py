@@ -116,24 +116,23 @@ class ResNetTrainPlan:
             st.act = out if relu else None
             return out, st
         y2 = y.view(-1, Cout)
-        m = y2.shape[0]
         if batch_stats:
             momentum = 0.0 if bn.momentum is None else bn.momentum
             if bn.track_running_stats and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
                 if bn.momentum is None:
                     momentum = 1.0 / float(bn.num_batches_tracked)
-            mean = ops.colsum(y2) / m
-            var = ops.colsum(y2, y2, mean, mean) / m             # x.var(unbiased=False), batchnorm_uncentered.py:36-44
-            if bn.track_running_stats and bn.running_var is not None:
-                bn.running_var.copy_((1 - momentum) * bn.running_var + momentum * var)
+            # ONE pass over y: mean, centred variance (x.var(unbiased=False), batchnorm_uncentered.py:36-44), 1 / std, weight / std and
+            # the running_var update -- was two column-sum passes and ~10 torch launches per layer
+            rv = bn.running_var if (bn.track_running_stats and bn.running_var is not None) else None
+            mean, _, rstd, g = ops.bn_batch_stats(y2, bn.weight.detach() if bn.weight is not None else None, bn.eps, running_var=rv,
+                                                  momentum=momentum)
         else:
             if bn.running_var is None:
                 raise BcosHipError("train plan: a BatchNormUncentered2d in eval() needs its running_var")
             mean = torch.zeros(Cout, device=x.device)
-            var = bn.running_var.detach()
-        rstd = torch.rsqrt(var + bn.eps)
-        g = (rstd if bn.weight is None else bn.weight.detach() * rstd).contiguous()
+            rstd = torch.rsqrt(bn.running_var.detach() + bn.eps)
+            g = (rstd if bn.weight is None else bn.weight.detach() * rstd).contiguous()
         shift = bn.bias.detach().contiguous() if isinstance(bn.bias, torch.Tensor) else None
         if addend is None:
             out = ops.channel_affine(y, g, shift, relu=relu)
@@ -146,27 +145,33 @@ class ResNetTrainPlan:
         """-> (gradient w.r.t. the unit's input or None, gradient w.r.t. the shortcut addend or None)"""
         c, bn = st.conv, st.bn
         conv = c.module
-        if st.relu:
-            ga = ops.relu_bwd(ga if ga.is_contiguous() else ga.contiguous(), st.act)      # ReLU gate (also the gradient that reaches the shortcut)
-        g_addend = ga if st.has_addend else None
         N, Ho, Wo, Cout = st.y.shape
         y2 = st.y.view(-1, Cout)
+        ga = ga if ga.is_contiguous() else ga.contiguous()
+        if bn is not None:
+            # ONE pass: the ReLU gate (also the gradient that reaches the shortcut) and the column sums of the BatchNorm backward
+            # (batchnorm_uncentered.py: _BatchStatsFn.backward), the weight gradient and the variance-term coefficient from its finish
+            has_w, has_b = isinstance(bn.weight, nn.Parameter), isinstance(bn.bias, nn.Parameter)
+            need_var = not (bn.detach or not st.batch_stats)      # (variance a constant in explanation mode, or for a layer in eval())
+            ga2, sgx, sg, gw, coef = ops.relu_bwd_colsums(ga.view(-1, Cout), st.act.view(-1, Cout) if st.relu else None, y2,
+                                                          rstd=st.rstd, gvec=st.g, want_sg=has_b and bn.bias.requires_grad,
+                                                          want_gw=has_w and bn.weight.requires_grad, want_coef=need_var)
+            ga = ga2.view(N, Ho, Wo, Cout)
+            if gw is not None:
+                grads[bn.weight] = gw
+            if sg is not None:
+                grads[bn.bias] = sg
+            if not need_var:
+                gy = ops.channel_affine(ga, st.g, None)
+            else:
+                gy = ops.channel_axpby(ga, st.g, st.y, st.mean.contiguous(), coef)
+        else:
+            if st.relu:
+                ga = ops.relu_bwd(ga, st.act)
+            gy = ga
+        g_addend = ga if st.has_addend else None
         g2 = ga.reshape(-1, Cout)
         m = y2.shape[0]
-        if bn is not None:
-            has_w, has_b = isinstance(bn.weight, nn.Parameter), isinstance(bn.bias, nn.Parameter)
-            sgx = ops.colsum(g2, y2)                              # batchnorm_uncentered.py: _BatchStatsFn.backward, same launches
-            if has_w and bn.weight.requires_grad:
-                grads[bn.weight] = sgx * st.rstd
-            if has_b and bn.bias.requires_grad:
-                grads[bn.bias] = ops.colsum(g2)
-            if bn.detach or not st.batch_stats:       # the variance is a constant (explanation mode, or a layer in eval()): a per-channel scale
-                gy = ops.channel_affine(ga.contiguous(), st.g, None)
-            else:
-                coef = (-(st.g * sgx) * st.rstd * st.rstd / m).contiguous()
-                gy = ops.channel_axpby(ga.contiguous(), st.g, st.y, st.mean.contiguous(), coef)
-        else:
-            gy = ga.contiguous()
         # the convolution: scale derivative, patch-norm term, weight / bias / input gradients (_hipfn.BcosConv2dFn.backward)
         x = st.x
         H, W = st.in_hw

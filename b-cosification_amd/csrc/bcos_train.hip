@@ -13,6 +13,7 @@
 // gradients and the batch statistics of BatchNormUncentered2d (batchnorm_uncentered.py:36-44).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "bcos_hip.h"
 #include "bcos_internal.h"
 
@@ -418,6 +419,186 @@ __global__ __launch_bounds__(256) void channel_axpby_kernel(const float* __restr
     }
 }
 
+
+// ---- round 5: the batch statistics of a BatchNormUncentered2d in ONE pass over y, and the sums of its backward fused with the ReLU gate
+// (profiles/r04_kernel_stats_train_resnet50.csv: colsum_kernel was the largest entry of a training step -- four streaming passes per
+// BatchNorm, each behind ~10 tiny torch launches) ----------------------------------------------------------------------------------------
+// Workgroup b owns rows [b rpb, (b + 1) rpb).  It sums (y - c) and (y - c)^2 per channel with the shift c = its FIRST row (the data
+// itself: |mean_b - c| is of the order of the spread, so the one-pass second moment loses no more than a bit or two to cancellation)
+// and leaves (c, S1, S2) in the workspace; bn_stats_finish_kernel combines the workgroups' (n_b, mean_b, M2_b) in one fixed order
+// (Chan et al.): mean = sum n_b mean_b / m, M2 = sum [M2_b + n_b (mean_b - mean)^2] -- the centred variance x.var(unbiased=False)
+// of batchnorm_uncentered.py:36-44 without a second pass over the tensor.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ partial, int64_t rows, int C,
+                                                               int64_t rows_per_block) {
+    __shared__ float red[2][256 * 4];
+    const int c4 = C / 4;
+    const int tpc = c4 < 256 ? c4 : 256;
+    const int rstride = 256 / tpc;
+    const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+    const int64_t r_lo = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_hi = r_lo + rows_per_block < rows ? r_lo + rows_per_block : rows;
+    for (int base = 0; base < c4; base += tpc) {
+        const int cg = base + tc;
+        const bool live = cg < c4 && tr < rstride;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            c = *reinterpret_cast<const f32x4*>(y + r_lo * C + cg * 4);
+            int64_t r = r_lo + tr;
+            for (; r + 3 * rstride < r_hi; r += 4 * rstride) {      // four rows in flight per thread (one fixed order: the chain below)
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(y + (r + u * rstride) * C + cg * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const f32x4 d = v[u] - c; s1 += d; s2 += d * d; }
+            }
+            for (; r < r_hi; r += rstride) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + cg * 4) - c;
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { red[0][threadIdx.x * 4 + q] = s1[q]; red[1][threadIdx.x * 4 + q] = s2[q]; }
+        __syncthreads();
+        if (tr == 0 && cg < c4) {
+            for (int k = 1; k < rstride; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { s1[q] += red[0][(k * tpc + tc) * 4 + q]; s2[q] += red[1][(k * tpc + tc) * 4 + q]; }
+            float* dst = partial + (int64_t)blockIdx.x * 3 * C + cg * 4;
+            *reinterpret_cast<f32x4*>(dst) = c;
+            *reinterpret_cast<f32x4*>(dst + C) = s1;
+            *reinterpret_cast<f32x4*>(dst + 2 * C) = s2;
+        }
+    }
+}
+
+// fixed-order sum over the workgroups b of f(b) for one channel: 16 lanes, lane t takes b = t, t + 16, ... in order, the 16 partial
+// sums meet in order (the shape of colsum_finish_kernel)
+template <typename F>
+__device__ __forceinline__ float ordered_block_sum(float* red, int tc, int tr, int nblk, bool live, F f) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four interleaved chains per lane: independent loads in flight
+    if (live) {
+        int b = tr;
+        for (; b + 48 < nblk; b += 64) { a0 += f(b); a1 += f(b + 16); a2 += f(b + 32); a3 += f(b + 48); }
+        for (; b < nblk; b += 16) a0 += f(b);
+    }
+    __syncthreads();
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    float acc = red[tc];
+    for (int k = 1; k < 16; ++k) acc += red[k * 16 + tc];
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ partial, const float* __restrict__ weight,
+                                                              float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                              float* __restrict__ var_out, float* __restrict__ rstd_out, float* __restrict__ g_out,
+                                                              int nblk, int C, int64_t rows, int64_t rpb, float eps, float momentum) {
+    __shared__ float red[256];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc;
+    const bool live = c < C;
+    auto nb = [&](int b) { const int64_t lo = (int64_t)b * rpb; return (float)((lo + rpb < rows ? lo + rpb : rows) - lo); };
+    const float m = (float)rows;
+    const float total = ordered_block_sum(red, tc, tr, nblk, live, [&](int b) {
+        const float* q = partial + (int64_t)b * 3 * C + c;
+        return nb(b) * q[0] + q[C];
+    });
+    const float mean = total / m;
+    const float m2 = ordered_block_sum(red, tc, tr, nblk, live, [&](int b) {
+        const float* q = partial + (int64_t)b * 3 * C + c;
+        const float n = nb(b), s1 = q[C];
+        const float d = q[0] + s1 / n - mean;
+        return q[2 * C] - s1 * s1 / n + n * d * d;
+    });
+    if (tr == 0 && live) {
+        const float var = fmaxf(m2 / m, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        mean_out[c] = mean;
+        var_out[c] = var;
+        rstd_out[c] = rstd;
+        g_out[c] = weight ? weight[c] * rstd : rstd;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var;
+    }
+}
+
+// ga = act > 0 ? g : 0 (act NULL: ga = g, not written) with the two column sums of the BatchNorm backward from the same pass:
+// partial[b] = (sum ga y, sum ga) per channel
+__global__ __launch_bounds__(256) void relu_bwd_colsums_kernel(const float* __restrict__ g, const float* __restrict__ act, const float* __restrict__ y,
+                                                               float* __restrict__ ga, float* __restrict__ partial, int64_t rows, int C,
+                                                               int64_t rows_per_block) {
+    __shared__ float red[2][256 * 4];
+    const int c4 = C / 4;
+    const int tpc = c4 < 256 ? c4 : 256;
+    const int rstride = 256 / tpc;
+    const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+    const int64_t r_lo = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_hi = r_lo + rows_per_block < rows ? r_lo + rows_per_block : rows;
+    for (int base = 0; base < c4; base += tpc) {
+        const int cg = base + tc;
+        const bool live = cg < c4 && tr < rstride;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            auto rows_u = [&](auto u_c, int64_t r) {                 // U rows in flight per thread: all loads first, then the chain in row order
+                constexpr int U = decltype(u_c)::value;
+                f32x4 v[U], a[U], yy[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t o = (r + u * rstride) * C + cg * 4;
+                    v[u] = *reinterpret_cast<const f32x4*>(g + o);
+                    yy[u] = *reinterpret_cast<const f32x4*>(y + o);
+                    if (act) a[u] = *reinterpret_cast<const f32x4*>(act + o);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[u][q] = a[u][q] > 0.f ? v[u][q] : 0.f;
+                        *reinterpret_cast<f32x4*>(ga + (r + u * rstride) * C + cg * 4) = v[u];
+                    }
+                    s1 += v[u] * yy[u];
+                    s2 += v[u];
+                }
+            };
+            int64_t r = r_lo + tr;
+            for (; r + 3 * rstride < r_hi; r += 4 * rstride) rows_u(std::integral_constant<int, 4>{}, r);
+            for (; r < r_hi; r += rstride) rows_u(std::integral_constant<int, 1>{}, r);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { red[0][threadIdx.x * 4 + q] = s1[q]; red[1][threadIdx.x * 4 + q] = s2[q]; }
+        __syncthreads();
+        if (tr == 0 && cg < c4) {
+            for (int k = 1; k < rstride; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { s1[q] += red[0][(k * tpc + tc) * 4 + q]; s2[q] += red[1][(k * tpc + tc) * 4 + q]; }
+            float* dst = partial + (int64_t)blockIdx.x * 2 * C + cg * 4;
+            *reinterpret_cast<f32x4*>(dst) = s1;
+            *reinterpret_cast<f32x4*>(dst + C) = s2;
+        }
+    }
+}
+
+// sgx = sum_b partial[b][0], sg = sum_b partial[b][1] in one fixed order; with the forward's rstd and g = weight rstd also the weight
+// gradient sgx rstd and the coefficient of the variance term of the input gradient, -(g sgx) rstd^2 / m (batchnorm_uncentered.py:36-44)
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, const float* __restrict__ rstd, const float* __restrict__ gvec,
+                                                            float* __restrict__ sgx_out, float* __restrict__ sg_out, float* __restrict__ gw_out,
+                                                            float* __restrict__ coef_out, int nblk, int C, int64_t rows) {
+    __shared__ float red[256];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc;
+    const bool live = c < C;
+    const float sgx = ordered_block_sum(red, tc, tr, nblk, live, [&](int b) { return partial[(int64_t)b * 2 * C + c]; });
+    const float sg = ordered_block_sum(red, tc, tr, nblk, live, [&](int b) { return partial[(int64_t)b * 2 * C + C + c]; });
+    if (tr == 0 && live) {
+        sgx_out[c] = sgx;
+        if (sg_out) sg_out[c] = sg;
+        if (gw_out) gw_out[c] = sgx * rstd[c];
+        if (coef_out) coef_out[c] = -(gvec[c] * sgx) * rstd[c] * rstd[c] / (float)rows;
+    }
+}
+
 }  // namespace
 
 extern "C" int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin,
@@ -554,6 +735,55 @@ extern "C" int bcos_colsum_ws(const float* a, const float* b, const float* shift
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, shift_a, shift_b, out, rows, C, rpb, workspace);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, workspace, out, (int)blocks, C);
     return check_launch("colsum_ws launch");
+}
+
+static void bn_ws_plan(int64_t rows, int64_t* blocks, int64_t* rpb) {
+    int64_t nb = (rows + 127) / 128;        // >= 128 rows per workgroup, <= 2048 workgroups (eight per CU keep the loads of a pass in flight)
+    if (nb > 2048) nb = 2048;
+    *rpb = (rows + nb - 1) / nb;
+    *blocks = (rows + *rpb - 1) / *rpb;
+}
+
+extern "C" int bcos_bn_train_ws_floats(int64_t rows, int C, int64_t* floats) {
+    if (rows <= 0 || C <= 0 || C % 4 != 0 || !floats) return bcos_set_error(BCOS_E_INVAL, "bcos_bn_train_ws_floats: bad argument");
+    int64_t blocks, rpb;
+    bn_ws_plan(rows, &blocks, &rpb);
+    *floats = blocks * 3 * C;
+    return BCOS_OK;
+}
+
+extern "C" int bcos_bn_batch_stats(const float* y, const float* weight, float* running_var, float* mean, float* var, float* rstd, float* g,
+                                   float* workspace, int64_t workspace_floats, int64_t rows, int C, float eps, float momentum, void* stream) {
+    if (!y || !mean || !var || !rstd || !g || !workspace || rows <= 0 || C <= 0 || C % 4 != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_bn_batch_stats: bad argument (C must be a multiple of 4)");
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_bn_batch_stats: y and workspace must be 16-byte aligned");
+    int64_t blocks, rpb;
+    bn_ws_plan(rows, &blocks, &rpb);
+    if (workspace_floats < blocks * 3 * C) return bcos_set_error(BCOS_E_INVAL, "bcos_bn_batch_stats: workspace smaller than bcos_bn_train_ws_floats");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, workspace, rows, C, rpb);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, workspace, weight, running_var, mean, var, rstd, g,
+                       (int)blocks, C, rows, rpb, eps, momentum);
+    return check_launch("bn_batch_stats launch");
+}
+
+extern "C" int bcos_relu_bwd_colsums(const float* g, const float* act, const float* y, float* ga, const float* rstd, const float* gvec,
+                                     float* sgx, float* sg, float* gw, float* coef, float* workspace, int64_t workspace_floats, int64_t rows,
+                                     int C, void* stream) {
+    if (!g || !y || !sgx || !workspace || rows <= 0 || C <= 0 || C % 4 != 0 || (act && !ga) || ((gw || coef) && !rstd) || (coef && !gvec))
+        return bcos_set_error(BCOS_E_INVAL, "bcos_relu_bwd_colsums: bad argument (C % 4 == 0; act needs ga; gw / coef need rstd, coef needs gvec)");
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(act) |
+         reinterpret_cast<uintptr_t>(ga)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_relu_bwd_colsums: tensors must be 16-byte aligned");
+    int64_t blocks, rpb;
+    bn_ws_plan(rows, &blocks, &rpb);
+    if (workspace_floats < blocks * 2 * C) return bcos_set_error(BCOS_E_INVAL, "bcos_relu_bwd_colsums: workspace smaller than bcos_bn_train_ws_floats");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(relu_bwd_colsums_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, act, y, ga, workspace, rows, C, rpb);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, workspace, rstd, gvec, sgx, sg, gw, coef, (int)blocks, C,
+                       rows);
+    return check_launch("relu_bwd_colsums launch");
 }
 
 extern "C" int bcos_colsum_ordered(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out,

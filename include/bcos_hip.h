@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 7
+#define BCOS_ABI_VERSION 8
 
 enum {
     BCOS_OK = 0,
@@ -540,6 +540,22 @@ int bcos_colsum_ws(const float* a, const float* b, const float* shift_a, const f
  * (bcos_hip/synth.py: calibrate).  (ABI v7) */
 int bcos_colsum_ordered(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out, int64_t rows, int C,
                         void* stream);
+
+/* BatchNormUncentered2d in training mode without separate statistics passes (ABI v8; reference batchnorm_uncentered.py:36-44,
+ * trainer step bcos/training/trainer.py:666-784).  Both entry points take a caller-owned workspace of bcos_bn_train_ws_floats(rows, C)
+ * floats (16-byte aligned) and sum in one fixed order per (rows, C): bit-identical from run to run.
+ *   bcos_bn_batch_stats: ONE pass over y [rows, C]: mean[c], var[c] = the centred variance y.var(unbiased=False) (per-workgroup shifted
+ *     sums combined as (n, mean, M2) triples), rstd = 1 / sqrt(var + eps), g = weight * rstd (weight NULL: rstd), and -- running_var not
+ *     NULL -- running_var = (1 - momentum) running_var + momentum var in place.
+ *   bcos_relu_bwd_colsums: ga = act > 0 ? g : 0 (act NULL: ga = g and nothing is written) together with sgx[c] = sum_r ga y and
+ *     (sg not NULL) sg[c] = sum_r ga; with the forward's rstd / gvec = g also gw = sgx rstd (the weight gradient) and
+ *     coef = -(gvec sgx) rstd^2 / rows (the coefficient bcos_channel_axpby takes for the variance term of the input gradient). */
+int bcos_bn_train_ws_floats(int64_t rows, int C, int64_t* floats);
+int bcos_bn_batch_stats(const float* y, const float* weight, float* running_var, float* mean, float* var, float* rstd, float* g,
+                        float* workspace, int64_t workspace_floats, int64_t rows, int C, float eps, float momentum, void* stream);
+int bcos_relu_bwd_colsums(const float* g, const float* act, const float* y, float* ga, const float* rstd, const float* gvec,
+                          float* sgx, float* sg, float* gw, float* coef, float* workspace, int64_t workspace_floats, int64_t rows,
+                          int C, void* stream);
 
 /* out[r,c] = a[r,c] * sa[c] + (b[r,c] - mb[c]) * sb[c]   (b / mb / sb may be NULL: out = a * sa): the input gradient of the
  * training-mode uncentered batch norm, gx = gy * w / std + (x - mean) * coef. */

@@ -450,6 +450,25 @@ def colsum(a2d, b2d=None, shift_a=None, shift_b=None):
     return a.sum(0).float()
 
 
+def bn_batch_stats(y2d, weight, eps, running_var=None, momentum=0.0):
+    mean = y2d.mean(0)
+    var = y2d.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    g = rstd if weight is None else weight * rstd
+    if running_var is not None:
+        running_var.copy_((1 - momentum) * running_var + momentum * var)
+    return mean, var, rstd, g
+
+
+def relu_bwd_colsums(g2d, act2d, y2d, rstd=None, gvec=None, want_sg=False, want_gw=False, want_coef=False):
+    ga = g2d * (act2d > 0) if act2d is not None else g2d
+    sgx = (ga * y2d).sum(0)
+    sg = ga.sum(0) if want_sg else None
+    gw = sgx * rstd if want_gw else None
+    coef = -(gvec * sgx) * rstd * rstd / y2d.shape[0] if want_coef else None
+    return ga, sgx, sg, gw, coef
+
+
 def channel_axpby(a, sa, b=None, mb=None, sb=None, out=None):
     r = a * sa
     if b is not None:
@@ -473,7 +492,7 @@ def install(monkeypatch):
                  "weight_rownorm_scale", "rows_normalize", "cosine_grad", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_stats", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
-                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "maxout_expand",
+                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "bn_batch_stats", "relu_bwd_colsums", "maxout_expand",
                  "weight_rownorm_bwd", "maxout_scatter", "groupnorm_fwd", "groupnorm_bwd_detached",
                  "layernorm_bwd", "gelu_bwd", "attention_bwd", "groupnorm_bwd"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -1836,6 +1836,63 @@ def test_colsum_ordered_is_exact_enough_and_reproducible(lib):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(ops.channel_moments_ordered(x)[:2], (mean, var)))
 
 
+def test_fused_batchnorm_training_kernels(lib):
+    """bcos_bn_batch_stats / bcos_relu_bwd_colsums (ABI v8): the batch statistics of a BatchNormUncentered2d from ONE pass (shifted
+    per-workgroup sums combined as (n, mean, M2) triples) against fp64 -- columns whose mean is 30 x their spread included --, the running
+    variance update, the gated gradient and the sums / weight gradient / variance coefficient of the backward; bit-identical from call
+    to call; argument validation through ctypes."""
+    import ctypes as C
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(5)
+    for (rows, Cc) in [(1, 4), (7, 8), (3136 * 4, 64), (1000, 256), (200704, 64), (12544, 2048), (333, 12)]:
+        off = torch.randn(Cc, generator=g) * torch.tensor([0.0, 1.0, 30.0, 300.0])[torch.arange(Cc) % 4]
+        y = (torch.randn(rows, Cc, generator=g) * (torch.rand(Cc, generator=g) + 0.1) + off).to(DEV)
+        w = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+        rv0 = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+        rv = rv0.clone()
+        mean, var, rstd, gv = ops.bn_batch_stats(y, w, 1e-5, running_var=rv, momentum=0.1)
+        m2, v2, r2, g2 = ops.bn_batch_stats(y, w, 1e-5)
+        assert all(torch.equal(a, b) for a, b in ((mean, m2), (var, v2), (rstd, r2), (gv, g2)))
+        yd = y.double()
+        mref, vref = yd.mean(0), yd.var(0, unbiased=False)
+        spread = yd.std(0, unbiased=False) + 1e-30
+        if rows > 1:
+            assert float(((mean.double() - mref).abs() / (spread + mref.abs() * 1e-1)).max()) <= 2e-6, (rows, Cc)
+            # the centred variance to fp32 rounding of a TWO-pass evaluation: relative to var + (ulp of the column's magnitude)^2 terms
+            tol = 4e-6 * vref + 4e-7 * (mref.abs() + spread) * spread
+            assert bool(((var.double() - vref).abs() <= tol).all()), (rows, Cc, float(((var.double() - vref).abs() / tol).max()))
+        assert rel(rstd, torch.rsqrt(var.double() + 1e-5)) <= 1e-6 and rel(gv, w.double() * torch.rsqrt(var.double() + 1e-5)) <= 1e-6
+        assert rel(rv, 0.9 * rv0.double() + 0.1 * var.double()) <= 1e-6
+        gr = torch.randn(rows, Cc, generator=g).to(DEV)
+        act = torch.randn(rows, Cc, generator=g).clamp_min(0).to(DEV)
+        for use_act in (True, False):
+            ga, sgx, sg, gw, coef = ops.relu_bwd_colsums(gr, act if use_act else None, y, rstd=rstd, gvec=gv, want_sg=True, want_gw=True, want_coef=True)
+            ga_b = ops.relu_bwd_colsums(gr, act if use_act else None, y, rstd=rstd, gvec=gv, want_sg=True, want_gw=True, want_coef=True)
+            assert all(torch.equal(a, b) for a, b in zip((ga, sgx, sg, gw, coef), ga_b))
+            ga_ref = gr * (act > 0) if use_act else gr
+            assert torch.equal(ga, ga_ref) and (use_act or ga.data_ptr() == gr.data_ptr())
+            sref = (ga_ref.double() * yd).sum(0)
+            scale = (ga_ref.double().abs() * yd.abs()).sum(0) + 1e-30
+            assert float(((sgx.double() - sref).abs() / scale).max()) <= 2e-6
+            assert float(((sg.double() - ga_ref.double().sum(0)).abs() / (ga_ref.double().abs().sum(0) + 1e-30)).max()) <= 2e-6
+            assert rel(gw, sgx.double() * rstd.double()) <= 1e-6
+            assert rel(coef, -(gv.double() * sgx.double()) * rstd.double() ** 2 / rows) <= 1e-6
+    # validation: C % 4, missing outputs, act without ga, coef without gvec, a workspace that is too small
+    y = torch.randn(64, 8, device=DEV)
+    ws = torch.empty(8 * 3 * 4, device=DEV)
+    o = [torch.empty(8, device=DEV) for _ in range(4)]
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.bcos_bn_batch_stats(P(y), None, None, P(o[0]), P(o[1]), P(o[2]), P(o[3]), P(ws), ws.numel(), 64, 8, 1e-5, 0.0, st) == 0
+    assert lib.bcos_bn_batch_stats(P(y), None, None, P(o[0]), P(o[1]), P(o[2]), P(o[3]), P(ws), ws.numel(), 64, 6, 1e-5, 0.0, st) != 0
+    assert lib.bcos_bn_batch_stats(P(y), None, None, None, P(o[1]), P(o[2]), P(o[3]), P(ws), ws.numel(), 64, 8, 1e-5, 0.0, st) != 0
+    assert lib.bcos_bn_batch_stats(P(y), None, None, P(o[0]), P(o[1]), P(o[2]), P(o[3]), P(ws), 8, 64, 8, 1e-5, 0.0, st) != 0
+    assert lib.bcos_relu_bwd_colsums(P(y), P(y), P(y), None, None, None, P(o[0]), None, None, None, P(ws), ws.numel(), 64, 8, st) != 0
+    assert lib.bcos_relu_bwd_colsums(P(y), None, P(y), None, P(o[1]), None, P(o[0]), None, None, P(o[2]), P(ws), ws.numel(), 64, 8, st) != 0
+    assert lib.bcos_relu_bwd_colsums(P(y), None, P(y), None, None, None, P(o[0]), None, None, None, P(ws), ws.numel(), 64, 8, st) == 0
+    torch.cuda.synchronize()
+
+
 def test_option_table_switches_code_paths_not_results(lib):
     """bcos_set_option (ABI v7) through ctypes: defaults, range checks, and that an option selects between code paths of the SAME
     operator -- a 3 x 3 launch under every setting of the loop / tile / epilogue switches agrees with the default to fp32 rounding
