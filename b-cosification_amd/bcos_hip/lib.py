@@ -86,6 +86,7 @@ SIGNATURES = {
     "bcos_weight_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "bcos_maxout_scatter": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "bcos_patch_norm_bwd": (C.c_int, [_P, _P, _P] + [_I] * 15 + [_P]),
+    "bcos_patch_norm_bwd_add": (C.c_int, [_P, _P, _P, _P] + [_I] * 15 + [_P]),
     "bcos_conv2d_wgrad": (C.c_int, [_P, _P, _P] + [_I] * 18 + [_P]),
     "bcos_colsum": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_colsum_ordered": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),

@@ -446,6 +446,16 @@ def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None, track_absmax=None, bi
     return out
 
 
+def _take_taps(w, dim, idx, k):
+    """w indexed by the tap list `idx` along `dim` without device index tensors where the list is the whole axis in order (1 x 1
+    layers: nothing to do) or reversed (stride 1: one flip) -- a training step rebuilds every layer's plan from the updated weights."""
+    if idx == list(range(k)):
+        return w
+    if idx == list(range(k - 1, -1, -1)):
+        return torch.flip(w, (dim,))
+    return w.index_select(dim, torch.tensor(idx, device=w.device))
+
+
 class DgradPlan:
     """Input-gradient launches of one convolution: one tapconv per output parity class.
 
@@ -479,7 +489,7 @@ class DgradPlan:
                 if len(rs_h) == 0 or len(rs_w) == 0:
                     self.classes.append((rh, rw, 0, 0, 0, 0, 1, 1, None))
                     continue
-                sub = w_oihw[:, :, rs_h][:, :, :, rs_w]                    # [Cout,Cin/G,TH,TW]
+                sub = _take_taps(_take_taps(w_oihw, 2, rs_h, kh), 3, rs_w, kw)      # [Cout,Cin/G,TH,TW]
                 if G == 1:
                     wt = sub.permute(1, 2, 3, 0).contiguous()               # [Cin,TH,TW,Cout]
                 else:                                                       # [G Cin/G, TH, TW, Cout/G]: the groups' transposed filters, stacked
@@ -861,16 +871,18 @@ def maxout_scatter(g2d, argmax2d, max_out):
     return full
 
 
-def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation):
-    """x [N,H,W,pitch] (first C_used channels), rnorm [N,P,Q] -> x * PatchSum^T(rnorm) [N,H,W,C_used]
-    (include/bcos_hip.h: bcos_patch_norm_bwd)."""
+def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation, addend=None):
+    """x [N,H,W,pitch] (first C_used channels), rnorm [N,P,Q] -> x * PatchSum^T(rnorm) (+ addend) [N,H,W,C_used]
+    (include/bcos_hip.h: bcos_patch_norm_bwd / bcos_patch_norm_bwd_add)."""
     lib = _l.load()
     N, H, W, pitch = x.shape
     _, P, Q = rnorm.shape
     out = torch.empty((N, H, W, C_used), device=x.device, dtype=torch.float32)
-    _l.check(lib.bcos_patch_norm_bwd(_dev(x, "x"), _dev(rnorm, "rnorm"), _dev(out, "out"), N, H, W, C_used, pitch, P, Q,
-                                     kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
-                                     _stream()), "bcos_patch_norm_bwd")
+    if addend is not None and tuple(addend.shape) != (N, H, W, C_used):
+        raise BcosHipError(f"patch_norm_bwd: addend {tuple(addend.shape)} does not match the output {(N, H, W, C_used)}")
+    _l.check(lib.bcos_patch_norm_bwd_add(_dev(x, "x"), _dev(rnorm, "rnorm"), _dev(addend, "addend"), _dev(out, "out"), N, H, W, C_used, pitch,
+                                         P, Q, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                         _stream()), "bcos_patch_norm_bwd")
     return out
 
 

@@ -141,8 +141,10 @@ class ResNetTrainPlan:
         st.mean, st.rstd, st.g, st.act = mean, rstd, g, (out if relu else None)
         return out, st
 
-    def _unit_bwd(self, st: _UnitState, ga: torch.Tensor, grads: Dict, need_x: bool = True):
-        """-> (gradient w.r.t. the unit's input or None, gradient w.r.t. the shortcut addend or None)"""
+    def _unit_bwd(self, st: _UnitState, ga: torch.Tensor, grads: Dict, need_x: bool = True, extra: Optional[torch.Tensor] = None):
+        """-> (gradient w.r.t. the unit's input or None, gradient w.r.t. the shortcut addend or None).  `extra`: a gradient that reaches
+        the unit's INPUT by another path (the shortcut of a residual block) -- added by the launches that finish the input gradient
+        (the patch-norm term, or the input-gradient launch's epilogue) instead of by an elementwise pass of its own."""
         c, bn = st.conv, st.bn
         conv = c.module
         N, Ho, Wo, Cout = st.y.shape
@@ -176,14 +178,14 @@ class ResNetTrainPlan:
         x = st.x
         H, W = st.in_hw
         cin = c.cin
-        addend = None
+        addend = extra if (extra is None or extra.is_contiguous()) else extra.contiguous()
         if st.b != 1.0 and not conv.detach:
             from bcos.modules._hipfn import _scale_bwd_cols
             glin, rnorm, _ = _scale_bwd_cols(gy.reshape(-1, Cout), y2, st.scale.view(-1, Cout), st.norm.view(-1), BCOS_CONV_EPS,
                                              dict(b=st.b, force_pow=st.force_pow), False)
             glin = glin.view(N, Ho, Wo, Cout)
             if need_x:
-                addend = ops.patch_norm_bwd(x, rnorm.view(N, Ho, Wo), cin, c.k, c.stride, c.padding, c.dilation)
+                addend = ops.patch_norm_bwd(x, rnorm.view(N, Ho, Wo), cin, c.k, c.stride, c.padding, c.dilation, addend=addend)
         elif st.b != 1.0:
             glin = ops.mul(gy, st.scale)
         else:
@@ -254,13 +256,12 @@ class ResNetTrainPlan:
             blk, rec = eng.blocks[bi], st["blocks"][bi]
             units = rec["units"]
             gh, g_idn = self._unit_bwd(units[-1], g, grads)
-            for u in reversed(units[:-1]):
-                gh, _ = self._unit_bwd(u, gh, grads)
             if rec["shortcut"] is not None:
-                g_sc, _ = self._unit_bwd(rec["shortcut"], g_idn, grads)
-                g = gh + g_sc
-            else:
-                g = gh + g_idn
+                g_idn, _ = self._unit_bwd(rec["shortcut"], g_idn, grads)
+            # the shortcut's gradient joins the main path's inside the launches that finish the block input's gradient
+            for u in reversed(units[1:-1]):
+                gh, _ = self._unit_bwd(u, gh, grads)
+            g, _ = self._unit_bwd(units[0], gh, grads, extra=g_idn)
         k, s, p = eng.pool
         a_h, a_w = st["a0_hw"]
         ga0 = ops.avgpool2d_bwd(g.contiguous(), a_h, a_w, k, s, p)

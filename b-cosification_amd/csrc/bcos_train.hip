@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void maxout_scatter_kernel(const float* __rest
 }
 
 // ---- transposed patch sum times x: out[n,h,w,:] = x[n,h,w,:] * sum_{(i,j): patch(i,j) contains (h,w)} r[n,i,j] -----------
-__global__ __launch_bounds__(256) void patch_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+__global__ __launch_bounds__(256) void patch_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ add,
                                                              float* __restrict__ out, int N, int H, int W, int C, int x_pitch,
                                                              int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                                                              int dw, int vec) {
@@ -150,10 +150,15 @@ __global__ __launch_bounds__(256) void patch_norm_bwd_kernel(const float* __rest
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
     const float* src = x + pix * x_pitch;
     float* dst = out + pix * C;
+    const float* ad = add ? add + pix * C : nullptr;          // (bcos_patch_norm_bwd_add: a gradient that reaches the same tensor by another path)
     if (vec) {
-        for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c) * t;
+        for (int c = lane * 4; c < C; c += 256) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + c) * t;
+            if (ad) v += *reinterpret_cast<const f32x4*>(ad + c);
+            *reinterpret_cast<f32x4*>(dst + c) = v;
+        }
     } else {                                       // C % 4 != 0 (e.g. the 6-channel network input): element by element
-        for (int c = lane; c < C; c += 64) dst[c] = src[c] * t;
+        for (int c = lane; c < C; c += 64) dst[c] = src[c] * t + (ad ? ad[c] : 0.f);
     }
 }
 
@@ -184,6 +189,16 @@ constexpr int WG_T = 128;          // tile edge (channels)
 constexpr int WG_K = 32;           // pixels per stage
 constexpr int WG_LD = WG_T + 4;    // LDS row pitch (floats): rows of different pixels start in different banks
 
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+
+// X3 = true (round 5): the products run on the bf16 matrix pipe over EXACT 3-way splits of both operands, x = h + m + l (8 + 8 + 8
+// significand bits, fp32's exponent range: no scaling), a b = a_h b_h + (a_h b_m + a_m b_h) + (a_m b_m + a_h b_l + a_l b_h): six
+// v_mfma_f32_32x32x16_bf16 per 16 pixels (192 matrix-pipe cycles) where eight v_mfma_f32_32x32x2_f32 took 512; the dropped terms are
+// <= 2^-21 |a b| -- the arithmetic of the forward / input-gradient contractions in mode bf16x3 (csrc/bcos_tapconv.hip: tile_body_x3).
+// The fp32 operands stay in LDS as they are (pixel-major); a lane gathers its 8 pixels of a channel and splits them in registers.
+// X3 = false: exact fp32 MFMA (contraction mode f32).
+template <bool X3>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float* sA = wsm;                               // [2][WG_K][WG_LD] glin
@@ -264,6 +279,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             if (st + 1 < nst) load(m_lo + (int64_t)(st + 1) * WG_K);
             const float* a = sA + cur * WG_K * WG_LD + wave_m * 64 + fr;
             const float* b = sB + cur * WG_K * WG_LD + wave_n * 64 + fr;
+            if constexpr (X3) {
+                // exact split of 8 fp32 values (pixels kk + 8 fk .. + 7 of one channel) into three bf16x8 fragments: truncation keeps
+                // every remainder exact (x - h has <= 16 significant bits, x - h - m <= 8: a bf16 holds it as is)
+                auto frag3 = [&](const float* src, wg_bf16x8 (&out)[3]) {
+                    unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float x = src[q * WG_LD];
+                        const unsigned hu = __float_as_uint(x) & 0xffff0000u;
+                        const float r1 = x - __uint_as_float(hu);
+                        const unsigned mu = __float_as_uint(r1) & 0xffff0000u;
+                        const float r2 = r1 - __uint_as_float(mu);
+                        hh[q] = hu; mm[q] = mu; ll[q] = __float_as_uint(r2);
+                    }
+                    wg_u32x4 ph, pm, pl;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ph[q] = hh[2 * q + 1] | (hh[2 * q] >> 16);
+                        pm[q] = mm[2 * q + 1] | (mm[2 * q] >> 16);
+                        pl[q] = (ll[2 * q + 1] & 0xffff0000u) | (ll[2 * q] >> 16);
+                    }
+                    out[0] = __builtin_bit_cast(wg_bf16x8, ph);
+                    out[1] = __builtin_bit_cast(wg_bf16x8, pm);
+                    out[2] = __builtin_bit_cast(wg_bf16x8, pl);
+                };
+#pragma unroll
+                for (int kk = 0; kk < WG_K; kk += 16) {
+                    wg_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) frag3(a + (kk + 8 * fk) * WG_LD + i * 32, af[i]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) frag3(b + (kk + 8 * fk) * WG_LD + j * 32, bf[j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {       // smallest terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                        }
+                }
+            } else {
 #pragma unroll
             for (int kk = 0; kk < WG_K; kk += 2) {
                 float af[2], bf[2];
@@ -276,6 +336,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
             }
             if (st + 1 < nst) store(cur ^ 1);
             __syncthreads();
@@ -640,18 +701,24 @@ extern "C" int bcos_maxout_scatter(const float* g, const int32_t* argmax, float*
     return check_launch("maxout_scatter launch");
 }
 
-extern "C" int bcos_patch_norm_bwd(const float* x, const float* rnorm, float* out, int N, int H, int W, int C, int x_pitch,
-                                   int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream) {
+extern "C" int bcos_patch_norm_bwd_add(const float* x, const float* rnorm, const float* addend, float* out, int N, int H, int W, int C,
+                                       int x_pitch, int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream) {
     if (!x || !rnorm || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || kh <= 0 || kw <= 0 ||
         sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_patch_norm_bwd: bad argument");
     if (x_pitch == 0) x_pitch = C;
     if (x_pitch < C) return bcos_set_error(BCOS_E_INVAL, "bcos_patch_norm_bwd: bad x_pitch");
-    const int vec = (C % 4 == 0 && x_pitch % 4 == 0 && !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15)) ? 1 : 0;
+    const int vec = (C % 4 == 0 && x_pitch % 4 == 0 &&
+                     !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(addend)) & 15)) ? 1 : 0;
     const int64_t total = (int64_t)N * H * W;
     hipLaunchKernelGGL(patch_norm_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       x, rnorm, out, N, H, W, C, x_pitch, P, Q, kh, kw, sh, sw, ph, pw, dh, dw, vec);
+                       x, rnorm, addend, out, N, H, W, C, x_pitch, P, Q, kh, kw, sh, sw, ph, pw, dh, dw, vec);
     return check_launch("patch_norm_bwd launch");
+}
+
+extern "C" int bcos_patch_norm_bwd(const float* x, const float* rnorm, float* out, int N, int H, int W, int C, int x_pitch,
+                                   int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream) {
+    return bcos_patch_norm_bwd_add(x, rnorm, nullptr, out, N, H, W, C, x_pitch, P, Q, kh, kw, sh, sw, ph, pw, dh, dw, stream);
 }
 
 extern "C" int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, int N, int H, int W, int C, int x_pitch, int P,
@@ -689,11 +756,15 @@ extern "C" int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, i
     p.chunk = (((p.M + split - 1) / split) + WG_K - 1) / WG_K * WG_K;
     split = (p.M + p.chunk - 1) / p.chunk;
     const size_t lds = (size_t)4 * WG_K * WG_LD * sizeof(float);
-    static std::atomic<size_t> lds_hw{0};
-    hipError_t e = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_kernel), lds, lds_hw);
+    static std::atomic<size_t> lds_hw[2];
+    // exact fp32 MFMA in contraction mode f32, the 6-product bf16 split otherwise (the split modes of the other contractions)
+    const bool x3 = bcos_get_contraction_mode() != 0;
+    const dim3 grid((unsigned)(tiles_co * p.tiles_ci), (unsigned)grid_y, (unsigned)split);
+    hipError_t e = x3 ? bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_kernel<true>), lds, lds_hw[1])
+                      : bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_kernel<false>), lds, lds_hw[0]);
     if (e != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", e);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(tiles_co * p.tiles_ci), (unsigned)grid_y, (unsigned)split), dim3(256), lds,
-                       reinterpret_cast<hipStream_t>(stream), p);
+    if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("wgrad launch");
 }
 

@@ -511,6 +511,11 @@ int bcos_maxout_scatter(const float* g, const int32_t* argmax, float* full, int6
  * (C channels used, x_pitch 0 = C), rnorm [N,P,Q], out [N,H,W,C]; handed to the dgrad launch as its epilogue addend. */
 int bcos_patch_norm_bwd(const float* x, const float* rnorm, float* out, int N, int H, int W, int C, int x_pitch, int P, int Q,
                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream);
+/* The same plus a gradient that reaches the same tensor by another path: out = x * PatchSum^T(rnorm) + addend (addend [N,H,W,C] dense,
+ * may be NULL) -- the shortcut gradient of a residual block folded into the patch-norm term of the block's first convolution, one
+ * elementwise pass less per block and training step.  (ABI v8) */
+int bcos_patch_norm_bwd_add(const float* x, const float* rnorm, const float* addend, float* out, int N, int H, int W, int C, int x_pitch,
+                            int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream);
 
 /* Weight gradient of a convolution / linear layer: gw[co][th][tw][ci] += sum over output pixels (n,i,j) of
  * glin[n,i,j,co] * x[n, i*sh - ph + th*dh, j*sw - pw + tw*dw, ci]   (the autograd convolution_backward weight branch).

@@ -425,13 +425,14 @@ def maxout_scatter(g2d, argmax2d, max_out):
     return full.view(rows, Cout * max_out)
 
 
-def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation):
+def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation, addend=None):
     N, H, W, _ = x.shape
     with torch.enable_grad():          # the transposed patch sum = adjoint of a convolution with a kernel of ones
         z = torch.zeros(N, 1, H, W, requires_grad=True)
         patch_sum = F.conv2d(z, torch.ones(1, 1, kernel[0], kernel[1]), None, stride, padding, dilation)
         (t,) = torch.autograd.grad(patch_sum, z, rnorm[:, None].detach())
-    return x[..., :C_used] * t[:, 0, :, :, None]
+    out = x[..., :C_used] * t[:, 0, :, :, None]
+    return out + addend if addend is not None else out
 
 
 def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation):
