@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2700 -- 'bash scripts/collect_profiles.sh r04'
+#   gpurun --timeout 2700 -- 'bash scripts/collect_profiles.sh r05'
 # Writes gpurun_out/prof_<tag>/{stats,fetch,write,...}/ and gpurun_out/profiles_<tag>/ (the summaries to copy into profiles/).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -37,8 +37,8 @@ for spec in "resnet50 --forward-only" "resnet18" "vit_ti --batch 512" "vit_ti --
   f=$(find "$OUT/stats_${name}" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$SUM/${TAG}_kernel_stats_${name}.csv"
 done
-# 4b. the training-step diagnostic (bench.py --train: nn.Module path, reference batch 64 per GPU) and its kernel stats
-for spec in "resnet50" "vit_ti"; do
+# 4b. the training-step diagnostic (bench.py --train: training plan for the ResNets, nn.Module path for the ViT; reference batch 64 per GPU) and its kernel stats
+for spec in "resnet50" "resnet18" "vit_ti"; do
   python3 bench.py --train --arch $spec --steps 10 --warmup 3 > "$SUM/${TAG}_bench_train_${spec}.json" 2> "$OUT/bench_train_${spec}.err"
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train_${spec}" -- python3 "$ROOT/bench.py" --train --arch $spec --steps 3 --warmup 2 > /dev/null 2> "$OUT/stats_train_${spec}.err"

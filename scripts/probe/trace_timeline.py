@@ -14,7 +14,7 @@ starts = [s for s, e, n, q in rows if "prep_input" in n]
 if len(starts) < 8:
     print("no step markers"); sys.exit(0)
 # take the middle half of the run
-per_step = 2
+per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 2       # prep_input launches per step = sub-batch streams
 nsteps = len(starts) // per_step
 lo, hi = starts[per_step * (nsteps // 2)], starts[per_step * (nsteps - 2)]
 n_mid = (nsteps - 2) - nsteps // 2
@@ -32,7 +32,9 @@ tot = hi - lo
 print(f"{n_mid} steps, {tot / n_mid / 1e6:.3f} ms per step; time with k kernels executing: " + ", ".join(f"k={k}: {hist[k] / n_mid / 1e6:.3f} ms" for k in sorted(hist)))
 byname = collections.Counter(); cnt = collections.Counter()
 for s, e, n, q in sel:
-    key = n.split("(")[0][:90]
+    import re
+    m_ = re.match(r"(?:void )?(?:\(anonymous namespace\)::)?([A-Za-z0-9_:<>, ]+)", n)
+    key = (m_.group(1) if m_ else n)[:70]
     byname[key] += e - s; cnt[key] += 1
 print(f"sum of kernel durations per step: {sum(byname.values()) / n_mid / 1e6:.3f} ms")
 for k, v in byname.most_common(25):
