@@ -1048,6 +1048,196 @@ __global__ __launch_bounds__(256) void attention_bwd_full_kernel(const float* __
     }
 }
 
+
+// ---- round 5: the full attention gradient on the fp32 matrix pipe --------------------------------------------------------------------
+// attention_bwd_full_kernel above evaluates the five T x T x 64 products of a head with scalar FMA chains (one key per thread):
+// 1.09 ms per call at ViT-Ti batch 64, HALF of a training step (profiles/r05_kernel_stats_train_vit_ti.csv).  Here one workgroup per
+// (image, head) keeps K and V in LDS ([T][65]: a lane reads "its" key's or query's element k without bank conflicts) and walks the
+// query rows in tiles of 32; wave w owns the key tiles w and w + 4.  Per (row tile i, key tile j), all on v_mfma_f32_32x32x2_f32:
+//   S = Q_i K_j^T, dP = dO_i V_j^T                     (A, B from LDS)
+//   P = exp(S scale - m) / l,  dS = P (dP - D) scale   in the accumulator layout (lane = key, 16 query rows per lane)
+//   dV_j += P^T dO_i,  dK_j += dS^T Q_i                A = the accumulator registers AS THEY ARE (an accumulator register of lane
+//                                                      (key, half) is A[m = key][k = row 8 g + 4 half + r]: the contraction index is walked
+//                                                      in that order), B from LDS; dK / dV stay in the owning wave's registers
+//   dQ_i += dS K_j                                     the contraction runs over the lane index: dS goes through a wave-private LDS tile
+// dQ_i of the four waves meets in LDS in wave order (fixed summation order).  T <= ATP - 1 = 207 tokens, head dim 64.
+constexpr int AKP = DH + 1;       // LDS row pitch (floats)
+constexpr int ATP = 208;          // K / V rows held (rows T .. ATP - 1 are zero: keys beyond T read a zero row)
+constexpr int ASP = 33;           // pitch of a wave's dS tile
+constexpr size_t attention_bwd_mfma_lds() {
+    return ((size_t)2 * ATP * AKP + 2 * 32 * AKP + 4 * 32 * ASP + 32 * DH + 3 * 32) * sizeof(float);
+}
+
+__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ stats,
+                                                                 const float* __restrict__ out, const float* __restrict__ gout,
+                                                                 float* __restrict__ gqkv, int B, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sK = sm;                          // [ATP][AKP]
+    float* sV = sK + ATP * AKP;              // [ATP][AKP]
+    float* sQ = sV + ATP * AKP;              // [32][AKP]
+    float* sdO = sQ + 32 * AKP;              // [32][AKP]
+    float* sdS = sdO + 32 * AKP;             // [4][32][ASP]   per-wave dS tile
+    float* sRed = sdS + 4 * 32 * ASP;        // [32][DH]       dQ_i of the waves, summed in wave order
+    float* sM = sRed + 32 * DH;              // [32] row maximum (natural-log units of the scaled scores)
+    float* sI = sM + 32;                     // [32] 1 / row sum
+    float* sD = sI + 32;                     // [32] sum_d dO O
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int inner = H * DH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const float* base = qkv + (int64_t)b * T * 3 * inner + h * DH;
+    for (int i = tid; i < ATP * (DH / 4); i += 256) {
+        const int t = i / (DH / 4), d4 = (i - t * (DH / 4)) * 4;
+        f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            k4 = *reinterpret_cast<const f32x4*>(base + (int64_t)t * 3 * inner + inner + d4);
+            v4 = *reinterpret_cast<const f32x4*>(base + (int64_t)t * 3 * inner + 2 * inner + d4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sK[t * AKP + d4 + q] = k4[q]; sV[t * AKP + d4 + q] = v4[q]; }
+    }
+    const int ntile = (T + 31) / 32;
+    f32x16 dK[2][2], dV[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dK[a][t][r] = 0.f; dV[a][t][r] = 0.f; }
+    float* my_dS = sdS + wave * 32 * ASP;
+    for (int it = 0; it < ntile; ++it) {
+        const int i0 = it * 32;
+        __syncthreads();                                     // the previous row tile is consumed (first trip: K / V staged)
+        {   // Q_i, dO_i: thread = (row tid / 8, eight consecutive d); D = sum_d dO O over the row's eight threads
+            const int r = tid >> 3, d0 = (tid & 7) * 8;
+            const int t = i0 + r;
+            f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, g0 = q0, g1 = q0, o0 = q0, o1 = q0;
+            if (t < T) {
+                const float* qp = base + (int64_t)t * 3 * inner + d0;
+                const float* gp = gout + ((int64_t)b * T + t) * inner + h * DH + d0;
+                const float* op = out + ((int64_t)b * T + t) * inner + h * DH + d0;
+                q0 = *reinterpret_cast<const f32x4*>(qp); q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+                g0 = *reinterpret_cast<const f32x4*>(gp); g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                o0 = *reinterpret_cast<const f32x4*>(op); o1 = *reinterpret_cast<const f32x4*>(op + 4);
+            }
+            float dd = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sQ[r * AKP + d0 + q] = q0[q]; sQ[r * AKP + d0 + 4 + q] = q1[q];
+                sdO[r * AKP + d0 + q] = g0[q]; sdO[r * AKP + d0 + 4 + q] = g1[q];
+                dd = fmaf(g0[q], o0[q], dd); dd = fmaf(g1[q], o1[q], dd);
+            }
+            dd += __shfl_xor(dd, 1); dd += __shfl_xor(dd, 2); dd += __shfl_xor(dd, 4);
+            if ((tid & 7) == 0) {
+                sD[r] = dd;
+                if (t < T) {
+                    sM[r] = stats[(((int64_t)b * H + h) * T + t) * 2];
+                    sI[r] = stats[(((int64_t)b * H + h) * T + t) * 2 + 1];
+                } else {
+                    sM[r] = INFINITY;                        // padded query rows: p = exp(-inf) * 0 = 0
+                    sI[r] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        f32x16 dQp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dQp[t][r] = 0.f;
+#pragma unroll
+        for (int js = 0; js < 2; ++js) {
+            const int j = wave + 4 * js;
+            if (j < ntile) {                                 // (wave-uniform)
+                const int key = 32 * j + l32;
+                const int krow = key < ATP - 1 ? key : ATP - 1;                  // keys beyond T: a zero row
+                f32x16 S, dP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll 8
+                for (int st = 0; st < DH / 2; ++st) {
+                    const int d = 2 * st + half;
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[l32 * AKP + d], sK[krow * AKP + d], S, 0, 0, 0);
+                    dP = __builtin_amdgcn_mfma_f32_32x32x2f32(sdO[l32 * AKP + d], sV[krow * AKP + d], dP, 0, 0, 0);
+                }
+                const bool kvalid = key < T;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+                    const float pr = kvalid ? expf(S[r] * scale - sM[row]) * sI[row] : 0.f;
+                    const float ds = pr * (dP[r] - sD[row]) * scale;
+                    S[r] = pr;
+                    dP[r] = ds;
+                    my_dS[row * ASP + l32] = ds;
+                }
+                // dV_j += P^T dO_i, dK_j += dS^T Q_i: A = the accumulator registers, contraction index = their row order
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        dV[js][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[r], sdO[row * AKP + l32 + 32 * t], dV[js][t], 0, 0, 0);
+                        dK[js][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dP[r], sQ[row * AKP + l32 + 32 * t], dK[js][t], 0, 0, 0);
+                    }
+                }
+                // dQ_i += dS K_j: A[m = row][k = key] from the wave's dS tile (its own writes: ordered within the wave)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+                for (int st = 0; st < 16; ++st) {
+                    const int kk = 2 * st + half;
+                    const int kr = 32 * j + kk < ATP - 1 ? 32 * j + kk : ATP - 1;
+                    const float a = my_dS[l32 * ASP + kk];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        dQp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sK[kr * AKP + l32 + 32 * t], dQp[t], 0, 0, 0);
+                }
+            }
+        }
+        // dQ_i: the waves' partial tiles meet in LDS in wave order (waves without a key tile contribute zeros)
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+                        float* dst = sRed + row * DH + l32 + 32 * t;
+                        *dst = w == 0 ? dQp[t][r] : *dst + dQp[t][r];
+                    }
+            }
+        }
+        __syncthreads();
+        {
+            const int r = tid >> 3, d0 = (tid & 7) * 8;
+            const int t = i0 + r;
+            if (t < T) {
+                float* dst = gqkv + ((int64_t)b * T + t) * 3 * inner + h * DH + d0;
+                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sRed + r * DH + d0);
+                *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sRed + r * DH + d0 + 4);
+            }
+        }
+    }
+    // dK_j, dV_j: accumulator tile (row = key, column = d)
+#pragma unroll
+    for (int js = 0; js < 2; ++js) {
+        const int j = wave + 4 * js;
+        if (j < ntile) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * j + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (key < T) {
+                        float* gk = gqkv + ((int64_t)b * T + key) * 3 * inner + inner + h * DH + l32 + 32 * t;
+                        gk[0] = dK[js][t][r];
+                        gk[inner] = dV[js][t][r];
+                    }
+                }
+        }
+    }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -1228,6 +1418,17 @@ extern "C" int bcos_attention_bwd(const float* qkv, const float* stats, const fl
         return bcos_set_error(BCOS_E_INVAL, "bcos_attention_bwd: bad argument");
     if (Dh != DH) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_bwd: head dim must be 64");
     if (T > 256) return bcos_set_error(BCOS_E_NOSUP, "bcos_attention_bwd: at most 256 tokens");
+    if (T <= ATP - 1 && !((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gout) |
+                           reinterpret_cast<uintptr_t>(gqkv)) & 15)) {
+        // the five products of a head on the fp32 matrix pipe (attention_bwd_mfma_kernel); longer sequences keep the scalar kernel
+        const size_t lds = attention_bwd_mfma_lds();
+        static std::atomic<size_t> lds_hw2;
+        hipError_t e2 = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_bwd_mfma_kernel), lds, lds_hw2);
+        if (e2 != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", e2);
+        hipLaunchKernelGGL(attention_bwd_mfma_kernel, dim3((unsigned)(B * H)), dim3(256), lds, STREAM(stream), qkv, stats, out, gout, gqkv, B, T,
+                           H, scale);
+        return check_launch("attention_bwd_mfma_kernel");
+    }
     const size_t bytes = ((size_t)2 * T * AKLD + 2 * ARB * DH + 3 * ARB + (size_t)ARB * T) * sizeof(float);
     static std::atomic<size_t> lds_hw;
     hipError_t err = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_bwd_full_kernel), bytes, lds_hw);

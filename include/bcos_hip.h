@@ -633,7 +633,9 @@ int bcos_groupnorm_bwd(const float* gy, const float* x, const float* weight, con
 /* MyGELU with the gate differentiated (bcosify_vit.py:27-32 with detach off): gx = gy (Phi(x) + x phi(x)). */
 int bcos_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream);
 /* Softmax attention with q, k, v all differentiated (vit.py:143-158 outside explanation mode): gqkv [B, T, 3*H*64] from qkv,
- * the forward's stats and output, and gout [B, T, H*64].  T <= 256. */
+ * the forward's stats and output, and gout [B, T, H*64].  T <= 256.  Up to 207 tokens (16-byte aligned tensors) the five T x T x 64
+ * products of a head run on the fp32 matrix pipe, one workgroup per (image, head), fixed summation order (round 5); longer sequences
+ * on scalar FMA chains. */
 int bcos_attention_bwd(const float* qkv, const float* stats, const float* out, const float* gout, float* gqkv,
                        int B, int T, int H, int Dh, float scale, void* stream);
 

@@ -1836,6 +1836,32 @@ def test_colsum_ordered_is_exact_enough_and_reproducible(lib):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(ops.channel_moments_ordered(x)[:2], (mean, var)))
 
 
+def test_attention_gradient_on_the_matrix_pipe(lib):
+    """bcos_attention_bwd (q, k and v differentiated: `Attention.forward` outside explanation mode, bcos/models/vit.py:143-158).  Up to
+    207 tokens the five T x T x 64 products of a head run on the fp32 matrix pipe (attention_bwd_mfma_kernel, round 5), longer
+    sequences on the scalar kernel: both against fp64 autograd, ragged token counts (key / query tiles partly empty), scores with a
+    wide spread, bit-identical from call to call."""
+    import cpu_emulation as E
+    from bcos_hip import ops
+    g = torch.Generator().manual_seed(11)
+    for (B, T, H, spread) in [(2, 196, 3, 1.0), (3, 197, 3, 4.0), (1, 1, 1, 1.0), (2, 33, 2, 1.0), (2, 64, 1, 2.0), (1, 207, 2, 1.0),
+                              (1, 208, 2, 1.0), (2, 50, 32, 1.0)]:
+        qkv = (torch.randn(B, T, 3 * H * 64, generator=g) * spread).to(DEV)
+        go = torch.randn(B, T, H * 64, generator=g).to(DEV)
+        out, stats = ops.attention_fwd(qkv, H, 0.125, want_stats=True)
+        g1 = ops.attention_bwd(qkv, stats, out, go, H, 0.125)
+        g2 = ops.attention_bwd(qkv, stats, out, go, H, 0.125)
+        assert torch.equal(g1, g2), (B, T, H)
+        ref = E.attention_bwd(qkv.cpu(), None, None, go.cpu(), H, 0.125)        # fp64 formulae of the documented semantics
+        inner = H * 64
+        scale_all = float(ref.double().norm())
+        for name, sl in (("q", slice(0, inner)), ("k", slice(inner, 2 * inner)), ("v", slice(2 * inner, 3 * inner))):
+            # (a single token has P = 1, dS = 0: the q / k gradients are exactly zero -- judged against the whole gradient's norm)
+            err = float((g1[..., sl].double().cpu() - ref[..., sl].double()).norm())
+            assert err <= max(2e-5 * float(ref[..., sl].double().norm()), 1e-6 * scale_all), (B, T, H, name, err, scale_all)
+        assert bool(torch.isfinite(g1).all())
+
+
 def test_fused_batchnorm_training_kernels(lib):
     """bcos_bn_batch_stats / bcos_relu_bwd_colsums (ABI v8): the batch statistics of a BatchNormUncentered2d from ONE pass (shifted
     per-workgroup sums combined as (n, mean, M2) triples) against fp64 -- columns whose mean is 30 x their spread included --, the running
