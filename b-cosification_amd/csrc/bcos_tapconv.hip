@@ -3746,6 +3746,10 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // 129 ... 192 columns (the 192-wide linears of the SimpleViTs: to_out, linear2, their gradients): ONE tile of 192 columns
             // (six accumulator tiles per wave) instead of 128 + a half-empty second 128
             if (dma && g.Cout > 128 && g.Cout <= 192 && !force) return bcos_tc_d_128x192(&p, norm, s);
+            // multiples of 192 that are not multiples of 256 (the 576-wide to_qkv of the SimpleViTs: 3 x 192 exactly, against 5 x 128 with
+            // 64 empty columns or 3 x 256 with 192): whole 192-column tiles -- ViT-Ti batch 512 forward+explanation 18.26 -> 17.97 ms per step
+            // in three same-node pairs (round 5); 768 = 4 x 192 against 3 x 256: no gain, stays on the 256-column tiles.  Bits unchanged.
+            if (dma && g.Cout % 192 == 0 && g.Cout % 256 != 0 && g.Cout <= 1152 && !force) return bcos_tc_d_128x192(&p, norm, s);
             if (wide) return dma ? bcos_tc_d_128x256(&p, norm, s) : bcos_tc_h2_128x256(&p, norm, s);
             return dma ? bcos_tc_d_128x128(&p, norm, s) : bcos_tc_h2_128x128(&p, norm, s);
         }

@@ -1300,3 +1300,39 @@ def test_linear_b_schedule_hook_and_learnable_b_setup(monkeypatch):
     net[0].batch_size = 3
     g = h(torch.ones(()))
     assert abs(float(net[0].b) - (1 + 1e-6)) < 1e-7 and float(g) == -3.0                 # put back on the ramp's first point
+
+
+def test_telemetry_sampler_and_bench_thread_pinning(tmp_path):
+    """bench.py's clock / power sampler (bcos_hip/telemetry.py) is a CHILD process: on a box without a readable SMI
+    source it says so in one line and the window is empty (fields None -- never a crash, never a made-up clock); a recorded sample
+    file is parsed into mean / min / max over the requested wall-clock window only.  And the CPU baseline's OpenMP pinning is decided
+    from the command line alone, before torch is imported: never for multi-rank runs (eight ranks bound to core 0)."""
+    import subprocess
+    import sys
+    import time
+    from bcos_hip import telemetry
+    s = telemetry.Sampler(interval=0.01).start()
+    assert s.wait_ready(timeout=20.0)
+    t0 = time.time()
+    time.sleep(0.2)
+    w = s.window(t0, time.time())
+    assert set(w) == {"sclk_mhz_mean", "sclk_mhz_min", "sclk_mhz_max", "power_w_mean", "power_w_max", "samples", "source"}
+    if w["samples"] == 0:                       # (no GPU here)
+        assert w["sclk_mhz_mean"] is None and w["power_w_mean"] is None and "unavailable" in (w["source"] or "")
+    # a recorded file: only the samples inside the window count; malformed lines are skipped
+    f = tmp_path / "samples.txt"
+    f.write_text("# source: test\n10.0 2000.0 1200.0 2010.0 1990.0\n11.0 2100.0 1300.0 2110.0 2090.0\ngarbage line | x y z w\n"
+                 "12.0 nan 1250.0 nan nan\n50.0 100.0 240.0 100.0 100.0\n")
+    s2 = telemetry.Sampler()
+    s2.path = str(f)
+    w2 = s2.window(9.5, 12.5)
+    assert w2["samples"] == 2 and w2["sclk_mhz_mean"] == 2050.0 and w2["sclk_mhz_min"] == 1990.0 and w2["sclk_mhz_max"] == 2110.0
+    assert w2["power_w_mean"] == 1250.0 and w2["power_w_max"] == 1300.0 and w2["source"] == "source: test"
+    # thread pinning: decided from argv before `import torch`
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = ("import sys, os; sys.argv = ['bench.py'] + {args!r}; os.environ.pop('OMP_PROC_BIND', None); os.environ.pop('WORLD_SIZE', None); "
+             "src = open(os.path.join({repo!r}, 'bench.py')).read(); head = src[:src.index('import torch  # noqa')]; "
+             "exec(compile(head, 'bench_head', 'exec'), dict(__file__=os.path.join({repo!r}, 'bench.py'), __name__='bench_head')); print(os.environ.get('OMP_PROC_BIND'), os.environ.get('OMP_PLACES'))")
+    for args, want in (([], "close cores"), (["--gpus", "8"], "None None"), (["--no-cpu-baseline"], "None None"), (["--train"], "None None")):
+        out = subprocess.run([sys.executable, "-c", probe.format(args=args, repo=repo)], capture_output=True, text=True, timeout=60)
+        assert out.stdout.strip() == want, (args, out.stdout, out.stderr[-300:])
