@@ -150,7 +150,17 @@ class Sampler:
         except Exception:
             self.proc = None
         os.close(fd)
+        import atexit
+        atexit.register(self._cleanup)          # a run that dies before window() must not leave the child sampling for ever
         return self
+
+    def _cleanup(self):
+        self.stop()
+        try:
+            if self.path and os.path.exists(self.path):
+                os.unlink(self.path)
+        except OSError:
+            pass
 
     def wait_ready(self, timeout=10.0):
         """block until the child has printed its first line (source found, or none available)"""
