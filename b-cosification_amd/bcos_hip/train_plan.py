@@ -16,9 +16,11 @@ batchnorm_uncentered.py:36-44):
 The arithmetic is the per-layer path's (bcos/modules/_hipfn.py: BcosConv2dFn, batchnorm_uncentered.py: _BatchStatsFn) launch for
 launch, so both are held to the same reference-recorded fixtures (tests/golden/resnet18_train_step.npz).
 
-Scope: torchvision-topology ResNets with the GAP + 1x1 `fc` head (BASELINE configs), groups == 1, max_out == 1, fixed B.  Anything
-else -- CLIP's attention-pool head, grouped / MaxOut layers, a learnable exponent, native unit-norm layers -- is refused by
-`supported()` and keeps the per-layer path.
+Scope: torchvision-topology ResNets with the GAP + 1x1 `fc` head (BASELINE configs) and, since round 5, CLIP's ModifiedResNet
+(CLIP/clip/model.py:10-154: three-convolution stem, anti-aliasing AvgPool2d between conv2 and conv3 and in front of the shortcut
+convolution; its attention-pool head runs as the module it is, under autograd, on the feature map the plan returns); groups == 1,
+max_out == 1, fixed B.  Anything else -- the `attn_unpool` head, grouped / MaxOut layers, a learnable exponent, native unit-norm
+layers -- is refused by `supported()` and keeps the per-layer path.
 """
 from typing import Dict, List, Optional
 
@@ -52,12 +54,12 @@ class ResNetTrainPlan:
     @staticmethod
     def supported(eng):
         from bcos.modules.bcosconv2d import NormedConv2d
-        if getattr(eng, "head_kind", None) != "gap_fc":
-            return False, "only the global-average-pool + fc head"
-        if any(b.hybrid or b.pool or b.shortcut_pool or not b.relu for b in eng.blocks):
-            return False, "grouped / MaxOut / anti-aliased / ReLU-free blocks keep the per-layer path"
-        if len(eng.stem) != 1 or not eng.stem[0][1]:
-            return False, "single-conv stem with ReLU"
+        if getattr(eng, "head_kind", None) not in ("gap_fc", "attnpool"):
+            return False, "only the global-average-pool + fc head and the (pooled) attention-pool head"
+        if any(b.hybrid or not b.relu for b in eng.blocks):
+            return False, "grouped / MaxOut / ReLU-free blocks keep the per-layer path"
+        if not all(relu for _, relu in eng.stem):
+            return False, "stem convolutions with ReLU"
         for c in eng._all_convs():
             m = c.module
             if isinstance(getattr(m, "b", None), torch.Tensor) and m.b.requires_grad:
@@ -218,20 +220,27 @@ class ResNetTrainPlan:
         mean, std = eng._consts(x.device)
         st = dict(x=xd, add_inverse=xd.shape[1] == 3, H=xd.shape[2], W=xd.shape[3])
         xn = ops.prep_input(xd, mean, std, cpad=8, add_inverse=st["add_inverse"], want_absmax=False)
-        a0, st["stem"] = self._unit_fwd(eng.stem[0][0], xn, relu=True)
+        a0, st["stem"] = xn, []
+        for conv, _ in eng.stem:                      # torchvision: one 7 x 7 convolution; CLIP (CLIP/clip/model.py:94-154): three 3 x 3
+            a0, u = self._unit_fwd(conv, a0, relu=True)
+            st["stem"].append(u)
         st["a0_hw"] = (a0.shape[1], a0.shape[2])
         k, s, p = eng.pool
         cur = ops.avgpool2d_fwd(a0, k, s, p)
         blocks = []
         for blk in eng.blocks:
             inp = cur
-            rec = dict(units=[], shortcut=None)
+            rec = dict(units=[], shortcut=None, in_hw=(inp.shape[1], inp.shape[2]), pre_pool_hw=None)
             h = inp
             for c in blk.convs[:-1]:
                 h, u = self._unit_fwd(c, h, relu=True)
                 rec["units"].append(u)
+            if blk.pool:                               # CLIP's anti-aliasing pool between conv2 and conv3 (CLIP/clip/model.py:25,47)
+                rec["pre_pool_hw"] = (h.shape[1], h.shape[2])
+                h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0)
             if blk.shortcut is not None:
-                idn, rec["shortcut"] = self._unit_fwd(blk.shortcut, inp, relu=False)
+                sc_in = ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0) if blk.shortcut_pool else inp
+                idn, rec["shortcut"] = self._unit_fwd(blk.shortcut, sc_in, relu=False)
             else:
                 idn = inp
             out, u = self._unit_fwd(blk.convs[-1], h, addend=idn, relu=True)
@@ -239,6 +248,9 @@ class ResNetTrainPlan:
             blocks.append(rec)
             cur = out
         st["blocks"] = blocks
+        if eng.head is None:                           # attention-pool head: the feature map leaves the plan, the head runs under autograd
+            st["head"] = None
+            return cur.permute(0, 3, 1, 2), st
         f, st["head"] = self._unit_fwd(eng.head, cur, relu=False)
         st["feat_hw"] = (f.shape[1], f.shape[2])
         logits = ops.global_avgpool_logits(f, eng.logit_temperature, eng.logit_bias)
@@ -247,25 +259,34 @@ class ResNetTrainPlan:
     def backward(self, st, g_logits: torch.Tensor, need_x: bool = True):
         eng = self.eng
         grads: Dict = {}
-        fh, fw = st["feat_hw"]
-        N = g_logits.shape[0]
-        inv_t = 1.0 if eng.logit_temperature is None else 1.0 / float(eng.logit_temperature)
-        gf = (g_logits.to(torch.float32) * (inv_t / float(fh * fw))).view(N, 1, 1, -1).expand(N, fh, fw, g_logits.shape[1]).contiguous()
-        g, _ = self._unit_bwd(st["head"], gf, grads)
+        if st["head"] is None:                         # gradient of the feature map [N, C, H, W] from the head's own autograd nodes
+            g = g_logits.to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        else:
+            fh, fw = st["feat_hw"]
+            N = g_logits.shape[0]
+            inv_t = 1.0 if eng.logit_temperature is None else 1.0 / float(eng.logit_temperature)
+            gf = (g_logits.to(torch.float32) * (inv_t / float(fh * fw))).view(N, 1, 1, -1).expand(N, fh, fw, g_logits.shape[1]).contiguous()
+            g, _ = self._unit_bwd(st["head"], gf, grads)
         for bi in range(len(eng.blocks) - 1, -1, -1):
             blk, rec = eng.blocks[bi], st["blocks"][bi]
             units = rec["units"]
             gh, g_idn = self._unit_bwd(units[-1], g, grads)
             if rec["shortcut"] is not None:
                 g_idn, _ = self._unit_bwd(rec["shortcut"], g_idn, grads)
+                if blk.shortcut_pool:
+                    g_idn = ops.avgpool2d_bwd(g_idn.contiguous(), rec["in_hw"][0], rec["in_hw"][1], blk.shortcut_pool, blk.shortcut_pool, 0)
+            if blk.pool:
+                gh = ops.avgpool2d_bwd(gh.contiguous(), rec["pre_pool_hw"][0], rec["pre_pool_hw"][1], blk.pool, blk.pool, 0)
             # the shortcut's gradient joins the main path's inside the launches that finish the block input's gradient
             for u in reversed(units[1:-1]):
                 gh, _ = self._unit_bwd(u, gh, grads)
             g, _ = self._unit_bwd(units[0], gh, grads, extra=g_idn)
         k, s, p = eng.pool
         a_h, a_w = st["a0_hw"]
-        ga0 = ops.avgpool2d_bwd(g.contiguous(), a_h, a_w, k, s, p)
-        gxn, _ = self._unit_bwd(st["stem"], ga0, grads, need_x=need_x)       # [N,H,W,6]: w.r.t. the normalised, AddInverse-encoded input
+        gl = ops.avgpool2d_bwd(g.contiguous(), a_h, a_w, k, s, p)
+        for si in range(len(st["stem"]) - 1, -1, -1):
+            gl, _ = self._unit_bwd(st["stem"][si], gl, grads, need_x=(need_x or si > 0))
+        gxn = gl                                        # [N,H,W,6]: w.r.t. the normalised, AddInverse-encoded input
         gx = None
         if need_x:
             _, std = eng._consts(g_logits.device)
@@ -286,7 +307,7 @@ class _TrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_logits):
-        gx, grads = ctx.plan.backward(ctx.st, g_logits.contiguous(), need_x=ctx.need_x)
+        gx, grads = ctx.plan.backward(ctx.st, g_logits if ctx.st["head"] is None else g_logits.contiguous(), need_x=ctx.need_x)
         ctx.st = None
         return (None, gx) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
 
@@ -300,4 +321,11 @@ def train_forward(eng, x: torch.Tensor) -> Optional[torch.Tensor]:
         eng._train_plan = plan
     if plan is False:
         return None
-    return _TrainStepFn.apply(plan, x, *plan.parameters())
+    out = _TrainStepFn.apply(plan, x, *plan.parameters())
+    if eng.head is None:
+        # attention-pool head (bcos/modules/bcosattnpool.py:33-59 with nothing detached): the module itself, under autograd, on the
+        # feature map the plan hands out; then the LogitLayer as BcosifyNetwork.forward applies it (bcosify.py:50-53)
+        out = eng.attnpool(out)
+        ll = eng.net.logit_layer
+        out = ll(out) if ll else out
+    return out

@@ -91,6 +91,7 @@ def parse():
                          "every BatchNormUncentered2d, dynamic scales differentiated), BCE-with-logits loss, backward to every parameter, "
                          "(N > 1) bucketed gradient all-reduce, SGD-momentum update -- the reference trainer's step "
                          "(bcos/training/trainer.py:666-784) at its ImageNet batch of 64 per GPU unless --batch is given")
+    ap.add_argument("--no-train-plan", action="store_true", help="diagnostic (--train): no engine attached, every layer its own autograd node")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (engine.CapturedPass) instead of launching eagerly; "
                          "measured 1 %% SLOWER than eager launches on ROCm 7.2 (6 667 vs 6 745 images/s), hence off")
@@ -259,7 +260,7 @@ def train_main(args):
     if spec["family"] == "vit":
         net = synth.build_bcosified_vit(seed=0).to(dev)
     elif spec["family"] == "clip":
-        raise SystemExit("--train: resnet18 / resnet50 / vit_ti")
+        net = synth.build_bcosified_clip_rn50(seed=0).to(dev)
     else:
         net = synth.build_bcosified_resnet(args.arch, seed=0).to(dev)
     with torch.no_grad():
@@ -267,13 +268,14 @@ def train_main(args):
         replica_diff = bdist.replicate_parameters(net) if world > 1 else []
     if replica_diff:
         raise SystemExit(f"bench.py: replicas differ after the broadcast of rank 0's parameters: {replica_diff[:5]}")
-    if spec["family"] == "resnet":
+    if spec["family"] in ("resnet", "clip") and not args.no_train_plan:
         from bcos_hip import engine
         engine.attach(net)               # (in eval mode: the inference plan; its layer list also drives the training plan)
     net.train()
     B = args.batch
     x = synth.synthetic_images(B, seed=1000 + rank).to(dev)
-    target = F.one_hot(torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(rank)), 1000).float().to(dev)
+    n_out = 1024 if spec["family"] == "clip" else 1000          # (CLIP RN50: the 1024 embedding coordinates stand in for the classes)
+    target = F.one_hot(torch.randint(0, n_out, (B,), generator=torch.Generator().manual_seed(rank)), n_out).float().to(dev)
     params = [p for p in net.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9)
 
@@ -283,6 +285,7 @@ def train_main(args):
         opt.zero_grad(set_to_none=True)
         logits = net(x)
         path["node"] = type(logits.grad_fn).__name__
+        path["plan"] = getattr(getattr(net, "_bcos_engine", None), "_train_plan", None) not in (None, False)
         loss = F.binary_cross_entropy_with_logits(logits, target)
         loss.backward()
         if world > 1:
@@ -328,7 +331,7 @@ def train_main(args):
                                f"SGD-momentum update), batch {B} per GPU, 224x224x6, calibrated random-init weights",
                    "global_batch": B * world, "parallelism": f"dp{world}", "contraction": contraction,
                    "path": ("training plan (bcos_hip/train_plan.py): the whole network ONE autograd node whose forward / backward walk the engine's "
-                            "layer list" if path.get("node") == "_TrainStepFnBackward" else
+                            "layer list" if path.get("plan") else
                             "nn.Module path: one HIP launch sequence per layer under autograd (no training plan for this topology)"),
                    "collective": "bucketed asynchronous all_reduce of the gradients (bcos_hip.dist.allreduce_gradients)" if world > 1 else "none",
                    "final_loss": round(float(loss.detach()), 6)},

@@ -1836,6 +1836,17 @@ def test_colsum_ordered_is_exact_enough_and_reproducible(lib):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(ops.channel_moments_ordered(x)[:2], (mean, var)))
 
 
+def test_training_plan_covers_clip_modified_resnet_on_device(lib):
+    """the CLIP ModifiedResNet training step through the plan against the per-layer path, on the device (the check of
+    tests/test_host_cpu.py without the emulated kernels; ReLU gates near zero may open differently under another summation order:
+    the gradient floor of the ResNet-18 training fixture applies)"""
+    import test_host_cpu as H
+    # (one-pass against two-pass batch statistics: 2e-5 on the embeddings after 55 layers; the head's gradients agree to 1e-5 .. 8e-5,
+    #  behind the first ReLU of the trunk ONE gate that opens differently in a 64-pixel x 2048-channel tensor is 3e-3 of its gradient's
+    #  norm: measured 1e-3 at layer4.2.bn3, 5-7e-3 at the stem.  The exact check of the plan's logic is the emulated-kernel test.)
+    H.check_clip_training_plan("cuda", tol=2e-2, tol_fwd=2e-4, n=4, size=128)
+
+
 def test_attention_gradient_on_the_matrix_pipe(lib):
     """bcos_attention_bwd (q, k and v differentiated: `Attention.forward` outside explanation mode, bcos/models/vit.py:143-158).  Up to
     207 tokens the five T x T x 64 products of a head run on the fp32 matrix pipe (attention_bwd_mfma_kernel, round 5), longer

@@ -803,6 +803,60 @@ def test_engine_launch_list_matches_reference_execution_trace(monkeypatch, golde
     check_engine_against_reference_trace(arch, calls, pools, golden_dir)
 
 
+def test_training_plan_covers_clip_modified_resnet(monkeypatch):
+    """Round 5: the training plan takes CLIP's ModifiedResNet (CLIP/clip/model.py:10-154, recipe
+    bcos/experiments/ImageNet/clip_bcosification/model.py:8-25): three-convolution stem, anti-aliasing AvgPool2d between conv2 and conv3
+    and in front of the shortcut convolution inside the plan, the attention-pool head as the module it is on the feature map the plan
+    returns.  Same embeddings, input gradient, every parameter gradient (trunk AND head) and BatchNorm statistics as the per-layer path."""
+    cpu_emulation.install(monkeypatch)
+    check_clip_training_plan("cpu")
+
+
+def check_clip_training_plan(device, tol=2e-4, tol_fwd=1e-5, n=2, size=64):
+    import copy
+    from bcos_hip import engine, synth, train_plan
+    torch.manual_seed(0)
+    net = synth.build_bcosified_clip_rn50().to(device)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "linear") and isinstance(m.linear, nn.Conv2d):
+                m.linear.weight.mul_(3.0)
+    ref = copy.deepcopy(net)
+    eng = engine.attach(net)
+    ok, why = train_plan.ResNetTrainPlan.supported(eng)
+    assert ok, why
+    x = synth.synthetic_images(n, size=size).to(device)
+    net.train(); ref.train()
+
+    def step(n):
+        xr = x.clone().requires_grad_(True)
+        emb = n(xr)
+        loss = (emb * torch.linspace(-1, 1, emb.shape[1], device=device)).sum() / emb.shape[0]
+        ps = [p for p in n.parameters() if p.requires_grad]
+        return emb, torch.autograd.grad(loss, [xr] + ps, allow_unused=True)
+
+    ep, gp = step(net)
+    er, gr = step(ref)
+    node = ep.grad_fn
+    seen, stack, found = set(), [node], False
+    while stack and not found:                      # the plan's node sits below the head's autograd nodes
+        f = stack.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        found = type(f).__name__ == "_TrainStepFnBackward"
+        stack.extend(g for g, _ in f.next_functions)
+    assert found
+    assert rel(ep, er) <= tol_fwd, rel(ep, er)
+    names = ["x"] + [n for n, p in net.named_parameters() if p.requires_grad]
+    for name, a, b in zip(names, gp, gr):
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert rel(a, b) <= tol, (name, rel(a, b))
+    for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 10 * tol_fwd, k
+
+
 def test_fused_engine_plan_with_grouped_and_maxout_blocks(monkeypatch):
     """Round 3: networks with grouped or MaxOut B-cos convolutions (bcosconv2d.py:84-140, 166-170) attach to the
     fused plan too -- such a block is a hybrid node that runs layer by layer on the nn.Module path inside the plan (bcos_hip/engine.py:
