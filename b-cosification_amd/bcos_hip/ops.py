@@ -823,6 +823,20 @@ def channel_affine_add(x, scale, shift, addend, relu=False, out=None):
     return out
 
 
+def channel_affine_rows(x, scale, shift=None, addend=None, relu=False):
+    """out = [relu](x * scale[c] + shift[c] (+ addend)) with the per-row maxima of `out` attached (include/bcos_hip.h:
+    bcos_channel_affine_rows): the contraction that reads `out` then runs the split-f16 loop."""
+    lib = _l.load()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    out = torch.empty_like(x)
+    am = torch.empty((rows,), device=x.device, dtype=torch.int32)
+    _l.check(lib.bcos_channel_affine_rows(_dev(x, "x"), _dev(scale, "scale"), _dev(shift, "shift"), _dev(addend, "addend"), _dev(out, "y"),
+                                          C.c_void_p(am.data_ptr()), rows, Cc, int(bool(relu)), _stream()), "bcos_channel_affine_rows")
+    _attach_absmax(out, am)
+    return out
+
+
 def relu_bwd(g, act, out=None):
     """out = act > 0 ? g : 0 (include/bcos_hip.h: bcos_relu_bwd)."""
     lib = _l.load()
@@ -833,7 +847,7 @@ def relu_bwd(g, act, out=None):
 
 
 # ---- training-mode backward (csrc/bcos_train.hip) --------------------------------------------
-def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False):
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False, want_absmax=False):
     """(gy * dy/dlin [rows,C], dL/dnorm / norm-denominator [rows], dL/dB_eff [1] or None) of y = s(lin, norm) * lin with s not
     detached (include/bcos_hip.h: bcos_train_scale_bwd)."""
     lib = _l.load()
@@ -841,10 +855,13 @@ def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=F
     glin = torch.empty_like(gy2d)
     rnorm = torch.empty((rows,), device=gy2d.device, dtype=torch.float32)
     bgrad = torch.zeros((1,), device=gy2d.device, dtype=torch.float32) if want_bgrad else None
-    _l.check(lib.bcos_train_scale_bwd(_dev(gy2d, "gy"), _dev(y2d, "y"), _dev(s2d, "s"), _dev(norm, "norm"), _dev(glin, "glin"),
-                                      _dev(rnorm, "rnorm"), _dev(bgrad, "bgrad"), rows, Cc, int(mode), float(b),
-                                      int(bool(force_pow)), _stream()),
+    am = torch.empty((rows,), device=gy2d.device, dtype=torch.int32) if want_absmax else None      # per-row max |glin| (the reader's operand scale)
+    _l.check(lib.bcos_train_scale_bwd_absmax(_dev(gy2d, "gy"), _dev(y2d, "y"), _dev(s2d, "s"), _dev(norm, "norm"), _dev(glin, "glin"),
+                                             _dev(rnorm, "rnorm"), _dev(bgrad, "bgrad"), C.c_void_p(am.data_ptr()) if am is not None else None,
+                                             rows, Cc, int(mode), float(b), int(bool(force_pow)), _stream()),
              "bcos_train_scale_bwd")
+    if am is not None:
+        _attach_absmax(glin, am)
     return glin, rnorm, bgrad
 
 

@@ -136,10 +136,10 @@ class ResNetTrainPlan:
             rstd = torch.rsqrt(bn.running_var.detach() + bn.eps)
             g = (rstd if bn.weight is None else bn.weight.detach() * rstd).contiguous()
         shift = bn.bias.detach().contiguous() if isinstance(bn.bias, torch.Tensor) else None
-        if addend is None:
-            out = ops.channel_affine(y, g, shift, relu=relu)
-        else:
-            out = ops.channel_affine_add(y, g, shift, addend if addend.is_contiguous() else addend.contiguous(), relu=relu)
+        # normalisation + affine (+ shortcut) + ReLU in one pass that also leaves the per-pixel maxima of its output: the contraction
+        # that reads it runs the 3-product split-f16 loop (bf16x3 -- 6 products -- without them)
+        out = ops.channel_affine_rows(y, g, shift, None if addend is None else (addend if addend.is_contiguous() else addend.contiguous()),
+                                      relu=relu)
         st.mean, st.rstd, st.g, st.act = mean, rstd, g, (out if relu else None)
         return out, st
 
@@ -182,10 +182,18 @@ class ResNetTrainPlan:
         cin = c.cin
         addend = extra if (extra is None or extra.is_contiguous()) else extra.contiguous()
         if st.b != 1.0 and not conv.detach:
-            from bcos.modules._hipfn import _scale_bwd_cols
-            glin, rnorm, _ = _scale_bwd_cols(gy.reshape(-1, Cout), y2, st.scale.view(-1, Cout), st.norm.view(-1), BCOS_CONV_EPS,
-                                             dict(b=st.b, force_pow=st.force_pow), False)
-            glin = glin.view(N, Ho, Wo, Cout)
+            if Cout % 4 == 0:          # (+ the per-pixel maxima of glin for the input-gradient launches)
+                gl2, rnorm, _ = ops.train_scale_bwd(gy.reshape(-1, Cout).contiguous(), y2, st.scale.view(-1, Cout), st.norm.view(-1),
+                                                    BCOS_CONV_EPS, st.b, st.force_pow, want_absmax=True)
+                glin = gl2.view(N, Ho, Wo, Cout)
+                am = ops.absmax_of(gl2)
+                if am is not None:
+                    ops._attach_absmax(glin, am)
+            else:
+                from bcos.modules._hipfn import _scale_bwd_cols
+                glin, rnorm, _ = _scale_bwd_cols(gy.reshape(-1, Cout), y2, st.scale.view(-1, Cout), st.norm.view(-1), BCOS_CONV_EPS,
+                                                 dict(b=st.b, force_pow=st.force_pow), False)
+                glin = glin.view(N, Ho, Wo, Cout)
             if need_x:
                 addend = ops.patch_norm_bwd(x, rnorm.view(N, Ho, Wo), cin, c.k, c.stride, c.padding, c.dilation, addend=addend)
         elif st.b != 1.0:
@@ -219,14 +227,14 @@ class ResNetTrainPlan:
         xd = xd if xd.is_contiguous() else xd.contiguous()
         mean, std = eng._consts(x.device)
         st = dict(x=xd, add_inverse=xd.shape[1] == 3, H=xd.shape[2], W=xd.shape[3])
-        xn = ops.prep_input(xd, mean, std, cpad=8, add_inverse=st["add_inverse"], want_absmax=False)
+        xn = ops.prep_input(xd, mean, std, cpad=8, add_inverse=st["add_inverse"], want_absmax=True)
         a0, st["stem"] = xn, []
         for conv, _ in eng.stem:                      # torchvision: one 7 x 7 convolution; CLIP (CLIP/clip/model.py:94-154): three 3 x 3
             a0, u = self._unit_fwd(conv, a0, relu=True)
             st["stem"].append(u)
         st["a0_hw"] = (a0.shape[1], a0.shape[2])
         k, s, p = eng.pool
-        cur = ops.avgpool2d_fwd(a0, k, s, p)
+        cur = ops.ensure_absmax(ops.avgpool2d_fwd(a0, k, s, p))
         blocks = []
         for blk in eng.blocks:
             inp = cur
@@ -237,9 +245,9 @@ class ResNetTrainPlan:
                 rec["units"].append(u)
             if blk.pool:                               # CLIP's anti-aliasing pool between conv2 and conv3 (CLIP/clip/model.py:25,47)
                 rec["pre_pool_hw"] = (h.shape[1], h.shape[2])
-                h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0)
+                h = ops.ensure_absmax(ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0))
             if blk.shortcut is not None:
-                sc_in = ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0) if blk.shortcut_pool else inp
+                sc_in = ops.ensure_absmax(ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0)) if blk.shortcut_pool else inp
                 idn, rec["shortcut"] = self._unit_fwd(blk.shortcut, sc_in, relu=False)
             else:
                 idn = inp

@@ -35,6 +35,7 @@ inline int check_launch(const char* what) {
 __global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                         const float* __restrict__ s, const float* __restrict__ norm,
                                                         float* __restrict__ glin, float* __restrict__ rnorm, float* __restrict__ bgrad,
+                                                        unsigned* __restrict__ glin_absmax,
                                                         int64_t rows, int C, int linear_eps, float b, int pow_form) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict_
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float nrm = norm[row];
         float acc = 0.f;
+        unsigned mx = 0u;
         for (int c = lane * 4; c < C; c += 256) {
             const int64_t i = row * C + c;
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(gy + i);
@@ -65,9 +67,16 @@ __global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict_
                 }
             }
             *reinterpret_cast<f32x4*>(glin + i) = o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mx = max(mx, __float_as_uint(o[q]) & 0x7fffffffu);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (glin_absmax) {      // per-row max |glin| (fp32 bit pattern): the operand scale of the input-gradient launch that reads glin
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+            if (lane == 0) glin_absmax[row] = mx;
+        }
         if (lane == 0) {
             // d norm / d x_j = x_j / ||.||: sqrt(S + 1e-6) differentiates to x / norm, ||x|| + 1e-12 to x / (norm - 1e-12)
             const float div = linear_eps ? fmaxf(nrm - 1e-12f, 1e-30f) : nrm;
@@ -660,11 +669,48 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restr
     }
 }
 
+
+// y = [relu](x * scale[c] + shift[c] (+ addend)) row by row, with the per-row max |y| (fp32 bit pattern) the next contraction takes as
+// its operand scale (round 5: forward and input-gradient contractions of a training step on the 3-product split-f16 loop instead of the
+// 6-product bf16 one).  LPR lanes per row: C / 4 when that divides 64 (8 / 4 / 2 rows per wavefront), else 64 lanes looping over the row.
+template <int LPR>
+__global__ __launch_bounds__(256) void channel_affine_rows_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ addend,
+                                                                  float* __restrict__ y, unsigned* __restrict__ absmax, int64_t rows, int C,
+                                                                  int relu) {
+    constexpr int RPW = 64 / LPR;                        // rows per wavefront
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, l = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {        // (wave-uniform trip count: the shuffles below see every lane)
+        const int64_t row = r0 + sub;
+        const bool live = row < rows;
+        unsigned mx = 0u;
+        if (live)
+            for (int c = l * 4; c < C; c += LPR * 4) {
+                const int64_t i = row * C + c;
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + i) * *reinterpret_cast<const f32x4*>(scale + c);
+                if (shift) v += *reinterpret_cast<const f32x4*>(shift + c);
+                if (addend) v += *reinterpret_cast<const f32x4*>(addend + i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (relu) v[q] = fmaxf(v[q], 0.f);
+                    mx = max(mx, __float_as_uint(v[q]) & 0x7fffffffu);
+                }
+                *reinterpret_cast<f32x4*>(y + i) = v;
+            }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if (live && l == 0) absmax[row] = mx;
+    }
+}
+
 }  // namespace
 
-extern "C" int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin,
-                                    float* rnorm, float* bgrad, int64_t rows, int C, int bcos_mode, float b, int force_pow,
-                                    void* stream) {
+extern "C" int bcos_train_scale_bwd_absmax(const float* gy, const float* y, const float* s, const float* norm, float* glin,
+                                           float* rnorm, float* bgrad, uint32_t* glin_absmax, int64_t rows, int C, int bcos_mode, float b,
+                                           int force_pow, void* stream) {
     if (!gy || !y || !s || !norm || !glin || !rnorm || rows <= 0 || C <= 0 || C % 4 != 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: bad argument (C must be a multiple of 4)");
     if (bcos_mode != BCOS_CONV_EPS && bcos_mode != BCOS_LINEAR_EPS)
@@ -676,8 +722,41 @@ extern "C" int bcos_train_scale_bwd(const float* gy, const float* y, const float
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scale_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       gy, y, s, norm, glin, rnorm, bgrad, rows, C, bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b, pow_form);
+                       gy, y, s, norm, glin, rnorm, bgrad, glin_absmax, rows, C, bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b, pow_form);
     return check_launch("train_scale_bwd launch");
+}
+
+extern "C" int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin,
+                                    float* rnorm, float* bgrad, int64_t rows, int C, int bcos_mode, float b, int force_pow,
+                                    void* stream) {
+    return bcos_train_scale_bwd_absmax(gy, y, s, norm, glin, rnorm, bgrad, nullptr, rows, C, bcos_mode, b, force_pow, stream);
+}
+
+extern "C" int bcos_channel_affine_rows(const float* x, const float* scale, const float* shift, const float* addend, float* y,
+                                        uint32_t* y_absmax, int64_t rows, int C, int relu, void* stream) {
+    if (!x || !scale || !y || !y_absmax || rows <= 0 || C <= 0 || C % 4 != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_channel_affine_rows: bad argument (C % 4)");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(addend) | reinterpret_cast<uintptr_t>(scale) |
+         reinterpret_cast<uintptr_t>(shift)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_channel_affine_rows: tensors must be 16-byte aligned");
+    const int C4 = C / 4;
+    const int lpr = (C4 < 64 && 64 % C4 == 0) ? C4 : 64;
+    const int64_t waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define BCOS_CAR(L) hipLaunchKernelGGL(channel_affine_rows_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, st, x, scale, shift, addend, y, y_absmax, rows, C, relu)
+    switch (lpr) {
+        case 1: BCOS_CAR(1); break;
+        case 2: BCOS_CAR(2); break;
+        case 4: BCOS_CAR(4); break;
+        case 8: BCOS_CAR(8); break;
+        case 16: BCOS_CAR(16); break;
+        case 32: BCOS_CAR(32); break;
+        default: BCOS_CAR(64); break;
+    }
+#undef BCOS_CAR
+    return check_launch("channel_affine_rows launch");
 }
 
 extern "C" int bcos_weight_rownorm_bwd(const float* w, const float* g_eff, const float* gain, float* gw, float* ggain, int rows,

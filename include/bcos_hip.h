@@ -479,6 +479,12 @@ int bcos_channel_affine_add(const float* x, const float* scale, const float* shi
                             int C, int relu, void* stream);
 int bcos_relu_bwd(const float* g, const float* act, float* out, int64_t n, void* stream);
 
+/* The same map row by row with the per-row max |y| (fp32 bit pattern, like bcos_epilogue.out_absmax) written to y_absmax [rows]:
+ * a training-mode unit's output carries the operand scale of the contraction that reads it, so that the forward and input-gradient
+ * contractions of a training step run the 3-product split-f16 loop.  addend / shift may be NULL; tensors 16-byte aligned.  (ABI v8) */
+int bcos_channel_affine_rows(const float* x, const float* scale, const float* shift, const float* addend, float* y,
+                             uint32_t* y_absmax, int64_t rows, int C, int relu, void* stream);
+
 /* -- training-mode backward (bcos_train.hip) ------------------------------------------ */
 /* Outside explanation mode the dynamic scale is not detached (bcosconv2d.py:176-194), so with lin = conv(x, W) (+ bias),
  * y = s(lin, norm) * lin:   gx = dgrad(gy * dy/dlin, W) + x (.) PatchSum^T(dL/dnorm / norm),   gW = wgrad(gy * dy/dlin, x).
@@ -494,6 +500,10 @@ int bcos_relu_bwd(const float* g, const float* act, float* out, int64_t n, void*
  *   caller zeroes it and applies d B_eff / d b (clamping: [b >= 1 + 1e-6]; b_loss: 1). */
 int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin, float* rnorm,
                          float* bgrad, int64_t rows, int C, int bcos_mode, float b, int force_pow, void* stream);
+/* The same with glin_absmax [rows] (may be NULL): the per-row max |glin| for the input-gradient launch that reads glin.  (ABI v8) */
+int bcos_train_scale_bwd_absmax(const float* gy, const float* y, const float* s, const float* norm, float* glin, float* rnorm,
+                                float* bgrad, uint32_t* glin_absmax, int64_t rows, int C, int bcos_mode, float b, int force_pow,
+                                void* stream);
 
 /* Backward of bcos_weight_rownorm_scale (NormedConv2d / NormedLinear in training mode, bcosconv2d.py:26-35,
  * bcoslinear.py:25-27): with w_hat = w / ||w|| per row and w_eff = gain * w_hat,

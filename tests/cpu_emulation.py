@@ -262,6 +262,13 @@ def channel_affine_add(x, scale, shift, addend, relu=False, out=None):
     return y
 
 
+def channel_affine_rows(x, scale, shift=None, addend=None, relu=False):
+    r = x * scale + (shift if shift is not None else 0)
+    if addend is not None:
+        r = r + addend
+    return torch.relu(r) if relu else r
+
+
 def relu_bwd(g, act, out=None):
     r = torch.where(act > 0, g, torch.zeros_like(g))
     if out is not None:
@@ -330,7 +337,7 @@ def maxout_expand(gy2d, t2d, max_out):
 
 
 # ---- training-mode backward (include/bcos_hip.h: bcos_train_scale_bwd ... bcos_channel_axpby) ----------------------------
-def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False):
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False, want_absmax=False):
     nrm = norm.view(-1, 1)
     bgrad = None
     if b == 2 and not force_pow:
@@ -493,7 +500,7 @@ def install(monkeypatch):
                  "weight_rownorm_scale", "rows_normalize", "cosine_grad", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_stats", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",
-                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "bn_batch_stats", "relu_bwd_colsums", "maxout_expand",
+                 "train_scale_bwd", "patch_norm_bwd", "conv2d_wgrad", "colsum", "channel_axpby", "bn_batch_stats", "relu_bwd_colsums", "channel_affine_rows", "maxout_expand",
                  "weight_rownorm_bwd", "maxout_scatter", "groupnorm_fwd", "groupnorm_bwd_detached",
                  "layernorm_bwd", "gelu_bwd", "attention_bwd", "groupnorm_bwd"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -1914,6 +1914,24 @@ def test_fused_batchnorm_training_kernels(lib):
             assert float(((sg.double() - ga_ref.double().sum(0)).abs() / (ga_ref.double().abs().sum(0) + 1e-30)).max()) <= 2e-6
             assert rel(gw, sgx.double() * rstd.double()) <= 1e-6
             assert rel(coef, -(gv.double() * sgx.double()) * rstd.double() ** 2 / rows) <= 1e-6
+    # bcos_channel_affine_rows / bcos_train_scale_bwd_absmax: same values as the plain entry points + the EXACT per-row maxima
+    for (rows, Cc) in [(5, 8), (1000, 32), (3136 * 2, 64), (777, 128), (333, 256), (50, 1000), (64, 2048)]:
+        xx = torch.randn(rows, Cc, generator=g).to(DEV)
+        sc_, sh_ = (torch.rand(Cc, generator=g) + 0.5).to(DEV), torch.randn(Cc, generator=g).to(DEV)
+        ad = torch.randn(rows, Cc, generator=g).to(DEV)
+        for addend, relu in ((None, True), (ad, True), (ad, False), (None, False)):
+            o = ops.channel_affine_rows(xx, sc_, sh_, addend, relu=relu)
+            ref_o = ops.channel_affine_add(xx, sc_, sh_, addend, relu=relu) if addend is not None else ops.channel_affine(xx, sc_, sh_, relu=relu)
+            assert torch.equal(o, ref_o), (rows, Cc, relu)
+            am = ops.absmax_of(o)
+            assert am is not None and torch.equal(am.view(torch.float32), o.abs().amax(1)), (rows, Cc, relu)
+        yy, ss = torch.randn(rows, Cc, generator=g).to(DEV), (torch.rand(rows, Cc, generator=g) + 0.1).to(DEV)
+        nn_ = (torch.rand(rows, generator=g) + 0.5).to(DEV)
+        from bcos_hip.lib import BCOS_CONV_EPS
+        g_a, r_a, _ = ops.train_scale_bwd(xx, yy, ss, nn_, BCOS_CONV_EPS, 2.0, want_absmax=True)
+        g_b, r_b, _ = ops.train_scale_bwd(xx, yy, ss, nn_, BCOS_CONV_EPS, 2.0)
+        assert torch.equal(g_a, g_b) and torch.equal(r_a, r_b) and ops.absmax_of(g_b) is None
+        assert torch.equal(ops.absmax_of(g_a).view(torch.float32), g_a.abs().amax(1))
     # validation: C % 4, missing outputs, act without ga, coef without gvec, a workspace that is too small
     y = torch.randn(64, 8, device=DEV)
     ws = torch.empty(8 * 3 * 4, device=DEV)
