@@ -38,7 +38,7 @@ for spec in "resnet50 --forward-only" "resnet18" "vit_ti --batch 512" "vit_ti --
   [ -n "$f" ] && cp "$f" "$SUM/${TAG}_kernel_stats_${name}.csv"
 done
 # 4b. the training-step diagnostic (bench.py --train: training plan for the ResNets, nn.Module path for the ViT; reference batch 64 per GPU) and its kernel stats
-for spec in "resnet50" "resnet18" "vit_ti"; do
+for spec in "resnet50" "resnet18" "vit_ti" "clip_rn50"; do
   python3 bench.py --train --arch $spec --steps 10 --warmup 3 > "$SUM/${TAG}_bench_train_${spec}.json" 2> "$OUT/bench_train_${spec}.err"
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train_${spec}" -- python3 "$ROOT/bench.py" --train --arch $spec --steps 3 --warmup 2 > /dev/null 2> "$OUT/stats_train_${spec}.err"
