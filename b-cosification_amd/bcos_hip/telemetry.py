@@ -109,6 +109,10 @@ def open_source(index=0):
 
 
 def main():
+    try:        # (the benchmark may have pinned itself -- OMP_PROC_BIND -- before starting this child: do not share its core)
+        os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
+    except (AttributeError, OSError):
+        pass
     index = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     interval = float(sys.argv[2]) if len(sys.argv) > 2 else 0.02
     try:
