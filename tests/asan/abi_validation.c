@@ -114,6 +114,21 @@ int main(void) {
     EXPECT(bcos_conv2d_wgrad(buf, buf, buf, 1, 4, 4, 8, 6, 4, 4, 8, 0, 1, 1, 1, 1, 0, 0, 1, 1, 0, NULL), BCOS_E_INVAL);
     EXPECT(bcos_colsum(buf, NULL, NULL, NULL, buf, 4, 6, NULL), BCOS_E_INVAL);
     EXPECT(bcos_channel_axpby(buf, buf, buf, NULL, NULL, buf, 4, 8, NULL), BCOS_E_INVAL);
+    /* ABI v8 entry points (training plan) */
+    { int64_t n = 0;
+      EXPECT(bcos_bn_train_ws_floats(0, 8, &n), BCOS_E_INVAL);
+      EXPECT(bcos_bn_train_ws_floats(64, 6, &n), BCOS_E_INVAL);
+      EXPECT(bcos_bn_train_ws_floats(64, 8, NULL), BCOS_E_INVAL); }
+    EXPECT(bcos_bn_batch_stats(NULL, NULL, NULL, buf, buf, buf, buf, buf, 1 << 20, 64, 8, 1e-5f, 0.1f, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_bn_batch_stats(buf, NULL, NULL, buf, buf, buf, buf, buf, 1 << 20, 64, 6, 1e-5f, 0.1f, NULL), BCOS_E_INVAL);     /* C % 4 */
+    EXPECT(bcos_bn_batch_stats(buf, NULL, NULL, buf, buf, buf, buf, buf, 3, 64, 8, 1e-5f, 0.1f, NULL), BCOS_E_INVAL);           /* workspace too small */
+    EXPECT(bcos_relu_bwd_colsums(buf, buf, buf, NULL, NULL, NULL, buf, NULL, NULL, NULL, buf, 1 << 20, 64, 8, NULL), BCOS_E_INVAL);   /* act without ga */
+    EXPECT(bcos_relu_bwd_colsums(buf, NULL, buf, NULL, NULL, NULL, buf, NULL, buf, NULL, buf, 1 << 20, 64, 8, NULL), BCOS_E_INVAL);   /* gw without rstd */
+    EXPECT(bcos_relu_bwd_colsums(buf, NULL, buf, NULL, buf, NULL, buf, NULL, NULL, buf, buf, 1 << 20, 64, 8, NULL), BCOS_E_INVAL);    /* coef without gvec */
+    EXPECT(bcos_channel_affine_rows(buf, buf, NULL, NULL, buf, NULL, 4, 8, 1, NULL), BCOS_E_INVAL);                                  /* maxima are the point */
+    EXPECT(bcos_channel_affine_rows(buf, buf, NULL, NULL, buf, am, 4, 6, 1, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd_absmax(buf, buf, buf, buf, buf, buf, NULL, am, 4, 6, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_patch_norm_bwd_add(buf, buf, buf, NULL, 1, 4, 4, 8, 0, 4, 4, 1, 1, 1, 1, 0, 0, 1, 1, NULL), BCOS_E_INVAL);
     /* ABI v5 entry points */
     EXPECT(bcos_rows_normalize(NULL, buf, NULL, 4, 8, NULL), BCOS_E_INVAL);
     EXPECT(bcos_rows_normalize(buf, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);                       /* neither output */
