@@ -466,7 +466,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                 } else if (e.relu == 2) {     // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
+                        const float gate = bcos_gelu_gate(val[q]);
                         s[q] *= gate;
                         val[q] *= gate;
                     }
@@ -525,7 +525,7 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
                         s = open_gate ? (gate_lsb ? __uint_as_float(__float_as_uint(s) | 1u) : s) : 0.f;
                         v = open_gate ? v : 0.f;
                     } else if (e.relu == 2) {
-                        const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
+                        const float gate = bcos_gelu_gate(v);
                         s *= gate;
                         v *= gate;
                     }
@@ -802,7 +802,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
             if (GELU) {           // GELU with the gate treated as a constant (MyGELU, bcosify_vit.py:27-32)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float gate = 0.5f * (1.0f + erff(val[q] / 1.4142135623730951f));
+                    const float gate = bcos_gelu_gate(val[q]);
                     s[q] *= gate;
                     val[q] *= gate;
                 }

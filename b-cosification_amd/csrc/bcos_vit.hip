@@ -274,7 +274,7 @@ __global__ __launch_bounds__(TPB) void gelu_gate_kernel(const float* __restrict_
     const int64_t stride = (int64_t)gridDim.x * TPB;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
         const float v = x[i];
-        const float gate = 0.5f * (1.0f + erff(v / 1.4142135623730951f));
+        const float gate = bcos_gelu_gate(v);
         y[i] = gate * v;
         if (gate_out) gate_out[i] = gate;
     }
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(TPB) void gelu_bwd_full_kernel(const float* __restr
     const int64_t stride = (int64_t)gridDim.x * TPB;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
         const float v = x[i];
-        const float Phi = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        const float Phi = bcos_gelu_gate(v);
         const float phi = 0.3989422804014327f * expf(-0.5f * v * v);
         gx[i] = gy[i] * (Phi + v * phi);
     }
