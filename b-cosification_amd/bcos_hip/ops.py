@@ -93,10 +93,28 @@ def split_weights_f16x2(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
     return out
 
 
+_PUBLISH = True
+
+
+class transient_weights:
+    """Context of the training plans: weight images made inside live for ONE pass and are read on the stream that made them, so
+    `publish_cached` has nothing to complete -- its device synchronisation per image (about a hundred per training step) kept the
+    host from running ahead of the device: issue time == device time in scripts/probe/train_host_probe.py."""
+
+    def __enter__(self):
+        global _PUBLISH
+        self._prev, _PUBLISH = _PUBLISH, False
+
+    def __exit__(self, *exc):
+        global _PUBLISH
+        _PUBLISH = self._prev
+        return False
+
+
 def publish_cached(t: torch.Tensor):
     """A device object that has just been made on the CURRENT stream and is about to be cached for later launches, whichever stream
     those run on (the engines process sub-batches on side streams): complete it first.  Once per cached object."""
-    if t is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if _PUBLISH and t is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
         torch.cuda.current_stream(t.device).synchronize()
 
 

@@ -22,6 +22,7 @@ convolution; its attention-pool head runs as the module it is, under autograd, o
 max_out == 1, fixed B.  Anything else -- the `attn_unpool` head, grouped / MaxOut layers, a learnable exponent, native unit-norm
 layers -- is refused by `supported()` and keeps the per-layer path.
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -37,6 +38,57 @@ def _pad4(t: torch.Tensor) -> torch.Tensor:
     return F.pad(t, (0, r)) if r else t
 
 
+_SIDE_STREAM = os.environ.get("BCOS_TRAIN_SIDE_STREAM", "1") != "0"
+
+
+class ParamGradQueue:
+    """Parameter gradients off the critical path of a backward pass: the chain of input gradients runs on the caller's stream, the
+    launches nothing else in the pass waits for -- weight gradients, bias / affine column sums -- on a second stream that follows it
+    (they are short of a machine-filling size at the reference's batch 64 per GPU: 200-600 workgroups, and 20-25 % of the kernel time
+    of a step).  `run(fn, reads)` issues fn() there once everything enqueued so far on the caller's stream has finished; `end()` makes
+    the caller's stream wait for all of it.  The tensors a launch reads are recorded on the side stream (the caching allocator must
+    not hand their blocks out again before it has passed), the results on the caller's.  CPU tensors (emulated kernels): inline."""
+
+    def __init__(self):
+        self._streams = {}
+        self.main = self.side = None
+        self._outs = []
+
+    def begin(self, device):
+        self.main = self.side = None
+        self._outs = []
+        device = torch.device(device)
+        if device.type != "cuda" or not _SIDE_STREAM or torch.cuda.is_current_stream_capturing():
+            return
+        key = str(device)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        self.main, self.side = torch.cuda.current_stream(device), self._streams[key]
+
+    def run(self, fn, reads=()):
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        for t in reads:
+            if t is not None:
+                t.record_stream(self.side)
+        self._outs.append(out)
+        return out
+
+    def end(self):
+        if self.side is None:
+            return
+        self.main.wait_stream(self.side)
+        for o in self._outs:
+            for t in (o if isinstance(o, (tuple, list)) else (o,)):
+                if torch.is_tensor(t):
+                    t.record_stream(self.main)
+        self._outs = []
+        self.main = self.side = None
+
+
 class _UnitState:
     __slots__ = ("x", "y", "scale", "norm", "w", "bias", "b", "force_pow", "mean", "rstd", "g", "act", "relu", "bn", "conv",
                  "has_addend", "in_hw", "batch_stats")
@@ -49,6 +101,7 @@ class ResNetTrainPlan:
         ok, why = self.supported(eng)
         if not ok:
             raise BcosHipError(f"train plan: {why}")
+        self._pq = ParamGradQueue()
 
     # ------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -202,11 +255,11 @@ class ResNetTrainPlan:
             glin = gy
         lin = conv.linear
         gl4 = _pad4(glin).contiguous()
-        if lin.weight.requires_grad:
-            gwk = ops.conv2d_wgrad(gl4, x, cin, Cout, c.k, c.stride, c.padding, c.dilation)
-            grads[lin.weight] = gwk.permute(0, 3, 1, 2).contiguous()          # [Cout,kh,kw,Cin] -> OIHW
+        if lin.weight.requires_grad:              # (on the side stream: nothing in the pass waits for a parameter gradient)
+            grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4, x, cin, Cout, c.k, c.stride, c.padding, c.dilation)
+                                             .permute(0, 3, 1, 2).contiguous(), (gl4, x))          # [Cout,kh,kw,Cin] -> OIHW
         if lin.bias is not None and lin.bias.requires_grad:
-            grads[lin.bias] = ops.colsum(gl4.view(-1, gl4.shape[3]))[:Cout].contiguous()
+            grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4.view(-1, gl4.shape[3]))[:Cout].contiguous(), (gl4,))
         gx = None
         if need_x:
             wq = st.w
@@ -219,6 +272,10 @@ class ResNetTrainPlan:
 
     # ------------------------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
+        with ops.transient_weights():
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor):
         eng = self.eng
         if x.dim() != 4 or x.shape[1] not in (3, 6):
             raise ValueError(f"expected [N,6,H,W] (or [N,3,H,W] to be AddInverse-encoded), got {tuple(x.shape)}")
@@ -265,6 +322,14 @@ class ResNetTrainPlan:
         return logits, st
 
     def backward(self, st, g_logits: torch.Tensor, need_x: bool = True):
+        self._pq.begin(g_logits.device)
+        try:
+            with ops.transient_weights():
+                return self._backward(st, g_logits, need_x)
+        finally:
+            self._pq.end()
+
+    def _backward(self, st, g_logits: torch.Tensor, need_x: bool = True):
         eng = self.eng
         grads: Dict = {}
         if st["head"] is None:                         # gradient of the feature map [N, C, H, W] from the head's own autograd nodes

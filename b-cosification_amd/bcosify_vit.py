@@ -90,6 +90,13 @@ class BcosifyNetwork(BcosUtilMixin, nn.Module):
         engine = getattr(self, "_bcos_engine", None)
         if engine is not None and not torch.is_grad_enabled() and not self.training:
             return engine.forward(x)          # eval + no_grad: the fused plan (it re-reads parameters that changed)
+        if engine is not None and self.training and torch.is_grad_enabled():
+            # train() + autograd: the whole network as ONE autograd node over the engine's block list (bcos_hip/vit_train_plan.py);
+            # conv-stem models, MaxOut / unit-norm / learnable-B layers and modules in explanation mode return None here
+            from bcos_hip import vit_train_plan
+            out = vit_train_plan.train_forward(engine, x)
+            if out is not None:
+                return out
         out = self.model(self.bcosifynormalize(x))
         return self.logit_layer(out) if self.logit_layer else out
 

@@ -239,8 +239,8 @@ def self_launch(args):
 
 
 def train_main(args):
-    """`--train`: images/s of whole training steps of the B-cosified network on the HIP kernels -- ResNets through the engine's training
-    plan (bcos_hip/train_plan.py), other topologies per layer on the nn.Module path.  One JSON line of the same shape as the metric's; the roofline prices the
+    """`--train`: images/s of whole training steps of the B-cosified network on the HIP kernels -- through the engines' training plans
+    (bcos_hip/train_plan.py, bcos_hip/vit_train_plan.py), or per layer on the nn.Module path (--no-train-plan).  One JSON line of the same shape as the metric's; the roofline prices the
     algorithmic work of a step -- forward + input-gradient + weight-gradient contractions = 3 x the forward FLOPs -- against the whole
     step time (no per-kernel events: the weight-gradient kernel runs on the fp32 matrix pipe, the others on the 16-bit one)."""
     import torch.nn.functional as F
@@ -268,9 +268,13 @@ def train_main(args):
         replica_diff = bdist.replicate_parameters(net) if world > 1 else []
     if replica_diff:
         raise SystemExit(f"bench.py: replicas differ after the broadcast of rank 0's parameters: {replica_diff[:5]}")
-    if spec["family"] in ("resnet", "clip") and not args.no_train_plan:
-        from bcos_hip import engine
-        engine.attach(net)               # (in eval mode: the inference plan; its layer list also drives the training plan)
+    if not args.no_train_plan:           # (in eval mode: the inference plan; its layer / block list also drives the training plan)
+        if spec["family"] == "vit":
+            from bcos_hip import vit_engine
+            vit_engine.attach(net)
+        else:
+            from bcos_hip import engine
+            engine.attach(net)
     net.train()
     B = args.batch
     x = synth.synthetic_images(B, seed=1000 + rank).to(dev)
@@ -330,8 +334,8 @@ def train_main(args):
         "config": {"workload": f"B-cosified {args.arch} TRAINING step (train-mode forward with batch statistics, BCE-with-logits, backward, "
                                f"SGD-momentum update), batch {B} per GPU, 224x224x6, calibrated random-init weights",
                    "global_batch": B * world, "parallelism": f"dp{world}", "contraction": contraction,
-                   "path": ("training plan (bcos_hip/train_plan.py): the whole network ONE autograd node whose forward / backward walk the engine's "
-                            "layer list" if path.get("plan") else
+                   "path": (f"training plan (bcos_hip/{'vit_' if spec['family'] == 'vit' else ''}train_plan.py): the whole network ONE autograd node whose "
+                            "forward / backward walk the engine's layer list" if path.get("plan") else
                             "nn.Module path: one HIP launch sequence per layer under autograd (no training plan for this topology)"),
                    "collective": "bucketed asynchronous all_reduce of the gradients (bcos_hip.dist.allreduce_gradients)" if world > 1 else "none",
                    "final_loss": round(float(loss.detach()), 6)},

@@ -775,11 +775,13 @@ def test_clip_rn50_non_detached_gradient_against_oracle(lib):
     assert rel(yp, yo) <= 1e-5 and rel(gf, go) <= 1e-5, (rel(yp, yo), rel(gf, go))
 
 
-def test_vit_training_mode_against_reference_golden(lib, golden_dir):
+@pytest.mark.parametrize("plan", [False, True], ids=["per_layer", "plan"])
+def test_vit_training_mode_against_reference_golden(lib, golden_dir, plan):
     """Training mode of the token path on the device: full LayerNorm / GELU / softmax-attention gradients and a BCE training
-    step of a small B-cosified SimpleViT against the reference's recorded gradients."""
+    step of a small B-cosified SimpleViT against the reference's recorded gradients -- per layer and as ONE autograd node over
+    the engine's block list (bcos_hip/vit_train_plan.py)."""
     from test_host_cpu import run_vit_training_goldens
-    run_vit_training_goldens(golden_dir, DEV, 1e-5)
+    run_vit_training_goldens(golden_dir, DEV, 1e-5, plan=plan)
 
 
 def test_vitc_ti_and_groupnorm_against_reference_golden(lib, golden_dir):

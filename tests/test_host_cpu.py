@@ -490,7 +490,7 @@ def run_vitc_goldens(golden_dir, dev, tol):
     assert rel(eng.forward(x), data["logits"]) <= 1e-4
 
 
-def run_vit_training_goldens(golden_dir, dev, tol):
+def run_vit_training_goldens(golden_dir, dev, tol, plan=False):
     """N4 on the token path: DetachableLayerNorm, MyGELU and Attention in TRAINING mode (bcos_layernorm_bwd, bcos_gelu_bwd,
     bcos_attention_bwd) and one BCE training step of a small B-cosified SimpleViT against gradients recorded from the reference
     (tests/golden/vit_train.npz)."""
@@ -540,10 +540,14 @@ def run_vit_training_goldens(golden_dir, dev, tol):
         for n, p_ in params:
             p_.copy_(torch.from_numpy(data[f"vit/param/{n}"]))
     net = net.to(dev).train()
+    if plan:                        # the same step as ONE autograd node over the engine's block list (bcos_hip/vit_train_plan.py)
+        from bcos_hip import vit_engine
+        vit_engine.attach(net)
     params = [(n, p_) for n, p_ in net.named_parameters() if p_.requires_grad]
     xs = synth.synthetic_images(3, seed=77, size=64).to(dev).requires_grad_(True)
     target = F.one_hot(torch.tensor([1, 7, 4]), 10).float().to(dev)
     logits = net(xs)
+    assert (type(logits.grad_fn).__name__ == "_TrainStepFnBackward") == bool(plan)
     loss = F.binary_cross_entropy_with_logits(logits, target)
     grads = torch.autograd.grad(loss, [xs] + [p_ for _, p_ in params])
     assert rel(logits, data["vit/logits"]) <= 10 * tol and abs(float(loss) - float(data["vit/loss"])) <= 10 * tol * abs(float(data["vit/loss"]))
@@ -555,9 +559,76 @@ def run_vit_training_goldens(golden_dir, dev, tol):
             assert rel(gr, data[f"vit/grad/{n}"]) <= 1e-4, (n, rel(gr, data[f"vit/grad/{n}"]))
 
 
-def test_vit_training_mode_matches_reference_golden(monkeypatch, golden_dir):
+@pytest.mark.parametrize("plan", [False, True], ids=["per_layer", "plan"])
+def test_vit_training_mode_matches_reference_golden(monkeypatch, golden_dir, plan):
     cpu_emulation.install(monkeypatch)
-    run_vit_training_goldens(golden_dir, "cpu", 4e-6)
+    run_vit_training_goldens(golden_dir, "cpu", 4e-6, plan=plan)
+
+
+@pytest.mark.parametrize("gap_reorder,use_bias", [(True, False), (False, True)])
+def test_vit_training_plan_equals_per_layer_path(monkeypatch, gap_reorder, use_bias):
+    """bcos_hip/vit_train_plan.py: `net.train(); net(x)` on a SimpleViT with a ViTEngine attached is ONE autograd
+    node.  On emulated kernels: the logits, the input gradient and every parameter gradient of the per-layer nn.Module path, with and
+    without biases, for both head orders (vit.py:197-202), 3-channel (AddInverse) and 6-channel input; a module switched to
+    explanation mode under train() sends the step back to the per-layer path; conv-stem models are outside the plan."""
+    import copy
+    import bcos.models.vit as vit
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import synth, vit_engine, vit_train_plan
+    from bcosify_vit import BcosifyNetwork
+    torch.manual_seed(3)
+    cfg = synth.vit_model_config("simple_vit_ti_patch16_224")
+    cfg = dict(cfg, args=dict(cfg["args"], gap_reorder=gap_reorder), bcosify_args=dict(cfg["bcosify_args"], use_bias=use_bias))
+    std = vit.SimpleViT(image_size=64, patch_size=16, num_classes=12, dim=64, depth=2, heads=1, mlp_dim=96, channels=3,
+                        linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU)
+    net = BcosifyNetwork(std, cfg, add_channels=True, logit_layer=cfg["logit_layer"])
+    synth.finish_vit_conversion(net, cfg)
+    assert net.model.gap_reorder == gap_reorder
+    with torch.no_grad():
+        for p_ in net.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))          # LayerNorm affine parameters and biases away from 1 / 0
+    net_ref = copy.deepcopy(net)
+    vit_engine.attach(net)
+    net.train(); net_ref.train()
+    x = synth.synthetic_images(3, seed=5, size=64)
+    target = F.one_hot(torch.tensor([1, 7, 4]), 12).float()
+
+    def step(n, xin):
+        xr = xin.clone().requires_grad_(True)
+        logits = n(xr)
+        ps = [p_ for p_ in n.parameters() if p_.requires_grad]
+        return logits, torch.autograd.grad(F.binary_cross_entropy_with_logits(logits, target), [xr] + ps)
+
+    lp, gp = step(net, x)
+    lr, gr = step(net_ref, x)
+    assert type(lp.grad_fn).__name__ == "_TrainStepFnBackward" and type(lr.grad_fn).__name__ != "_TrainStepFnBackward"
+    assert rel(lp, lr) <= 1e-5
+    names = [n for n, p_ in net.named_parameters() if p_.requires_grad]
+    assert use_bias == any(n.endswith("linear.bias") for n in names)
+    for name, a, b in zip(["x"] + names, gp, gr):
+        assert a.shape == b.shape and rel(a, b) <= 1e-4, (name, rel(a, b))
+    # AddInverse entry
+    l3, g3 = step(net, x[:, :3].contiguous())
+    x3 = x[:, :3].clone().requires_grad_(True)
+    l3r = net_ref(torch.cat([x3, 1 - x3], 1))
+    (g3r,) = torch.autograd.grad(F.binary_cross_entropy_with_logits(l3r, target), [x3])
+    assert g3[0].shape == (3, 3, 64, 64) and rel(l3, l3r) <= 1e-5 and rel(g3[0], g3r) <= 1e-4
+    # no gradient asked for the images (the trainer's case): parameter gradients only
+    logits = net(x)
+    ps = [p_ for p_ in net.parameters() if p_.requires_grad]
+    for a, b in zip(torch.autograd.grad(F.binary_cross_entropy_with_logits(logits, target), ps), gr[1:]):
+        assert rel(a, b) <= 1e-4
+    # explanation mode under train(): the per-layer path (its detached gradients are the modules' business)
+    with net.explanation_mode():
+        assert type(net(x.clone().requires_grad_(True)).grad_fn).__name__ != "_TrainStepFnBackward"
+    assert type(net(x.clone().requires_grad_(True)).grad_fn).__name__ == "_TrainStepFnBackward"
+    net.eval()
+    with torch.no_grad():
+        assert rel(net(x), net_ref.eval()(x)) <= 1e-5
+    vc = synth.build_bcosified_vit("vitc_ti_patch1_14") if hasattr(synth, "build_bcosified_vit") else None
+    if vc is not None:
+        assert not vit_train_plan.ViTTrainPlan.supported(vit_engine.attach(vc))[0]
 
 
 def test_vitc_and_groupnorm_match_reference_golden(monkeypatch, golden_dir):
