@@ -122,6 +122,7 @@ SIGNATURES = {
     "bcos_gelu_gate": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_groupnorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "bcos_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_gelu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "bcos_groupnorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "bcos_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

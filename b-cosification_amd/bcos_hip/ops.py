@@ -19,7 +19,15 @@ from .lib import BCOS_CONV_EPS, BCOS_LINEAR_EPS, BCOS_NONE, BcosHipError, Epilog
 KERNEL_TIMING = None
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """handle of torch's current stream on the current device (the raw accessor: torch.cuda.current_stream() builds a Stream object
+    per call, ~8 us -- a tenth of the host time of a launch-bound training step)"""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_GET_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -921,13 +929,43 @@ def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation, addend=N
     return out
 
 
-def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation):
+class ZeroArena:
+    """The zero-filled accumulators of one backward pass (weight gradients: pixel chunks meet in them through atomics) from ONE fill:
+    `begin()` allocates what the previous pass asked for, `take(shape)` hands out the next slice (torch.zeros while the arena is
+    missing or exhausted -- the first pass)."""
+
+    def __init__(self):
+        self.buf, self.used, self.want = None, 0, 0
+
+    def begin(self, device):
+        self.buf = torch.zeros(self.want, device=device, dtype=torch.float32) if self.want else None
+        self.used = self.want = 0
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 3) & ~3
+        self.want += n_al
+        if self.buf is None or self.buf.device != torch.device(device) or self.used + n_al > self.buf.numel():
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        out = self.buf[self.used:self.used + n].view(shape)
+        self.used += n_al
+        return out
+
+    def end(self):
+        self.buf = None          # (the slices keep the storage alive for as long as the gradients live)
+
+
+def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation, out=None):
     """glin [N,P,Q,g_pitch] (first Cout channels), x [N,H,W,x_pitch] (first C_used) -> gw [Cout,kh,kw,C_used]
-    (include/bcos_hip.h: bcos_conv2d_wgrad; fp32 MFMA, pixel chunks combined with atomics)."""
+    (include/bcos_hip.h: bcos_conv2d_wgrad; fp32 MFMA, pixel chunks combined with atomics).  `out`: a ZEROED [Cout,kh,kw,C_used]."""
     lib = _l.load()
     N, H, W, x_pitch = x.shape
     _, P, Q, g_pitch = glin.shape
-    gw = torch.zeros((Cout, kernel[0], kernel[1], C_used), device=x.device, dtype=torch.float32)
+    gw = out if out is not None else torch.zeros((Cout, kernel[0], kernel[1], C_used), device=x.device, dtype=torch.float32)
+    if tuple(gw.shape) != (Cout, kernel[0], kernel[1], C_used) or not gw.is_contiguous():
+        raise BcosHipError(f"conv2d_wgrad: out must be a contiguous {(Cout, kernel[0], kernel[1], C_used)} tensor")
     _l.check(lib.bcos_conv2d_wgrad(_dev(glin, "glin"), _dev(x, "x"), _dev(gw, "gw"), N, H, W, C_used, x_pitch, P, Q, Cout, g_pitch,
                                    kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
                                    C_used, _stream()), "bcos_conv2d_wgrad")
@@ -1075,14 +1113,17 @@ def layernorm_bwd_detached(gy2d, weight, rstd, addend=None, mul2=None, want_out=
     return o, o2
 
 
-def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False):
-    """Full LayerNorm input gradient (+ x_hat for the weight gradient), include/bcos_hip.h: bcos_layernorm_bwd."""
+def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False, addend=None):
+    """Full LayerNorm input gradient (+ x_hat for the weight gradient; + `addend`, the residual stream's gradient),
+    include/bcos_hip.h: bcos_layernorm_bwd_add."""
     lib = _l.load()
     rows, D = gy2d.shape
     gx = torch.empty_like(gy2d)
     xhat = torch.empty_like(gy2d) if want_xhat else None
-    _l.check(lib.bcos_layernorm_bwd(_dev(gy2d, "gy"), _dev(x2d, "x"), _dev(weight, "weight"), _dev(rstd, "rstd"), _dev(gx, "gx"),
-                                    _dev(xhat, "xhat"), rows, D, _stream()), "bcos_layernorm_bwd")
+    if addend is not None and tuple(addend.shape) != (rows, D):
+        raise BcosHipError(f"layernorm_bwd: addend {tuple(addend.shape)} does not match {(rows, D)}")
+    _l.check(lib.bcos_layernorm_bwd_add(_dev(gy2d, "gy"), _dev(x2d, "x"), _dev(weight, "weight"), _dev(rstd, "rstd"), _dev(addend, "addend"),
+                                        _dev(gx, "gx"), _dev(xhat, "xhat"), rows, D, _stream()), "bcos_layernorm_bwd")
     return gx, xhat
 
 

@@ -102,6 +102,7 @@ class ResNetTrainPlan:
         if not ok:
             raise BcosHipError(f"train plan: {why}")
         self._pq = ParamGradQueue()
+        self._zeros = ops.ZeroArena()
 
     # ------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -256,7 +257,8 @@ class ResNetTrainPlan:
         lin = conv.linear
         gl4 = _pad4(glin).contiguous()
         if lin.weight.requires_grad:              # (on the side stream: nothing in the pass waits for a parameter gradient)
-            grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4, x, cin, Cout, c.k, c.stride, c.padding, c.dilation)
+            acc = self._zeros.take((Cout, c.k[0], c.k[1], cin), x.device)
+            grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4, x, cin, Cout, c.k, c.stride, c.padding, c.dilation, out=acc)
                                              .permute(0, 3, 1, 2).contiguous(), (gl4, x))          # [Cout,kh,kw,Cin] -> OIHW
         if lin.bias is not None and lin.bias.requires_grad:
             grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4.view(-1, gl4.shape[3]))[:Cout].contiguous(), (gl4,))
@@ -322,12 +324,14 @@ class ResNetTrainPlan:
         return logits, st
 
     def backward(self, st, g_logits: torch.Tensor, need_x: bool = True):
+        self._zeros.begin(g_logits.device)
         self._pq.begin(g_logits.device)
         try:
             with ops.transient_weights():
                 return self._backward(st, g_logits, need_x)
         finally:
             self._pq.end()
+            self._zeros.end()
 
     def _backward(self, st, g_logits: torch.Tensor, need_x: bool = True):
         eng = self.eng

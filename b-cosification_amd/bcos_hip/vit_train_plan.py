@@ -48,6 +48,7 @@ class ViTTrainPlan:
         self._arena_f, self._arena_b = ops.AbsmaxArena(), ops.AbsmaxArena()
         from .train_plan import ParamGradQueue
         self._pq = ParamGradQueue()           # weight gradients and column sums on a second stream
+        self._zeros = ops.ZeroArena()         # their accumulators from one zero fill per pass
 
     # ------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -146,8 +147,9 @@ class ViTTrainPlan:
         lin = st.mod.linear
         x = st.x
         if lin.weight.requires_grad:
+            acc = self._zeros.take((Cout, 1, 1, Cin), x.device)
             grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4.view(1, 1, rows, gl4.shape[1]), x.view(1, 1, rows, Cin), Cin, Cout,
-                                                                      (1, 1), (1, 1), (0, 0), (1, 1)).view(Cout, Cin), (gl4, x))
+                                                                      (1, 1), (1, 1), (0, 0), (1, 1), out=acc).view(Cout, Cin), (gl4, x))
         if lin.bias is not None and lin.bias.requires_grad:
             grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4)[:Cout].contiguous(), (gl4,))
         if not need_x:
@@ -166,12 +168,13 @@ class ViTTrainPlan:
         y, rstd = ops.layernorm_fwd(x2, w, b, m.eps, want_rstd=True, want_absmax=want_absmax)
         return y, (m, x2, w, rstd)
 
-    def _ln_bwd(self, rec, gy, grads):
+    def _ln_bwd(self, rec, gy, grads, addend=None):
+        """-> gradient w.r.t. the LayerNorm's input (+ `addend`: what reaches the same tensor around the sub-block)"""
         m, x2, w, rstd = rec
         gy = gy if gy.is_contiguous() else gy.contiguous()
         need_w = isinstance(m.weight, nn.Parameter) and m.weight.requires_grad
         need_b = isinstance(m.bias, nn.Parameter) and m.bias.requires_grad
-        gx, xhat = ops.layernorm_bwd(gy, x2, w, rstd, want_xhat=need_w)
+        gx, xhat = ops.layernorm_bwd(gy, x2, w, rstd, want_xhat=need_w, addend=addend)
         D = gy.shape[1]
         if need_w:
             grads[m.weight] = self._pq.run(lambda: ops.colsum(gy, xhat) if D % 4 == 0 else (gy * xhat).sum(0), (gy, xhat))
@@ -259,12 +262,14 @@ class ViTTrainPlan:
         return logits, st
 
     def backward(self, st, g_logits: torch.Tensor, need_x: bool = True):
+        self._zeros.begin(g_logits.device)
         self._pq.begin(g_logits.device)
         try:
             with ops.transient_weights(), ops.no_absmax(), ops.absmax_arena(self._arena_b, g_logits.device):
                 return self._backward(st, g_logits, need_x)
         finally:
             self._pq.end()
+            self._zeros.end()
 
     def _backward(self, st, g_logits, need_x):
         eng = self.eng
@@ -286,7 +291,7 @@ class ViTTrainPlan:
             gz = self._lin_bwd(rec["l2"], g, grads)
             gy1 = ops.gelu_bwd(gz, rec["l1"].y) if blk["act"] == 2 else gz
             gh2 = self._lin_bwd(rec["l1"], gy1, grads)
-            g_x1 = self._ln_bwd(rec["ln2"], gh2, grads) + g
+            g_x1 = self._ln_bwd(rec["ln2"], gh2, grads, addend=g if g.is_contiguous() else g.contiguous())
             ga = self._lin_bwd(rec["out"], g_x1, grads)
             gqkv = ops.attention_bwd(rec["qkv"].view(N, T, -1), rec["stats"], rec["a"], ga.view(N, T, -1), blk["heads"], blk["scale"])
             gq2 = gqkv.view(N * T, -1)
@@ -295,10 +300,11 @@ class ViTTrainPlan:
                 rows, Cq = gq2.shape
                 h1 = rec["h1"]
                 Cin = h1.shape[1]
+                acc = self._zeros.take((Cq, 1, 1, Cin), gq2.device)
                 grads[wp] = self._pq.run(lambda: ops.conv2d_wgrad(gq2.view(1, 1, rows, Cq), h1.view(1, 1, rows, Cin), Cin, Cq, (1, 1), (1, 1),
-                                                                  (0, 0), (1, 1)).view(Cq, Cin), (gq2, h1))
+                                                                  (0, 0), (1, 1), out=acc).view(Cq, Cin), (gq2, h1))
             gh1 = ops.matmul_nt(ops.ensure_absmax(gq2), ops.mark_static(rec["wq"].t().contiguous()), track_absmax=False)
-            g = self._ln_bwd(rec["ln1"], gh1, grads) + g_x1
+            g = self._ln_bwd(rec["ln1"], gh1, grads, addend=g_x1)
             st["blocks"][bi] = None
         # patch embedding (the positional table is a constant): a p x p / stride p convolution over the NHWC input
         e = st["embed"]

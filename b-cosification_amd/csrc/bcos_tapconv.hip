@@ -3353,6 +3353,48 @@ __global__ __launch_bounds__(256) void split_weights_h2_kernel(const float* __re
     dst[64] = __builtin_bit_cast(uint4, l);
 }
 
+// both steps in one launch for small weight tensors (one workgroup per 32-row tile: row maxima, then its fragments) -- a training step
+// re-splits every weight twice (the forward and the transposed input-gradient image), ~100 images of 37-400 K elements for ViT-Ti:
+// half the launches of that.  Same arithmetic as the two kernels above.
+__global__ __launch_bounds__(256) void split_weights_h2_fused_kernel(const float* __restrict__ wt, uint4* __restrict__ wt2,
+                                                                     float* __restrict__ cinv, int rows, int Ktot, int nk, int taps, int C) {
+    __shared__ float s_scale[32];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    {
+        const int r = tid >> 3, sub = tid & 7, row = tile * 32 + r;
+        unsigned m = 0u;
+        if (row < rows)
+            for (int k = sub; k < Ktot; k += 8) m = max(m, __float_as_uint(wt[(int64_t)row * Ktot + k]) & 0x7fffffffu);
+#pragma unroll
+        for (int o = 4; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        unsigned E = m >> 23;
+        E = E < 15u ? 15u : E;
+        if (sub == 0) {
+            const float ci = __uint_as_float((E - 14u) << 23);
+            cinv[row] = ci;
+            s_scale[r] = 1.0f / ci;                                   // exact: a power of two
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int row = tile * 32 + (lane & 31);
+    const float scale = s_scale[lane & 31];
+    for (int ks = tid >> 6; ks < nk; ks += 4) {
+        const int k0 = taps > 1 ? (ks % taps) * C + (ks / taps) * 16 + 8 * (lane >> 5) : ks * 16 + 8 * (lane >> 5);
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (row < rows && k0 + e < Ktot) ? wt[(int64_t)row * Ktot + k0 + e] * scale : 0.f;
+            const _Float16 hh = (_Float16)x;
+            h[e] = hh;
+            l[e] = (_Float16)(x - (float)hh);
+        }
+        uint4* dst = wt2 + ((int64_t)tile * nk + ks) * 2 * 64 + lane;
+        dst[0] = __builtin_bit_cast(uint4, h);
+        dst[64] = __builtin_bit_cast(uint4, l);
+    }
+}
+
 inline int64_t h2_tiles(int rows) { return (((int64_t)rows + 127) / 128) * 4; }
 inline int64_t h2_image_bytes(int rows, int Ktot) { return h2_tiles(rows) * (((int64_t)Ktot + 15) / 16) * 2 * 1024; }
 
@@ -3379,10 +3421,15 @@ extern "C" int bcos_split_weights_f16x2_conv(const float* wt, void* wt2, int row
     const int rows_pad = (int)h2_tiles(rows) * 32;
     float* cinv = reinterpret_cast<float*>(static_cast<char*>(wt2) + h2_image_bytes(rows, Ktot));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(weight_rowscale_kernel, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, wt, cinv, rows, rows_pad, Ktot);
-    const int64_t total = h2_tiles(rows) * nk * 64;
-    hipLaunchKernelGGL(split_weights_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wt,
-                       reinterpret_cast<uint4*>(wt2), cinv, rows, Ktot, nk, total, ktaps, C);
+    if ((int64_t)rows_pad * Ktot <= (1 << 20)) {
+        hipLaunchKernelGGL(split_weights_h2_fused_kernel, dim3((unsigned)h2_tiles(rows)), dim3(256), 0, s, wt, reinterpret_cast<uint4*>(wt2),
+                           cinv, rows, Ktot, nk, ktaps, C);
+    } else {
+        hipLaunchKernelGGL(weight_rowscale_kernel, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, wt, cinv, rows, rows_pad, Ktot);
+        const int64_t total = h2_tiles(rows) * nk * 64;
+        hipLaunchKernelGGL(split_weights_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wt,
+                           reinterpret_cast<uint4*>(wt2), cinv, rows, Ktot, nk, total, ktaps, C);
+    }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("split_weights_f16x2 launch", err);
     return BCOS_OK;

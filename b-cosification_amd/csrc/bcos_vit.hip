@@ -918,7 +918,8 @@ __global__ __launch_bounds__(TPB) void groupnorm_bwd_full_kernel(const float* __
 // written out for the weight gradient (sum_rows gy x_hat, a column reduction).  One wavefront per row.
 __global__ __launch_bounds__(TPB) void layernorm_bwd_full_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                  const float* __restrict__ w, const float* __restrict__ rstd,
-                                                                 float* __restrict__ gx, float* __restrict__ xhat, int64_t rows, int D) {
+                                                                 const float* __restrict__ addend, float* __restrict__ gx,
+                                                                 float* __restrict__ xhat, int64_t rows, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
@@ -940,7 +941,8 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_full_kernel(const float* __
         for (int c = lane; c < D; c += 64) {
             const float xh = (xs[c] - mean) * rs;
             const float h = gs[c] * (w ? w[c] : 1.0f);
-            gx[r * D + c] = rs * (h - mh - xh * mhx);
+            const float g = rs * (h - mh - xh * mhx);
+            gx[r * D + c] = addend ? g + addend[r * D + c] : g;        // (the residual stream's gradient joins here)
             if (xhat) xhat[r * D + c] = xh;
         }
     }
@@ -1396,12 +1398,17 @@ extern "C" int bcos_groupnorm_bwd_detached(const float* gy, const float* weight,
     return check_launch("groupnorm_bwd_detached_kernel");
 }
 
+extern "C" int bcos_layernorm_bwd_add(const float* gy, const float* x, const float* weight, const float* rstd, const float* addend,
+                                      float* gx, float* xhat_out, int64_t rows, int D, void* stream) {
+    if (!gy || !x || !rstd || !gx || rows <= 0 || D <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_layernorm_bwd: bad argument");
+    hipLaunchKernelGGL(layernorm_bwd_full_kernel, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), gy, x, weight, rstd, addend, gx,
+                       xhat_out, rows, D);
+    return check_launch("layernorm_bwd_full_kernel");
+}
+
 extern "C" int bcos_layernorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,
                                   int64_t rows, int D, void* stream) {
-    if (!gy || !x || !rstd || !gx || rows <= 0 || D <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_layernorm_bwd: bad argument");
-    hipLaunchKernelGGL(layernorm_bwd_full_kernel, dim3(grid_rows(rows)), dim3(TPB), 0, STREAM(stream), gy, x, weight, rstd, gx, xhat_out,
-                       rows, D);
-    return check_launch("layernorm_bwd_full_kernel");
+    return bcos_layernorm_bwd_add(gy, x, weight, rstd, nullptr, gx, xhat_out, rows, D, stream);
 }
 
 extern "C" int bcos_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream) {

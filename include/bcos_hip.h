@@ -636,6 +636,10 @@ int bcos_attention_bwd_v(const float* qkv, const float* stats, const float* gout
  * receives x_hat for the weight gradient sum_rows gy x_hat (bcos_colsum). */
 int bcos_layernorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,
                        int64_t rows, int D, void* stream);
+/* The same plus the gradient that reaches the LayerNorm's input by the residual connection around it: gx = (above) + addend
+ * (addend [rows, D], may be NULL) -- one elementwise pass less per LayerNorm and training step.  (ABI v8) */
+int bcos_layernorm_bwd_add(const float* gy, const float* x, const float* weight, const float* rstd, const float* addend, float* gx,
+                           float* xhat_out, int64_t rows, int D, void* stream);
 /* DetachableGroupNorm2d outside explanation mode (= F.group_norm's gradient, centered_norms.py:109-113): per (image, group)
  * gx = rstd (h - mean(h) - x_hat mean(h x_hat)), h = gy * weight; xhat_out (NULL or like x) for the affine gradients. */
 int bcos_groupnorm_bwd(const float* gy, const float* x, const float* weight, const float* rstd, float* gx, float* xhat_out,

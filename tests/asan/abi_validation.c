@@ -139,6 +139,8 @@ int main(void) {
     EXPECT(bcos_layernorm_stats(buf, NULL, NULL, NULL, buf, am, 4, 8, 1e-5f, NULL), BCOS_E_INVAL);               /* rstd_out is required */
     EXPECT(bcos_layernorm_stats(NULL, NULL, NULL, buf, NULL, NULL, 4, 8, 1e-5f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_layernorm_bwd_detached(buf, NULL, buf, NULL, NULL, buf, NULL, am, 4, 8, NULL), BCOS_E_INVAL);   /* maxima of an absent out2 */
+    EXPECT(bcos_layernorm_bwd_add(buf, buf, NULL, buf, buf, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);                    /* no output */
+    EXPECT(bcos_layernorm_bwd_add(buf, buf, NULL, NULL, buf, buf, NULL, 4, 8, NULL), BCOS_E_INVAL);                    /* no rstd */
     EXPECT(bcos_attention_fwd(buf, NULL, NULL, am, 1, 4, 1, 64, 1.0f, NULL), BCOS_E_INVAL);
     EXPECT(bcos_attention_bwd_v(buf, buf, buf, buf, am, 1, 4, 1, 32, 1.0f, NULL), BCOS_E_NOSUP);               /* head dimension */
     free(buf); free(am);

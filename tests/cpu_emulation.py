@@ -364,11 +364,13 @@ def weight_rownorm_bwd(w2d, g2d, gain=None, want_gw=True, want_ggain=False):
     return gw, (dot.view(-1) if want_ggain else None)
 
 
-def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False):
+def layernorm_bwd(gy2d, x2d, weight, rstd, want_xhat=False, addend=None):
     x = x2d.double()
     xhat = (x - x.mean(1, keepdim=True)) * rstd.double().view(-1, 1)
     h = gy2d.double() * (weight.double() if weight is not None else 1.0)
     gx = rstd.double().view(-1, 1) * (h - h.mean(1, keepdim=True) - xhat * (h * xhat).mean(1, keepdim=True))
+    if addend is not None:
+        gx = gx.float().double() + addend.double()          # (the kernel rounds the LayerNorm term to fp32 first)
     return gx.float(), (xhat.float() if want_xhat else None)
 
 
@@ -442,12 +444,15 @@ def patch_norm_bwd(x, rnorm, C_used, kernel, stride, padding, dilation, addend=N
     return out + addend if addend is not None else out
 
 
-def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation):
+def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation, out=None):
     xn = x[..., :C_used].permute(0, 3, 1, 2).double()
     g = glin[..., :Cout].permute(0, 3, 1, 2).double()
     with torch.enable_grad():          # called from inside autograd.Function.backward, where grad mode is off
         w = torch.zeros(Cout, C_used, kernel[0], kernel[1], dtype=torch.float64, requires_grad=True)
         (gw,) = torch.autograd.grad(F.conv2d(xn.detach(), w, None, stride, padding, dilation), w, g.detach())
+    if out is not None:                # the kernel ACCUMULATES into a zeroed tensor
+        assert not out.any()
+        return out.add_(gw.permute(0, 2, 3, 1).float())
     return gw.permute(0, 2, 3, 1).float().contiguous()
 
 

@@ -784,6 +784,27 @@ def test_vit_training_mode_against_reference_golden(lib, golden_dir, plan):
     run_vit_training_goldens(golden_dir, DEV, 1e-5, plan=plan)
 
 
+def test_layernorm_gradient_takes_the_residual_gradient(lib):
+    """bcos_layernorm_bwd_add: the residual stream's gradient added by the LayerNorm-gradient launch is the separate addition, bit for bit;
+    and the fused row-scale + split of small weight tensors feeds the same contraction results as the fp64 product."""
+    from bcos_hip import ops
+    torch.manual_seed(11)
+    x = torch.randn(1000, 192, device=DEV) * 3 + 0.5
+    gy, add, w = torch.randn(1000, 192, device=DEV), torch.randn(1000, 192, device=DEV), torch.rand(192, device=DEV) + 0.5
+    _, rstd = ops.layernorm_fwd(x, w, None, 1e-5, want_rstd=True)
+    g0, xh0 = ops.layernorm_bwd(gy, x, w, rstd, want_xhat=True)
+    g1, xh1 = ops.layernorm_bwd(gy, x, w, rstd, want_xhat=True, addend=add)
+    assert torch.equal(g1, g0 + add) and torch.equal(xh0, xh1)
+    xr = x.double().requires_grad_(True)
+    F.layer_norm(xr, (192,), w.double(), None, 1e-5).backward(gy.double())
+    assert rel(g0, xr.grad) <= 1e-5
+    for rows, K in ((192, 192), (1000, 192), (192, 2048), (40, 68)):          # one-launch images (rows_pad * K <= 2^20)
+        a = ops.ensure_absmax(torch.randn(700, K, device=DEV))
+        wt = ops.mark_static(torch.randn(rows, K, device=DEV) * torch.logspace(-3, 2, rows, device=DEV).view(-1, 1))
+        y = ops.matmul_nt(a, wt, track_absmax=False)
+        assert rel(y, a.double() @ wt.double().t()) <= 2e-6, (rows, K)
+
+
 def test_vitc_ti_and_groupnorm_against_reference_golden(lib, golden_dir):
     """The conv-stem ViT (vitc_ti_patch1_14) and DetachableGroupNorm2d on the device: bcos_groupnorm_fwd /
     bcos_groupnorm_bwd_detached, MyGELU on channels_last activations, the stem convolutions on the fused B-cos kernel --
