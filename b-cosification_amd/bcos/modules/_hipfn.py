@@ -137,21 +137,26 @@ class WeightCache:
         self._key = None
         self._fwd = None
         self._dgrad = {}
+        self._transient = False
 
     def _sync(self, w, w_eff):
         # keyed on the parameter AND on the effective weight derived from it: NormedConv2d's unit-norm projection /
         # set_scale / toggle_weight_norm change w_eff while the parameter stays the same (bcosconv2d.py:26-41)
         key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device), w_eff.data_ptr(), w_eff._version)
         if key != self._key:
-            self._key, self._fwd, self._dgrad = key, None, {}
+            self._key, self._fwd, self._dgrad, self._transient = key, None, {}, False
 
     def fwd(self, w_eff, src):
         """w_eff: effective OIHW (or [O,I]) weight actually used (after unit-norm projection if any)."""
         self._sync(src, w_eff)
         if self._fwd is None:
+            # a weight under autograd is about to change: its copies live for one step on this stream and are not published to other
+            # streams (one device synchronisation per copy and image -- a training step of the per-layer path made ~150 of them)
+            self._transient = bool(torch.is_grad_enabled() and src.requires_grad)
             w4 = w_eff if w_eff.dim() == 4 else w_eff[:, :, None, None]
-            self._fwd = ops.mark_static(_pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous())
-            ops.publish_cached(self._fwd)          # (made on this stream, read by launches on any stream later)
+            self._fwd = ops.mark_static(_pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous(), self._transient)
+            if not self._transient:
+                ops.publish_cached(self._fwd)      # (made on this stream, read by launches on any stream later)
         return self._fwd
 
     def dgrad(self, w_eff, src, stride, padding, dilation, groups):
@@ -167,8 +172,9 @@ class WeightCache:
                 r = (-wg.shape[0]) % 4
                 if r:
                     wg = torch.cat([wg, wg.new_zeros((r,) + tuple(wg.shape[1:]))], 0)
-                plans.append(ops.DgradPlan(wg, stride, padding, dilation))
-            ops.publish_cached(w4)
+                plans.append(ops.DgradPlan(wg, stride, padding, dilation, transient=self._transient))
+            if not self._transient:
+                ops.publish_cached(w4)
             self._dgrad[k] = plans
         return self._dgrad[k]
 

@@ -64,11 +64,14 @@ _NO_GROUP = bool(os.environ.get("BCOS_NO_GROUP"))           # development switch
 _NO_D2S = bool(os.environ.get("BCOS_NO_D2S"))               # development switch: narrow strided gradients on the grouped direct kernel
 
 
-def mark_static(w: torch.Tensor) -> torch.Tensor:
+def mark_static(w: torch.Tensor, transient: bool = False) -> torch.Tensor:
     """Declare `w` an inference-time constant (a layer's effective weight): tapconv() then keeps its pre-split images
     (bcos_split_weights / bcos_split_weights_f16x2) next to it.  In-place updates are noticed through the tensor version
-    counter; the images are dropped with the tensor."""
+    counter; the images are dropped with the tensor.  `transient`: the weight is being trained -- the images live for one step on the
+    stream that made them and are not published to other streams (publish_cached: a device synchronisation per image)."""
     w._bcos_static = True
+    if transient:
+        w._bcos_transient = True
     return w
 
 
@@ -131,7 +134,8 @@ def _image_of(wt: torch.Tensor, attr: str, make):
     if cached is None or cached[0] != wt._version:
         cached = (wt._version, make(wt))
         setattr(wt, attr, cached)
-        publish_cached(cached[1])
+        if not getattr(wt, "_bcos_transient", False):
+            publish_cached(cached[1])
     return cached[1]
 
 
@@ -490,8 +494,8 @@ class DgradPlan:
     r0 = (rho + p) % s; with th = U-1-u the gathered g coordinate is i + dh0 + th, dh0 = (rho+p-r0)/s - U + 1.
     """
 
-    def __init__(self, w_oihw: torch.Tensor, stride, padding, dilation=(1, 1), groups: int = 1):
-        """`groups` > 1 (w_oihw [Cout, Cin / groups, kh, kw], the layout of nn.Conv2d): every class is ONE grouped launch
+    def __init__(self, w_oihw: torch.Tensor, stride, padding, dilation=(1, 1), groups: int = 1, transient: bool = False):
+        """`transient`: see mark_static.  `groups` > 1 (w_oihw [Cout, Cin / groups, kh, kw], the layout of nn.Conv2d): every class is ONE grouped launch
         (bcos_tapconv_geom.groups) -- group g contracts its Cout / groups gradient channels with its own transposed filters and
         writes its Cin / groups columns; Cin below is the layer's total input width."""
         Cout, Cin_g, kh, kw = w_oihw.shape
@@ -521,9 +525,10 @@ class DgradPlan:
                 else:                                                       # [G Cin/G, TH, TW, Cout/G]: the groups' transposed filters, stacked
                     cg = Cout // G
                     wt = torch.cat([sub[k * cg:(k + 1) * cg].permute(1, 2, 3, 0) for k in range(G)], 0).contiguous()
-                mark_static(wt)     # a DgradPlan is built once per weight version (engine plan / WeightCache)
+                mark_static(wt, transient)     # a DgradPlan is built once per weight version (engine plan / WeightCache)
                 self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
         self.has_empty = any(c[8] is None for c in self.classes)
+        self.transient = bool(transient)
         self._d2s = {}        # channel pitch -> (weights [sh*sw*pitch, TH, TW, Cout], TH, TW, dh0, dw0), see _depth_to_space
 
     def _depth_to_space(self, pitch: int):
@@ -546,8 +551,9 @@ class DgradPlan:
         for (rh, rw, th, tw, h0, w0, _, _, wt) in live:
             base = (rh * sw + rw) * pitch
             wc[base:base + self.Cin, h0 - dh0:h0 - dh0 + th, w0 - dw0:w0 - dw0 + tw] = wt
-        mark_static(wc)
-        publish_cached(wc)
+        mark_static(wc, self.transient)
+        if not self.transient:
+            publish_cached(wc)
         self._d2s[pitch] = (wc, TH, TW, dh0, dw0)
         return self._d2s[pitch]
 
