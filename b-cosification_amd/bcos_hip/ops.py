@@ -70,7 +70,7 @@ def mark_static(w: torch.Tensor, transient: bool = False) -> torch.Tensor:
     counter; the images are dropped with the tensor.  `transient`: the weight is being trained -- the images live for one step on the
     stream that made them and are not published to other streams (publish_cached: a device synchronisation per image)."""
     w._bcos_static = True
-    if transient:
+    if transient and not _PUBLISH_ALWAYS:
         w._bcos_transient = True
     return w
 
@@ -105,6 +105,7 @@ def split_weights_f16x2(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
 
 
 _PUBLISH = True
+_PUBLISH_ALWAYS = os.environ.get("BCOS_PUBLISH_ALWAYS", "0") == "1"       # development A/B: every weight image is published (round-4 behaviour)
 
 
 class transient_weights:

@@ -242,7 +242,7 @@ def train_main(args):
     """`--train`: images/s of whole training steps of the B-cosified network on the HIP kernels -- through the engines' training plans
     (bcos_hip/train_plan.py, bcos_hip/vit_train_plan.py), or per layer on the nn.Module path (--no-train-plan).  One JSON line of the same shape as the metric's; the roofline prices the
     algorithmic work of a step -- forward + input-gradient + weight-gradient contractions = 3 x the forward FLOPs -- against the whole
-    step time (no per-kernel events: the weight-gradient kernel runs on the fp32 matrix pipe, the others on the 16-bit one)."""
+    step time (no per-kernel events: the parameter-gradient launches run on a second stream beside the input-gradient chain)."""
     import torch.nn.functional as F
     from bcos_hip import dist as bdist, lib, synth
     lib.load()
@@ -329,7 +329,7 @@ def train_main(args):
         "step_times": dict(unit="ms", median=round(step_ms[len(step_ms) // 2], 3), min=round(step_ms[0], 3), max=round(step_ms[-1], 3)),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (parameters, activations, gradients, accumulation; forward / input-gradient contractions: " + DTYPES[contraction].format(min_k=0)
-                 + "; weight-gradient contraction: fp32 MFMA)",
+                 + "; weight-gradient contraction: " + ("fp32 MFMA" if contraction == "f32" else "exact 3-way bf16 split of both operands, 6 bf16 MFMA products, fp32 accumulate") + ")",
         "data": "synthetic",
         "config": {"workload": f"B-cosified {args.arch} TRAINING step (train-mode forward with batch statistics, BCE-with-logits, backward, "
                                f"SGD-momentum update), batch {B} per GPU, 224x224x6, calibrated random-init weights",

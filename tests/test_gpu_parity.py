@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+import torch.nn as nn
 
 from oracle import bcos_oracle as O
 
@@ -782,6 +783,44 @@ def test_vit_training_mode_against_reference_golden(lib, golden_dir, plan):
     the engine's block list (bcos_hip/vit_train_plan.py)."""
     from test_host_cpu import run_vit_training_goldens
     run_vit_training_goldens(golden_dir, DEV, 1e-5, plan=plan)
+
+
+def test_vit_training_plan_accumulates_over_two_forwards(lib):
+    """Two forward passes through the ViT training plan before one backward (gradient accumulation): the second pass resets the plan's
+    arenas of operand maxima while the first one's state is still waiting for its backward -- the sum of the two losses must give the
+    per-layer path's gradients, and a second identical step the same gradients again (the zero-fill arena of the weight gradients)."""
+    import copy
+    import bcos.models.vit as vit
+    from bcos_hip import synth, vit_engine
+    from bcosify_vit import BcosifyNetwork
+    torch.manual_seed(4)
+    cfg = synth.vit_model_config("simple_vit_ti_patch16_224")
+    std = vit.SimpleViT(image_size=64, patch_size=16, num_classes=12, dim=128, depth=2, heads=2, mlp_dim=256, channels=3,
+                        linear_layer=nn.Linear, norm_layer=nn.LayerNorm, act_layer=nn.GELU)
+    net = BcosifyNetwork(std, cfg, add_channels=True, logit_layer=cfg["logit_layer"])
+    synth.finish_vit_conversion(net, cfg)
+    net = net.to(DEV)
+    ref = copy.deepcopy(net)
+    vit_engine.attach(net)
+    net.train(); ref.train()
+    xa, xb = synth.synthetic_images(4, seed=1, size=64).to(DEV), synth.synthetic_images(4, seed=2, size=64).to(DEV)
+    tgt = F.one_hot(torch.tensor([1, 7, 4, 0]), 12).float().to(DEV)
+
+    def grads(n):
+        la, lb = n(xa), n(xb)
+        ps = [p_ for p_ in n.parameters() if p_.requires_grad]
+        loss = F.binary_cross_entropy_with_logits(la, tgt) + 0.5 * F.binary_cross_entropy_with_logits(lb, tgt)
+        return la, torch.autograd.grad(loss, ps)
+
+    la, gp = grads(net)
+    assert type(la.grad_fn).__name__ == "_TrainStepFnBackward"
+    lr_, gr = grads(ref)
+    names = [n for n, p_ in net.named_parameters() if p_.requires_grad]
+    for n, a, b in zip(names, gp, gr):
+        assert rel(a, b) <= 1e-4, (n, rel(a, b))
+    _, gp2 = grads(net)
+    for n, a, b in zip(names, gp, gp2):
+        assert rel(a, b) <= 1e-5, (n, rel(a, b))          # (atomics in the weight gradient: not bit-identical)
 
 
 def test_layernorm_gradient_takes_the_residual_gradient(lib):
