@@ -94,6 +94,7 @@ SIGNATURES = {
     "bcos_colsum_ws": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "bcos_channel_axpby": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_train_scale_bwd_absmax": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "bcos_train_scale_bwd_bn": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
     "bcos_channel_affine_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "bcos_bn_train_ws_floats": (C.c_int, [_L, _I, C.POINTER(C.c_int64)]),
     "bcos_bn_batch_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _F, _P]),

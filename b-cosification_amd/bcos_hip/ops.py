@@ -880,13 +880,26 @@ def relu_bwd(g, act, out=None):
 
 
 # ---- training-mode backward (csrc/bcos_train.hip) --------------------------------------------
-def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False, want_absmax=False):
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False, want_absmax=False, bn=None):
     """(gy * dy/dlin [rows,C], dL/dnorm / norm-denominator [rows], dL/dB_eff [1] or None) of y = s(lin, norm) * lin with s not
-    detached (include/bcos_hip.h: bcos_train_scale_bwd)."""
+    detached (include/bcos_hip.h: bcos_train_scale_bwd).  `bn` = (g, mean or None, coef or None): gy2d is the gradient w.r.t. the output
+    of the BatchNormUncentered2d behind the layer; the launch applies the norm's input gradient on the way (bcos_train_scale_bwd_bn)."""
     lib = _l.load()
     rows, Cc = gy2d.shape
     glin = torch.empty_like(gy2d)
     rnorm = torch.empty((rows,), device=gy2d.device, dtype=torch.float32)
+    if bn is not None:
+        if want_bgrad:
+            raise BcosHipError("train_scale_bwd: the fused BatchNorm form has no exponent gradient")
+        am = torch.empty((rows,), device=gy2d.device, dtype=torch.int32) if want_absmax else None
+        g, mean, coef = bn
+        _l.check(lib.bcos_train_scale_bwd_bn(_dev(gy2d, "g_out"), _dev(y2d, "y"), _dev(s2d, "s"), _dev(norm, "norm"), _dev(g, "bn_g"),
+                                             _dev(mean, "bn_mean"), _dev(coef, "bn_coef"), _dev(glin, "glin"), _dev(rnorm, "rnorm"),
+                                             C.c_void_p(am.data_ptr()) if am is not None else None, rows, Cc, int(mode), float(b),
+                                             int(bool(force_pow)), _stream()), "bcos_train_scale_bwd_bn")
+        if am is not None:
+            _attach_absmax(glin, am)
+        return glin, rnorm, None
     bgrad = torch.zeros((1,), device=gy2d.device, dtype=torch.float32) if want_bgrad else None
     am = torch.empty((rows,), device=gy2d.device, dtype=torch.int32) if want_absmax else None      # per-row max |glin| (the reader's operand scale)
     _l.check(lib.bcos_train_scale_bwd_absmax(_dev(gy2d, "gy"), _dev(y2d, "y"), _dev(s2d, "s"), _dev(norm, "norm"), _dev(glin, "glin"),

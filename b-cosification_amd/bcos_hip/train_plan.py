@@ -219,7 +219,13 @@ class ResNetTrainPlan:
                 grads[bn.weight] = gw
             if sg is not None:
                 grads[bn.bias] = sg
-            if not need_var:
+            # the norm's input gradient gy = ga g + (y - mean) coef: formed inside the scale derivative's launch where there is one
+            # (bcos_train_scale_bwd_bn), else by its own elementwise pass
+            fuse_bn = st.b != 1.0 and not conv.detach and Cout % 4 == 0
+            bn_terms = (st.g, st.mean.contiguous() if need_var else None, coef if need_var else None)
+            if fuse_bn:
+                gy = None
+            elif not need_var:
                 gy = ops.channel_affine(ga, st.g, None)
             else:
                 gy = ops.channel_axpby(ga, st.g, st.y, st.mean.contiguous(), coef)
@@ -227,6 +233,7 @@ class ResNetTrainPlan:
             if st.relu:
                 ga = ops.relu_bwd(ga, st.act)
             gy = ga
+            fuse_bn = False
         g_addend = ga if st.has_addend else None
         g2 = ga.reshape(-1, Cout)
         m = y2.shape[0]
@@ -237,8 +244,9 @@ class ResNetTrainPlan:
         addend = extra if (extra is None or extra.is_contiguous()) else extra.contiguous()
         if st.b != 1.0 and not conv.detach:
             if Cout % 4 == 0:          # (+ the per-pixel maxima of glin for the input-gradient launches)
-                gl2, rnorm, _ = ops.train_scale_bwd(gy.reshape(-1, Cout).contiguous(), y2, st.scale.view(-1, Cout), st.norm.view(-1),
-                                                    BCOS_CONV_EPS, st.b, st.force_pow, want_absmax=True)
+                gl2, rnorm, _ = ops.train_scale_bwd((ga if fuse_bn else gy).reshape(-1, Cout).contiguous(), y2, st.scale.view(-1, Cout),
+                                                    st.norm.view(-1), BCOS_CONV_EPS, st.b, st.force_pow, want_absmax=True,
+                                                    bn=bn_terms if fuse_bn else None)
                 glin = gl2.view(N, Ho, Wo, Cout)
                 am = ops.absmax_of(gl2)
                 if am is not None:

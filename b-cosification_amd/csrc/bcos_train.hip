@@ -32,8 +32,14 @@ inline int check_launch(const char* what) {
 // General form: s = c^(B-1), c = q + 1e-6, q = |lin| / norm.  q is rebuilt from lin = y / s (s > 0 in this form) rather than
 // from s^(1/(B-1)): a learnable B starts at 1 + 1e-6 (bcos/training/trainer.py:463), where s is 1 to fp32 precision and
 // carries no information about q.  `bgrad` (optional): dL/dB_eff = sum gy * y * ln c, one atomic per workgroup.
+// BN (round 5): `gy` is the gradient w.r.t. the OUTPUT of the BatchNormUncentered2d behind the layer and the kernel forms the gradient
+// w.r.t. y itself: gy_y = gy * bn_g[c] + (y - bn_mean[c]) * bn_coef[c] (bn_coef NULL: variance a constant) -- bcos_channel_axpby's
+// pass over the tensor (one write and one read of a layer output per layer and training step) folded into this one.
+template <bool BN>
 __global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                         const float* __restrict__ s, const float* __restrict__ norm,
+                                                        const float* __restrict__ bn_g, const float* __restrict__ bn_mean,
+                                                        const float* __restrict__ bn_coef,
                                                         float* __restrict__ glin, float* __restrict__ rnorm, float* __restrict__ bgrad,
                                                         unsigned* __restrict__ glin_absmax,
                                                         int64_t rows, int C, int linear_eps, float b, int pow_form) {
@@ -48,9 +54,17 @@ __global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict_
         unsigned mx = 0u;
         for (int c = lane * 4; c < C; c += 256) {
             const int64_t i = row * C + c;
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gy + i);
+            f32x4 g4 = *reinterpret_cast<const f32x4*>(gy + i);
             const f32x4 y4 = *reinterpret_cast<const f32x4*>(y + i);
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(s + i);
+            if constexpr (BN) {
+                g4 *= *reinterpret_cast<const f32x4*>(bn_g + c);
+                if (bn_coef) {
+                    f32x4 w = y4;
+                    if (bn_mean) w -= *reinterpret_cast<const f32x4*>(bn_mean + c);
+                    g4 += w * *reinterpret_cast<const f32x4*>(bn_coef + c);
+                }
+            }
             f32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -721,9 +735,30 @@ extern "C" int bcos_train_scale_bwd_absmax(const float* gy, const float* y, cons
         return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd: the |lin| / norm form (B == 2 without force_pow) does not depend on B");
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(scale_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       gy, y, s, norm, glin, rnorm, bgrad, glin_absmax, rows, C, bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b, pow_form);
+    hipLaunchKernelGGL(scale_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       gy, y, s, norm, nullptr, nullptr, nullptr, glin, rnorm, bgrad, glin_absmax, rows, C, bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b,
+                       pow_form);
     return check_launch("train_scale_bwd launch");
+}
+
+extern "C" int bcos_train_scale_bwd_bn(const float* g_out, const float* y, const float* s, const float* norm, const float* bn_g,
+                                       const float* bn_mean, const float* bn_coef, float* glin, float* rnorm, uint32_t* glin_absmax,
+                                       int64_t rows, int C, int bcos_mode, float b, int force_pow, void* stream) {
+    if (!g_out || !y || !s || !norm || !bn_g || !glin || !rnorm || rows <= 0 || C <= 0 || C % 4 != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd_bn: bad argument (C must be a multiple of 4)");
+    if (bn_mean && !bn_coef) return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd_bn: bn_mean without bn_coef");
+    if (bcos_mode != BCOS_CONV_EPS && bcos_mode != BCOS_LINEAR_EPS)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd_bn: bcos_mode must be BCOS_CONV_EPS or BCOS_LINEAR_EPS");
+    if (b == 1.0f) return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd_bn: B == 1 has no dynamic scale");
+    if ((reinterpret_cast<uintptr_t>(bn_g) | reinterpret_cast<uintptr_t>(bn_mean) | reinterpret_cast<uintptr_t>(bn_coef)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_train_scale_bwd_bn: the channel vectors must be 16-byte aligned");
+    const int pow_form = (b != 2.0f || force_pow) ? 1 : 0;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       g_out, y, s, norm, bn_g, bn_mean, bn_coef, glin, rnorm, nullptr, glin_absmax, rows, C,
+                       bcos_mode == BCOS_LINEAR_EPS ? 1 : 0, b, pow_form);
+    return check_launch("train_scale_bwd_bn launch");
 }
 
 extern "C" int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const float* norm, float* glin,

@@ -504,6 +504,13 @@ int bcos_train_scale_bwd(const float* gy, const float* y, const float* s, const 
 int bcos_train_scale_bwd_absmax(const float* gy, const float* y, const float* s, const float* norm, float* glin, float* rnorm,
                                 float* bgrad, uint32_t* glin_absmax, int64_t rows, int C, int bcos_mode, float b, int force_pow,
                                 void* stream);
+/* The same behind a BatchNormUncentered2d (batchnorm_uncentered.py:36-44): g_out is the gradient w.r.t. the NORM's output and the launch
+ * forms the gradient w.r.t. y itself on the way -- gy = g_out * bn_g[c] + (y - bn_mean[c]) * bn_coef[c] with bn_g = weight / std and
+ * bn_coef the variance-term coefficient of bcos_relu_bwd_colsums (NULL: the variance is a constant -- explanation mode or a layer in
+ * eval(); bn_mean NULL: 0) -- what bcos_channel_axpby would write and this launch read back.  Channel vectors 16-byte aligned.  (ABI v8) */
+int bcos_train_scale_bwd_bn(const float* g_out, const float* y, const float* s, const float* norm, const float* bn_g,
+                            const float* bn_mean, const float* bn_coef, float* glin, float* rnorm, uint32_t* glin_absmax, int64_t rows,
+                            int C, int bcos_mode, float b, int force_pow, void* stream);
 
 /* Backward of bcos_weight_rownorm_scale (NormedConv2d / NormedLinear in training mode, bcosconv2d.py:26-35,
  * bcoslinear.py:25-27): with w_hat = w / ||w|| per row and w_eff = gain * w_hat,

@@ -128,6 +128,10 @@ int main(void) {
     EXPECT(bcos_channel_affine_rows(buf, buf, NULL, NULL, buf, NULL, 4, 8, 1, NULL), BCOS_E_INVAL);                                  /* maxima are the point */
     EXPECT(bcos_channel_affine_rows(buf, buf, NULL, NULL, buf, am, 4, 6, 1, NULL), BCOS_E_INVAL);
     EXPECT(bcos_train_scale_bwd_absmax(buf, buf, buf, buf, buf, buf, NULL, am, 4, 6, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_train_scale_bwd_bn(buf, buf, buf, buf, NULL, NULL, NULL, buf, buf, am, 4, 8, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);      /* no bn_g */
+    EXPECT(bcos_train_scale_bwd_bn(buf, buf, buf, buf, buf, buf, NULL, buf, buf, am, 4, 8, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);        /* mean without coef */
+    EXPECT(bcos_train_scale_bwd_bn(buf, buf, buf, buf, buf, NULL, buf + 1, buf, buf, am, 4, 8, BCOS_CONV_EPS, 2.0f, 0, NULL), BCOS_E_INVAL);   /* misaligned vector */
+    EXPECT(bcos_train_scale_bwd_bn(buf, buf, buf, buf, buf, NULL, NULL, buf, buf, am, 4, 8, BCOS_CONV_EPS, 1.0f, 0, NULL), BCOS_E_INVAL);       /* B == 1 */
     EXPECT(bcos_patch_norm_bwd_add(buf, buf, buf, NULL, 1, 4, 4, 8, 0, 4, 4, 1, 1, 1, 1, 0, 0, 1, 1, NULL), BCOS_E_INVAL);
     /* ABI v5 entry points */
     EXPECT(bcos_rows_normalize(NULL, buf, NULL, 4, 8, NULL), BCOS_E_INVAL);

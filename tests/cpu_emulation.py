@@ -337,7 +337,12 @@ def maxout_expand(gy2d, t2d, max_out):
 
 
 # ---- training-mode backward (include/bcos_hip.h: bcos_train_scale_bwd ... bcos_channel_axpby) ----------------------------
-def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False, want_absmax=False):
+def train_scale_bwd(gy2d, y2d, s2d, norm, mode, b, force_pow=False, want_bgrad=False, want_absmax=False, bn=None):
+    if bn is not None:                     # include/bcos_hip.h: bcos_train_scale_bwd_bn
+        g, mean, coef = bn
+        gy2d = gy2d * g
+        if coef is not None:
+            gy2d = gy2d + (y2d - (mean if mean is not None else 0)) * coef
     nrm = norm.view(-1, 1)
     bgrad = None
     if b == 2 and not force_pow:

@@ -1935,6 +1935,28 @@ def test_attention_gradient_on_the_matrix_pipe(lib):
         assert bool(torch.isfinite(g1).all())
 
 
+def test_scale_derivative_applies_the_batchnorm_gradient(lib):
+    """bcos_train_scale_bwd_bn: the input gradient of the BatchNormUncentered2d behind a layer formed inside the scale derivative's
+    launch equals bcos_channel_axpby followed by bcos_train_scale_bwd_absmax (same expressions: 2 ulp), with and without the variance
+    term, both epsilon modes, the pow form, maxima included."""
+    from bcos_hip import ops
+    from bcos_hip.lib import BCOS_CONV_EPS, BCOS_LINEAR_EPS
+    torch.manual_seed(9)
+    for rows, Cc in ((777, 64), (3136, 256), (50, 2048)):
+        ga, y = torch.randn(rows, Cc, device=DEV), torch.randn(rows, Cc, device=DEV)
+        s = torch.rand(rows, Cc, device=DEV) + 0.05
+        norm = torch.rand(rows, device=DEV) + 0.5
+        g, mean, coef = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV), torch.randn(Cc, device=DEV) * 0.1
+        for mode, b, fp in ((BCOS_CONV_EPS, 2.0, False), (BCOS_LINEAR_EPS, 2.0, True), (BCOS_CONV_EPS, 1.5, False)):
+            for with_var in (True, False):
+                gy = ops.channel_axpby(ga, g, y, mean, coef) if with_var else ops.channel_affine(ga, g, None)
+                r0 = ops.train_scale_bwd(gy, y, s, norm, mode, b, fp, want_absmax=True)
+                r1 = ops.train_scale_bwd(ga, y, s, norm, mode, b, fp, want_absmax=True, bn=(g, mean if with_var else None, coef if with_var else None))
+                assert rel(r1[0], r0[0]) <= 1e-6 and rel(r1[1], r0[1]) <= 1e-6, (rows, Cc, mode, b, with_var)
+                am = ops.absmax_of(r1[0])
+                assert am is not None and torch.equal(am.view(torch.float32), r1[0].abs().amax(dim=1))
+
+
 def test_fused_batchnorm_training_kernels(lib):
     """bcos_bn_batch_stats / bcos_relu_bwd_colsums (ABI v8): the batch statistics of a BatchNormUncentered2d from ONE pass (shifted
     per-workgroup sums combined as (n, mean, M2) triples) against fp64 -- columns whose mean is 30 x their spread included --, the running
