@@ -3355,31 +3355,45 @@ __global__ __launch_bounds__(256) void split_weights_h2_kernel(const float* __re
 
 // both steps in one launch for small weight tensors (one workgroup per 32-row tile: row maxima, then its fragments) -- a training step
 // re-splits every weight twice (the forward and the transposed input-gradient image), ~100 images of 37-400 K elements for ViT-Ti:
-// half the launches of that.  Same arithmetic as the two kernels above.
+// half the launches of that for the block weights.  Same arithmetic as the two kernels above.
 __global__ __launch_bounds__(256) void split_weights_h2_fused_kernel(const float* __restrict__ wt, uint4* __restrict__ wt2,
                                                                      float* __restrict__ cinv, int rows, int Ktot, int nk, int taps, int C) {
+    // grid (32-row tile, K part): every workgroup takes the maxima of its tile's rows (coalesced 16-byte loads, the rows meet in LDS
+    // atomics; redundant across the K parts: the tensors are L2-sized) and writes the fragments of its share of the 16-k steps
+    __shared__ unsigned s_max[32];
     __shared__ float s_scale[32];
     const int tile = blockIdx.x, tid = threadIdx.x;
-    {
-        const int r = tid >> 3, sub = tid & 7, row = tile * 32 + r;
-        unsigned m = 0u;
-        if (row < rows)
-            for (int k = sub; k < Ktot; k += 8) m = max(m, __float_as_uint(wt[(int64_t)row * Ktot + k]) & 0x7fffffffu);
+    if (tid < 32) s_max[tid] = 0u;
+    __syncthreads();
+    const int row0 = tile * 32;
+    const int live = rows - row0 < 32 ? rows - row0 : 32;
+    const float* base = wt + (int64_t)row0 * Ktot;
+    if ((Ktot & 3) == 0 && !(reinterpret_cast<uintptr_t>(wt) & 15)) {
+        const int per_row = Ktot >> 2, n4 = live * per_row;
+        for (int i = tid; i < n4; i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(base)[i];
+            unsigned m = 0u;
 #pragma unroll
-        for (int o = 4; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        unsigned E = m >> 23;
-        E = E < 15u ? 15u : E;
-        if (sub == 0) {
-            const float ci = __uint_as_float((E - 14u) << 23);
-            cinv[row] = ci;
-            s_scale[r] = 1.0f / ci;                                   // exact: a power of two
+            for (int q = 0; q < 4; ++q) m = max(m, __float_as_uint(v[q]) & 0x7fffffffu);
+            atomicMax(&s_max[i / per_row], m);
         }
+    } else {
+        const int n = live * Ktot;
+        for (int i = tid; i < n; i += 256) atomicMax(&s_max[i / Ktot], __float_as_uint(base[i]) & 0x7fffffffu);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        unsigned E = s_max[tid] >> 23;
+        E = E < 15u ? 15u : E;
+        const float ci = __uint_as_float((E - 14u) << 23);
+        if (blockIdx.y == 0) cinv[row0 + tid] = ci;
+        s_scale[tid] = 1.0f / ci;                                     // exact: a power of two
     }
     __syncthreads();
     const int lane = tid & 63;
-    const int row = tile * 32 + (lane & 31);
+    const int row = row0 + (lane & 31);
     const float scale = s_scale[lane & 31];
-    for (int ks = tid >> 6; ks < nk; ks += 4) {
+    for (int ks = (int)blockIdx.y * 4 + (tid >> 6); ks < nk; ks += 4 * (int)gridDim.y) {
         const int k0 = taps > 1 ? (ks % taps) * C + (ks / taps) * 16 + 8 * (lane >> 5) : ks * 16 + 8 * (lane >> 5);
         f16x8 h, l;
 #pragma unroll
@@ -3421,9 +3435,13 @@ extern "C" int bcos_split_weights_f16x2_conv(const float* wt, void* wt2, int row
     const int rows_pad = (int)h2_tiles(rows) * 32;
     float* cinv = reinterpret_cast<float*>(static_cast<char*>(wt2) + h2_image_bytes(rows, Ktot));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if ((int64_t)rows_pad * Ktot <= (1 << 20)) {
-        hipLaunchKernelGGL(split_weights_h2_fused_kernel, dim3((unsigned)h2_tiles(rows)), dim3(256), 0, s, wt, reinterpret_cast<uint4*>(wt2),
-                           cinv, rows, Ktot, nk, ktaps, C);
+    // (one workgroup per 32 rows walks its whole K: beyond ~150 K elements or K > 1024 the two wide launches are faster -- at 2^20
+    //  elements the one-launch form cost a ResNet-50 training step 43 us per image, 4.6 ms per step)
+    if ((int64_t)rows_pad * Ktot <= 160 * 1024 && Ktot <= 1024) {
+        int parts = nk / 8;                                   // two 16-k steps per wave and workgroup
+        parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+        hipLaunchKernelGGL(split_weights_h2_fused_kernel, dim3((unsigned)h2_tiles(rows), (unsigned)parts), dim3(256), 0, s, wt,
+                           reinterpret_cast<uint4*>(wt2), cinv, rows, Ktot, nk, ktaps, C);
     } else {
         hipLaunchKernelGGL(weight_rowscale_kernel, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, wt, cinv, rows, rows_pad, Ktot);
         const int64_t total = h2_tiles(rows) * nk * 64;

@@ -837,7 +837,7 @@ def test_layernorm_gradient_takes_the_residual_gradient(lib):
     xr = x.double().requires_grad_(True)
     F.layer_norm(xr, (192,), w.double(), None, 1e-5).backward(gy.double())
     assert rel(g0, xr.grad) <= 1e-5
-    for rows, K in ((192, 192), (1000, 192), (192, 2048), (40, 68)):          # one-launch images (rows_pad * K <= 2^20)
+    for rows, K in ((192, 192), (768, 192), (192, 768), (1000, 192), (192, 2048), (40, 68)):          # one- and two-launch images
         a = ops.ensure_absmax(torch.randn(700, K, device=DEV))
         wt = ops.mark_static(torch.randn(rows, K, device=DEV) * torch.logspace(-3, 2, rows, device=DEV).view(-1, 1))
         y = ops.matmul_nt(a, wt, track_absmax=False)
