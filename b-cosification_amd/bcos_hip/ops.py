@@ -104,7 +104,10 @@ def split_weights_f16x2(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
     return out
 
 
-_PUBLISH = True
+import threading
+
+_TLS = threading.local()          # per thread: a training pass (autograd runs the backward on its own thread) must not switch off the
+                                  # publication of images another thread's inference plan is making at the same moment
 _PUBLISH_ALWAYS = os.environ.get("BCOS_PUBLISH_ALWAYS", "0") == "1"       # development A/B: every weight image is published (round-4 behaviour)
 
 
@@ -114,19 +117,18 @@ class transient_weights:
     host from running ahead of the device: issue time == device time in scripts/probe/train_host_probe.py."""
 
     def __enter__(self):
-        global _PUBLISH
-        self._prev, _PUBLISH = _PUBLISH, False
+        self._prev = getattr(_TLS, "publish", True)
+        _TLS.publish = False
 
     def __exit__(self, *exc):
-        global _PUBLISH
-        _PUBLISH = self._prev
+        _TLS.publish = self._prev
         return False
 
 
 def publish_cached(t: torch.Tensor):
     """A device object that has just been made on the CURRENT stream and is about to be cached for later launches, whichever stream
     those run on (the engines process sub-batches on side streams): complete it first.  Once per cached object."""
-    if _PUBLISH and t is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if getattr(_TLS, "publish", True) and t is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
         torch.cuda.current_stream(t.device).synchronize()
 
 

@@ -1461,3 +1461,31 @@ def test_telemetry_sampler_and_bench_thread_pinning(tmp_path):
     for args, want in (([], "close cores"), (["--gpus", "8"], "None None"), (["--no-cpu-baseline"], "None None"), (["--train"], "None None")):
         out = subprocess.run([sys.executable, "-c", probe.format(args=args, repo=repo)], capture_output=True, text=True, timeout=60)
         assert out.stdout.strip() == want, (args, out.stdout, out.stderr[-300:])
+
+
+def test_training_pass_helpers_are_thread_local_and_bump_allocated():
+    """ops.transient_weights switches image publication off for the calling thread only (autograd runs a plan's backward on its own thread
+    while another thread's inference plan may be making images); ops.ZeroArena hands out disjoint zeroed slices of one fill from the
+    second pass on and falls back to torch.zeros when it has no room; mark_static(transient=True) marks the tensor."""
+    import threading
+    from bcos_hip import ops
+    seen = {}
+    with ops.transient_weights():
+        assert getattr(ops._TLS, "publish", True) is False
+        th = threading.Thread(target=lambda: seen.setdefault("other", getattr(ops._TLS, "publish", True)))
+        th.start(); th.join()
+        with ops.transient_weights():
+            pass
+        assert getattr(ops._TLS, "publish", True) is False           # nesting restores the outer state
+    assert seen["other"] is True and getattr(ops._TLS, "publish", True) is True
+    za = ops.ZeroArena()
+    za.begin("cpu")
+    a = za.take((3, 5), "cpu"); b = za.take((2, 2), "cpu")          # first pass: nothing to draw from
+    assert a.shape == (3, 5) and not a.any() and not b.any()
+    za.end(); za.begin("cpu")
+    a = za.take((3, 5), "cpu"); b = za.take((2, 2), "cpu"); c = za.take((7,), "cpu")     # c: more than the previous pass asked for
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() != c.untyped_storage().data_ptr()
+    a.fill_(1.0)
+    assert not b.any() and not c.any() and a.is_contiguous() and b.is_contiguous()
+    w = torch.zeros(4, 4)
+    assert getattr(ops.mark_static(w, transient=True), "_bcos_transient", False) and not hasattr(ops.mark_static(torch.zeros(2)), "_bcos_transient")
