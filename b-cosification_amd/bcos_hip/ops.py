@@ -372,7 +372,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         if addend is not None:
             epi_tensors += 1.0 / max(int(addend_sub), 1) ** 2          # a subsampled addend holds 1 / s^2 of the pixels
         nbytes = int(4 * (int(g.N) * int(g.H) * int(g.W) * int(g.C) + ktot * int(g.Cout) + m_rows * int(g.Cout) * epi_tensors))
-        timing.append((ev0, ev1, 2.0 * m_rows * ktot * int(g.Cout), nbytes))
+        timing.append((ev0, ev1, 2.0 * m_rows * ktot * int(g.Cout), nbytes, (m_rows, ktot, int(g.Cout))))
     _l.check(code, "bcos_tapconv")
 
 
@@ -405,7 +405,7 @@ def tapconv_group(a: torch.Tensor, wts, geoms, *, out, addend=None, mul=None):
         g0 = geoms[0]
         rows_out = sum(q["N"] * q["P"] * q["Q"] for q in geoms)
         nbytes = 4 * (g0["N"] * g0["H"] * g0["W"] * g0["C"] + rows_out * g0["Cout"] * (1 + (addend is not None) + (mul is not None)))
-        timing.append((ev0, ev1, fl, nbytes))
+        timing.append((ev0, ev1, fl, nbytes, None))
     _l.check(code, "bcos_tapconv_group")
 
 

@@ -91,6 +91,7 @@ def parse():
                          "every BatchNormUncentered2d, dynamic scales differentiated), BCE-with-logits loss, backward to every parameter, "
                          "(N > 1) bucketed gradient all-reduce, SGD-momentum update -- the reference trainer's step "
                          "(bcos/training/trainer.py:666-784) at its ImageNet batch of 64 per GPU unless --batch is given")
+    ap.add_argument("--no-vendor-ref", action="store_true", help="skip the vendor fp16 GEMM reference of the matrix-bound launches (a few seconds, outside the timed region)")
     ap.add_argument("--no-train-plan", action="store_true", help="diagnostic (--train): no engine attached, every layer its own autograd node")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (engine.CapturedPass) instead of launching eagerly; "
@@ -236,6 +237,46 @@ def self_launch(args):
     for ln in (lines[-1:] if lines else proc.stdout.splitlines()[-20:]):
         print(ln, flush=True)
     return proc.returncode if (proc.returncode != 0 or lines) else 1
+
+
+def vendor_gemm_reference(shapes, ours_ms, prod, n_ev, pipe_peak, dev):
+    """Time torch.matmul in fp16 on (M, prod * K, N) for every distinct matrix-bound launch shape; -> the sum over the step's launches
+    beside the sum of this repo's launch times for the same launches."""
+    import collections
+    count = collections.Counter(s for s in shapes if s is not None)
+    ours = collections.defaultdict(float)
+    for s, ms in zip(shapes, ours_ms):
+        if s is not None:
+            ours[s] += ms
+    vend_ms = flops = 0.0
+    worst = None
+    for (M, K, N), c in sorted(count.items()):
+        a = torch.randn(M, K * prod, device=dev, dtype=torch.float16)
+        b = torch.randn(K * prod, N, device=dev, dtype=torch.float16)
+        for _ in range(2):
+            torch.matmul(a, b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            torch.matmul(a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        one = e0.elapsed_time(e1) / 5
+        vend_ms += one * c
+        flops += 2.0 * M * K * prod * N * c
+        ratio = (ours[(M, K, N)] / c) / one
+        if worst is None or ratio > worst[0]:
+            worst = (ratio, (M, K, N), round(1e3 * ours[(M, K, N)] / c, 1), round(1e3 * one, 1))
+        del a, b
+    ours_total = sum(ours.values())
+    return dict(ms_per_step=round(vend_ms / n_ev, 3), ours_ms_per_step=round(ours_total / n_ev, 3), launches_per_step=sum(count.values()) // n_ev,
+                distinct_shapes=len(count), tflops=round(flops / vend_ms / 1e9, 1), frac_of_executing_pipe=round(flops / vend_ms / 1e9 / pipe_peak, 4),
+                ours_over_vendor_time=round(ours_total / vend_ms, 3),
+                slowest_against_vendor=dict(ratio=round(worst[0], 3), M_K_N=list(worst[1]), ours_us=worst[2], vendor_us=worst[3]),
+                note=(f"torch.matmul fp16 (fp32 accumulate) on (M, {prod} K, N) per matrix-bound launch shape, 5 timed calls each after 2, HIP "
+                      "events, outside the timed region: the same matrix instructions on the same pipe with none of the launch's other work "
+                      "(no fp32 -> f16 split of the operands, no patch gather for the 3x3 / 7x7 layers -- the vendor GEMM gets the unfolded "
+                      "matrix for free --, no patch norms, no B-cos / BatchNorm / ReLU epilogue, no multiplier or maxima tensors)"))
 
 
 def train_main(args):
@@ -537,7 +578,8 @@ def main():
     images = args.batch * world * args.steps
     value = images / elapsed
 
-    per_launch = [(e0.elapsed_time(e1), fl, nb) for (e0, e1, fl, nb) in events]   # (ms, algorithmic flops, algorithmic bytes)
+    shapes = [ev[4] for ev in events]                                   # (M, K, N) of the launch's implicit GEMM, or None
+    per_launch = [(e0.elapsed_time(e1), fl, nb) for (e0, e1, fl, nb, _) in events]   # (ms, algorithmic flops, algorithmic bytes)
     kernel_ms = sum(ms for ms, _, _ in per_launch)                   # all contraction launches of the sampled steps
     launches = len(per_launch)
     n_ev = max(len(event_steps), 1)
@@ -560,6 +602,7 @@ def main():
     # balance of what the contraction sustains (~250 TFLOP/s fp32-equivalent against ~5 TB/s => 50 FLOP/B)
     hbm = [(ms, fl, nb) for ms, fl, nb in per_launch if fl / max(nb, 1) < 50.0]
     mfma = [(ms, fl, nb) for ms, fl, nb in per_launch if fl / max(nb, 1) >= 50.0]
+    mfma_shapes = [sh for (ms, fl, nb), sh in zip(per_launch, shapes) if fl / max(nb, 1) >= 50.0]
     hbm_ms, mfma_ms = sum(m for m, _, _ in hbm), sum(m for m, _, _ in mfma)
     hbm_gbps = sum(nb for _, _, nb in hbm) / hbm_ms / 1e6 if hbm_ms > 0 else 0.0
     mfma_tf = sum(fl for _, fl, _ in mfma) / mfma_ms / 1e9 if mfma_ms > 0 else 0.0
@@ -604,6 +647,15 @@ def main():
                           f"{gflop_step:.1f} GFLOP per step, SURVEY.md section 8(d): 17.22 GFLOP/image forward+explanation) / the time of "
                           "the contraction launches measured with HIP events on the launch stream, against that pipe's dense peak; "
                           "vs_fp32_mfma_peak = algorithmic TFLOP/s / 157.3 (the fp32 matrix pipe the contraction does not run on)"))
+
+    # What the vendor's GEMM reaches on the same pipe at the same shapes: every matrix-bound launch of the step as ONE plain fp16 GEMM
+    # (torch.matmul -> hipBLASLt / rocBLAS, fp32 accumulate) of the launch's M and N and `prod` x its K -- the matrix work the
+    # split-f16 loop executes, without the split, the patch gather, the B-cos epilogue or any tensor beyond C.  Outside the timed region.
+    if rank == 0 and world == 1 and prod > 1 and not args.no_vendor_ref and mfma_shapes:
+        try:
+            roofline["by_bound"]["mfma"]["vendor_f16_gemm"] = vendor_gemm_reference(mfma_shapes, [m for m, _, _ in mfma], prod, n_ev, pipe_peak, dev)
+        except Exception as exc:           # (an allocation failure of the reference must not cost the bench line)
+            roofline["by_bound"]["mfma"]["vendor_f16_gemm"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # the same fraction at the clock the part sustained during the timed region: the pipe's dense peak scales with the shader
     # clock (PEAK_16BIT_MFMA_TFLOPS is quoted at SPEC_SCLK_MHZ); `frac` itself stays priced at the specification clock

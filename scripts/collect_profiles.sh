@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-vendor-ref"
 # 1. the headline command as the driver runs it (CPU baseline included)
 python3 bench.py --steps 20 --warmup 5 > "$SUM/${TAG}_bench.json" 2> "$OUT/bench.err"
 # 2. kernel stats + HBM counters of the same workload (counters in their own passes, MI355X_MICROARCH.md).  The profiled runs keep
