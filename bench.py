@@ -656,6 +656,28 @@ def main():
             roofline["by_bound"]["mfma"]["vendor_f16_gemm"] = vendor_gemm_reference(mfma_shapes, [m for m, _, _ in mfma], prod, n_ev, pipe_peak, dev)
         except Exception as exc:           # (an allocation failure of the reference must not cost the bench line)
             roofline["by_bound"]["mfma"]["vendor_f16_gemm"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    # ... and what a plain device copy reaches against the 8 TB/s the bandwidth-bound launches are priced at (read + write bytes of a
+    # 1 GiB fp32 tensor copied onto another, torch's copy kernel, outside the timed region)
+    if rank == 0 and world == 1 and not args.no_vendor_ref and hbm:
+        try:
+            src = torch.empty(1 << 28, device=dev, dtype=torch.float32).normal_()
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 10 * 2 * src.numel() * 4 / c0.elapsed_time(c1) / 1e6
+            roofline["by_bound"]["hbm"].update(stream_copy_gbps=round(copy_gbps, 1), frac_of_stream_copy=round(hbm_gbps / copy_gbps, 4),
+                                               stream_copy_note="read + written bytes / time of dst.copy_(src) on 1 GiB fp32 tensors (10 calls "
+                                                                "after 3): the rate a kernel with nothing but one coalesced read and one "
+                                                                "coalesced write reaches on this part")
+            del src, dst
+        except Exception as exc:
+            roofline["by_bound"]["hbm"]["stream_copy_gbps"] = None
 
     # the same fraction at the clock the part sustained during the timed region: the pipe's dense peak scales with the shader
     # clock (PEAK_16BIT_MFMA_TFLOPS is quoted at SPEC_SCLK_MHZ); `frac` itself stays priced at the specification clock
