@@ -19,6 +19,11 @@ Per encoder block (vit.py:143-158):
 Scope: plain SimpleViT (patch embedding by rearrangement, no convolution stem), B-cos linears with max_out == 1, a fixed exponent and
 plain (not unit-norm) weights, MyGELU or no activation.  Anything else, and any module switched to explanation mode (`detach`) while
 the network is in train(), keeps the per-layer path.
+
+Like the inference plans (and the reference's own training loop) a plan is single-threaded: its arenas of operand maxima, the zero-fill
+arena of the weight gradients and the second stream belong to ONE pass at a time.  Several forward passes before their backward passes
+(gradient accumulation) are fine -- a pass's state lives in its autograd node, a stale arena slice is refused by ops.absmax_of -- but
+two threads driving the same network are not.
 """
 from typing import Dict, List
 
@@ -197,6 +202,8 @@ class ViTTrainPlan:
         eng = self.eng
         N, _, H, W = xd.shape
         p = eng.patch
+        if H % p or W % p:
+            raise ValueError(f"image size {H} x {W} is not a multiple of the patch size {p} (vit.py:166-167)")
         gh, gw = H // p, W // p
         T = gh * gw
         mean, std = eng._consts(xd.device)
