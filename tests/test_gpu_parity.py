@@ -2106,6 +2106,35 @@ def test_bench_train_diagnostic_line(lib):
     assert math.isfinite(res["config"]["final_loss"]) and res["roofline"]["achieved"] > 0 and res["step_times"]["min"] > 0
 
 
+def test_bench_headline_line_carries_the_contract_and_the_references(lib):
+    """`python bench.py` at a small batch: ONE JSON line with the contract's keys, the roofline of the dominant kernel measured with HIP
+    events inside the run, the clock telemetry, and -- round 5 -- what the vendor's primitives reach beside it: the plain fp16 GEMMs of
+    the matrix-bound launches' shapes and a device copy for the bandwidth-bound ones.  (The CPU baseline has its own leg; off here.)"""
+    import subprocess
+    import sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([_sys.executable, os.path.join(repo, "bench.py"), "--batch", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in res, k
+    assert res["unit"] == "images/s" and res["value"] > 0 and res["steps"] == 3 and res["n_gpus"] == 1 and res["vs_baseline"] is None
+    assert res["scaling"] == "weak" and res["higher_is_better"] is True and "workload" in res["config"] and "model" not in res["config"]
+    rf = res["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("mfma", "hbm") and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["avg_launch_us"] > 0 and rf["launches_per_step"] == 117
+    v = rf["by_bound"]["mfma"]["vendor_f16_gemm"]
+    assert "error" not in v and v["ms_per_step"] > 0 and v["ours_ms_per_step"] > 0 and v["launches_per_step"] == rf["by_bound"]["mfma"]["launches_per_step"]
+    h = rf["by_bound"]["hbm"]
+    assert h["stream_copy_gbps"] and 1000 < h["stream_copy_gbps"] < 8000 and h["frac_of_stream_copy"] > 0
+
+
 def test_c_abi_image_absmax(lib):
     """bcos_image_absmax (ABI v6) through the C ABI: per-image maxima of per-pixel maxima, image sizes on either side of the
     kernel's 4096-pixel stride, bit-exact (integer maxima of fp32 bit patterns)."""
