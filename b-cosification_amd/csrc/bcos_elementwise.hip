@@ -291,6 +291,48 @@ __global__ __launch_bounds__(TPB) void gap_logits_kernel(const float* __restrict
     }
 }
 
+// the same mean for many positions per image (the token path: 197 tokens x 1000 classes per image ran at 1 TB/s with one thread walking
+// all positions of a column): a workgroup takes 64 columns of one image, four thread groups walk every fourth position, their partial
+// sums meet in LDS in a fixed order
+__global__ __launch_bounds__(256) void gap_logits_wide_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int cblocks,
+                                                              float inv_t, float bias) {
+    __shared__ float part[4][64];
+    const int n = blockIdx.x / cblocks, cb = blockIdx.x - n * cblocks;
+    const int c = cb * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        const float* src = x + (int64_t)n * HW * C + c;
+        int hw = g;
+        for (; hw + 4 < HW; hw += 8) {
+            a0 += src[(int64_t)hw * C];
+            a1 += src[(int64_t)(hw + 4) * C];
+        }
+        if (hw < HW) a0 += src[(int64_t)hw * C];
+    }
+    part[g][threadIdx.x & 63] = a0 + a1;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) / (float)HW;
+        if (inv_t != 1.0f) v *= inv_t;
+        y[(int64_t)n * C + c] = v + bias;
+    }
+}
+
+// four columns per thread (C % 4 == 0, 16-byte aligned tensors): the tensor is zeros but for one column per image -- 16-byte stores
+__global__ __launch_bounds__(TPB) void head_onehot4_kernel(const int64_t* __restrict__ cls, const float* __restrict__ scale,
+                                                           float* __restrict__ glin, int N, int HW, int C4, float coef) {
+    const int64_t total = (int64_t)N * HW * C4;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        const int64_t n = i / ((int64_t)HW * C4);
+        const int k = (int)cls[n];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((k >> 2) == c4) v[k & 3] = scale[i * 4 + (k & 3)] * coef;
+        reinterpret_cast<f32x4*>(glin)[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void head_onehot_kernel(const int64_t* __restrict__ cls,
                                                           const float* __restrict__ scale, float* __restrict__ glin,
                                                           int N, int HW, int C, float coef) {
@@ -559,6 +601,12 @@ extern "C" int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, 
 extern "C" int bcos_global_avgpool_logits(const float* x, float* y, int N, int HW, int C, float inv_temperature,
                                           float logit_bias, void* stream) {
     if (!x || !y || N <= 0 || HW <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_global_avgpool_logits: bad argument");
+    if (HW >= 64) {        // many positions per image (token path): see gap_logits_wide_kernel
+        const int cblocks = (C + 63) / 64;
+        hipLaunchKernelGGL(gap_logits_wide_kernel, dim3((unsigned)((int64_t)N * cblocks)), dim3(256), 0, STREAM(stream), x, y, HW, C, cblocks,
+                           inv_temperature, logit_bias);
+        return check_launch("gap_logits_wide_kernel");
+    }
     hipLaunchKernelGGL(gap_logits_kernel, dim3(grid_for((int64_t)N * C)), dim3(TPB), 0, STREAM(stream), x, y, N, HW, C,
                        inv_temperature, logit_bias);
     return check_launch("gap_logits_kernel");
@@ -568,6 +616,11 @@ extern "C" int bcos_head_onehot_grad(const int64_t* cls, const float* scale, flo
                                      float inv_temperature, void* stream) {
     if (!cls || !scale || !glin || N <= 0 || HW <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_head_onehot_grad: bad argument");
     const float coef = inv_temperature / (float)HW;
+    if (C % 4 == 0 && !((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(glin)) & 15)) {
+        hipLaunchKernelGGL(head_onehot4_kernel, dim3(grid_for((int64_t)N * HW * (C / 4))), dim3(TPB), 0, STREAM(stream), cls, scale, glin, N, HW,
+                           C / 4, coef);
+        return check_launch("head_onehot_kernel");
+    }
     hipLaunchKernelGGL(head_onehot_kernel, dim3(grid_for((int64_t)N * HW * C)), dim3(TPB), 0, STREAM(stream), cls, scale,
                        glin, N, HW, C, coef);
     return check_launch("head_onehot_kernel");
