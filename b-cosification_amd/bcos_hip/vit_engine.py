@@ -134,6 +134,7 @@ _VIT_SUBBATCH_STREAMS = int(os.environ.get("BCOS_VIT_SUBBATCH_STREAMS", os.envir
 # the residual add and the next layer's stored scale in its epilogue.  No LayerNorm output or gradient tensor is written or
 # read.  BCOS_VIT_LN_FUSED=0: the round-3 plan (layernorm_fwd / layernorm_bwd_detached kernels between the GEMMs).
 _LN_FUSED = os.environ.get("BCOS_VIT_LN_FUSED", "1") != "0"
+_HEAD_RANK1 = os.environ.get("BCOS_VIT_HEAD_RANK1", "1") != "0"      # 0: the round-4 head gradient (one-hot tensor + contraction), for A/B
 
 
 def _absmax_policy():
@@ -433,7 +434,12 @@ class ViTEngine:
         cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
         nb = len(self.blocks)
         t_last = st["blocks"][-1]["t2"] if nb else st["t_embed"]
-        if self.gap_reorder:
+        if self.gap_reorder and _LN_FUSED and _HEAD_RANK1 and self.dim % 4 == 0:
+            # d mean-logit[cls] / d (head input) is rank one per image: one class column of the stored scale times one row of the folded
+            # weights -- a streaming launch instead of the [N T, K] one-hot tensor and a K-long contraction over it
+            g_lin, g_x = ops.head_rank1_grad(cls, st["t_head"].view(N, T, -1), self.head.w_ln, self.logit_temperature, row_scale=st["rstd_h"],
+                                             mul=t_last, want_out2=True, want_absmax=_F16X2)
+        elif self.gap_reorder:
             g_head = ops.head_onehot_grad(cls, st["t_head"].view(N, T, 1, -1), self.logit_temperature)     # [N,T,1,K]
             if _LN_FUSED:
                 g_lin, g_x = self.head.dgrad_ln(_mx(g_head.view(N * T, -1)), st["rstd_h"], mul=t_last)

@@ -345,6 +345,42 @@ __global__ __launch_bounds__(TPB) void head_onehot_kernel(const int64_t* __restr
     }
 }
 
+// The gradient of ONE class's mean logit w.r.t. the head layer's input is rank one per image: d logit[cls] / d lin[n, r, k] is zero but for
+// k = cls_n, so  v[n, r, :] = coef * scale[n, r, cls_n] * row_scale[n r] * W[cls_n, :]  -- what the one-hot tensor [N, R, K] followed by
+// a K-long contraction computes (head_onehot_kernel + the input-gradient launch), without writing that tensor, reading it back for its
+// row maxima and contracting over K - 1 zero columns.  out = v * mul (mul NULL: v), out2 = v (optional), per-row max |out|.
+// One wavefront per row, 16-byte columns.
+__global__ __launch_bounds__(256) void head_rank1_kernel(const int64_t* __restrict__ cls, const float* __restrict__ scale,
+                                                         const float* __restrict__ w, const float* __restrict__ row_scale,
+                                                         const float* __restrict__ mul, float* __restrict__ out, float* __restrict__ out2,
+                                                         unsigned* __restrict__ out_absmax, int64_t rows, int R, int K, int D4, float coef) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        const int64_t n = row / R;
+        const int k = (int)cls[n];
+        float a = coef * scale[row * K + k];
+        if (row_scale) a *= row_scale[row];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(w + (int64_t)k * D4 * 4);
+        unsigned mx = 0u;
+        for (int d = lane; d < D4; d += 64) {
+            const f32x4 v = wr[d] * a;
+            f32x4 o = v;
+            if (mul) o *= reinterpret_cast<const f32x4*>(mul)[row * D4 + d];
+            reinterpret_cast<f32x4*>(out)[row * D4 + d] = o;
+            if (out2) reinterpret_cast<f32x4*>(out2)[row * D4 + d] = v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mx = max(mx, __float_as_uint(o[q]) & 0x7fffffffu);
+        }
+        if (out_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+            if (lane == 0) out_absmax[row] = mx;
+        }
+    }
+}
+
 // one wavefront per row; ties -> lowest index
 __global__ __launch_bounds__(TPB) void argmax_rows_kernel(const float* __restrict__ x, int64_t* __restrict__ idx,
                                                           float* __restrict__ val, int N, int C) {
@@ -624,6 +660,21 @@ extern "C" int bcos_head_onehot_grad(const int64_t* cls, const float* scale, flo
     hipLaunchKernelGGL(head_onehot_kernel, dim3(grid_for((int64_t)N * HW * C)), dim3(TPB), 0, STREAM(stream), cls, scale,
                        glin, N, HW, C, coef);
     return check_launch("head_onehot_kernel");
+}
+
+extern "C" int bcos_head_rank1_grad(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul,
+                                    float* out, float* out2, uint32_t* out_absmax, int N, int R, int K, int D, float inv_temperature,
+                                    void* stream) {
+    if (!cls || !scale || !w || !out || N <= 0 || R <= 0 || K <= 0 || D <= 0 || D % 4 != 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_head_rank1_grad: bad argument (D must be a multiple of 4)");
+    if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mul) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_head_rank1_grad: tensors must be 16-byte aligned");
+    const int64_t rows = (int64_t)N * R;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(head_rank1_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), cls, scale, w, row_scale, mul, out, out2,
+                       out_absmax, rows, R, K, D / 4, inv_temperature / (float)R);
+    return check_launch("head_rank1_kernel");
 }
 
 extern "C" int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N, int C, void* stream) {

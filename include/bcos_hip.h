@@ -463,6 +463,14 @@ int bcos_global_avgpool_logits(const float* x, float* y, int N, int HW, int C,
  * (the gradient of logit cls[n] w.r.t. the head's `lin`, bcos/common.py:166-177). */
 int bcos_head_onehot_grad(const int64_t* cls, const float* scale, float* glin,
                           int N, int HW, int C, float inv_temperature, void* stream);
+/* The same gradient carried THROUGH the head layer in one launch: it is rank one per image (only column cls[n] of the one-hot tensor
+ * is non-zero), so the input gradient of the head's linear map is  v[n, r, :] = inv_temperature / R * scale[n, r, cls[n]] *
+ * row_scale[n r] * w[cls[n], :]  -- bcos_head_onehot_grad followed by the K-long input-gradient contraction, without the [N, R, K]
+ * tensor.  scale [N, R, K] (the head's stored multiplier), w [K, D] (its weight rows, D % 4 == 0), row_scale [N R] or NULL (the rstd of
+ * a LayerNorm folded into the head), mul [N R, D] or NULL.  out = v * mul (mul NULL: v), out2 = v (may be NULL), out_absmax [N R] or
+ * NULL: per-row max |out| bit patterns.  16-byte aligned tensors.  (ABI v8; gap-reordered SimpleViT head, vit.py:197-199) */
+int bcos_head_rank1_grad(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul, float* out,
+                         float* out2, uint32_t* out_absmax, int N, int R, int K, int D, float inv_temperature, void* stream);
 
 /* Row-wise arg-max over logits [N,C] -> idx [N] (int64), val [N]; ties -> lowest index
  * (torch.max semantics used at bcos/common.py:166). */

@@ -228,6 +228,16 @@ def head_onehot_grad(cls, scale, temperature=None, out=None):
     return onehot * scale * coef
 
 
+def head_rank1_grad(cls, scale, w, temperature=None, row_scale=None, mul=None, want_out2=False, want_absmax=False):
+    N, R, K = scale.shape
+    coef = (1.0 if temperature is None else 1.0 / temperature) / R
+    a = coef * scale[torch.arange(N), :, cls]                      # [N, R]
+    if row_scale is not None:
+        a = a * row_scale.view(N, R)
+    v = (a.unsqueeze(-1) * w[cls].unsqueeze(1)).reshape(N * R, -1)
+    return (v * mul if mul is not None else v), (v if want_out2 else None)
+
+
 def argmax_rows(x2d):
     v, i = x2d.max(1)
     return i, v
@@ -506,7 +516,7 @@ def install(monkeypatch):
     """Patch bcos_hip.ops with the emulators (pytest monkeypatch fixture) and lift the HIP-device checks."""
     from bcos_hip import ops
     for name in ("tapconv", "prep_input", "finalize_explanation", "avgpool2d_fwd", "avgpool2d_bwd",
-                 "global_avgpool_logits", "head_onehot_grad", "argmax_rows", "mul", "channel_affine", "channel_affine_add", "relu_bwd",
+                 "global_avgpool_logits", "head_onehot_grad", "head_rank1_grad", "argmax_rows", "mul", "channel_affine", "channel_affine_add", "relu_bwd",
                  "weight_rownorm_scale", "rows_normalize", "cosine_grad", "contrib_map", "maxout_scale", "layernorm_fwd", "layernorm_stats", "layernorm_bwd_detached",
                  "gelu_gate", "add_rows_bcast", "attention_fwd", "attention_bwd_v", "finalize_explanation_patches",
                  "render_explanations", "box_filter", "localisation_fractions", "tapconv_group", "ensure_absmax",

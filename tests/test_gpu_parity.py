@@ -847,6 +847,47 @@ def test_vit_training_plan_accumulates_over_two_forwards(lib):
         assert rel(a, b) <= 1e-5, (n, rel(a, b))          # (atomics in the weight gradient: not bit-identical)
 
 
+def test_head_gradient_is_rank_one_per_image(lib):
+    """bcos_head_rank1_grad against what it replaces -- the one-hot tensor [N, R, K] (bcos_head_onehot_grad) followed by the K-long
+    input-gradient contraction with the LayerNorm's rstd as row factor and the previous layer's scale as multiplier -- and against fp64;
+    row maxima exact; through the ViT plan: same logits, maps within the contraction's own rounding."""
+    from bcos_hip import ops, synth, vit_engine
+    import bcos_hip.vit_engine as ve
+    torch.manual_seed(21)
+    for (N, R, K, D) in ((3, 197, 1000, 192), (2, 5, 20, 8), (4, 16, 12, 384)):
+        scale = torch.rand(N, R, K, device=DEV) + 0.1
+        w = torch.randn(K, D, device=DEV)
+        rstd = torch.rand(N * R, device=DEV) + 0.5
+        mul = torch.randn(N * R, D, device=DEV)
+        cls = torch.randint(0, K, (N,), device=DEV)
+        out, out2 = ops.head_rank1_grad(cls, scale, w, 2.0, row_scale=rstd, mul=mul, want_out2=True, want_absmax=True)
+        a = (0.5 / R) * scale.double()[torch.arange(N), :, cls].reshape(-1) * rstd.double()
+        v = a.unsqueeze(1) * w.double()[cls].repeat_interleave(R, dim=0)
+        assert rel(out2, v) <= 1e-6 and rel(out, v * mul.double()) <= 1e-6
+        am = ops.absmax_of(out)
+        assert am is not None and torch.equal(am.view(torch.float32), out.abs().amax(dim=1))
+        g_head = ops.head_onehot_grad(cls, scale.view(N, R, 1, K), 2.0).view(N * R, K)
+        ref = torch.empty_like(out); ref2 = torch.empty_like(out)
+        ops.matmul_nt(ops.ensure_absmax(g_head), ops.mark_static(w.t().contiguous()), out=ref, out2=ref2, mul=mul, row_scale=rstd)
+        assert rel(out, ref) <= 2e-6 and rel(out2, ref2) <= 2e-6
+        o3, none = ops.head_rank1_grad(cls, scale, w)
+        assert none is None and rel(o3, (1.0 / R) * scale.double()[torch.arange(N), :, cls].reshape(-1, 1) * w.double()[cls].repeat_interleave(R, dim=0)) <= 1e-6
+    net = synth.build_bcosified_vit("simple_vit_ti_patch16_224").to(DEV)
+    x = synth.synthetic_images(6, seed=3).to(DEV)
+    with torch.no_grad():
+        synth.calibrate(net, x[:4])
+    eng = vit_engine.attach(net)
+    new = eng.explain(x)
+    prev = ve._HEAD_RANK1
+    try:
+        ve._HEAD_RANK1 = False
+        old = eng.explain(x)
+    finally:
+        ve._HEAD_RANK1 = prev
+    assert torch.equal(new["logits"], old["logits"]) and torch.equal(new["prediction"], old["prediction"])
+    assert rel(new["dynamic_linear_weights"], old["dynamic_linear_weights"]) <= 1e-5 and rel(new["contribution_map"], old["contribution_map"]) <= 1e-5
+
+
 def test_layernorm_gradient_takes_the_residual_gradient(lib):
     """bcos_layernorm_bwd_add: the residual stream's gradient added by the LayerNorm-gradient launch is the separate addition, bit for bit;
     and the fused row-scale + split of small weight tensors feeds the same contraction results as the fp64 product."""
