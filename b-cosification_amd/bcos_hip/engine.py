@@ -35,6 +35,7 @@ _GATE_TENSOR = bool(os.environ.get("BCOS_GATE_TENSOR"))   # development switch: 
 # rebuild cost +0.76 ms in the issue-bound gradient epilogues against -0.57 ms in the forward; with the specialised kinds
 # (csrc/bcos_tapconv.hip: EF_MULACT) the step time is the same or slightly lower (same-node A/B: 29.60 vs 29.60, 29.48 vs 29.58
 # ms).  BCOS_STORE_T=1 keeps the stored multipliers (same results to 1e-5: tests run both).
+_HEAD_RANK1 = os.environ.get("BCOS_HEAD_RANK1", "1") != "0"     # 0: the head gradient of rounds 1-4 (one-hot tensor + K = 1000 contraction), for A/B
 _SUB_ADDEND = not os.environ.get("BCOS_NO_SUB_ADDEND")     # development switch: scatter shortcut gradients into full-size tensors
 _STORE_T = bool(os.environ.get("BCOS_STORE_T"))
 # The rebuild recovers s from |a - bn_shift|: where |bn_scale s lin| << |bn_shift| the subtraction cancels (a = fl(csc v + csh)
@@ -859,10 +860,18 @@ class ResNetEngine:
             consumer = _Consumer(self.ap_vconv, self._attn_unpool_backward(st, g_head, consume), None, None, 0)
         else:
             # d logit[cls] / d (head lin): one-hot * 1/(T*HW) * head scale
-            g_head = ops.ensure_absmax(ops.head_onehot_grad(cls, st["tf"], self.logit_temperature))
+            hc = self.head
+            if (_HEAD_RANK1 and hc.k == (1, 1) and hc.stride == (1, 1) and hc.padding == (0, 0) and getattr(hc, "groups", 1) == 1
+                    and int(getattr(hc.module, "max_out", 1)) == 1 and hc.w_fwd.shape[-1] % 4 == 0 and hc.w_fwd.shape[-1] == hc.cin):
+                # ... carried through the head's 1 x 1 convolution at once: the gradient is rank one per image (one class column of
+                # the head's scale x one weight row), a streaming launch instead of the [N, 7, 7, 1000] one-hot tensor, a pass for its
+                # row maxima and a K = 1000 contraction over 999 zero columns
+                consumer = _HeadRank1Consumer(cls, st["tf"], hc.w_fwd.view(hc.w_fwd.shape[0], -1), self.logit_temperature)
+            else:
+                g_head = ops.ensure_absmax(ops.head_onehot_grad(cls, st["tf"], self.logit_temperature))
+                consumer = _Consumer(self.head, g_head, None, None, 0)
             if consume:
                 st["tf"] = None
-            consumer = _Consumer(self.head, g_head, None, None, 0)
         nb = len(self.blocks)
         for bi in range(nb - 1, -1, -1):
             blk, rec = self.blocks[bi], st["blocks"][bi]
@@ -974,6 +983,34 @@ class _Consumer:
             addend = self.g_sc
         out = self.conv.dgrad.run(g, H, W, addend=addend, track_absmax=track, track_absmax2=track2, **kw)
         return out, (out2 if out2 is not None else out)
+
+
+class _HeadRank1Consumer:
+    """The GAP + fc head as the reader of the last feature map: d logit[cls] / d X = coef * scale[n, hw, cls_n] * W[cls_n, :] per
+    pixel (ops.head_rank1_grad), with the multipliers / gates of the producing block applied by the same launch."""
+
+    def __init__(self, cls, tf, w, temperature):
+        self.cls, self.tf, self.w, self.temperature = cls, tf, w, temperature
+
+    def run(self, H, W, t_main, td, gated, gate_t=None, track=None, track2=None):
+        N, K, D = self.tf.shape[0], self.tf.shape[-1], self.w.shape[1]
+        tf = self.tf.view(N, H * W, K)
+        if t_main is None:
+            out, _ = ops.head_rank1_grad(self.cls, tf, self.w, self.temperature, want_absmax=bool(track))
+            out = self._nhwc(out, N, H, W, D)
+            return out, out
+        flat = lambda t: None if t is None else (t if t.is_contiguous() else t.contiguous()).view(N * H * W, D)      # noqa: E731
+        out, out2 = ops.head_rank1_grad(self.cls, tf, self.w, self.temperature, mul=flat(t_main), want_out2=True, mul2=flat(td), gate2=flat(gate_t),
+                                        gate2_from_mul=bool(gated and gate_t is None), want_absmax=bool(track), want_absmax2=bool(track2))
+        return self._nhwc(out, N, H, W, D), self._nhwc(out2, N, H, W, D)
+
+    @staticmethod
+    def _nhwc(t, N, H, W, D):
+        v = t.view(N, H, W, D)
+        am = ops.absmax_of(t)
+        if am is not None:
+            ops._attach_absmax(v, am)
+        return v
 
 
 class _RawConsumer:

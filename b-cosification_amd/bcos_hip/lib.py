@@ -114,6 +114,7 @@ SIGNATURES = {
     "bcos_global_avgpool_logits": (C.c_int, [_P, _P, _I, _I, _I, _F, _F, _P]),
     "bcos_head_onehot_grad": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "bcos_head_rank1_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "bcos_head_rank1_grad_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "bcos_argmax_rows": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "bcos_channel_affine": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
     "bcos_channel_affine_add": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),

@@ -828,25 +828,36 @@ def head_onehot_grad(cls, scale, temperature=None, out=None):
     return out
 
 
-def head_rank1_grad(cls, scale, w, temperature=None, row_scale=None, mul=None, want_out2=False, want_absmax=False):
-    """The one-hot head gradient carried through the head's linear map in one launch (include/bcos_hip.h: bcos_head_rank1_grad):
-    scale [N, R, K], w [K, D] -> (out [N R, D] = v * mul, out2 = v or None) with v = inv_t / R * scale[n, r, cls_n] * row_scale * w[cls_n]."""
+def head_rank1_grad(cls, scale, w, temperature=None, row_scale=None, mul=None, want_out2=False, want_absmax=False, mul2=None, gate2=None,
+                    gate2_from_mul=False, want_absmax2=False):
+    """The one-hot head gradient carried through the head's linear map in one launch (include/bcos_hip.h: bcos_head_rank1_grad[_ex]):
+    scale [N, R, K], w [K, D] -> (out [N R, D] = v * mul, out2 or None) with v = inv_t / R * scale[n, r, cls_n] * row_scale * w[cls_n];
+    out2 = v [* mul2], zeroed where gate2 <= 0 / where the low mantissa bit of mul is clear (the gradient epilogue's second output)."""
     lib = _l.load()
     N, R, K = scale.shape
     D = w.shape[1]
     if cls.dtype != torch.int64 or not cls.is_cuda:
         raise BcosHipError("head_rank1_grad: cls must be an int64 HIP tensor")
-    if tuple(w.shape) != (K, D) or (mul is not None and tuple(mul.shape) != (N * R, D)):
-        raise BcosHipError(f"head_rank1_grad: w {tuple(w.shape)} / mul do not match scale {tuple(scale.shape)}")
+    for name, t in (("mul", mul), ("mul2", mul2), ("gate2", gate2)):
+        if t is not None and (t.numel() != N * R * D or not t.is_contiguous()):
+            raise BcosHipError(f"head_rank1_grad: {name} {tuple(t.shape)} does not match {(N * R, D)}")
+    if tuple(w.shape) != (K, D):
+        raise BcosHipError(f"head_rank1_grad: w {tuple(w.shape)} does not match scale {tuple(scale.shape)}")
+    want_out2 = bool(want_out2 or mul2 is not None or gate2 is not None or gate2_from_mul or want_absmax2)
     out = torch.empty((N * R, D), device=scale.device, dtype=torch.float32)
     out2 = torch.empty_like(out) if want_out2 else None
-    am = torch.empty((N * R,), device=scale.device, dtype=torch.int32) if (want_absmax and _l.get_contraction_mode() == "f16x2") else None
+    f16 = _l.get_contraction_mode() == "f16x2"
+    am = torch.empty((N * R,), device=scale.device, dtype=torch.int32) if (want_absmax and f16) else None
+    am2 = torch.empty((N * R,), device=scale.device, dtype=torch.int32) if (want_absmax2 and f16 and want_out2) else None
     inv_t = 1.0 if temperature is None else 1.0 / float(temperature)
-    _l.check(lib.bcos_head_rank1_grad(C.c_void_p(cls.data_ptr()), _dev(scale, "scale"), _dev(w, "w"), _dev(row_scale, "row_scale"), _dev(mul, "mul"),
-                                      _dev(out, "out"), _dev(out2, "out2"), C.c_void_p(am.data_ptr()) if am is not None else None, N, R, K, D,
-                                      inv_t, _stream()), "bcos_head_rank1_grad")
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    _l.check(lib.bcos_head_rank1_grad_ex(ptr(cls), _dev(scale, "scale"), _dev(w, "w"), _dev(row_scale, "row_scale"), _dev(mul, "mul"),
+                                         _dev(mul2, "mul2"), _dev(gate2, "gate2"), int(bool(gate2_from_mul)), _dev(out, "out"), _dev(out2, "out2"),
+                                         ptr(am), ptr(am2), N, R, K, D, inv_t, _stream()), "bcos_head_rank1_grad")
     if am is not None:
         _attach_absmax(out, am)
+    if am2 is not None:
+        _attach_absmax(out2, am2)
     return out, out2
 
 

@@ -352,8 +352,10 @@ __global__ __launch_bounds__(TPB) void head_onehot_kernel(const int64_t* __restr
 // One wavefront per row, 16-byte columns.
 __global__ __launch_bounds__(256) void head_rank1_kernel(const int64_t* __restrict__ cls, const float* __restrict__ scale,
                                                          const float* __restrict__ w, const float* __restrict__ row_scale,
-                                                         const float* __restrict__ mul, float* __restrict__ out, float* __restrict__ out2,
-                                                         unsigned* __restrict__ out_absmax, int64_t rows, int R, int K, int D4, float coef) {
+                                                         const float* __restrict__ mul, const float* __restrict__ mul2,
+                                                         const float* __restrict__ gate2, float* __restrict__ out, float* __restrict__ out2,
+                                                         unsigned* __restrict__ out_absmax, unsigned* __restrict__ out2_absmax, int64_t rows,
+                                                         int R, int K, int D4, float coef, int gate_from_mul) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -363,20 +365,39 @@ __global__ __launch_bounds__(256) void head_rank1_kernel(const int64_t* __restri
         float a = coef * scale[row * K + k];
         if (row_scale) a *= row_scale[row];
         const f32x4* wr = reinterpret_cast<const f32x4*>(w + (int64_t)k * D4 * 4);
-        unsigned mx = 0u;
+        unsigned mx = 0u, mx2 = 0u;
         for (int d = lane; d < D4; d += 64) {
+            const int64_t i = row * D4 + d;
             const f32x4 v = wr[d] * a;
-            f32x4 o = v;
-            if (mul) o *= reinterpret_cast<const f32x4*>(mul)[row * D4 + d];
-            reinterpret_cast<f32x4*>(out)[row * D4 + d] = o;
-            if (out2) reinterpret_cast<f32x4*>(out2)[row * D4 + d] = v;
+            f32x4 o = v, m = {0.f, 0.f, 0.f, 0.f};
+            if (mul) { m = reinterpret_cast<const f32x4*>(mul)[i]; o *= m; }
+            reinterpret_cast<f32x4*>(out)[i] = o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) mx = max(mx, __float_as_uint(o[q]) & 0x7fffffffu);
-        }
-        if (out_absmax) {
+            if (out2) {                      // the second output of the gradient epilogue (bcos_epilogue.out2): v [* mul2] [gated]
+                f32x4 o2 = v;
+                if (mul2) o2 *= reinterpret_cast<const f32x4*>(mul2)[i];
+                if (gate_from_mul) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-            if (lane == 0) out_absmax[row] = mx;
+                    for (int q = 0; q < 4; ++q) o2[q] = (__float_as_uint(m[q]) & 1u) ? o2[q] : 0.f;
+                } else if (gate2) {
+                    const f32x4 gt = reinterpret_cast<const f32x4*>(gate2)[i];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o2[q] = gt[q] > 0.f ? o2[q] : 0.f;
+                }
+                reinterpret_cast<f32x4*>(out2)[i] = o2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mx2 = max(mx2, __float_as_uint(o2[q]) & 0x7fffffffu);
+            }
+        }
+        if (out_absmax || out2_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+                mx2 = max(mx2, (unsigned)__shfl_xor((int)mx2, o));
+            }
+            if (lane == 0 && out_absmax) out_absmax[row] = mx;
+            if (lane == 0 && out2_absmax) out2_absmax[row] = mx2;
         }
     }
 }
@@ -662,19 +683,31 @@ extern "C" int bcos_head_onehot_grad(const int64_t* cls, const float* scale, flo
     return check_launch("head_onehot_kernel");
 }
 
-extern "C" int bcos_head_rank1_grad(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul,
-                                    float* out, float* out2, uint32_t* out_absmax, int N, int R, int K, int D, float inv_temperature,
-                                    void* stream) {
+extern "C" int bcos_head_rank1_grad_ex(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul,
+                                       const float* mul2, const float* gate2, int gate2_from_mul, float* out, float* out2,
+                                       uint32_t* out_absmax, uint32_t* out2_absmax, int N, int R, int K, int D, float inv_temperature,
+                                       void* stream) {
     if (!cls || !scale || !w || !out || N <= 0 || R <= 0 || K <= 0 || D <= 0 || D % 4 != 0)
         return bcos_set_error(BCOS_E_INVAL, "bcos_head_rank1_grad: bad argument (D must be a multiple of 4)");
-    if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mul) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15)
+    if ((mul2 || gate2 || gate2_from_mul || out2_absmax) && !out2)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_head_rank1_grad: mul2 / gate2 / out2_absmax belong to out2");
+    if (gate2_from_mul && (!mul || gate2)) return bcos_set_error(BCOS_E_INVAL, "bcos_head_rank1_grad: gate2_from_mul needs mul and excludes gate2");
+    if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mul) | reinterpret_cast<uintptr_t>(mul2) | reinterpret_cast<uintptr_t>(gate2) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15)
         return bcos_set_error(BCOS_E_INVAL, "bcos_head_rank1_grad: tensors must be 16-byte aligned");
     const int64_t rows = (int64_t)N * R;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(head_rank1_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), cls, scale, w, row_scale, mul, out, out2,
-                       out_absmax, rows, R, K, D / 4, inv_temperature / (float)R);
+    hipLaunchKernelGGL(head_rank1_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), cls, scale, w, row_scale, mul, mul2, gate2, out,
+                       out2, out_absmax, out2_absmax, rows, R, K, D / 4, inv_temperature / (float)R, gate2_from_mul ? 1 : 0);
     return check_launch("head_rank1_kernel");
+}
+
+extern "C" int bcos_head_rank1_grad(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul,
+                                    float* out, float* out2, uint32_t* out_absmax, int N, int R, int K, int D, float inv_temperature,
+                                    void* stream) {
+    return bcos_head_rank1_grad_ex(cls, scale, w, row_scale, mul, nullptr, nullptr, 0, out, out2, out_absmax, nullptr, N, R, K, D,
+                                   inv_temperature, stream);
 }
 
 extern "C" int bcos_argmax_rows(const float* x, int64_t* idx, float* val, int N, int C, void* stream) {

@@ -471,6 +471,13 @@ int bcos_head_onehot_grad(const int64_t* cls, const float* scale, float* glin,
  * NULL: per-row max |out| bit patterns.  16-byte aligned tensors.  (ABI v8; gap-reordered SimpleViT head, vit.py:197-199) */
 int bcos_head_rank1_grad(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul, float* out,
                          float* out2, uint32_t* out_absmax, int N, int R, int K, int D, float inv_temperature, void* stream);
+/* ... with the whole second output of the gradient epilogue (bcos_epilogue.out2, the shortcut's share behind a residual block):
+ * out2 = v [* mul2], zeroed where the producing block's ReLU was closed -- gate2 [N R, D] > 0, or (gate2_from_mul) the low mantissa
+ * bit of mul, as BCOS_EPI_GATE2_FROM_MUL reads it -- and its row maxima.  The GAP + fc head of the ResNets (N x 7 x 7 x 1000 one-hot
+ * tensor and a K = 1000 contraction in rounds 1-4).  (ABI v8) */
+int bcos_head_rank1_grad_ex(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul,
+                            const float* mul2, const float* gate2, int gate2_from_mul, float* out, float* out2, uint32_t* out_absmax,
+                            uint32_t* out2_absmax, int N, int R, int K, int D, float inv_temperature, void* stream);
 
 /* Row-wise arg-max over logits [N,C] -> idx [N] (int64), val [N]; ties -> lowest index
  * (torch.max semantics used at bcos/common.py:166). */

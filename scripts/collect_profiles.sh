@@ -13,7 +13,7 @@ ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-vendor-ref"
 # 1. the headline command as the driver runs it (CPU baseline included)
 python3 bench.py --steps 20 --warmup 5 > "$SUM/${TAG}_bench.json" 2> "$OUT/bench.err"
 # 2. kernel stats + HBM counters of the same workload (counters in their own passes, MI355X_MICROARCH.md).  The profiled runs keep
-#    every launch on ONE stream (BCOS_SUBBATCH_STREAMS=1: 117 contraction launches per step, each over the whole batch) -- the form
+#    every launch on ONE stream (BCOS_SUBBATCH_STREAMS=1: 116 contraction launches per step, each over the whole batch) -- the form
 #    bench.py's own event-carrying steps use -- so that a launch in the trace is the launch bench.py's HIP events bracket; with the
 #    default two sub-batch streams a step is 234 half-batch launches that overlap in time.
 export BCOS_SUBBATCH_STREAMS=1

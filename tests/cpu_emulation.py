@@ -228,14 +228,23 @@ def head_onehot_grad(cls, scale, temperature=None, out=None):
     return onehot * scale * coef
 
 
-def head_rank1_grad(cls, scale, w, temperature=None, row_scale=None, mul=None, want_out2=False, want_absmax=False):
+def head_rank1_grad(cls, scale, w, temperature=None, row_scale=None, mul=None, want_out2=False, want_absmax=False, mul2=None, gate2=None,
+                    gate2_from_mul=False, want_absmax2=False):
     N, R, K = scale.shape
     coef = (1.0 if temperature is None else 1.0 / temperature) / R
     a = coef * scale[torch.arange(N), :, cls]                      # [N, R]
     if row_scale is not None:
         a = a * row_scale.view(N, R)
     v = (a.unsqueeze(-1) * w[cls].unsqueeze(1)).reshape(N * R, -1)
-    return (v * mul if mul is not None else v), (v if want_out2 else None)
+    out = v * mul.reshape(v.shape) if mul is not None else v
+    out2 = None
+    if want_out2 or mul2 is not None or gate2 is not None or gate2_from_mul or want_absmax2:
+        out2 = v * mul2.reshape(v.shape) if mul2 is not None else v
+        if gate2_from_mul:
+            out2 = out2 * (mul.reshape(v.shape).contiguous().view(torch.int32) & 1).to(out2.dtype)
+        elif gate2 is not None:
+            out2 = out2 * (gate2.reshape(v.shape) > 0).to(out2.dtype)
+    return out, out2
 
 
 def argmax_rows(x2d):
