@@ -7,7 +7,7 @@ import csv, glob, json, os, shutil, sys
 out, summ, tag = sys.argv[1:4]
 STEPS_PROFILED = 3          # --steps 2 --warmup 1
 KERNELS = ("tapconv_kernel", "tappatch_kernel", "skinny_kernel", "skinny_group_kernel")     # the contraction launches bench.py brackets with HIP events
-LAUNCHES_PER_STEP = 117     # ResNet-50 forward + explanation: 54 forward + 63 input-gradient launches (stem gradient fused)
+LAUNCHES_PER_STEP = 116     # ResNet-50 forward + explanation: 54 forward + 62 input-gradient launches (stem gradient fused; the head gradient is a streaming launch since the end of round 5: 117 before)
 
 
 def find(d, suffix):
