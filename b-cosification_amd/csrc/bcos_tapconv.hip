@@ -1437,6 +1437,55 @@ constexpr int H2_MAX_TAPS = 16;    // channel-chunk-major K walk for up to this 
 #define H2_PIPE_SMALL 2           // pipeline of the <= 4-accumulator tiles: 2 = one 16-k step per barrier, 3 = two
 #endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#ifndef H2_MIX_SPLIT
+#define H2_MIX_SPLIT 1            // 1 = the (h, l) split as two v_fma_mix{lo,hi}_f16 per element (split4_f16), 0 = the scalar expressions left to the compiler (rounds 2-5); same bits
+#endif
+// (h, l) f16 split of fp32 values times a power of two `s`, two values into the two halves of one register each:
+//   h = f16(x s),  l = f16(x s - h).
+// x s and x s - h are exact in fp32 (s is a power of two, h holds the leading 11 bits of x s), so each result is rounded ONCE, to f16
+// -- bit for bit what (_Float16)(x * s) and (_Float16)(x * s - (float)h) give.  Written as the instructions themselves: v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 take fp32 (or, per source, f16-half) operands, compute the fma in fp32 and write the f16 result into the low / high
+// half of the destination -- two vector instructions per element and no packing.  Left to the compiler the same expressions become
+// multiply / convert / convert back / subtract / convert / pack over register PAIRS (v_pk_mul_f32, v_pk_fma_f32 ...: ~6 instructions
+// per element plus the moves that build the pairs, and packed fp32 instructions beside matrix instructions cost more than their issue slot).
+// One 16-byte piece (four fp32 values) -> two registers of h halves and two of l halves; SUMSQ: acc += x^2 of the four values (one
+// v_fmac_f32 each: the compiler pairs neighbouring chains into v_pk_fma_f32 behind two moves).  ONE asm statement, so that nothing is
+// padded between its instructions; inside it every instruction that reads a register half written by a v_fma_mix{lo,hi}_f16 is at
+// least two instructions behind that write (gfx940+: a result written with a destination half-select needs one wait state before a
+// vector instruction reads it).
+template <bool SUMSQ>
+__device__ __forceinline__ void split4_f16(const f32x4& x, const float s, unsigned& h01, unsigned& h23, unsigned& l01, unsigned& l23, float& acc) {
+    unsigned a, b, c, d;
+    if constexpr (SUMSQ) {
+        asm("v_fma_mixlo_f16 %0, %5, %9, 0\n\t"
+            "v_fma_mixlo_f16 %1, %7, %9, 0\n\t"
+            "v_fma_mixhi_f16 %0, %6, %9, 0\n\t"
+            "v_fma_mixhi_f16 %1, %8, %9, 0\n\t"
+            "v_fmac_f32 %4, %5, %5\n\t"
+            "v_fma_mixlo_f16 %2, %5, %9, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %3, %7, %9, -%1 op_sel_hi:[0,0,1]\n\t"
+            "v_fmac_f32 %4, %6, %6\n\t"
+            "v_fma_mixhi_f16 %2, %6, %9, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fmac_f32 %4, %7, %7\n\t"
+            "v_fma_mixhi_f16 %3, %8, %9, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fmac_f32 %4, %8, %8"
+            : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "+v"(acc)
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(s));
+    } else {
+        asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+            "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+            "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+            "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+            "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(s));
+    }
+    h01 = a; h23 = b; l01 = c; l23 = d;
+}
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // pipeline of a split-f16 tile: 1 for the 8-accumulator tiles, H2_PIPE_SMALL otherwise -- except the 32-column gradient tiles
@@ -2023,10 +2072,18 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
         walk_a(walk_c, ks, [&](int j, unsigned voff, int soff) { piece_a(j, slot_off, voff, soff); });
     };
     // B: wave w copies blocks w, w + NW, ... of the step (block = (32-column tile c, plane sp) = 1 KB, lane-linear)
+    // (the source offset of block j at step 0 is fixed per wave: kept in scalar registers, a step adds ks * 2048 -- recomputed from
+    //  the tile index it cost a scalar multiply and half a dozen scalar instructions per piece and step)
+    int b_soff0[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int blk = wave + NW * j;
+        b_soff0[j] = __builtin_amdgcn_readfirstlane((b_tile0 + (blk >> 1)) * nk * 2048 + (blk & 1) * 1024);
+    }
     auto piece_b = [&](int j, int ks, int slot_off) {
         const int blk = wave + NW * j;
         if (NBLK % NW == 0 || blk < NBLK) {
-            const int soff = ((b_tile0 + (blk >> 1)) * nk + ks) * 2048 + (blk & 1) * 1024;
+            const int soff = b_soff0[j] + ks * 2048;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(lds + slot_off + A_BYTES + blk * 1024), 16, lane * 16, soff, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, BCOS_LDS_PTR(s_dummy), 16, (int)OOB, 0, 0, 0);   // keeps every wave's DMA count equal
@@ -2155,6 +2212,27 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             x1[i] = *reinterpret_cast<const f32x4*>(lds + off + (a_frag[i] ^ 16));     // k = 8 half + 4 .. + 7
         }
     };
+#if H2_MIX_SPLIT
+    // ... -> patch-norm partial sums and the (h, l) f16 fragments, in 2 TM slices of one 16-byte piece each (slice = (row tile i, piece
+    // x0 | x1)) so that the vector instructions can be dealt out between matrix instructions
+    constexpr int NSLICE = 2 * TM;
+    auto split_slice = [&](auto slice_c, const f32x4 (&x0)[TM], const f32x4 (&x1)[TM]) {
+        constexpr int SL = decltype(slice_c)::value;
+        constexpr int i = SL / 2, piece = SL & 1;
+        u32x4v h4 = __builtin_bit_cast(u32x4v, af[0][i]), l4 = __builtin_bit_cast(u32x4v, af[1][i]);
+        unsigned h01, h23, l01, l23;
+        split4_f16<NORM>(piece ? x1[i] : x0[i], f_scale[i], h01, h23, l01, l23, piece ? pb[i] : pa[i]);
+        h4[piece * 2] = h01; h4[piece * 2 + 1] = h23;
+        l4[piece * 2] = l01; l4[piece * 2 + 1] = l23;
+        af[0][i] = __builtin_bit_cast(f16x8, h4);
+        af[1][i] = __builtin_bit_cast(f16x8, l4);
+    };
+    auto split_a = [&](const f32x4 (&x0)[TM], const f32x4 (&x1)[TM]) {
+        split_slice(std::integral_constant<int, 0>{}, x0, x1); split_slice(std::integral_constant<int, 1>{}, x0, x1);
+        if constexpr (TM > 1) { split_slice(std::integral_constant<int, 2>{}, x0, x1); split_slice(std::integral_constant<int, 3>{}, x0, x1); }
+        static_assert(TM <= 2, "slices");
+    };
+#else
     // ... -> patch-norm partial sums and the (h, l) f16 fragments, in 4 TM slices of two elements each (slice = (row tile i,
     // piece x0 | x1, element pair)) so that the vector instructions can be dealt out between matrix instructions
     constexpr int NSLICE = 4 * TM;
@@ -2183,6 +2261,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
         }
         static_assert(TM <= 2, "slices");
     };
+#endif
     // The matrix instructions of one step on slot `off`, af = this step's A fragments.  `NEXT` (wave-private A rows only): the
     // next step's A rows (slot `off_nx`, already landed) are read up front and split slice by slice BETWEEN this step's matrix
     // instructions, whose shadow hides the vector work.  The issue order is pinned (sched_barrier between the chunks): left
@@ -2676,6 +2755,19 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
     f16x8 ph[NI], pl[NI];
     auto convert_item = [&](auto it_c) {
         constexpr int it = decltype(it_c)::value;
+#if H2_MIX_SPLIT
+        if (!clamp_h) {            // (uniform; level 0, i.e. every pass of an image without the ladder: two instructions per element, see split4_f16)
+            u32x4v h4, l4;
+            unsigned h01, h23, l01, l23;
+            split4_f16<NORM>(xr[it][0], isc[it], h01, h23, l01, l23, pss[it]);
+            h4[0] = h01; h4[1] = h23; l4[0] = l01; l4[1] = l23;
+            split4_f16<NORM>(xr[it][1], isc[it], h01, h23, l01, l23, pss[it]);
+            h4[2] = h01; h4[3] = h23; l4[2] = l01; l4[3] = l23;
+            ph[it] = __builtin_bit_cast(f16x8, h4);
+            pl[it] = __builtin_bit_cast(f16x8, l4);
+            return;
+        }
+#endif
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float x = xr[it][q >> 2][q & 3];
