@@ -157,6 +157,10 @@ class WeightCache:
             self._fwd = ops.mark_static(_pad_last(w4.detach().permute(0, 2, 3, 1)).contiguous(), self._transient)
             if not self._transient:
                 ops.publish_cached(self._fwd)      # (made on this stream, read by launches on any stream later)
+            else:
+                ops.note_unpublished(self._fwd)    # (completed by the first reader outside a training pass, should this version live that long)
+        elif not (torch.is_grad_enabled() and src.requires_grad):
+            ops.publish_pending()
         return self._fwd
 
     def dgrad(self, w_eff, src, stride, padding, dilation, groups):
@@ -175,6 +179,8 @@ class WeightCache:
                 plans.append(ops.DgradPlan(wg, stride, padding, dilation, transient=self._transient))
             if not self._transient:
                 ops.publish_cached(w4)
+            else:
+                ops.note_unpublished(w4)
             self._dgrad[k] = plans
         return self._dgrad[k]
 

@@ -478,6 +478,7 @@ class ResNetEngine:
 
     def _ensure_fresh(self):
         """Cheap staleness check (a few hundred integer compares): refresh the layers whose parameters changed."""
+        ops.publish_pending()          # (objects a training pass cached without publication are completed before an inference pass reads them)
         for c in self._all_convs():
             if c.fingerprint() != c._fp:
                 c.refresh()
@@ -731,6 +732,8 @@ class ResNetEngine:
         for an `attn_unpool` head -- and returns d(scalar to explain) / d(head output) of the same shape; the input-gradient
         pass then starts from it instead of from a one-hot coordinate (the zero-shot text logit of
         interpretability/analyses/text_localisation.py:68-126: bcos_hip.clip_head.zeroshot_attribution)."""
+        if targets is not None and self.head_kind == "gap_fc":
+            targets = ops.check_targets(targets, self.head.cout)       # IndexError like the reference's out[0, idx]; negative indices wrap
         S = self.n_streams(x, cotangent=cotangent)
         if S > 1:
             return self._explain_subbatches(x, targets, want_weights, S, gates)
@@ -816,6 +819,8 @@ class ResNetEngine:
             raise BcosHipError("engine: an attn_unpool head has no class logits of its own: pass `cotangent` "
                                "(bcos_hip.clip_head.zeroshot_attribution builds it from the text embeddings)")
         pred, _ = ops.argmax_rows(logits)
+        if targets is not None and self.head_kind != "gap_fc":
+            targets = ops.check_targets(targets, logits.shape[1])      # (attention-pool head: the embedding width; gap_fc heads were checked in explain())
         cls = pred if targets is None else targets.to(device=logits.device, dtype=torch.int64).contiguous()
         wts, contrib = yield from self._backward_gen(x, st, cls, want_weights, consume=True, outs=outs)
         return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
@@ -828,8 +833,11 @@ class ResNetEngine:
         bcos/common.py:319-344) re-runs the forward for every target; the dynamic weights of the forward do not depend on
         the explained logit, so they are kept and only the backward is repeated.
         Returns logits [N,K], contribution_maps [N,T,H,W] and, if requested, dynamic_linear_weights [N,T,6,H,W]."""
+        if self.head_kind == "gap_fc":
+            targets = ops.check_targets(targets, self.head.cout)
         with ops.absmax_arena(self._absmax_arena, x.device):
             logits, st = self._run_forward(x, keep=True)
+            targets = ops.check_targets(targets, logits.shape[1]) if self.head_kind != "gap_fc" else targets
             tg = targets.to(device=logits.device, dtype=torch.int64)
             if tg.dim() == 1:
                 tg = tg.view(1, -1).expand(x.shape[0], -1)

@@ -28,7 +28,8 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 BCOS_EPI_UNIT_NORM_W = 32
-ABI_VERSION = 8
+ABI_VERSION = 9
+VERSION_DEV_FLAG = 0x40000000          # include/bcos_hip.h: BCOS_VERSION_DEV_FLAG
 TAPCONV_PARTS = 11
 
 
@@ -101,6 +102,7 @@ SIGNATURES = {
     "bcos_relu_bwd_colsums": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "bcos_weight_rownorm_scale": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_mul": (C.c_int, [_P, _P, _P, _L, _P]),
+    "bcos_stream_copy": (C.c_int, [_P, _P, _L, _P]),
     "bcos_weight_row_invnorm": (C.c_int, [_P, _P, _P, _I, _L, _P]),
     "bcos_rows_normalize": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "bcos_cosine_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
@@ -202,6 +204,14 @@ def load():
         fn.restype = res
         fn.argtypes = args
     v = lib.bcos_version()
+    if v & VERSION_DEV_FLAG:
+        # a -DBCOS_DEV_BUILD library: the only kind in which timing knock-outs (wrong results) can be compiled in (csrc/bcos_internal.h)
+        if os.environ.get("BCOS_ALLOW_DEV_BUILD") != "1":
+            raise BcosHipError(f"{LIB_PATH} is a development build (bcos_version() carries BCOS_VERSION_DEV_FLAG: compiled with "
+                               "-DBCOS_DEV_BUILD, possibly with timing knock-outs that compute wrong results); set BCOS_ALLOW_DEV_BUILD=1 "
+                               "to load it for a timing experiment, or rebuild without BCOS_HIPCC_FLAGS")
+        print(f"[bcos_hip] WARNING: {LIB_PATH} is a DEVELOPMENT build (BCOS_ALLOW_DEV_BUILD=1): results may be wrong", file=sys.stderr)
+        v &= ~VERSION_DEV_FLAG
     if v != ABI_VERSION:
         raise BcosHipError(f"libbcos_hip.so ABI version {v}, bindings expect {ABI_VERSION}")
     _lib = lib

@@ -125,11 +125,41 @@ class transient_weights:
         return False
 
 
+_PENDING = set()                  # streams on which objects were cached WITHOUT publication (inside a training pass: transient_weights)
+_PENDING_LOCK = threading.Lock()
+
+
+def note_unpublished(t: torch.Tensor):
+    """`t` has just been made on the current stream and cached without the synchronisation publish_cached performs (a training pass).
+    Remember the stream: the first consumer outside a training pass completes it (publish_pending)."""
+    if t is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        with _PENDING_LOCK:
+            _PENDING.add(torch.cuda.current_stream(t.device))
+
+
+def publish_pending():
+    """Complete everything that was cached unpublished (engine constants, positional embeddings, weight images of a weight
+    version first used under transient_weights and used again, unchanged, by an inference pass on other streams).  Called where
+    cached objects are about to be read outside a training pass: one set lookup when nothing is pending."""
+    if not _PENDING or not getattr(_TLS, "publish", True) or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return
+    with _PENDING_LOCK:
+        streams = list(_PENDING)
+        _PENDING.clear()
+    for st in streams:
+        st.synchronize()
+
+
 def publish_cached(t: torch.Tensor):
     """A device object that has just been made on the CURRENT stream and is about to be cached for later launches, whichever stream
-    those run on (the engines process sub-batches on side streams): complete it first.  Once per cached object."""
-    if getattr(_TLS, "publish", True) and t is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+    those run on (the engines process sub-batches on side streams): complete it first.  Once per cached object.  Inside a training
+    pass (transient_weights) the synchronisation is deferred to the first reader outside one (publish_pending)."""
+    if t is None or not t.is_cuda or torch.cuda.is_current_stream_capturing():
+        return
+    if getattr(_TLS, "publish", True):
         torch.cuda.current_stream(t.device).synchronize()
+    else:
+        note_unpublished(t)
 
 
 def _image_of(wt: torch.Tensor, attr: str, make):
@@ -139,6 +169,10 @@ def _image_of(wt: torch.Tensor, attr: str, make):
         setattr(wt, attr, cached)
         if not getattr(wt, "_bcos_transient", False):
             publish_cached(cached[1])
+        else:
+            note_unpublished(cached[1])
+    elif _PENDING:
+        publish_pending()          # (an image of this version may have been made, unpublished, by a training pass)
     return cached[1]
 
 
@@ -826,6 +860,37 @@ def head_onehot_grad(cls, scale, temperature=None, out=None):
     _l.check(lib.bcos_head_onehot_grad(C.c_void_p(cls.data_ptr()), _dev(scale, "scale"), _dev(out, "glin"), N, H * W, Cc, inv_t,
                                        _stream()), "bcos_head_onehot_grad")
     return out
+
+
+def stream_copy(src: torch.Tensor, dst: torch.Tensor = None) -> torch.Tensor:
+    """dst <- src (contiguous fp32, numel % 4 == 0) by the library's own streaming kernel on the current stream
+    (include/bcos_hip.h: bcos_stream_copy): the bandwidth reference of bench.py."""
+    dst = torch.empty_like(src) if dst is None else dst
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_contiguous() or not dst.is_contiguous() or src.numel() != dst.numel():
+        raise BcosHipError("stream_copy: contiguous fp32 tensors of equal size")
+    _l.check(_l.load().bcos_stream_copy(_dev(src, "src"), _dev(dst, "dst"), src.numel(), _stream()), "bcos_stream_copy")
+    return dst
+
+
+def check_targets(targets, n_logits: int, what: str = "targets"):
+    """Class indices handed to an explanation pass, validated ONCE on the host before any launch: the reference explains
+    `out[0, idx]` (bcos/common.py:170-176), so an index in [-K, -1] counts from the end and anything outside [-K, K) is an IndexError --
+    never an out-of-range read on the device (the rank-one head gradient reads column cls[n] of the head's stored scale and row cls[n] of
+    its weights).  Returns an int64 tensor with the negative indices wrapped; None stays None.  A tensor that already lives on the
+    device costs one synchronisation of its stream here (its extrema are read back); host tensors and lists cost nothing."""
+    if targets is None:
+        return None
+    t = torch.as_tensor(targets)
+    if t.dtype.is_floating_point or t.dtype == torch.bool or t.is_complex():
+        raise TypeError(f"{what}: class indices must be integers, got {t.dtype}")
+    t = t.to(torch.int64)
+    if t.numel():
+        lo, hi = (int(v) for v in torch.aminmax(t))
+        if lo < -n_logits or hi >= n_logits:
+            raise IndexError(f"{what}: index {hi if hi >= n_logits else lo} is out of bounds for {n_logits} logits")
+        if lo < 0:
+            t = torch.where(t < 0, t + n_logits, t)
+    return t
 
 
 def head_rank1_grad(cls, scale, w, temperature=None, row_scale=None, mul=None, want_out2=False, want_absmax=False, mul2=None, gate2=None,

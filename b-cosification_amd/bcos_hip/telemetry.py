@@ -98,6 +98,41 @@ def _sysfs_source(index):
     return read, "sysfs (pp_dpm_sclk current level, hwmon power1)"
 
 
+def physical_index(logical: int, environ=None) -> int:
+    """Index of the PHYSICAL device behind logical HIP ordinal `logical` of this process: the SMI libraries and sysfs enumerate every
+    GPU of the node, HIP only those that HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (HIP runtime) and ROCR_VISIBLE_DEVICES (ROCr, applied
+    first) leave visible, renumbered from 0 (sampling the logical ordinal reads another, possibly idle, GPU's clock).
+    Entries that are not plain integers (UUIDs) cannot be resolved without the runtime: the logical ordinal is returned unchanged."""
+    env = os.environ if environ is None else environ
+
+    def parse(name):
+        val = env.get(name)
+        if val is None or val.strip() == "":
+            return None
+        ids = []
+        for tok in val.split(","):
+            tok = tok.strip()
+            if not tok.lstrip("-").isdigit():
+                return False
+            if int(tok) < 0:
+                break                      # (a negative entry ends the list, as in the runtimes)
+            ids.append(int(tok))
+        return ids
+    idx = int(logical)
+    hip = parse("HIP_VISIBLE_DEVICES")
+    if hip is None:
+        hip = parse("CUDA_VISIBLE_DEVICES")
+    rocr = parse("ROCR_VISIBLE_DEVICES")
+    for ids in (hip, rocr):                # HIP's list indexes what ROCr left visible
+        if ids is False:
+            return int(logical)
+        if ids is not None:
+            if idx >= len(ids):
+                return int(logical)
+            idx = ids[idx]
+    return idx
+
+
 def open_source(index=0):
     errs = []
     for mk in (_amdsmi_source, _rsmi_source, _sysfs_source):

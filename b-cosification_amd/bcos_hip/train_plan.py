@@ -267,7 +267,8 @@ class ResNetTrainPlan:
         if lin.weight.requires_grad:              # (on the side stream: nothing in the pass waits for a parameter gradient)
             acc = self._zeros.take((Cout, c.k[0], c.k[1], cin), x.device)
             grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4, x, cin, Cout, c.k, c.stride, c.padding, c.dilation, out=acc)
-                                             .permute(0, 3, 1, 2).contiguous(), (gl4, x))          # [Cout,kh,kw,Cin] -> OIHW
+                                             .permute(0, 3, 1, 2).contiguous(), (gl4, x, acc))     # [Cout,kh,kw,Cin] -> OIHW; `acc` too: a torch.zeros of the first pass
+                                                                                                   # lives in the caller's pool and is accumulated into on the side stream
         if lin.bias is not None and lin.bias.requires_grad:
             grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4.view(-1, gl4.shape[3]))[:Cout].contiguous(), (gl4,))
         gx = None

@@ -219,6 +219,7 @@ class ViTEngine:
         return tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
 
     def _ensure_fresh(self):
+        ops.publish_pending()          # (objects a training pass cached without publication are completed before an inference pass reads them)
         if self._fingerprint() != self._fp:
             self.refresh()
             ops.publish_cached(self.embed_w)    # (a refresh inside a sub-batch pass runs on that pass's side stream; the other one reads the result)
@@ -414,6 +415,7 @@ class ViTEngine:
     def explain(self, x, targets: Optional[torch.Tensor] = None, want_weights: bool = True) -> Dict[str, torch.Tensor]:
         x = x.detach()
         x = x if x.is_contiguous() else x.contiguous()
+        targets = ops.check_targets(targets, self.head.cout)      # IndexError like the reference's out[0, idx]; negative indices wrap
         tg = None if targets is None else targets.to(device=x.device, dtype=torch.int64).contiguous()
 
         def one(lo, hi):

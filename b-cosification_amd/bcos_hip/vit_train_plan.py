@@ -154,7 +154,7 @@ class ViTTrainPlan:
         if lin.weight.requires_grad:
             acc = self._zeros.take((Cout, 1, 1, Cin), x.device)
             grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4.view(1, 1, rows, gl4.shape[1]), x.view(1, 1, rows, Cin), Cin, Cout,
-                                                                      (1, 1), (1, 1), (0, 0), (1, 1), out=acc).view(Cout, Cin), (gl4, x))
+                                                                      (1, 1), (1, 1), (0, 0), (1, 1), out=acc).view(Cout, Cin), (gl4, x, acc))
         if lin.bias is not None and lin.bias.requires_grad:
             grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4)[:Cout].contiguous(), (gl4,))
         if not need_x:
@@ -309,7 +309,7 @@ class ViTTrainPlan:
                 Cin = h1.shape[1]
                 acc = self._zeros.take((Cq, 1, 1, Cin), gq2.device)
                 grads[wp] = self._pq.run(lambda: ops.conv2d_wgrad(gq2.view(1, 1, rows, Cq), h1.view(1, 1, rows, Cin), Cin, Cq, (1, 1), (1, 1),
-                                                                  (0, 0), (1, 1), out=acc).view(Cq, Cin), (gq2, h1))
+                                                                  (0, 0), (1, 1), out=acc).view(Cq, Cin), (gq2, h1, acc))
             gh1 = ops.matmul_nt(ops.ensure_absmax(gq2), ops.mark_static(rec["wq"].t().contiguous()), track_absmax=False)
             g = self._ln_bwd(rec["ln1"], gh1, grads, addend=g_x1)
             st["blocks"][bi] = None

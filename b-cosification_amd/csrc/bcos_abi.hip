@@ -23,7 +23,11 @@ int bcos_set_hip_error(const char* what, hipError_t err) {
     return BCOS_E_LAUNCH;
 }
 
+#ifdef BCOS_DEV_BUILD
+extern "C" int bcos_version(void) { return BCOS_ABI_VERSION | BCOS_VERSION_DEV_FLAG; }
+#else
 extern "C" int bcos_version(void) { return BCOS_ABI_VERSION; }
+#endif
 
 // -- option table (include/bcos_hip.h: bcos_option) ------------------------------------------------------------------------
 namespace {

@@ -361,8 +361,12 @@ __global__ __launch_bounds__(256) void head_rank1_kernel(const int64_t* __restri
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t row = wave; row < rows; row += nwaves) {
         const int64_t n = row / R;
-        const int k = (int)cls[n];
-        float a = coef * scale[row * K + k];
+        // a class index outside [0, K) explains nothing: a zero gradient, as the one-hot tensor this launch replaces gave (the host
+        // validates user-given targets -- bcos_hip/ops.py: check_targets --, this keeps a raw C-ABI caller off out-of-range reads)
+        const int64_t kc = cls[n];
+        const bool k_ok = kc >= 0 && kc < (int64_t)K;
+        const int k = k_ok ? (int)kc : 0;
+        float a = k_ok ? coef * scale[row * K + k] : 0.f;
         if (row_scale) a *= row_scale[row];
         const f32x4* wr = reinterpret_cast<const f32x4*>(w + (int64_t)k * D4 * 4);
         unsigned mx = 0u, mx2 = 0u;
@@ -556,6 +560,40 @@ extern "C" int bcos_cosine_grad(const float* u, const float* w, const float* l, 
     if (!u || !w || !l || !inv_norm || !out || rows <= 0 || C <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_cosine_grad: bad argument");
     hipLaunchKernelGGL(cosine_grad_kernel, dim3(grid_for(rows * C)), dim3(TPB), 0, STREAM(stream), u, w, l, inv_norm, coef, out, rows, C);
     return check_launch("cosine_grad_kernel");
+}
+
+namespace {
+// the plainest streaming kernel: 8 x 16 bytes in flight per thread, loads first, then the stores; non-temporal both ways
+__global__ __launch_bounds__(TPB) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4) {
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)gridDim.x * TPB * U;
+    for (int64_t base = (int64_t)blockIdx.x * TPB * U + threadIdx.x; base < n4; base += stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * TPB;
+            if (i < n4) v[u] = __builtin_nontemporal_load(src + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * TPB;
+            if (i < n4) __builtin_nontemporal_store(v[u], dst + i);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int bcos_stream_copy(const float* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 0 || (n & 3)) return bcos_set_error(BCOS_E_INVAL, "bcos_stream_copy: NULL buffer, negative n or n % 4 != 0");
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_stream_copy: buffers must be 16-byte aligned");
+    if (n == 0) return BCOS_OK;
+    const int64_t n4 = n / 4;
+    const int64_t want = (n4 + (int64_t)TPB * 8 - 1) / ((int64_t)TPB * 8);
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(TPB), 0, STREAM(stream), reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), n4);
+    return check_launch("stream_copy_kernel");
 }
 
 extern "C" int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {

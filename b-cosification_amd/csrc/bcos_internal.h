@@ -12,6 +12,19 @@ int bcos_set_hip_error(const char* what, hipError_t err);
 int64_t bcos_option(int option);
 
 
+// Development builds.  Some compile-time switches of the kernels drop work for TIMING experiments (the knock-outs D_KO, H2_KO, P_KO,
+// AH_KO: wrong results by design) or select code paths that were measured and never validated as the product configuration
+// (D_EARLY = 0, D_A_AUX != 0).  Such a value is accepted only together with -DBCOS_DEV_BUILD, and a library built with
+// BCOS_DEV_BUILD says so: bcos_version() carries BCOS_VERSION_DEV_FLAG (include/bcos_hip.h) and the Python binding refuses to load it
+// unless BCOS_ALLOW_DEV_BUILD=1 (bcos_hip/lib.py).  BCOS_DEV_SWITCH(NAME, default) goes right behind the #ifndef / #define / #endif
+// that gives the switch its default.
+#ifdef BCOS_DEV_BUILD
+#define BCOS_DEV_SWITCH(NAME, DEFAULT) static_assert(true, "")
+#else
+#define BCOS_DEV_SWITCH(NAME, DEFAULT) \
+    static_assert((NAME) == (DEFAULT), #NAME " is a development switch (timing-only or unvalidated code path): build with -DBCOS_DEV_BUILD")
+#endif
+
 struct bcos_tapconv_geom;
 struct bcos_epilogue;
 // narrow-output (Cout <= 8) path, bcos_skinny.hip: 1 = handled, 0 = not applicable, < 0 = error

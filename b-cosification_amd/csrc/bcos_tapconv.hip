@@ -1430,6 +1430,7 @@ constexpr int H2_MAX_TAPS = 16;    // channel-chunk-major K walk for up to this 
 #ifndef H2_KO
 #define H2_KO 0                   // development knock-outs (timing only, wrong results): 1 no MFMA, 2 no split VALU, 4 no global loads in the loop, 8 no fragment reads
 #endif
+BCOS_DEV_SWITCH(H2_KO, 0);
 #ifndef H2_MFMA_ORDER
 #define H2_MFMA_ORDER 0           // 0 = chosen by tile shape (see mma_step), 1 = accumulator-major, 2 = product-major
 #endif
@@ -1894,15 +1895,18 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
 #ifndef D_KO
 #define D_KO 0                    // development knock-outs (timing only, wrong results): 1 no DMA issue in the steady loop, 2 no split of the next A rows
 #endif
+BCOS_DEV_SWITCH(D_KO, 0);
 #ifndef D_DEAL_DMA
 #define D_DEAL_DMA 0              // 1 = issue the DMA pieces one by one behind the step's matrix instructions instead of together behind the barrier
 #endif
 #ifndef D_EARLY
 #define D_EARLY 1                 // 1 = the prologue's DMA pieces go out between the loads of the operand maxima and their use, no workgroup barrier ahead of the loop (every walk but the channel-chunk-major one); 0 = behind the scales and a barrier (round 3)
 #endif
+BCOS_DEV_SWITCH(D_EARLY, 1);
 #ifndef D_A_AUX
 #define D_A_AUX 0                 // cache policy bits of the A operand's LDS-DMA loads (2 = non-temporal: measured in round 4)
 #endif
+BCOS_DEV_SWITCH(D_A_AUX, 0);
 #ifndef D_SCHED
 #define D_SCHED 1                 // 1 = pin the issue order of a step's fragment reads / matrix / vector instructions (sched_group_barrier)
 #endif
@@ -2461,6 +2465,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
 #ifndef P_KO
 #define P_KO 0                    // development knock-outs (timing only, wrong results): 1 no patch refill, 2 no B DMA in the steady loop, 4 one barrier per chunk only, 8 no fragment reads after the first step, 16 first product only, 32 no vmcnt waits, 64 no image maxima
 #endif
+BCOS_DEV_SWITCH(P_KO, 0);
 #ifndef P_NSLOT
 #define P_NSLOT 3                 // B ring slots: 3 = the DMA of step ks + 2 is issued in step ks (two steps to land), 2 = of step ks + 1 (one step)
 #endif

@@ -470,6 +470,7 @@ constexpr float AH_LOG2E = 1.4426950408889634f, AH_LN2 = 0.6931471805599453f;
 #ifndef AH_KO
 #define AH_KO 0
 #endif
+BCOS_DEV_SWITCH(AH_KO, 0);
 #ifndef AH_TWO_CHAINS
 #define AH_TWO_CHAINS 0
 #endif

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BCOS_ABI_VERSION 8
+#define BCOS_ABI_VERSION 9
 
 enum {
     BCOS_OK = 0,
@@ -196,7 +196,10 @@ typedef struct bcos_epilogue {
 
 /* -- library -------------------------------------------------------------------------- */
 
-/* ABI version (BCOS_ABI_VERSION of the build). */
+/* ABI version (BCOS_ABI_VERSION of the build).  A library compiled with -DBCOS_DEV_BUILD -- the only builds in which the kernels'
+ * timing knock-outs and unvalidated code paths can be switched on (csrc/bcos_internal.h: BCOS_DEV_SWITCH) -- returns the version
+ * with BCOS_VERSION_DEV_FLAG set: such a library may compute wrong results and must not be used as the product. */
+#define BCOS_VERSION_DEV_FLAG 0x40000000
 int bcos_version(void);
 
 /* Human-readable description of the last error on this thread ("" if none). */
@@ -394,6 +397,13 @@ int bcos_weight_row_invnorm(const float* w, const float* gain, float* inv, int r
 /* out[i] = a[i] * b[i] */
 int bcos_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* dst[i] = src[i], n floats, 16-byte aligned, as the plainest streaming kernel this library can issue: every thread keeps eight
+ * global_load_dwordx4 in flight and stores them with global_store_dwordx4 (non-temporal both ways), 2048 workgroups walking the
+ * buffers with a grid stride.  It exists as the REFERENCE the bandwidth-bound launches are priced against (bench.py:
+ * roofline.by_bound.hbm.stream_copy_gbps -- /opt/skills/guides/MI355X_MICROARCH.md measures 6.29 TB/s for such a copy), and as the
+ * device-to-device copy of the engines where one is needed on a given stream.  (ABI v9) */
+int bcos_stream_copy(const float* src, float* dst, int64_t n, void* stream);
+
 /* Row-wise L2 normalisation y[r,:] = x[r,:] / ||x[r,:]||_2 and / or its inverse norms inv_norm[r] (either may be NULL): the
  * `attn_unpool` head of BcosAttentionPool2d (bcos/modules/bcosattnpool.py:23-32: x / x.norm(dim=-1), norm detached in
  * explanation mode) and `outa / outa.norm(dim=-1)` of the zero-shot attribution
@@ -468,7 +478,8 @@ int bcos_head_onehot_grad(const int64_t* cls, const float* scale, float* glin,
  * row_scale[n r] * w[cls[n], :]  -- bcos_head_onehot_grad followed by the K-long input-gradient contraction, without the [N, R, K]
  * tensor.  scale [N, R, K] (the head's stored multiplier), w [K, D] (its weight rows, D % 4 == 0), row_scale [N R] or NULL (the rstd of
  * a LayerNorm folded into the head), mul [N R, D] or NULL.  out = v * mul (mul NULL: v), out2 = v (may be NULL), out_absmax [N R] or
- * NULL: per-row max |out| bit patterns.  16-byte aligned tensors.  (ABI v8; gap-reordered SimpleViT head, vit.py:197-199) */
+ * NULL: per-row max |out| bit patterns.  16-byte aligned tensors.  An image whose cls[n] is outside [0, K) gets a ZERO gradient
+ * (what the one-hot tensor gave; nothing is read out of range).  (ABI v8; gap-reordered SimpleViT head, vit.py:197-199) */
 int bcos_head_rank1_grad(const int64_t* cls, const float* scale, const float* w, const float* row_scale, const float* mul, float* out,
                          float* out2, uint32_t* out_absmax, int N, int R, int K, int D, float inv_temperature, void* stream);
 /* ... with the whole second output of the gradient epilogue (bcos_epilogue.out2, the shortcut's share behind a residual block):

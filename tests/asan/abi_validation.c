@@ -148,6 +148,12 @@ int main(void) {
     EXPECT(bcos_head_rank1_grad((const int64_t*)buf, buf, buf + 1, NULL, NULL, buf, NULL, am, 2, 4, 10, 8, 1.0f, NULL), BCOS_E_INVAL);   /* misaligned w */
     EXPECT(bcos_head_rank1_grad_ex((const int64_t*)buf, buf, buf, NULL, buf, buf, NULL, 0, buf, NULL, am, NULL, 2, 4, 10, 8, 1.0f, NULL), BCOS_E_INVAL);   /* mul2 without out2 */
     EXPECT(bcos_head_rank1_grad_ex((const int64_t*)buf, buf, buf, NULL, NULL, NULL, NULL, 1, buf, buf, am, am, 2, 4, 10, 8, 1.0f, NULL), BCOS_E_INVAL);    /* gate from an absent mul */
+    /* ABI v9 */
+    EXPECT(bcos_stream_copy(NULL, buf, 16, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_stream_copy(buf, buf + 1, 16, NULL), BCOS_E_INVAL);      /* misaligned */
+    EXPECT(bcos_stream_copy(buf, buf, 6, NULL), BCOS_E_INVAL);           /* n % 4 */
+    EXPECT(bcos_stream_copy(buf, buf, -4, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_stream_copy(buf, buf, 0, NULL), BCOS_OK);                /* nothing to do: no launch */
     EXPECT(bcos_layernorm_bwd_add(buf, buf, NULL, buf, buf, NULL, NULL, 4, 8, NULL), BCOS_E_INVAL);                    /* no output */
     EXPECT(bcos_layernorm_bwd_add(buf, buf, NULL, NULL, buf, buf, NULL, 4, 8, NULL), BCOS_E_INVAL);                    /* no rstd */
     EXPECT(bcos_attention_fwd(buf, NULL, NULL, am, 1, 4, 1, 64, 1.0f, NULL), BCOS_E_INVAL);

@@ -847,6 +847,61 @@ def test_vit_training_plan_accumulates_over_two_forwards(lib):
         assert rel(a, b) <= 1e-5, (n, rel(a, b))          # (atomics in the weight gradient: not bit-identical)
 
 
+def test_out_of_range_targets(lib):
+    """a label outside [0, K) never becomes an out-of-range device read.  Engines: IndexError before any launch,
+    [-K, -1] wraps like the reference's out[0, idx] (bcos/common.py:170-176); raw launch: a zero gradient for that image (what the
+    one-hot tensor gave), the other images untouched."""
+    from bcos_hip import ops, synth, vit_engine
+    import bcos_hip.engine as en
+    torch.manual_seed(5)
+    N, R, K, D = 4, 7, 12, 16
+    scale, w = torch.rand(N, R, K, device=DEV) + 0.1, torch.randn(K, D, device=DEV)
+    good = torch.tensor([3, 0, 11, 5], device=DEV)
+    ref, _ = ops.head_rank1_grad(good, scale, w)
+    for bad_val in (-1, K, 1 << 40, -(1 << 40)):
+        cls = good.clone()
+        cls[1] = bad_val
+        out, _ = ops.head_rank1_grad(cls, scale, w, want_absmax=True)
+        assert torch.count_nonzero(out.view(N, R, D)[1]) == 0
+        keep = [0, 2, 3]
+        assert torch.equal(out.view(N, R, D)[keep], ref.view(N, R, D)[keep])
+    net = synth.build_bcosified_resnet("resnet18", seed=0).to(DEV)
+    x = synth.synthetic_images(4, seed=3).to(DEV)
+    with torch.no_grad():
+        synth.calibrate(net, x)
+    eng = en.attach(net)
+    Kc = eng.head.cout
+    for bad in (torch.tensor([0, 1, Kc, 2]), torch.tensor([0, -Kc - 1, 1, 2], device=DEV)):
+        with pytest.raises(IndexError):
+            eng.explain(x, targets=bad)
+    with pytest.raises(IndexError):
+        eng.explain_targets(x, torch.tensor([0, Kc + 5]))
+    a = eng.explain(x, targets=torch.tensor([-1, 5, -Kc, 7]))
+    b = eng.explain(x, targets=torch.tensor([Kc - 1, 5, 0, 7], device=DEV))
+    assert a["explained_class_idx"].tolist() == [Kc - 1, 5, 0, 7]
+    assert torch.equal(a["dynamic_linear_weights"], b["dynamic_linear_weights"])
+    vnet = synth.build_bcosified_vit("simple_vit_ti_patch16_224").to(DEV)
+    with torch.no_grad():
+        synth.calibrate(vnet, x)
+    veng = vit_engine.attach(vnet)
+    with pytest.raises(IndexError):
+        veng.explain(x, targets=torch.tensor([0, 1, 2, veng.head.cout], device=DEV))
+    assert veng.explain(x, targets=torch.tensor([-1, 0, 1, 2]))["explained_class_idx"].tolist() == [veng.head.cout - 1, 0, 1, 2]
+
+
+def test_stream_copy_is_a_copy(lib):
+    """bcos_stream_copy (ABI v9), the bandwidth reference of bench.py: bit-exact on ragged sizes, refuses what it cannot vectorise."""
+    from bcos_hip import ops
+    from bcos_hip.lib import BcosHipError
+    for n in (4, 1020, 256 * 8 * 4, 256 * 8 * 4 + 4, (1 << 22) + 12):
+        src = torch.randn(n, device=DEV)
+        dst = torch.full((n + 8,), 7.0, device=DEV)
+        ops.stream_copy(src, dst[4:4 + n])
+        assert torch.equal(dst[4:4 + n], src) and float(dst[:4].min()) == 7.0 and float(dst[4 + n:].min()) == 7.0
+    with pytest.raises(BcosHipError):
+        ops.stream_copy(torch.randn(6, device=DEV))
+
+
 def test_head_gradient_is_rank_one_per_image(lib):
     """bcos_head_rank1_grad against what it replaces -- the one-hot tensor [N, R, K] (bcos_head_onehot_grad) followed by the K-long
     input-gradient contraction with the LayerNorm's rstd as row factor and the previous layer's scale as multiplier -- and against fp64;

@@ -7,6 +7,7 @@ import json
 import math
 import os
 import re
+import sys
 import warnings
 
 import numpy as np
@@ -38,6 +39,45 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.bcos_version() == lib.ABI_VERSION
 
 
+def test_default_build_is_not_a_development_build(hip_lib, tmp_path):
+    """the timing knock-outs (D_KO, H2_KO, P_KO, AH_KO) and the unvalidated code paths (D_EARLY = 0, D_A_AUX) compile
+    only with -DBCOS_DEV_BUILD, such a library says so in bcos_version(), and the binding refuses to load it."""
+    import subprocess
+    from bcos_hip import lib
+    assert hip_lib.bcos_version() & lib.VERSION_DEV_FLAG == 0
+    assert not os.environ.get("BCOS_HIPCC_FLAGS"), "the test suite runs against a default build"
+    csrc = os.path.join(REPO, "b-cosification_amd", "csrc")
+    base = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-std=c++20", f"-I{os.path.join(REPO, 'include')}", f"-I{csrc}"]
+    # every fenced switch carries a BCOS_DEV_SWITCH behind the #define that gives it its default
+    for src, names in (("bcos_tapconv.hip", ("D_KO", "H2_KO", "P_KO", "D_EARLY", "D_A_AUX")), ("bcos_vit.hip", ("AH_KO",))):
+        text = open(os.path.join(csrc, src)).read()
+        for nm in names:
+            assert re.search(rf"#ifndef {nm}\n#define {nm} .*\n#endif\nBCOS_DEV_SWITCH\({nm}, \d+\);", text), nm
+    # a knock-out without BCOS_DEV_BUILD does not compile (host pass only: the static_assert fires in either pass) ...
+    r = subprocess.run(base + ["--cuda-host-only", "-fsyntax-only", "-DAH_KO=1", os.path.join(csrc, "bcos_vit.hip")], capture_output=True, text=True)
+    assert r.returncode != 0 and "development switch" in r.stderr, r.stderr[-2000:]
+    # ... and a BCOS_DEV_BUILD library is flagged and refused by the binding: bcos_abi.hip rebuilt with the flag, linked with the other
+    # objects of the in-tree build (b-cosification_amd/lib/obj, present wherever the library was built)
+    objdir = os.path.join(REPO, "b-cosification_amd", "lib", "obj")
+    others = [os.path.join(objdir, f) for f in sorted(os.listdir(objdir))] if os.path.isdir(objdir) else []
+    others = [o for o in others if o.endswith(".o") and not o.endswith("bcos_abi.o")]
+    if not others:
+        pytest.skip("no object files of the in-tree build to link a flagged library from")
+    abi_o, so = tmp_path / "abi_dev.o", tmp_path / "libdev.so"
+    subprocess.run(base + ["-O1", "-fPIC", "-DBCOS_DEV_BUILD", "-c", os.path.join(csrc, "bcos_abi.hip"), "-o", str(abi_o)], check=True)
+    subprocess.run([base[0], "--offload-arch=gfx950", "-shared", "-fPIC", str(abi_o)] + others + ["-o", str(so)], check=True)
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from bcos_hip import lib\n"
+            "try:\n    l = lib.load(); print('LOADED', l.bcos_version() == lib.ABI_VERSION | lib.VERSION_DEV_FLAG)\n"
+            "except lib.BcosHipError as e:\n    print('REFUSED', 'development build' in str(e))\n" % os.path.join(REPO, "b-cosification_amd"))
+    env = dict(os.environ, BCOS_HIP_LIB=str(so))
+    env.pop("BCOS_ALLOW_DEV_BUILD", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert "REFUSED True" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, BCOS_ALLOW_DEV_BUILD="1"))
+    assert "LOADED True" in out.stdout and "DEVELOPMENT build" in out.stderr, out.stdout + out.stderr
+
+
 def test_abi_argument_validation_without_gpu(hip_lib):
     """Bad arguments are rejected before any HIP call, with an errno-style code and a message."""
     from bcos_hip import lib
@@ -65,6 +105,63 @@ def test_abi_argument_validation_under_address_sanitizer():
     script = os.path.join(REPO, "scripts", "asan_host_check.sh")
     proc = subprocess.run(["bash", script], capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0 and "abi_validation: ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
+
+
+def test_targets_are_validated_on_the_host():
+    """class indices reach the rank-one head gradient only after a host-side range check with the reference's
+    `out[0, idx]` semantics (bcos/common.py:170-176): [-K, -1] wraps, anything else outside [0, K) is an IndexError."""
+    from bcos_hip import ops
+    assert ops.check_targets(None, 10) is None
+    t = ops.check_targets(torch.tensor([0, 9, -1, -10]), 10)
+    assert t.dtype == torch.int64 and t.tolist() == [0, 9, 9, 0]
+    assert ops.check_targets([[1, 2], [3, -2]], 5).tolist() == [[1, 2], [3, 3]]
+    for bad in ([10], [-11], [0, 1000], torch.tensor([[3, -12]])):
+        with pytest.raises(IndexError):
+            ops.check_targets(bad, 10)
+    with pytest.raises(TypeError):
+        ops.check_targets(torch.tensor([1.0]), 10)
+    assert ops.check_targets(torch.zeros(0, dtype=torch.int64), 10).numel() == 0
+    # the engines call it before any launch: a CPU emulation of the kernels is not needed to see the error
+    import inspect
+    from bcos_hip import engine, vit_engine
+    assert "check_targets" in inspect.getsource(engine.ResNetEngine.explain) and "check_targets" in inspect.getsource(engine.ResNetEngine.explain_targets)
+    assert "check_targets" in inspect.getsource(vit_engine.ViTEngine.explain)
+
+
+def test_telemetry_samples_the_physical_device():
+    """the SMI sources index physical devices, HIP ordinals are logical under *_VISIBLE_DEVICES."""
+    from bcos_hip.telemetry import physical_index
+    assert physical_index(0, {}) == 0 and physical_index(3, {}) == 3
+    assert physical_index(0, {"HIP_VISIBLE_DEVICES": "5"}) == 5
+    assert physical_index(1, {"HIP_VISIBLE_DEVICES": "4,6"}) == 6
+    assert physical_index(1, {"CUDA_VISIBLE_DEVICES": "2,3"}) == 3
+    assert physical_index(0, {"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1"}) == 3       # HIP's list indexes what ROCr left
+    assert physical_index(0, {"HIP_VISIBLE_DEVICES": "GPU-abc"}) == 0                                 # UUIDs: unresolved, unchanged
+    assert physical_index(2, {"HIP_VISIBLE_DEVICES": "0,1"}) == 2                                     # out of range: unchanged
+
+
+def test_deferred_publication_bookkeeping():
+    """objects cached inside a training pass (ops.transient_weights) are not synchronised there, but remembered, and the
+    first reader outside a training pass completes them (ops.publish_pending); CPU tensors never enter the bookkeeping."""
+    from bcos_hip import ops
+    ops._PENDING.clear()
+    with ops.transient_weights():
+        ops.publish_cached(torch.zeros(4))
+        ops.note_unpublished(torch.zeros(4))
+    assert not ops._PENDING
+    ops.publish_pending()
+
+    class _FakeStream:
+        synced = 0
+
+        def synchronize(self):
+            _FakeStream.synced += 1
+    ops._PENDING.add(_FakeStream())
+    with ops.transient_weights():
+        ops.publish_pending()                  # inside a training pass: nothing is completed
+    assert _FakeStream.synced == 0 and ops._PENDING
+    ops.publish_pending()
+    assert _FakeStream.synced == 1 and not ops._PENDING
 
 
 def test_gradient_to_image_has_no_cpu_formulation():
