@@ -523,9 +523,7 @@ class ResNetEngine:
             if keep:
                 st["stem_ts"].append(t)
         k, s, p = self.pool
-        cur = ops.avgpool2d_fwd(a, k, s, p)
-        if need(self.blocks[0].k_first):
-            ops.ensure_absmax(cur)
+        cur = ops.avgpool2d_fwd(a, k, s, p, want_absmax=need(self.blocks[0].k_first))      # (maxima from the pool's own launch)
         if keep:
             st["a0_hw"] = (a.shape[1], a.shape[2])
         del a
@@ -552,13 +550,10 @@ class ResNetEngine:
                 tw.append(c.take_wide())
             pre_pool_hw = (h.shape[1], h.shape[2])
             if blk.pool:
-                h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0)
-                if need(blk.convs[-1].k_fwd):
-                    ops.ensure_absmax(h)
+                h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0, want_absmax=need(blk.convs[-1].k_fwd))
             if blk.shortcut is not None:
-                sc_in = ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0) if blk.shortcut_pool else inp
-                if blk.shortcut_pool and need(blk.shortcut.k_fwd):
-                    ops.ensure_absmax(sc_in)
+                sc_in = (ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0, want_absmax=need(blk.shortcut.k_fwd))
+                         if blk.shortcut_pool else inp)
                 idn, td = blk.shortcut.fwd(sc_in, relu=False, want_scale=keep, track=False)      # only ever an addend
             else:
                 idn, td = inp, None

@@ -112,6 +112,7 @@ SIGNATURES = {
     "bcos_finalize_explanation": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bcos_contrib_map": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "bcos_avgpool2d_fwd": (C.c_int, [_P, _P] + [_I] * 9 + [_P]),
+    "bcos_avgpool2d_fwd_absmax": (C.c_int, [_P, _P, _P] + [_I] * 9 + [_P]),
     "bcos_avgpool2d_bwd": (C.c_int, [_P, _P, _P, _P] + [_I] * 9 + [_P]),
     "bcos_global_avgpool_logits": (C.c_int, [_P, _P, _I, _I, _I, _F, _F, _P]),
     "bcos_head_onehot_grad": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),

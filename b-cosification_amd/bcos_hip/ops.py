@@ -813,12 +813,20 @@ def contrib_map(x_nchw, gx_nchw):
     return out
 
 
-def avgpool2d_fwd(x, k, s, p, out=None):
+def avgpool2d_fwd(x, k, s, p, out=None, want_absmax=False):
+    """`want_absmax`: also emit the per-pixel maxima of the pooled tensor (k in {2, 3}, C / 4 a power of two <= 64: the pools of the
+    ResNets; other shapes fall back to the separate pass of ensure_absmax)."""
     lib = _l.load()
     N, H, W, Cc = x.shape
     OH, OW = conv_out_size(H, k, s, p), conv_out_size(W, k, s, p)
     y = out if out is not None else torch.empty((N, OH, OW, Cc), device=x.device, dtype=torch.float32)
-    _l.check(lib.bcos_avgpool2d_fwd(_dev(x, "x"), _dev(y, "y"), N, H, W, Cc, k, s, p, OH, OW, _stream()), "bcos_avgpool2d_fwd")
+    c4 = Cc // 4
+    fused = want_absmax and k in (2, 3) and Cc % 4 == 0 and c4 <= 64 and (c4 & (c4 - 1)) == 0 and H * W * c4 < (1 << 31)
+    am = _fused_absmax(y, fused)
+    _l.check(lib.bcos_avgpool2d_fwd_absmax(_dev(x, "x"), _dev(y, "y"), C.c_void_p(am.data_ptr()) if am is not None else None,
+                                           N, H, W, Cc, k, s, p, OH, OW, _stream()), "bcos_avgpool2d_fwd")
+    if want_absmax and am is None:
+        ensure_absmax(y)
     return y
 
 

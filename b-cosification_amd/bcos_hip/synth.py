@@ -283,6 +283,23 @@ def standard_clip_rn50(seed: int = 0, clip_module=None):
     return net
 
 
+def standard_clip_resnet(layers, output_dim, heads, width, seed: int = 0, clip_module=None, input_resolution: int = 64):
+    """A ModifiedResNet (CLIP/clip/model.py:94-154) of any depth / width with default init and randomised BatchNorm statistics -- the
+    small instance behind the tight training-step fixture (tests/golden/clip_tiny_train_step.*)."""
+    if clip_module is None:
+        from CLIP.clip import model as clip_module
+    torch.manual_seed(seed)
+    net = clip_module.ModifiedResNet(list(layers), output_dim, heads, input_resolution=input_resolution, width=width)
+    randomize_batchnorm(net, torch.Generator().manual_seed(seed + 1))
+    return net
+
+
+def build_bcosified_clip_resnet(layers, output_dim, heads, width, seed: int = 0):
+    from bcosify import BcosifyNetwork
+    net = BcosifyNetwork(standard_clip_resnet(layers, output_dim, heads, width, seed), clip_model_config(), add_channels=True, logit_layer=False)
+    return finish_clip_conversion(net).eval()
+
+
 def finish_clip_conversion(model: nn.Module, hip_pools: bool = True):
     """clip_bcosification/model.py:17-23: null every bias and the attention pool's positional embedding."""
     for mod in model.modules():

@@ -224,6 +224,53 @@ __global__ __launch_bounds__(TPB) void avgpool_fwd_kernel(const float* __restric
     }
 }
 
+// The same pool with one workgroup per OUTPUT row (n, oh) and the window expanded at compile time (K x K predicated loads, all in flight
+// together; out-of-image taps add +0, which leaves every partial sum as it was): 32-bit index arithmetic, optional per-pixel maxima of
+// the result for the f16x2 contraction that reads it (C4 a power of two <= 64: the C4 lanes of a pixel are an aligned lane group) --
+// the stem pool of the ResNets ran the flat kernel above at 4.7 TB/s and a separate pass for the maxima.  Same sums in the same
+// order as avgpool_fwd_kernel: bit-identical.
+template <int K>
+__global__ __launch_bounds__(TPB) void avgpool_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned* __restrict__ absmax,
+                                                              int H, int W, int C4, int s, int p, int OH, int OW) {
+    const int n = blockIdx.x / OH, oh = blockIdx.x - n * OH;
+    const int hs = oh * s - p;
+    const int he = min(hs + K, H + p);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + (int64_t)n * H * W * C4;
+    f32x4* y4 = reinterpret_cast<f32x4*>(y) + (int64_t)blockIdx.x * OW * C4;
+    const int c4_shift = (C4 & (C4 - 1)) == 0 ? __builtin_ctz(C4) : -1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < OW * C4; i0 += TPB) {
+        const int i = i0 + threadIdx.x;
+        const bool live = i < OW * C4;
+        const int ow = live ? (c4_shift >= 0 ? i >> c4_shift : i / C4) : 0, c4 = live ? i - ow * C4 : 0;
+        const int ws = ow * s - p;
+        const int we = min(ws + K, W + p);
+        const float pool = (float)((he - hs) * (we - ws));
+        f32x4 v[K][K];
+#pragma unroll
+        for (int dh = 0; dh < K; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < K; ++dw) {
+                const int h = hs + dh, w = ws + dw;
+                const bool ok = live && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+                v[dh][dw] = ok ? x4[(h * W + w) * C4 + c4] : zero4;
+            }
+        f32x4 acc = zero4;
+#pragma unroll
+        for (int dh = 0; dh < K; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < K; ++dw) acc += v[dh][dw];
+        acc = acc / pool;
+        if (live) y4[i] = acc;
+        if (absmax) {
+            unsigned m = max(max(__float_as_uint(acc[0]) & 0x7fffffffu, __float_as_uint(acc[1]) & 0x7fffffffu),
+                             max(__float_as_uint(acc[2]) & 0x7fffffffu, __float_as_uint(acc[3]) & 0x7fffffffu));
+            for (int o = C4 >> 1; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            if (live && c4 == 0) absmax[(int64_t)blockIdx.x * OW + ow] = m;
+        }
+    }
+}
+
 // One workgroup per input row (n, h): 32-bit index arithmetic only (the flat 64-bit div/mod version was ALU-bound at
 // 3.2 TB/s on the stem's 822 MB gradient).
 __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mul,
@@ -270,6 +317,79 @@ __global__ __launch_bounds__(TPB) void avgpool_bwd_kernel(const float* __restric
                              max(__float_as_uint(acc[2]) & 0x7fffffffu, __float_as_uint(acc[3]) & 0x7fffffffu));
             for (int o = C4 >> 1; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
             if (live && c4 == 0) absmax[((int64_t)n * H + h) * W + w] = m;
+        }
+    }
+}
+
+// ... with the windows of an input pixel expanded at compile time: a pixel lies in at most WMAX x WMAX = ceil(k / s)^2 windows (2 x 2 for
+// the 3 x 3 / 2 stem pool, 1 for the k = s pools of the CLIP ResNets); the loads of the windows it does not lie in are predicated off and
+// add 0 * rpool = +0 in the same place of the same sum (bit-identical), every thread handles TWO items per trip and issues their
+// multiplier and gradient loads together: 10 loads in flight where the loop above had 1-5.
+template <int WMAX>
+__global__ __launch_bounds__(TPB) void avgpool_bwd_win_kernel(const float* __restrict__ gy, const float* __restrict__ mul,
+                                                              float* __restrict__ gx, unsigned* __restrict__ absmax, int N, int H, int W,
+                                                              int C4, int k, int s, int p, int OH, int OW) {
+    constexpr int U = 2;
+    const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+    int oh_lo = (h + p - k + s) / s;
+    if (h + p - k + 1 <= 0) oh_lo = 0;
+    const int oh_hi = min((h + p) / s, OH - 1);
+    const int64_t row = ((int64_t)n * H + h) * W * C4;
+    const f32x4* gy4 = reinterpret_cast<const f32x4*>(gy) + (int64_t)n * OH * OW * C4;
+    const f32x4* mul4 = reinterpret_cast<const f32x4*>(mul) + row;
+    f32x4* gx4 = reinterpret_cast<f32x4*>(gx) + row;
+    const int c4_shift = (C4 & (C4 - 1)) == 0 ? __builtin_ctz(C4) : -1;
+    const int s_shift = (s & (s - 1)) == 0 ? __builtin_ctz(s) : -1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float rh[WMAX];              // (he - hs) of the row windows
+#pragma unroll
+    for (int a = 0; a < WMAX; ++a) {
+        const int hs = (oh_lo + a) * s - p;
+        rh[a] = (float)(min(hs + k, H + p) - hs);
+    }
+    for (int i0 = 0; i0 < W * C4; i0 += U * TPB) {
+        f32x4 g[U][WMAX][WMAX], m4[U];
+        float rp[U][WMAX][WMAX];
+        bool live[U];
+        int wq[U], cq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * TPB + threadIdx.x;
+            live[u] = i < W * C4;
+            const int w = live[u] ? (c4_shift >= 0 ? i >> c4_shift : i / C4) : 0, c4 = live[u] ? i - w * C4 : 0;
+            wq[u] = w; cq[u] = c4;
+            const int lo_num = w + p - k + s;
+            int ow_lo = s_shift >= 0 ? lo_num >> s_shift : lo_num / s;
+            if (w + p - k + 1 <= 0) ow_lo = 0;
+            const int ow_hi = min(s_shift >= 0 ? (w + p) >> s_shift : (w + p) / s, OW - 1);
+            m4[u] = (mul && live[u]) ? __builtin_nontemporal_load(mul4 + i) : zero4;
+#pragma unroll
+            for (int a = 0; a < WMAX; ++a)
+#pragma unroll
+                for (int b = 0; b < WMAX; ++b) {
+                    const int oh = oh_lo + a, ow = ow_lo + b;
+                    const bool ok = live[u] && oh <= oh_hi && ow <= ow_hi;
+                    const int ws = ow * s - p;
+                    rp[u][a][b] = ok ? 1.0f / (rh[a] * (float)(min(ws + k, W + p) - ws)) : 0.f;      // (a window the pixel is not in: 0 x 0, never 0 x inf)
+                    g[u][a][b] = ok ? gy4[(oh * OW + ow) * C4 + c4] : zero4;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 acc = zero4;
+#pragma unroll
+            for (int a = 0; a < WMAX; ++a)
+#pragma unroll
+                for (int b = 0; b < WMAX; ++b) acc += g[u][a][b] * rp[u][a][b];
+            if (mul) acc *= m4[u];
+            const int i = i0 + u * TPB + threadIdx.x;
+            if (live[u]) gx4[i] = acc;
+            if (absmax) {
+                unsigned m = max(max(__float_as_uint(acc[0]) & 0x7fffffffu, __float_as_uint(acc[1]) & 0x7fffffffu),
+                                 max(__float_as_uint(acc[2]) & 0x7fffffffu, __float_as_uint(acc[3]) & 0x7fffffffu));
+                for (int o = C4 >> 1; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+                if (live[u] && cq[u] == 0) absmax[((int64_t)n * H + h) * W + wq[u]] = m;
+            }
         }
     }
 }
@@ -676,6 +796,23 @@ static int pool_args_ok(int N, int H, int W, int C, int k, int s, int p, int OH,
 extern "C" int bcos_avgpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, int k, int s, int p, int OH,
                                   int OW, void* stream) {
     if (!x || !y || !pool_args_ok(N, H, W, C, k, s, p, OH, OW)) return bcos_set_error(BCOS_E_INVAL, "bcos_avgpool2d_fwd: bad argument");
+    return bcos_avgpool2d_fwd_absmax(x, y, nullptr, N, H, W, C, k, s, p, OH, OW, stream);
+}
+
+extern "C" int bcos_avgpool2d_fwd_absmax(const float* x, float* y, uint32_t* absmax_out, int N, int H, int W, int C, int k, int s, int p,
+                                         int OH, int OW, void* stream) {
+    if (!x || !y || !pool_args_ok(N, H, W, C, k, s, p, OH, OW)) return bcos_set_error(BCOS_E_INVAL, "bcos_avgpool2d_fwd: bad argument");
+    if (absmax_out && (C / 4 > 64 || ((C / 4) & (C / 4 - 1)) != 0 || (k != 2 && k != 3)))
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_avgpool2d_fwd_absmax: absmax_out needs k in {2, 3} and C / 4 a power of two <= 64");
+    // one workgroup per output row, the window expanded at compile time (k = 3: the stem pool of the ResNets; k = 2: the pools of CLIP's
+    // ModifiedResNet); the row kernels index an image with 32 bits
+    const bool rows_ok = (int64_t)N * OH < ((int64_t)1 << 31) && (int64_t)H * W * (C / 4) < ((int64_t)1 << 31);
+    if (rows_ok && (k == 2 || k == 3)) {
+        if (k == 3) hipLaunchKernelGGL(avgpool_fwd_row_kernel<3>, dim3((unsigned)(N * OH)), dim3(TPB), 0, STREAM(stream), x, y, absmax_out, H, W, C / 4, s, p, OH, OW);
+        else hipLaunchKernelGGL(avgpool_fwd_row_kernel<2>, dim3((unsigned)(N * OH)), dim3(TPB), 0, STREAM(stream), x, y, absmax_out, H, W, C / 4, s, p, OH, OW);
+        return check_launch("avgpool_fwd_row_kernel");
+    }
+    if (absmax_out) return bcos_set_error(BCOS_E_NOSUP, "bcos_avgpool2d_fwd_absmax: tensor too large for the row kernel");
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((int64_t)N * OH * OW * (C / 4))), dim3(TPB), 0, STREAM(stream),
                        x, y, N, H, W, C / 4, k, s, p, OH, OW);
     return check_launch("avgpool_fwd_kernel");
@@ -688,8 +825,11 @@ extern "C" int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, 
         return bcos_set_error(BCOS_E_NOSUP, "bcos_avgpool2d_bwd: tensor too large");
     if (absmax_out && (C / 4 > 64 || ((C / 4) & (C / 4 - 1)) != 0))
         return bcos_set_error(BCOS_E_NOSUP, "bcos_avgpool2d_bwd: absmax_out needs C / 4 to be a power of two <= 64");
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)(N * H)), dim3(TPB), 0, STREAM(stream), gy,
-                       mul, gx, absmax_out, N, H, W, C / 4, k, s, p, OH, OW);
+    const int wmax = (k + s - 1) / s;         // windows per input pixel and axis
+    if (wmax == 1) hipLaunchKernelGGL(avgpool_bwd_win_kernel<1>, dim3((unsigned)(N * H)), dim3(TPB), 0, STREAM(stream), gy, mul, gx, absmax_out, N, H, W, C / 4, k, s, p, OH, OW);
+    else if (wmax == 2) hipLaunchKernelGGL(avgpool_bwd_win_kernel<2>, dim3((unsigned)(N * H)), dim3(TPB), 0, STREAM(stream), gy, mul, gx, absmax_out, N, H, W, C / 4, k, s, p, OH, OW);
+    else hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)(N * H)), dim3(TPB), 0, STREAM(stream), gy,
+                            mul, gx, absmax_out, N, H, W, C / 4, k, s, p, OH, OW);
     return check_launch("avgpool_bwd_kernel");
 }
 

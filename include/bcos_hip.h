@@ -458,6 +458,10 @@ int bcos_contrib_map(const float* x, const float* gx, float* out,
  * nn.AvgPool2d(3,2,1): bcosification/experiment_parameters.py:99), NHWC. */
 int bcos_avgpool2d_fwd(const float* x, float* y, int N, int H, int W, int C,
                        int k, int s, int p, int OH, int OW, void* stream);
+/* ... also writing the per-pixel max |y| bit patterns of the pooled tensor (absmax_out [N*OH*OW], may be NULL) for the f16x2 contraction
+ * that reads it: k in {2, 3}, C / 4 a power of two <= 64.  (ABI v9) */
+int bcos_avgpool2d_fwd_absmax(const float* x, float* y, uint32_t* absmax_out, int N, int H, int W, int C, int k, int s, int p,
+                              int OH, int OW, void* stream);
 /* ... its input gradient, optionally multiplied elementwise by `mul` ([N,H,W,C]); absmax_out (NULL or [N*H*W], needs
  * C / 4 a power of two <= 64): per-pixel max |gx| bit patterns for the f16x2 contraction that reads gx. */
 int bcos_avgpool2d_bwd(const float* gy, const float* mul, float* gx, uint32_t* absmax_out, int N, int H, int W, int C,

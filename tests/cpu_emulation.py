@@ -190,7 +190,7 @@ def finalize_explanation(gxn, x, std6, add_inverse=False, want_weights=True, wan
     return wo, co
 
 
-def avgpool2d_fwd(x, k, s, p, out=None):
+def avgpool2d_fwd(x, k, s, p, out=None, want_absmax=False):
     y = F.avg_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
     if out is not None:
         out.copy_(y)

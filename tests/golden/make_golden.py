@@ -474,6 +474,96 @@ def resnet18_training_step():
                        param_names=names), f, indent=1)
 
 
+def _record_training_step(net, xs, loss_of, keep, keep_rv, stem, meta, record=None, extra=None):
+    """one train()-mode step of the reference network `net` on `xs`: output, loss, input gradient, the norm of every parameter gradient,
+    the full gradients named in `keep`, the updated running_var of the BatchNorms named in `keep_rv` -> tests/golden/<stem>.{npz,json}"""
+    net.train()
+    xr = xs.clone().requires_grad_(True)
+    out_t = net(xr)
+    loss = loss_of(out_t)
+    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    names = [n for n, _ in named]
+    grads = torch.autograd.grad(loss, [xr] + [p for _, p in named])
+    out = dict(output=out_t.detach(), loss=loss.detach(), gx=grads[0], grad_norms=torch.stack([g.norm() for g in grads[1:]]))
+    for k in keep:
+        g = grads[1 + names.index(k)]
+        if g.numel() >= (1 << 18):            # large matrices: their leading rows (<= 64 K elements; the norm of the whole is in grad_norms)
+            out["gradrows/" + k] = g[:max(1, (1 << 16) // max(g[0].numel(), 1))].clone()
+        else:
+            out["grad/" + k] = g
+    rv = dict(net.named_buffers())
+    for k in keep_rv:
+        out["running_var/" + k] = rv[k + ".running_var"].detach().clone()
+    if record is not None:
+        out.update({f"calib/{k}": v for k, v in record.items()})
+    if extra:
+        out.update(extra)
+    np.savez_compressed(os.path.join(HERE, stem + ".npz"), **t2n(out))
+    with open(os.path.join(HERE, stem + ".json"), "w") as f:
+        json.dump(dict(meta, param_names=names, calib_order=list(record.keys()) if record is not None else None,
+                       torch_version=torch.__version__), f, indent=1)
+    net.eval()
+    return out
+
+
+def resnet50_training_step():
+    """N4 end to end on the Bottleneck topology: one train()-mode BCE step of the reference's B-cosified ResNet-50 --
+    the calibrated weights of the resnet50_small fixture -- on 4 images of 64 x 64."""
+    net = reference_resnet("resnet50")
+    synth.calibrate(net, synth.synthetic_images(4))
+    small = json.load(open(os.path.join(HERE, "resnet50_small.json")))
+    assert state_checksum({k: v.detach() for k, v in net.state_dict().items()}) == small["state_checksum"], "not the weights of resnet50_small"
+    xs = synth.synthetic_images(4, seed=41, size=64)
+    labels = torch.tensor([7, 250, 999, 613])
+    target = torch.nn.functional.one_hot(labels, 1000).float()
+    _record_training_step(
+        net, xs, lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target),
+        keep=("model.conv1.linear.weight", "model.layer1.0.downsample.0.linear.weight", "model.layer2.0.conv2.linear.weight",
+              "model.layer3.2.conv3.linear.weight", "model.layer4.2.bn3.weight"),      # (fc: 8 MB; its norm is in grad_norms)
+        keep_rv=("model.bn1", "model.layer2.0.downsample.1", "model.layer4.2.bn3"), stem="resnet50_train_step",
+        meta=dict(arch="resnet50", weight_fixture="resnet50_small", image_seed=41, size=64, labels=labels.tolist(), loss="bce_with_logits"))
+
+
+def _clip_loss(emb):
+    return (emb * torch.linspace(-1, 1, emb.shape[1])).sum() / emb.shape[0]
+
+
+def clip_training_steps():
+    """... and on CLIP's ModifiedResNet (CLIP/clip/model.py:10-55, 94-154 through bcosify.py:74-114: three-convolution stem, anti-aliasing
+    average pools inside the strided Bottlenecks and their shortcuts, attention-pool head under autograd): the RN50 tower with the
+    calibrated weights of the clip_rn50 fixture on 4 images of 64 x 64 (free ReLU gates: the tolerance of the ResNet fixtures), and a SMALL
+    tower -- layers (1, 1, 1, 1), width 16, 8 heads, 64-d output, its own calibration record -- whose few thousand ReLU decisions leave no
+    gate floor: that fixture holds the pool / shortcut gradients of the plan to 1e-4."""
+    import importlib
+    ref_clip = importlib.import_module("CLIP.clip.model")
+    cfg = synth.clip_model_config()
+    net = R.bcosify.BcosifyNetwork(synth.standard_clip_rn50(0, clip_module=ref_clip), cfg, add_channels=True, logit_layer=False)
+    synth.finish_clip_conversion(net, hip_pools=False)
+    net.eval()
+    synth.calibrate(net, synth.synthetic_images(4))
+    big = json.load(open(os.path.join(HERE, "clip_rn50.json")))
+    assert state_checksum({k: v.detach() for k, v in net.state_dict().items()}) == big["state_checksum"], "not the weights of clip_rn50"
+    xs = synth.synthetic_images(4, seed=43, size=64)
+    _record_training_step(
+        net, xs, _clip_loss,
+        keep=("model.conv1.linear.weight", "model.conv3.linear.weight", "model.layer1.0.downsample.1.linear.weight", "model.layer2.0.conv2.linear.weight",
+              "model.layer4.2.bn3.weight", "model.attnpool.q_proj.weight", "model.attnpool.c_proj.linear.weight"),
+        keep_rv=("model.bn1", "model.layer2.0.downsample.2", "model.layer4.2.bn3"), stem="clip_rn50_train_step",
+        meta=dict(arch="clip_rn50", weight_fixture="clip_rn50", image_seed=43, size=64, loss="sum(emb * linspace(-1, 1, D)) / N"))
+    tiny = dict(layers=[1, 1, 1, 1], output_dim=64, heads=8, width=16)
+    net = R.bcosify.BcosifyNetwork(synth.standard_clip_resnet(seed=5, clip_module=ref_clip, **tiny), cfg, add_channels=True, logit_layer=False)
+    synth.finish_clip_conversion(net, hip_pools=False)
+    net.eval()
+    record = synth.calibrate(net, synth.synthetic_images(4, seed=77, size=64))
+    xs = synth.synthetic_images(4, seed=45, size=64)
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    _record_training_step(
+        net, xs, _clip_loss, keep=tuple(names),
+        keep_rv=tuple(n[:-len(".running_var")] for n, _ in net.named_buffers() if n.endswith(".running_var")), stem="clip_tiny_train_step",
+        meta=dict(arch="clip_modified_resnet", weight_seed=5, calib_seed=77, image_seed=45, size=64, loss="sum(emb * linspace(-1, 1, D)) / N", **tiny),
+        record=record)
+
+
 def state_checksum(sd):
     return {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items() if v.dtype.is_floating_point}
 
@@ -1128,6 +1218,10 @@ if __name__ == "__main__":
         vit_training_cases()
     if "train_r18" in which:
         resnet18_training_step()
+    if "train_r50" in which:
+        resnet50_training_step()
+    if "train_clip" in which:
+        clip_training_steps()
     if "inv" in which:
         small_invariants()
     if "r18" in which:

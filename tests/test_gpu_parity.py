@@ -151,6 +151,64 @@ def test_resnet18_training_step_against_reference_golden(lib, golden_dir, path):
         assert rel(le, lm) <= 1e-5
 
 
+def _check_training_step(*args, **kw):
+    import test_host_cpu as H
+    return H.check_training_step_fixture(*args, **kw)
+
+
+@pytest.mark.parametrize("path", ["plan", "layers"])
+def test_resnet50_training_step_against_reference_golden(lib, golden_dir, path):
+    """the Bottleneck training plan pinned to the REFERENCE -- one train()-mode BCE step of the reference's B-cosified
+    ResNet-50 (tests/golden/make_golden.py: resnet50_training_step; the calibrated weights of the resnet50_small fixture, 4 images of
+    64 x 64) through the plan and per layer, at the ResNet-18 fixture's tolerances (free ReLU gates: 2e-3)."""
+    from bcos_hip import synth
+    net, _, _ = _golden_net(golden_dir, "resnet50_small")
+    meta = json.load(open(os.path.join(golden_dir, "resnet50_train_step.json")))
+    data = np.load(os.path.join(golden_dir, "resnet50_train_step.npz"))
+    x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV)
+    target = F.one_hot(torch.tensor(meta["labels"]), 1000).float().to(DEV)
+    _check_training_step(net, x, data, meta, path, lambda lg: F.binary_cross_entropy_with_logits(lg, target), out_tol=1e-4, tol=2e-3)
+
+
+def _clip_loss(emb):
+    return (emb * torch.linspace(-1, 1, emb.shape[1], device=emb.device)).sum() / emb.shape[0]
+
+
+@pytest.mark.parametrize("path", ["plan", "layers"])
+def test_clip_training_step_against_reference_golden(lib, golden_dir, path):
+    """... and CLIP's ModifiedResNet (CLIP/clip/model.py:10-55, 94-154 through bcosify.py:74-114): the RN50 tower with the weights of the
+    clip_rn50 fixture, one train()-mode step recorded from the reference -- three-convolution stem, anti-aliasing pools inside the plan,
+    the attention-pool head under autograd behind it."""
+    from bcos_hip import synth
+    net, _, _ = _golden_clip(golden_dir)
+    meta = json.load(open(os.path.join(golden_dir, "clip_rn50_train_step.json")))
+    data = np.load(os.path.join(golden_dir, "clip_rn50_train_step.npz"))
+    x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV)
+    _check_training_step(net, x, data, meta, path, _clip_loss, out_tol=1e-4, tol=2e-3)
+
+
+@pytest.mark.parametrize("path", ["plan", "layers"])
+def test_small_clip_tower_training_step_to_1e4(lib, golden_dir, path):
+    """The tight variant the free-gate floor cannot hide behind: a ModifiedResNet of layers (1, 1, 1, 1), width 16 -- a few thousand ReLU
+    decisions, none of them near a tie -- recorded from the reference in train() mode; EVERY parameter gradient, the input gradient and
+    every running_var to 1e-4: a wrong anti-aliasing-pool or shortcut gradient in the plan shows at full size."""
+    from bcos_hip import synth
+    meta = json.load(open(os.path.join(golden_dir, "clip_tiny_train_step.json")))
+    data = np.load(os.path.join(golden_dir, "clip_tiny_train_step.npz"))
+    net = synth.build_bcosified_clip_resnet(meta["layers"], meta["output_dim"], meta["heads"], meta["width"], seed=meta["weight_seed"])
+    synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
+    x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV)
+    _check_training_step(net.to(DEV), x, data, meta, path, _clip_loss, out_tol=1e-5, tol=1e-4, rv_tol=1e-5)
+
+
+def test_training_plan_frozen_batchnorm_and_maxout_refusal_on_device(lib):
+    """ADVICE r04 (high / medium), on the device: frozen BatchNorms are normalised with their running variance by the plan and their
+    buffers do not move; a fused MaxOut node is refused by the plan before any buffer has been touched (the check of
+    tests/test_host_cpu.py without the emulated kernels; gradients behind free ReLU gates: the training fixtures' 2e-3)."""
+    import test_host_cpu as H
+    H.check_frozen_batchnorm_and_maxout("cuda", tol_out=1e-4, tol=2e-3)
+
+
 def test_wgrad_kernel_on_resnet_shapes(lib):
     """bcos_conv2d_wgrad at real layer sizes (several pixel chunks, atomically combined) against fp64 autograd."""
     from bcos_hip import ops
@@ -298,8 +356,25 @@ def test_streaming_kernels(lib):
         pr = F.avg_pool2d(ar, k, s, p)
         gp = torch.randn(pr.shape, generator=g)
         (ga,) = torch.autograd.grad(pr, ar, gp)
-        y = ops.avgpool2d_fwd(a.permute(0, 2, 3, 1).contiguous().to(DEV), k, s, p)
+        y = ops.avgpool2d_fwd(a.permute(0, 2, 3, 1).contiguous().to(DEV), k, s, p, want_absmax=True)
         assert rel(y.permute(0, 3, 1, 2), pr) <= 1e-6
+        if blib.get_contraction_mode() == "f16x2":       # (k = 3 / 2: emitted by the pool's own launch; k = 3, s = 1 too; always exact)
+            assert torch.equal(ops.absmax_of(y), y.abs().amax(dim=-1).reshape(-1).view(torch.int32))
+        # the row kernels (window expanded at compile time) against fp64 on a ragged shape with every border case, odd widths included
+        for (Hh, Ww, Cw) in ((7, 9, 24), (112, 112, 64), (5, 4, 8)):
+            xa = torch.randn(3, Hh, Ww, Cw, generator=g)
+            ref = F.avg_pool2d(xa.double().permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1)
+            got = ops.avgpool2d_fwd(xa.to(DEV), k, s, p, want_absmax=True)
+            assert rel(got, ref) <= 1e-7, (k, s, p, Hh, Ww, Cw)
+            gpa = torch.randn(ref.shape, generator=g)
+            xr = xa.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+            (gref,) = torch.autograd.grad(F.avg_pool2d(xr, k, s, p), xr, gpa.double().permute(0, 3, 1, 2))
+            mm = torch.randn(3, Hh, Ww, Cw, generator=g)
+            ggot = ops.avgpool2d_bwd(gpa.to(DEV), Hh, Ww, k, s, p, mul=mm.to(DEV), want_absmax=True)
+            assert rel(ggot, gref.permute(0, 2, 3, 1) * mm.double()) <= 1e-7 and bool(torch.isfinite(ggot).all()), (k, s, p, Hh, Ww, Cw)
+            if blib.get_contraction_mode() == "f16x2":
+                assert torch.equal(ops.absmax_of(ggot), ggot.abs().amax(dim=-1).reshape(-1).view(torch.int32))
+                assert torch.equal(ops.absmax_of(got), got.abs().amax(dim=-1).reshape(-1).view(torch.int32))
         m = torch.randn(2, 13, 12, 64, generator=g)
         gx = ops.avgpool2d_bwd(gp.permute(0, 2, 3, 1).contiguous().to(DEV), 13, 12, k, s, p, mul=m.to(DEV), want_absmax=True)
         assert rel(gx, ga.permute(0, 2, 3, 1) * m) <= 1e-6
@@ -2044,17 +2119,6 @@ def test_colsum_ordered_is_exact_enough_and_reproducible(lib):
     assert rel(mean, x.double().mean((0, 2, 3))) <= 1e-6 and rel(var, x.double().var((0, 2, 3), unbiased=False)) <= 1e-6
     assert abs(msq - float(x.double().pow(2).mean())) <= 1e-6 * msq
     assert all(torch.equal(a_, b_) for a_, b_ in zip(ops.channel_moments_ordered(x)[:2], (mean, var)))
-
-
-def test_training_plan_covers_clip_modified_resnet_on_device(lib):
-    """the CLIP ModifiedResNet training step through the plan against the per-layer path, on the device (the check of
-    tests/test_host_cpu.py without the emulated kernels; ReLU gates near zero may open differently under another summation order:
-    the gradient floor of the ResNet-18 training fixture applies)"""
-    import test_host_cpu as H
-    # (one-pass against two-pass batch statistics: 2e-5 on the embeddings after 55 layers; the head's gradients agree to 1e-5 .. 8e-5,
-    #  behind the first ReLU of the trunk ONE gate that opens differently in a 64-pixel x 2048-channel tensor is 3e-3 of its gradient's
-    #  norm: measured 1e-3 at layer4.2.bn3, 5-7e-3 at the stem.  The exact check of the plan's logic is the emulated-kernel test.)
-    H.check_clip_training_plan("cuda", tol=2e-2, tol_fwd=2e-4, n=4, size=128)
 
 
 def test_attention_gradient_on_the_matrix_pipe(lib):

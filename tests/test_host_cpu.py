@@ -839,14 +839,99 @@ def test_training_plan_follows_each_batchnorms_own_mode_and_refuses_maxout(monke
     """(high) a BatchNormUncentered2d put in eval() under net.train() -- frozen-BN fine-tuning -- must be normalised with its
     running variance by the training plan too, and its buffers must not move (the plan used batch statistics for every layer:
     17 % off and 40 corrupted buffers); (medium) a network with a fused MaxOut node is outside the plan and trains per layer."""
-    import copy
     cpu_emulation.install(monkeypatch)
+    check_frozen_batchnorm_and_maxout("cpu", tol_out=1e-5, tol=1e-4)
+
+
+def check_training_step_fixture(net, x, data, meta, path, loss_of, out_tol, tol, rv_tol=1e-4):
+    """one train()-mode step of `net` on the HIP path against a fixture recorded from the reference's step (make_golden.py:
+    _record_training_step): output, loss, input gradient, the norm of EVERY parameter gradient, the recorded full gradients (or their
+    leading rows), the updated running_var buffers.  `path`: "plan" = through the engine's training plan, "layers" = one autograd node
+    per layer on the nn.Module path."""
+    from bcos_hip import engine
+    if path == "plan":
+        engine.attach(net)
+    net.train()
+    x = x.clone().requires_grad_(True)
+    out = net(x)
+    node, seen, stack, found = out.grad_fn, set(), [out.grad_fn], False
+    while stack and not found:                      # (CLIP: the plan's node sits below the attention-pool head's autograd nodes)
+        f = stack.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        found = type(f).__name__ == "_TrainStepFnBackward"
+        stack.extend(g for g, _ in f.next_functions)
+    assert found == (path == "plan"), (path, type(node).__name__)
+    assert rel(out, data["output"]) <= out_tol, rel(out, data["output"])
+    loss = loss_of(out)
+    assert abs(float(loss.detach()) - float(data["loss"])) <= max(out_tol, 1e-5) * abs(float(data["loss"])), (float(loss.detach()), float(data["loss"]))
+    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    names = [n for n, _ in named]
+    assert names == meta["param_names"]
+    grads = torch.autograd.grad(loss, [x] + [p for _, p in named])
+    assert rel(grads[0], data["gx"]) <= tol, ("gx", rel(grads[0], data["gx"]))
+    norms = torch.stack([g.norm() for g in grads[1:]]).cpu().double()
+    ref = torch.from_numpy(data["grad_norms"]).double()
+    worst = int(((norms - ref).abs() / ref).argmax())
+    assert float(((norms - ref).abs() / ref).max()) <= tol, (names[worst], float(norms[worst]), float(ref[worst]))
+    for key in data.files:
+        if key.startswith("grad/"):
+            assert rel(grads[1 + names.index(key[5:])], data[key]) <= tol, (key, rel(grads[1 + names.index(key[5:])], data[key]))
+        elif key.startswith("gradrows/"):
+            g = grads[1 + names.index(key[9:])]
+            assert rel(g[:data[key].shape[0]], data[key]) <= tol, (key, rel(g[:data[key].shape[0]], data[key]))
+    bufs = dict(net.named_buffers())
+    for key in [k for k in data.files if k.startswith("running_var/")]:
+        assert rel(bufs[key[12:] + ".running_var"], data[key]) <= rv_tol, key
+    if path == "plan":
+        engine.detach(net)
+    net.eval()
+
+
+def test_small_clip_tower_training_fixture_through_the_plan_on_emulated_kernels(monkeypatch):
+    """VERDICT r05 item 2 on the CPU side: the LOGIC of the ModifiedResNet training plan (anti-aliasing pools and their gradients inside the
+    plan, shortcut pools, the attention-pool head under autograd behind it, batch statistics) held to a step recorded from the REFERENCE
+    in train() mode (tests/golden/clip_tiny_train_step.*), with every kernel emulated by torch -- no device involved."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import synth
+    golden = os.path.join(REPO, "tests", "golden")
+    meta = json.load(open(os.path.join(golden, "clip_tiny_train_step.json")))
+    data = np.load(os.path.join(golden, "clip_tiny_train_step.npz"))
+    for path in ("plan", "layers"):
+        net = synth.build_bcosified_clip_resnet(meta["layers"], meta["output_dim"], meta["heads"], meta["width"], seed=meta["weight_seed"])
+        synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
+        x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"])
+        check_training_step_fixture(net, x, data, meta, path, lambda emb: (emb * torch.linspace(-1, 1, emb.shape[1])).sum() / emb.shape[0],
+                                    out_tol=1e-5, tol=1e-4, rv_tol=1e-5)
+
+
+def test_resnet50_training_fixture_through_the_plan_on_emulated_kernels(monkeypatch):
+    """... and the Bottleneck plan (torchvision topology, downsample shortcuts) against the reference's recorded ResNet-50 step."""
+    cpu_emulation.install(monkeypatch)
+    from bcos_hip import synth
+    golden = os.path.join(REPO, "tests", "golden")
+    meta = json.load(open(os.path.join(golden, "resnet50_train_step.json")))
+    data = np.load(os.path.join(golden, "resnet50_train_step.npz"))
+    small_meta = json.load(open(os.path.join(golden, "resnet50_small.json")))
+    small = np.load(os.path.join(golden, "resnet50_small.npz"))
+    net = synth.build_bcosified_resnet("resnet50", seed=small_meta["weight_seed"])
+    synth.apply_calibration(net, {k: torch.from_numpy(small["calib/" + k]) for k in small_meta["calib_order"]})
+    x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"])
+    target = torch.nn.functional.one_hot(torch.tensor(meta["labels"]), 1000).float()
+    check_training_step_fixture(net, x, data, meta, "plan", lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target),
+                                out_tol=1e-5, tol=2e-3)      # (free ReLU gates behind 53 layers: the floor of the ResNet-18 fixture)
+
+
+def check_frozen_batchnorm_and_maxout(device, tol_out, tol):
+    """(shared with the device suite: tests/test_gpu_parity.py::test_training_plan_frozen_batchnorm_and_maxout_refusal_on_device)"""
+    import copy
     from bcos_hip import engine, synth, train_plan
     from bcos.modules.bcosifyconv2d import BcosifyConv2d
     from bcos.modules.norms.uncentered_norms.batchnorm_uncentered import BatchNormUncentered2d
     torch.manual_seed(0)
-    x = synth.synthetic_images(2, size=64)
-    target = torch.nn.functional.one_hot(torch.tensor([3, 500]), 1000).float()
+    x = synth.synthetic_images(2, size=64).to(device)
+    target = torch.nn.functional.one_hot(torch.tensor([3, 500]), 1000).float().to(device)
 
     def step(n):
         xr = x.clone().requires_grad_(True)
@@ -863,7 +948,7 @@ def test_training_plan_follows_each_batchnorms_own_mode_and_refuses_maxout(monke
 
     # -- frozen BatchNorm: every BN in eval(), the rest of the network in train(); then a MIXED network (layer3 / layer4 frozen only)
     for frozen in ("all", "late"):
-        net = synth.build_bcosified_resnet("resnet18")
+        net = synth.build_bcosified_resnet("resnet18").to(device)
         boost(net)
         ref = copy.deepcopy(net)
         engine.attach(net)
@@ -876,12 +961,12 @@ def test_training_plan_follows_each_batchnorms_own_mode_and_refuses_maxout(monke
         lp, gp = step(net)
         lr, gr = step(ref)
         assert type(lp.grad_fn).__name__ == "_TrainStepFnBackward" and type(lr.grad_fn).__name__ != "_TrainStepFnBackward"
-        assert rel(lp, lr) <= 1e-5, (frozen, rel(lp, lr))
+        assert rel(lp, lr) <= tol_out, (frozen, rel(lp, lr))
         for name, a, b in zip(["x"] + [n for n, p in net.named_parameters() if p.requires_grad], gp, gr):
-            assert rel(a, b) <= 1e-4, (frozen, name, rel(a, b))
+            assert rel(a, b) <= tol, (frozen, name, rel(a, b))
         changed = 0
         for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
-            assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 1e-5, (frozen, k)
+            assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 10 * tol_out, (frozen, k)
             changed += int(not torch.equal(a, before[k]))
         assert (changed == 0) if frozen == "all" else (changed > 0)
 
@@ -889,6 +974,7 @@ def test_training_plan_follows_each_batchnorms_own_mode_and_refuses_maxout(monke
     net = synth.build_bcosified_resnet("resnet18")
     blk = net.model.layer3[1]
     blk.conv2 = BcosifyConv2d(256, 256, 3, 1, 1, max_out=2, b=2)
+    net = net.to(device)
     boost(net)
     ref = copy.deepcopy(net)
     eng = engine.attach(net)
@@ -898,11 +984,11 @@ def test_training_plan_follows_each_batchnorms_own_mode_and_refuses_maxout(monke
     lp, gp = step(net)
     lr, gr = step(ref)
     assert type(lp.grad_fn).__name__ != "_TrainStepFnBackward"
-    assert rel(lp, lr) <= 1e-5
+    assert rel(lp, lr) <= tol_out
     for a, b in zip(gp, gr):
-        assert rel(a, b) <= 1e-4
+        assert rel(a, b) <= tol
     for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
-        assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 1e-5, k
+        assert torch.equal(a, b) if not a.dtype.is_floating_point else rel(a, b) <= 10 * tol_out, k
 
 
 def _engine_exec_trace(arch, monkeypatch, device="cpu"):
@@ -923,7 +1009,7 @@ def _engine_exec_trace(arch, monkeypatch, device="cpu"):
     monkeypatch.setattr(engine._Conv, "fwd", fwd)
     pools = []
     orig_pool = ops.avgpool2d_fwd
-    monkeypatch.setattr(ops, "avgpool2d_fwd", lambda a, k, s_, p_: (pools.append([list(a.shape), k, s_, p_]), orig_pool(a, k, s_, p_))[1])
+    monkeypatch.setattr(ops, "avgpool2d_fwd", lambda a, k, s_, p_, **kw: (pools.append([list(a.shape), k, s_, p_]), orig_pool(a, k, s_, p_, **kw))[1])
     with torch.no_grad():
         eng.forward(synth.synthetic_images(1, seed=5).to(next(net.parameters()).device))
     return calls, pools
