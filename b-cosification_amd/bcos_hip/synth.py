@@ -51,8 +51,9 @@ def standard_resnet(arch: str, seed: int = 0, resnet_cls=None, blocks=None):
     if resnet_cls is None:
         from bcos.models.standard_models import BasicBlock, Bottleneck, ResNetBcos
         resnet_cls, blocks = ResNetBcos, dict(basic=BasicBlock, bottleneck=Bottleneck)
+    # ("resnet14b": one Bottleneck per stage -- every block has a downsample shortcut; the shallow instance behind the tight training fixture)
     spec = {"resnet18": ("basic", [2, 2, 2, 2]), "resnet34": ("basic", [3, 4, 6, 3]),
-            "resnet50": ("bottleneck", [3, 4, 6, 3])}[arch]
+            "resnet50": ("bottleneck", [3, 4, 6, 3]), "resnet14b": ("bottleneck", [1, 1, 1, 1])}[arch]
     torch.manual_seed(seed)
     net = resnet_cls(blocks[spec[0]], spec[1])
     gen = torch.Generator().manual_seed(seed + 1)

@@ -1439,6 +1439,10 @@ BCOS_DEV_SWITCH(H2_KO, 0);
 #endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#ifndef H2_PRIO
+#define H2_PRIO 0                 // wave priority of the split-f16 main loops (s_setprio): 0 = never raised, 1 = raised around the matrix instructions of a step,
+                                  // 2 = raised for the whole K loop (prologue and epilogue at priority 0: the other workgroup of the CU is usually in one of them)
+#endif
 #ifndef H2_MIX_SPLIT
 #define H2_MIX_SPLIT 1            // 1 = the (h, l) split as two v_fma_mix{lo,hi}_f16 per element (split4_f16), 0 = the scalar expressions left to the compiler (rounds 2-5); same bits
 #endif
@@ -2307,6 +2311,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[sp][j] = *reinterpret_cast<const f16x8*>(bb + j * 2048 + sp * 1024);
             if constexpr (NEXT) read_a(off_nx, x0, x1);
+            if constexpr (H2_PRIO == 1) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             auto mm = [&](auto m_c) {
                 constexpr int m = decltype(m_c)::value;
@@ -2331,6 +2336,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             read_b(std::integral_constant<int, 0>{});
             read_b(std::integral_constant<int, 1>{});
             if constexpr (NEXT) read_a(off_nx, x0, x1);
+            if constexpr (H2_PRIO == 1) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             auto mm = [&](auto m_c) {
                 constexpr int m = decltype(m_c)::value;
@@ -2343,6 +2349,7 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (mm(std::integral_constant<int, Ms>{}), ...); }(std::make_integer_sequence<int, G>{});
         }
         static_assert((G - D0) * PER >= NACT, "every action is dealt out");
+        if constexpr (H2_PRIO == 1) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
     };
 
     // Ring: step s lives in slot s % D_NSLOT (A rows and B blocks).  The loops are peeled so that the steady state has no branch.
@@ -2415,10 +2422,12 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
         }
     };
     BCOS_PHASE_MARK(ph_t1);
+    if constexpr (H2_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     if (walk == 0) run(std::integral_constant<int, 0>{});
     else if (walk == 1) run(std::integral_constant<int, 1>{});
     else if (walk == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 3>{});
+    if constexpr (H2_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     __syncthreads();                           // the ring is free: the epilogue reuses it
     float a_inv[BM / (NT / 4)];      // inverse row scales in staging layout (what tile_epilogue takes): 2^-e from the row's 2^e
 #pragma unroll
@@ -2881,6 +2890,7 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
             if constexpr (ISSUE) { if (!(P_KO & 2) || ks == 0) issue_b(ks + AHEAD, boff_in); }
             if constexpr (REFILL) load_items((c + 1) * 64);
         }
+        if constexpr (H2_PRIO == 1) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -2905,6 +2915,7 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[i], bf[pr == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+        if constexpr (H2_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         ++ks;
         if constexpr (AHEAD == 2) { const int o = boff; boff = boff_nx; boff_nx = boff_in; boff_in = o; }
@@ -2919,8 +2930,10 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
         }
         if constexpr (P_DBUF) pbuf = 4 * PLANE - pbuf;
     };
+    if constexpr (H2_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     for (int c = 0; c + 1 < nch; ++c) chunk.template operator()<false>(c, std::make_integer_sequence<int, NTAPS>{});
     chunk.template operator()<true>(nch - 1, std::make_integer_sequence<int, NTAPS>{});
+    if constexpr (H2_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     __syncthreads();                   // patch and ring are free
     float rowss[BM / (NT / 4)], a_inv[BM / (NT / 4)];
     if (NORM) {

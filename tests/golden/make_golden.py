@@ -516,12 +516,65 @@ def resnet50_training_step():
     xs = synth.synthetic_images(4, seed=41, size=64)
     labels = torch.tensor([7, 250, 999, 613])
     target = torch.nn.functional.one_hot(labels, 1000).float()
+    floors = _training_self_floor(net, xs, lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target),
+                                  lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target.double()))
     _record_training_step(
         net, xs, lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target),
         keep=("model.conv1.linear.weight", "model.layer1.0.downsample.0.linear.weight", "model.layer2.0.conv2.linear.weight",
               "model.layer3.2.conv3.linear.weight", "model.layer4.2.bn3.weight"),      # (fc: 8 MB; its norm is in grad_norms)
         keep_rv=("model.bn1", "model.layer2.0.downsample.1", "model.layer4.2.bn3"), stem="resnet50_train_step",
-        meta=dict(arch="resnet50", weight_fixture="resnet50_small", image_seed=41, size=64, labels=labels.tolist(), loss="bce_with_logits"))
+        meta=dict(arch="resnet50", weight_fixture="resnet50_small", image_seed=41, size=64, labels=labels.tolist(), loss="bce_with_logits",
+                  reference_self_floor=floors))
+
+
+def resnet14b_training_step():
+    """The tight Bottleneck fixture: one Bottleneck per stage (torchvision topology, every block with a strided or widening downsample
+    shortcut), 4 images of 64 x 64, BCE -- 13 convolutions deep, so that the free ReLU gates leave no floor (the reference's own
+    fp32-vs-fp64 / thread-count differences are recorded beside the values) and the plan can be held to 1e-4."""
+    net = reference_resnet("resnet14b", seed=3)
+    record = synth.calibrate(net, synth.synthetic_images(4, seed=79, size=64))
+    xs = synth.synthetic_images(4, seed=47, size=64)
+    labels = torch.tensor([11, 402, 998, 0])
+    target = torch.nn.functional.one_hot(labels, 1000).float()
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    loss_of = lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target)  # noqa: E731
+    floors = _training_self_floor(net, xs, loss_of, lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target.double()))
+    _record_training_step(
+        net, xs, loss_of, keep=tuple(names), keep_rv=tuple(n[:-len(".running_var")] for n, _ in net.named_buffers() if n.endswith(".running_var")),
+        stem="resnet14b_train_step",
+        meta=dict(arch="resnet14b", weight_seed=3, calib_seed=79, image_seed=47, size=64, labels=labels.tolist(), loss="bce_with_logits",
+                  reference_self_floor=floors), record=record)
+
+
+def _training_self_floor(net, xs, loss_of, loss_of64):
+    """How far is the REFERENCE's own train()-mode step from itself?  (a) one thread against eight (another summation order inside the
+    convolutions), (b) fp32 against the same network in fp64: relative L2 distance of the output, the input gradient and the worst
+    parameter gradient.  ReLU gates with pre-activations at rounding level open differently; behind ~50 layers that is
+    1e-2 of a gradient, behind a dozen 1e-6."""
+    import copy
+    sd = copy.deepcopy(net.state_dict())
+
+    def step(n, x, lf):
+        n.train()
+        xr = x.clone().requires_grad_(True)
+        out = n(xr)
+        return [out.detach()] + list(torch.autograd.grad(lf(out), [xr] + [p for p in n.parameters() if p.requires_grad]))
+
+    def dist(a, b):
+        r = [rel(u, v)[0] for u, v in zip(a, b)]
+        return dict(output=r[0], gx=r[1], worst_param=max(r[2:]))
+    base = step(net, xs, loss_of)
+    net.load_state_dict(sd)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    one = step(net, xs, loss_of)
+    torch.set_num_threads(nt)
+    net.load_state_dict(sd)
+    net64 = copy.deepcopy(net).double()
+    f64 = step(net64, xs.double(), loss_of64)
+    net.load_state_dict(sd)
+    net.eval()
+    return dict(one_thread_vs_eight=dist(one, base), fp32_vs_fp64=dist(base, f64))
 
 
 def _clip_loss(emb):
@@ -544,12 +597,14 @@ def clip_training_steps():
     big = json.load(open(os.path.join(HERE, "clip_rn50.json")))
     assert state_checksum({k: v.detach() for k, v in net.state_dict().items()}) == big["state_checksum"], "not the weights of clip_rn50"
     xs = synth.synthetic_images(4, seed=43, size=64)
+    floors = _training_self_floor(net, xs, _clip_loss, lambda emb: (emb * torch.linspace(-1, 1, emb.shape[1], dtype=torch.float64)).sum() / emb.shape[0])
     _record_training_step(
         net, xs, _clip_loss,
         keep=("model.conv1.linear.weight", "model.conv3.linear.weight", "model.layer1.0.downsample.1.linear.weight", "model.layer2.0.conv2.linear.weight",
               "model.layer4.2.bn3.weight", "model.attnpool.q_proj.weight", "model.attnpool.c_proj.linear.weight"),
         keep_rv=("model.bn1", "model.layer2.0.downsample.2", "model.layer4.2.bn3"), stem="clip_rn50_train_step",
-        meta=dict(arch="clip_rn50", weight_fixture="clip_rn50", image_seed=43, size=64, loss="sum(emb * linspace(-1, 1, D)) / N"))
+        meta=dict(arch="clip_rn50", weight_fixture="clip_rn50", image_seed=43, size=64, loss="sum(emb * linspace(-1, 1, D)) / N",
+                  reference_self_floor=floors))
     tiny = dict(layers=[1, 1, 1, 1], output_dim=64, heads=8, width=16)
     net = R.bcosify.BcosifyNetwork(synth.standard_clip_resnet(seed=5, clip_module=ref_clip, **tiny), cfg, add_channels=True, logit_layer=False)
     synth.finish_clip_conversion(net, hip_pools=False)
@@ -557,10 +612,12 @@ def clip_training_steps():
     record = synth.calibrate(net, synth.synthetic_images(4, seed=77, size=64))
     xs = synth.synthetic_images(4, seed=45, size=64)
     names = [n for n, p in net.named_parameters() if p.requires_grad]
+    floors = _training_self_floor(net, xs, _clip_loss, lambda emb: (emb * torch.linspace(-1, 1, emb.shape[1], dtype=torch.float64)).sum() / emb.shape[0])
     _record_training_step(
         net, xs, _clip_loss, keep=tuple(names),
         keep_rv=tuple(n[:-len(".running_var")] for n, _ in net.named_buffers() if n.endswith(".running_var")), stem="clip_tiny_train_step",
-        meta=dict(arch="clip_modified_resnet", weight_seed=5, calib_seed=77, image_seed=45, size=64, loss="sum(emb * linspace(-1, 1, D)) / N", **tiny),
+        meta=dict(arch="clip_modified_resnet", weight_seed=5, calib_seed=77, image_seed=45, size=64, loss="sum(emb * linspace(-1, 1, D)) / N",
+                  reference_self_floor=floors, **tiny),
         record=record)
 
 
@@ -1220,6 +1277,7 @@ if __name__ == "__main__":
         resnet18_training_step()
     if "train_r50" in which:
         resnet50_training_step()
+        resnet14b_training_step()
     if "train_clip" in which:
         clip_training_steps()
     if "inv" in which:

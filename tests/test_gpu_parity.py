@@ -160,14 +160,41 @@ def _check_training_step(*args, **kw):
 def test_resnet50_training_step_against_reference_golden(lib, golden_dir, path):
     """the Bottleneck training plan pinned to the REFERENCE -- one train()-mode BCE step of the reference's B-cosified
     ResNet-50 (tests/golden/make_golden.py: resnet50_training_step; the calibrated weights of the resnet50_small fixture, 4 images of
-    64 x 64) through the plan and per layer, at the ResNet-18 fixture's tolerances (free ReLU gates: 2e-3)."""
+    64 x 64) through the plan and per layer.  Free ReLU gates behind 53 layers: the reference's own step moves by 1.4e-2 of the input
+    gradient between fp32 and fp64 (and between one thread and eight); the tolerance is 3 x that recorded floor (_floor_tol), the tight
+    check of the Bottleneck plan is test_shallow_bottleneck_resnet_training_step_to_1e4."""
     from bcos_hip import synth
     net, _, _ = _golden_net(golden_dir, "resnet50_small")
     meta = json.load(open(os.path.join(golden_dir, "resnet50_train_step.json")))
     data = np.load(os.path.join(golden_dir, "resnet50_train_step.npz"))
     x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV)
     target = F.one_hot(torch.tensor(meta["labels"]), 1000).float().to(DEV)
-    _check_training_step(net, x, data, meta, path, lambda lg: F.binary_cross_entropy_with_logits(lg, target), out_tol=1e-4, tol=2e-3)
+    _check_training_step(net, x, data, meta, path, lambda lg: F.binary_cross_entropy_with_logits(lg, target), out_tol=1e-4, tol=_floor_tol(meta))
+
+
+def _floor_tol(meta):
+    """Gradient tolerance of a deep training fixture: 3 x the distance the REFERENCE's own step moves when it is run in fp64 instead of
+    fp32 (recorded at generation, make_golden.py: _training_self_floor -- ReLU gates at rounding level, SURVEY.md H1: 1.4e-2 of the
+    input gradient behind ResNet-50's 53 layers, 1e-5 behind the 13 of the shallow fixtures, which are held to 1e-4 instead)."""
+    fl = meta["reference_self_floor"]["fp32_vs_fp64"]
+    return 3.0 * max(fl["gx"], fl["worst_param"])
+
+
+@pytest.mark.parametrize("path", ["plan", "layers"])
+def test_shallow_bottleneck_resnet_training_step_to_1e4(lib, golden_dir, path):
+    """The tight Bottleneck variant: one Bottleneck per stage (every block with its downsample shortcut), recorded from the reference in
+    train() mode; no gate floor (reference fp32 vs fp64: 1e-5), so EVERY parameter gradient, the input gradient and every running_var
+    are held to 1e-4 through the plan and per layer."""
+    from bcos_hip import synth
+    meta = json.load(open(os.path.join(golden_dir, "resnet14b_train_step.json")))
+    data = np.load(os.path.join(golden_dir, "resnet14b_train_step.npz"))
+    assert max(meta["reference_self_floor"]["fp32_vs_fp64"].values()) <= 2e-5
+    net = synth.build_bcosified_resnet("resnet14b", seed=meta["weight_seed"])
+    synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
+    x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV)
+    target = F.one_hot(torch.tensor(meta["labels"]), 1000).float().to(DEV)
+    _check_training_step(net.to(DEV), x, data, meta, path, lambda lg: F.binary_cross_entropy_with_logits(lg, target), out_tol=1e-5, tol=1e-4,
+                         rv_tol=1e-5)
 
 
 def _clip_loss(emb):
@@ -184,7 +211,7 @@ def test_clip_training_step_against_reference_golden(lib, golden_dir, path):
     meta = json.load(open(os.path.join(golden_dir, "clip_rn50_train_step.json")))
     data = np.load(os.path.join(golden_dir, "clip_rn50_train_step.npz"))
     x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"]).to(DEV)
-    _check_training_step(net, x, data, meta, path, _clip_loss, out_tol=1e-4, tol=2e-3)
+    _check_training_step(net, x, data, meta, path, _clip_loss, out_tol=1e-4, tol=_floor_tol(meta))
 
 
 @pytest.mark.parametrize("path", ["plan", "layers"])

@@ -871,7 +871,9 @@ def check_training_step_fixture(net, x, data, meta, path, loss_of, out_tol, tol,
     assert names == meta["param_names"]
     grads = torch.autograd.grad(loss, [x] + [p for _, p in named])
     assert rel(grads[0], data["gx"]) <= tol, ("gx", rel(grads[0], data["gx"]))
-    norms = torch.stack([g.norm() for g in grads[1:]]).cpu().double()
+    # (norms in fp64 on the host: torch's fp32 norm() of the 1000 x 2048 fc gradient ON THE DEVICE was measured 3.7e-4 off the norm of the
+    #  very same tensor copied to the host -- scripts/probe/fc_grad_probe2.py --, like the `var` reductions of HISTORY section 6)
+    norms = torch.stack([g.detach().cpu().double().norm() for g in grads[1:]])
     ref = torch.from_numpy(data["grad_norms"]).double()
     worst = int(((norms - ref).abs() / ref).argmax())
     assert float(((norms - ref).abs() / ref).max()) <= tol, (names[worst], float(norms[worst]), float(ref[worst]))
@@ -919,8 +921,19 @@ def test_resnet50_training_fixture_through_the_plan_on_emulated_kernels(monkeypa
     synth.apply_calibration(net, {k: torch.from_numpy(small["calib/" + k]) for k in small_meta["calib_order"]})
     x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"])
     target = torch.nn.functional.one_hot(torch.tensor(meta["labels"]), 1000).float()
+    fl = meta["reference_self_floor"]["fp32_vs_fp64"]        # (free ReLU gates behind 53 layers: 3 x the reference's own fp32 / fp64 distance)
     check_training_step_fixture(net, x, data, meta, "plan", lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target),
-                                out_tol=1e-5, tol=2e-3)      # (free ReLU gates behind 53 layers: the floor of the ResNet-18 fixture)
+                                out_tol=1e-5, tol=3.0 * max(fl["gx"], fl["worst_param"]))
+    # the shallow Bottleneck fixture (one block per stage: no gate floor): every gradient and buffer to 1e-4
+    meta = json.load(open(os.path.join(golden, "resnet14b_train_step.json")))
+    data = np.load(os.path.join(golden, "resnet14b_train_step.npz"))
+    for path in ("plan", "layers"):
+        net = synth.build_bcosified_resnet("resnet14b", seed=meta["weight_seed"])
+        synth.apply_calibration(net, {k: torch.from_numpy(data["calib/" + k]) for k in meta["calib_order"]})
+        x = synth.synthetic_images(4, seed=meta["image_seed"], size=meta["size"])
+        target = torch.nn.functional.one_hot(torch.tensor(meta["labels"]), 1000).float()
+        check_training_step_fixture(net, x, data, meta, path, lambda lg: torch.nn.functional.binary_cross_entropy_with_logits(lg, target),
+                                    out_tol=1e-5, tol=1e-4, rv_tol=1e-5)
 
 
 def check_frozen_batchnorm_and_maxout(device, tol_out, tol):
