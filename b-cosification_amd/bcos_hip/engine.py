@@ -128,6 +128,7 @@ class _Conv:
         # MaxOut (bcosconv2d.py:166-170; round 4): the contraction is max_out times as wide as the layer's output -- the launch takes
         # the max over each unit's adjacent filters before the B-cos scale and keeps the scale at the winning filter (d out / d lin)
         self.max_out = int(conv.max_out)
+        self.reads_image_range = ops.reads_image_range(lin.kernel_size, lin.stride, lin.dilation, lin.groups)    # (forward and input gradient alike)
         self.cin, self.cout_all = lin.in_channels, lin.out_channels
         self.cout = lin.out_channels // self.max_out
         self._wide = None
@@ -519,7 +520,8 @@ class ResNetEngine:
             if keep:
                 st["stem_hws"].append((a.shape[1], a.shape[2]))
             nxt = self.stem[si + 1][0].k_fwd if si + 1 < len(self.stem) else 0       # the last stem conv feeds a pool
-            a, t = conv.fwd(a, relu=relu, want_scale=keep, gates=gates, track=need(nxt))
+            with ops.image_range_reader(si + 1 < len(self.stem) and self.stem[si + 1][0].reads_image_range):
+                a, t = conv.fwd(a, relu=relu, want_scale=keep, gates=gates, track=need(nxt))
             if keep:
                 st["stem_ts"].append(t)
         k, s, p = self.pool
@@ -544,8 +546,9 @@ class ResNetEngine:
             for ci, c in enumerate(blk.convs[:-1]):
                 hws.append((h.shape[1], h.shape[2]))
                 pooled_next = blk.pool and ci == len(blk.convs) - 2              # a pool sits between this conv and the next
-                h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates, keep_act=not pooled_next and not _STORE_T,
-                             track=need(blk.convs[ci + 1].k_fwd) and not pooled_next)
+                with ops.image_range_reader(blk.convs[ci + 1].reads_image_range and not pooled_next):     # (a 3 x 3 layer reads this output: its per-image scales from this launch)
+                    h, t = c.fwd(h, relu=blk.relu, want_scale=keep, gates=gates, keep_act=not pooled_next and not _STORE_T,
+                                 track=need(blk.convs[ci + 1].k_fwd) and not pooled_next)
                 ts.append(t)
                 tw.append(c.take_wide())
             pre_pool_hw = (h.shape[1], h.shape[2])
@@ -892,9 +895,10 @@ class ResNetEngine:
                 continue
             # v = d logit / d out_b;  G_main = v * t_last (bn scale, ReLU gate and s of the block's last conv),
             # G_sc = v * gate(out_b) [* t_d]  for the shortcut
-            G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gated=rec["gated"], gate_t=rec["gate_t"],
-                                        track=blk.convs[-1].k_dgrad >= ops.F16X2_MIN_K,
-                                        track2=blk.shortcut is not None and blk.shortcut.k_dgrad >= ops.F16X2_MIN_K)
+            with ops.image_range_reader(blk.convs[-1].reads_image_range):
+                G_main, G_sc = consumer.run(H, W, t_main=rec["ts"][-1], td=rec["td"], gated=rec["gated"], gate_t=rec["gate_t"],
+                                            track=blk.convs[-1].k_dgrad >= ops.F16X2_MIN_K,
+                                            track2=blk.shortcut is not None and blk.shortcut.k_dgrad >= ops.F16X2_MIN_K)
             if consume:
                 rec["ts"][-1] = rec["td"] = rec["gate_t"] = None
             gl = G_main
@@ -912,8 +916,9 @@ class ResNetEngine:
                     gl = ops.avgpool2d_bwd(gp, ph, pw, blk.pool, blk.pool, 0, mul=rec["ts"][ci - 1],
                                            want_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K)
                 else:
-                    gl = convs[ci].dgrad.run(gl, h, w, track_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K,
-                                             **_mul_kwargs(rec["ts"][ci - 1]))
+                    with ops.image_range_reader(convs[ci - 1].reads_image_range):
+                        gl = convs[ci].dgrad.run(gl, h, w, track_absmax=convs[ci - 1].k_dgrad >= ops.F16X2_MIN_K,
+                                                 **_mul_kwargs(rec["ts"][ci - 1]))
                 if consume:
                     rec["ts"][ci - 1] = None
             gl = convs[0].expand(gl, rec["tw"][0])
@@ -932,8 +937,9 @@ class ResNetEngine:
             ts[-1] = None
         for si in range(len(self.stem) - 1, 0, -1):
             h, w = st["stem_hws"][si]
-            gl = self.stem[si][0].dgrad.run(gl, h, w, mul=ts[si - 1],
-                                            track_absmax=self.stem[si - 1][0].k_dgrad >= ops.F16X2_MIN_K)
+            with ops.image_range_reader(self.stem[si - 1][0].reads_image_range):
+                gl = self.stem[si][0].dgrad.run(gl, h, w, mul=ts[si - 1],
+                                                track_absmax=self.stem[si - 1][0].k_dgrad >= ops.F16X2_MIN_K)
             if consume:
                 ts[si - 1] = None
         gxn = torch.empty((x.shape[0], st["H"], st["W"], 8), device=x.device, dtype=torch.float32)

@@ -47,13 +47,15 @@ class TapconvGeom(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2", "relu_gate",
-        "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax", "mul_norm", "mul_csc", "mul_csh", "col_scale", "row_scale", "a_sumsq")] + [
+        "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax", "mul_norm", "mul_csc", "mul_csh", "col_scale", "row_scale", "a_sumsq",
+        "out_imgmax", "out_imgmin_c")] + [
         ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32), ("max_out", C.c_int32), ("addend_sub", C.c_int32)]
 
 
 class Operands(C.Structure):
     _fields_ = [("a", C.c_void_p), ("a_absmax", C.c_void_p), ("wt", C.c_void_p), ("wt_bf16x3", C.c_void_p),
-                ("wt_f16x2", C.c_void_p), ("contraction", C.c_int32), ("a_imgmax", C.c_void_p), ("a_imgmin", C.c_void_p)]
+                ("wt_f16x2", C.c_void_p), ("contraction", C.c_int32), ("a_imgmax", C.c_void_p), ("a_imgmin", C.c_void_p),
+                ("a_imgmin_c", C.c_void_p)]
 
 
 CONTRACT_DEFAULT, CONTRACT_F32, CONTRACT_BF16X3, CONTRACT_F16X2 = 0, 1, 2, 3
@@ -69,6 +71,7 @@ SIGNATURES = {
     "bcos_get_option": (C.c_int, [_I, C.POINTER(C.c_int64)]),
     "bcos_tapconv": (C.c_int, [_P, _P, C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
     "bcos_tapconv_ops": (C.c_int, [C.POINTER(Operands), C.POINTER(TapconvGeom), C.POINTER(Epilogue), _P]),
+    "bcos_tapconv_fuses_image_range": (C.c_int, [C.POINTER(Operands), C.POINTER(TapconvGeom), C.POINTER(Epilogue)]),
     "bcos_image_absmax": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_image_absrange": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),

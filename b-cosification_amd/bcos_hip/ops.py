@@ -274,18 +274,50 @@ def absmax_of(t: torch.Tensor) -> Optional[torch.Tensor]:
 PATCH_LOOP = os.environ.get("BCOS_PATCH", "1") != "0"     # development / test switch: 3 x 3 launches keep the per-tap loops
 
 
-def image_absmax(am: torch.Tensor, n_images: int, pixels_per_image: int) -> torch.Tensor:
-    """Per-image range [2, N] (row 0: maxima, row 1: minima over the nonzero pixels) of a per-pixel maxima tensor
-    (include/bcos_hip.h: bcos_image_absrange), cached on it: the maxima of a tensor are complete once its producer has been
-    enqueued; the cache is dropped whenever the side tensor is handed to a producer again (_out_absmax)."""
+FUSE_IMAGE_RANGE = os.environ.get("BCOS_FUSE_IMAGE_RANGE", "1") != "0"     # development / test switch: 0 = always the separate bcos_image_absrange pass
+_IMAGE_RANGE_READER = False
+
+
+class image_range_reader:
+    """Context of the engines: the tensor(s) the launches inside write will be read by a launch that takes one operand scale per IMAGE
+    (a 3 x 3 / stride-1 layer on the input-patch loop) -- their producers fold the per-image range of the maxima they emit into their own
+    epilogue (tapconv: bcos_epilogue.out_imgmax) instead of leaving it to a bcos_image_absrange pass ahead of the reader.  A hint: without
+    it (or where a producer cannot fold) the reader computes the range itself; with it and no such reader, a few atomics are wasted."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _IMAGE_RANGE_READER
+        self._prev = _IMAGE_RANGE_READER
+        _IMAGE_RANGE_READER = self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _IMAGE_RANGE_READER
+        _IMAGE_RANGE_READER = self._prev
+        return False
+
+
+def reads_image_range(kernel, stride=(1, 1), dilation=(1, 1), groups=1) -> bool:
+    """Does a convolution of this geometry take per-image operand scales (the patchable 3 x 3 of tapconv below)?"""
+    return tuple(kernel) == (3, 3) and tuple(stride) == (1, 1) and tuple(dilation) == (1, 1) and int(groups) == 1
+
+
+def image_absmax(am: torch.Tensor, n_images: int, pixels_per_image: int):
+    """Per-image range [2, N] of a per-pixel maxima tensor, cached on it -> (range, fused).  fused = False: row 0 maxima, row 1 minima
+    over the nonzero pixels, computed here by a pass of its own (include/bcos_hip.h: bcos_image_absrange) -- the maxima of a tensor are
+    complete once its producer has been enqueued; the cache is dropped whenever the side tensor is handed to a producer again
+    (_out_absmax).  fused = True: the producing launches folded the range into the arrays themselves (bcos_epilogue.out_imgmax /
+    out_imgmin_c, tapconv below): row 1 is a complemented lower bound of the minima (bcos_operands.a_imgmin_c)."""
     rec = getattr(am, "_bcos_imgmax", None)
     if rec is not None and rec[1] == (n_images, pixels_per_image):
-        return rec[0]
+        return rec[0], len(rec) > 2
     out = torch.empty(2, n_images, device=am.device, dtype=torch.int32)
     _l.check(_l.load().bcos_image_absrange(am.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), n_images, pixels_per_image, _stream()),
              "bcos_image_absrange")
     am._bcos_imgmax = (out, (n_images, pixels_per_image))
-    return out
+    return out, False
 
 
 def drop_absmax(t: torch.Tensor):
@@ -317,9 +349,9 @@ def _out_absmax(t: Optional[torch.Tensor], pixels: int):
     if am is None or am.numel() != pixels:
         am = _new_absmax(pixels, t.device)
         _attach_absmax(t, am)
-    elif hasattr(am, "_bcos_imgmax"):
+    elif hasattr(am, "_bcos_imgmax") and len(am._bcos_imgmax) < 3:
         del am._bcos_imgmax            # the maxima are about to grow: per-image values cached from an earlier fill are stale
-    return am
+    return am                          # (a range the producing launches fold in themselves grows with them: tapconv keeps or drops it)
 
 
 def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=None, scale_out=None,
@@ -383,15 +415,37 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
             if PATCH_LOOP and int(g.groups) <= 1 and (patchable or taps >= 25):      # (>= 25 taps, the 7 x 7 stem: image maxima replace the per-row scan of the taps)
                 # 3 x 3 launches (and the 4 x 4 tap union of a depth-to-space input gradient) contract over an LDS-resident input
                 # patch with one operand scale per image (include/bcos_hip.h: bcos_operands.a_imgmax): the per-image maxima, once per tensor
-                im = image_absmax(am_a, int(g.N), int(g.H) * int(g.W))
+                im, im_fused = image_absmax(am_a, int(g.N), int(g.H) * int(g.W))
                 o.a_imgmax = im[0].data_ptr()
-                o.a_imgmin = im[1].data_ptr()
+                if im_fused:
+                    o.a_imgmin_c = im[1].data_ptr()
+                else:
+                    o.a_imgmin = im[1].data_ptr()
                 keep.append(im)
             o.wt_f16x2 = _image_of(wt, f"_bcos_wt2_t{taps}", lambda w: split_weights_f16x2(w, taps)).data_ptr()
         elif static:
             o.wt_bf16x3 = _image_of(wt, "_bcos_wt3", split_weights).data_ptr()
     elif mode == "bf16x3" and static:
         o.wt_bf16x3 = _image_of(wt, "_bcos_wt3", split_weights).data_ptr()
+    # The per-image range of the maxima `out` leaves (what a 3 x 3 launch reading `out` takes as its operand scales) is folded into this
+    # launch's own epilogue where the library can (specialised epilogue, >= 19 rows per image ...: it is asked) instead of a pass of
+    # bcos_image_absrange ahead of the reader.  Engine passes only (their arena hands out zero-filled words without a fill launch).
+    am_out = absmax_of(out) if (mode == "f16x2" and e.out_absmax) else None
+    if am_out is not None:
+        rec = getattr(am_out, "_bcos_imgmax", None)
+        key = (int(g.N), int(g.OH) * int(g.OW))
+        fuses = (FUSE_IMAGE_RANGE and _IMAGE_RANGE_READER and _ARENA is not None and int(g.P) * int(g.Q) >= 19
+                 and lib.bcos_tapconv_fuses_image_range(C.byref(o), C.byref(g), C.byref(e)) == 1)
+        if fuses:
+            if rec is not None and len(rec) > 2 and rec[1] == key:
+                img = rec[0]               # another launch of the same tensor (parity classes of a strided gradient): the range accumulates
+            else:
+                img = _new_absmax(2 * key[0], out.device).view(2, key[0])
+                am_out._bcos_imgmax = (img, key, "fused")
+            e.out_imgmax, e.out_imgmin_c = img[0].data_ptr(), img[1].data_ptr()
+            keep.append(img)
+        elif rec is not None:
+            del am_out._bcos_imgmax        # (pixels are about to be filled that no cached range knows of)
     timing = KERNEL_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

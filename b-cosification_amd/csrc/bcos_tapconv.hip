@@ -78,6 +78,8 @@ struct KArgs {
     unsigned absmax_bytes;
     const unsigned* a_imgmax;     // ... per-image maxima of those (input-patch loop, tile_body_p), else NULL
     const unsigned* a_imgmin;     // ... per-image minima over the NONZERO pixels of those (dynamic range inside an image), else NULL
+    const unsigned* a_imgmin_c;   // ... or a LOWER BOUND of those minima, stored complemented (~v; 0 = no nonzero pixel), as the epilogue of the launch that
+                                  //     produced A leaves it (bcos_epilogue.out_imgmin_c): decides only whether a tile runs the level bookkeeping, never a bit
     int lvl_on;                   // input-patch loop: 1 = one pass per operand-scale level present in a tile (BCOS_OPT_PATCH_LEVELS)
     int lvl_off;                  // input-patch loop: byte offset, inside the dynamic LDS, of the row-level table (beyond everything the epilogue uses)
     const void* wt2;              // split-f16 path: pre-split, pre-scaled weights in MFMA fragment order (bcos_split_weights_f16x2)
@@ -604,6 +606,14 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
     EpiRow* sRow = reinterpret_cast<EpiRow*>(smem + SBM * LDC);    // [BM]
     float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
     const int out_pitch = g.out_pitch;
+    if (e.out_imgmax != nullptr && tid < 33) {
+        // per-image range of the per-pixel maxima this tile emits (bcos_epilogue.out_imgmax / out_imgmin_c): [16] maxima, [16] complemented
+        // minima over the nonzero pixels, [1] the image of the tile's first row -- a tile spans at most 16 images (host)
+        unsigned* sImg = reinterpret_cast<unsigned*>(epi_col_table<BM, BN, WAVES_M>(smem) + BN) + 2 * BM;
+        int n0i = 0, i0i = 0, j0i = 0;
+        tile_row_nij(p, m0, 0, n0i, i0i, j0i);
+        sImg[tid] = tid < 32 ? 0u : (unsigned)n0i;
+    }
     for (int r = tid; r < BM; r += NT) {
         int pix = -1;
         int n = 0, i = 0, jj = 0;
@@ -838,6 +848,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
             // atomicMax per row, part and tensor: 72 us of the 444 us of the 64 -> 256 @56^2 forward launch (scripts/probe/epi_knock.py).
             unsigned* sMax = reinterpret_cast<unsigned*>(epi_col_table<BM, BN, WAVES_M>(smem) + BN);      // [2][BM]
             const bool own = p.tiles_n == 1 && g.out_pitch == g.Cout;      // (a launch that writes a column slice of wider pixels shares them)
+            const bool img_on = e.out_imgmax != nullptr;
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 // lanes outside the tensor hold zeros or values whose stores were dropped: keep them out of the maxima
@@ -859,6 +870,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
                             if (want_max1 && a1) atomicMax(e.out_absmax + rw[u].pix, a1);
                             if (want_max2 && a2) atomicMax(e.out2_absmax + rw[u].pix, a2);
                         }
+                        if (want_max1 && img_on) sMax[trow] = a1;       // (kept for the per-image range: tile_epilogue folds the rows' maxima behind the last part)
                     }
                 }
             }
@@ -938,6 +950,33 @@ __device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16
     if constexpr (PM * PN > 1) drain(std::integral_constant<int, 1>{});
     if constexpr (PM * PN > 2) drain(std::integral_constant<int, 2>{});
     if constexpr (PM * PN > 3) drain(std::integral_constant<int, 3>{});
+    // Per-image range of the per-pixel maxima (bcos_epilogue.out_imgmax / out_imgmin_c, specialised epilogues): the rows of the tile have
+    // folded their maxima into at most 16 LDS cells per array; one atomic per touched image and array hands them to the launch-wide
+    // arrays, which the reader of the tensor (a 3 x 3 launch over an LDS-resident patch) takes as its per-image operand scale -- the
+    // separate bcos_image_absrange pass over the maxima (28 launches of a ResNet-50 step, ~6 us each on the critical path) is gone.
+    // The maximum is exact (max is associative); the minimum over the NONZERO pixels is exact when the tile owns its pixels (one column
+    // tile) and a lower bound otherwise (a column tile sees its own columns' maxima) -- it only switches the level bookkeeping on.
+    if (kind && p.e.out_imgmax != nullptr) {
+        __syncthreads();
+        unsigned* sMaxR = reinterpret_cast<unsigned*>(epi_col_table<BM, BN, WAVES_M>(smem) + BN);      // [BM]: every row's maximum over the tile's columns
+        unsigned* sImg = sMaxR + 2 * BM;
+        const EpiRow* sRowR = reinterpret_cast<const EpiRow*>(smem + SBM * LDC);
+        const int img_px = p.g.OH * p.g.OW;
+        for (int r = tid; r < BM; r += NT) {
+            const int pix = sRowR[r].pix;
+            const unsigned a1 = pix >= 0 ? sMaxR[r] : 0u;
+            if (a1) {
+                const int slot = pix / img_px - (int)sImg[32];
+                atomicMax(sImg + slot, a1);
+                atomicMax(sImg + 16 + slot, ~a1);
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const unsigned v = sImg[tid];
+            if (v) atomicMax((tid < 16 ? p.e.out_imgmax : p.e.out_imgmin_c) + sImg[32] + (tid & 15), v);
+        }
+    }
 }
 
 // One output tile [m0, m0+BM) x [n0, n0+BN): main loop + epilogue.  `tile_n` only tells whether this block is the one
@@ -2572,7 +2611,8 @@ __device__ __forceinline__ void tile_body_p(const PT& p, float* smem, const int 
     }
     // (the tile's image maxima: the OLDEST memory operation of the prologue, so that waiting for it leaves the loads below in flight)
     const unsigned my_imgmax = (tid < 16 && n_first + tid <= n_last) ? p.a_imgmax[n_first + tid] : 0u;      // (at most 16 images per tile: patch_fits)
-    const unsigned my_imgmin = (tid < 16 && n_first + tid <= n_last && p.a_imgmin) ? p.a_imgmin[n_first + tid] : 0u;   // (not given: range unknown = wide)
+    const unsigned my_imgmin = (tid < 16 && n_first + tid <= n_last && (p.a_imgmin || p.a_imgmin_c))      // (not given: range unknown = wide)
+                                   ? (p.a_imgmin ? p.a_imgmin[n_first + tid] : ~p.a_imgmin_c[n_first + tid]) : 0u;
     // this thread's NI items of the patch: item q = tid + NT it is (used pixel q >> 1 in row-major order of the PR x PW patch,
     // k-half q & 1): 8 channels = two 16-byte loads, stored at the pixel's rotated physical position
     unsigned voff[NI];
@@ -3093,7 +3133,7 @@ template <int BM, int BN, int WAVES_M>
 constexpr size_t epilogue_lds() {
     constexpr int PM = (BM > EPI_ROWS && (BM / WAVES_M) % (32 * (BM / EPI_ROWS)) == 0) ? BM / EPI_ROWS : 1;
     constexpr int SBM = BM / PM, SBN = BN / epi_pn<BN>();
-    return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20 + (size_t)BN * 4 + (size_t)BM * 8;      // (+ the row maxima of the column parts)
+    return (size_t)SBM * (SBN + 4) * sizeof(float) + (size_t)BM * 20 + (size_t)BN * 4 + (size_t)BM * 8 + 144;      // (+ the row maxima of the column parts + the per-image range cells)
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -3673,6 +3713,21 @@ extern "C" int bcos_tapconv_presplit(const float* a, const float* wt, const void
     return bcos_tapconv_ops(&o, geom, epi, stream);
 }
 
+namespace { thread_local bool t_query_image_range = false; }
+
+extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geom* geom, const bcos_epilogue* epi, void* stream);
+
+// 1: a bcos_tapconv_ops call with these arguments folds the per-image range of its out_absmax into bcos_epilogue.out_imgmax / out_imgmin_c
+// itself; 0: it does not (general epilogue, depth-to-space or grouped launch, fewer than 19 rows per image, no out_absmax) and rejects
+// the two fields; < 0: the arguments are invalid anyway.  Nothing is launched: the call walks bcos_tapconv_ops' own validation and
+// epilogue selection and stops ahead of the dispatch.
+extern "C" int bcos_tapconv_fuses_image_range(const bcos_operands* ops, const bcos_tapconv_geom* geom, const bcos_epilogue* epi) {
+    t_query_image_range = true;
+    const int rc = bcos_tapconv_ops(ops, geom, epi, nullptr);
+    t_query_image_range = false;
+    return rc;
+}
+
 extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geom* geom, const bcos_epilogue* epi, void* stream) {
     if (!ops || !geom || !epi) return bcos_set_error(BCOS_E_INVAL, "bcos_tapconv: NULL argument");
     const float* a = ops->a;
@@ -3759,6 +3814,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     p.a_absmax = nullptr;
     p.a_imgmax = nullptr;
     p.a_imgmin = nullptr;
+    p.a_imgmin_c = nullptr;
     p.lvl_off = 0;
     p.lvl_on = bcos_option(BCOS_OPT_PATCH_LEVELS) != 0;
     p.t2_bw = p.t2_nbx = p.t2_nb = p.t2_rows = 0;
@@ -3794,11 +3850,14 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 if (e2.a_sumsq) e2.a_sumsq += opix;
                 if (e2.out_absmax) e2.out_absmax += opix;
                 if (e2.out2_absmax) e2.out2_absmax += opix;
+                if (e2.out_imgmax) e2.out_imgmax += n0;
+                if (e2.out_imgmin_c) e2.out_imgmin_c += n0;
                 bcos_operands o2 = *ops;
                 o2.a = a + (int64_t)n0 * g.H * g.W * p.g.a_pitch;
                 if (o2.a_absmax) o2.a_absmax += (int64_t)n0 * g.H * g.W;
                 if (o2.a_imgmax) o2.a_imgmax += n0;          // (per-image maxima are indexed by the chunk's local image index)
                 if (o2.a_imgmin) o2.a_imgmin += n0;
+                if (o2.a_imgmin_c) o2.a_imgmin_c += n0;
                 const int rc = bcos_tapconv_ops(&o2, &g2, &e2, stream);
                 if (rc != BCOS_OK) return rc;
             }
@@ -3823,6 +3882,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             p.a_absmax = ops->a_absmax;
             p.a_imgmax = ops->a_imgmax;
             p.a_imgmin = ops->a_imgmax ? ops->a_imgmin : nullptr;
+            p.a_imgmin_c = (ops->a_imgmax && !ops->a_imgmin) ? ops->a_imgmin_c : nullptr;
             p.absmax_bytes = (unsigned)pixb;
             p.wt2 = ops->wt_f16x2;
             p.wt2_bytes = (unsigned)w2b;
@@ -3869,6 +3929,16 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 if (kinds[k] == ef) { p.epi_kind = k + 1; p.out_bytes = (unsigned)obytes; break; }
         }
     }
+    {   // per-image range of the emitted maxima (bcos_epilogue.out_imgmax / out_imgmin_c): folded into the specialised epilogues only, for
+        // launches whose tiles span at most 16 images (256 rows at >= 19 rows per image), plain output mapping, one group
+        const bool fuses = p.epi_kind > 0 && epi->out_absmax && g.out_cgroup == 0 && G == 1 && (int64_t)g.P * g.Q >= 19;
+        if (t_query_image_range) return fuses ? 1 : 0;
+        if (epi->out_imgmax || epi->out_imgmin_c) {
+            if (!epi->out_imgmax || !epi->out_imgmin_c || !fuses)
+                return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: out_imgmax / out_imgmin_c come as a pair, with out_absmax, and only for launches "
+                                                    "bcos_tapconv_fuses_image_range() answers 1 for");
+        }
+    }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1 && epi->addend_sub <= 1 && !epi->row_scale && !epi->a_sumsq) {
@@ -3883,7 +3953,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
             // never on the batch: the patch loop rounds differently from the per-tap loops (one operand scale per image), and an
             // image's bits must not depend on how many images share its launch.  BCOS_OPT_PATCH = 0: development / test switch.
             const bool patch_on = bcos_option(BCOS_OPT_PATCH) != 0;
-            if (!patch_on) p.a_imgmax = p.a_imgmin = nullptr;      // (per-row scales everywhere: the per-tap loops as they were)
+            if (!patch_on) { p.a_imgmax = p.a_imgmin = nullptr; p.a_imgmin_c = nullptr; }      // (per-row scales everywhere: the per-tap loops as they were)
             const int ntaps = g.TH * g.TW;
             const bool geom_ok = ((ntaps == 9 && g.TH == 3) || (ntaps == 16 && g.TH == 4)) && g.C % X3_BK == 0 && g.in_sh == 1 && g.in_sw == 1 &&
                                  g.dstep_h == 1 && g.dstep_w == 1 && p.g.a_pitch >= g.C;
@@ -3901,6 +3971,19 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 if (g.Cout > 32 && g.Cout <= 64 && g.in_sh == 1 && g.Q > 64) return bcos_tc_p2_256x64_b32(&p, norm, s);
                 if (g.Cout > 8 && g.Cout <= 32 && g.in_sh == 1 && g.Q > 64) return bcos_tc_p2_256x32_t9(&p, norm, s);
                 }
+            }
+        }
+        if (g.Cout > 64 && dma && bcos_option(BCOS_OPT_H2_TILE) == 0) {
+            // FEW-ROW launches (M <= a few hundred rows: the pooled token of CLIP's attention pool at batch 256 -- 2 row tiles --, small
+            // batches through every head): with 128- or 256-column tiles they occupy a handful of CUs and run at the latency of ONE
+            // workgroup's K loop (256 x 2048 -> 1024: 8 workgroups, 111 us against 28 for the vendor's GEMM).  Narrower
+            // column tiles multiply the workgroups -- 64 or 32 columns each, as many as it takes to put a workgroup on half the CUs -- at
+            // no cost in bits (an output element's K order does not depend on its tile).
+            const int64_t tm = (M64 + 127) / 128;
+            const int64_t t128 = tm * ((g.Cout + 127) / 128);
+            if (t128 < 64) {
+                if (tm * ((g.Cout + 63) / 64) >= 96 || g.Cout <= 128) return bcos_tc_d_128x64(&p, norm, s);
+                return bcos_tc_d_128x32(&p, norm, s);
             }
         }
         if (g.Cout > 64) {

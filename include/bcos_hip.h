@@ -149,6 +149,14 @@ typedef struct bcos_epilogue {
                                -- A = x, wt = W' (built once per weight), row_scale = r = 1 / sqrt(var + eps), bias = W beta,
                                a_sumsq = |z|^2 (both per row from bcos_layernorm_stats) -- and the gradient of the detached-variance
                                form, gx = r (gamma gz - mean(gamma gz)), is the input-gradient launch over W'^T with the same row_scale. */
+    uint32_t* out_imgmax;   /* NULL or [N] (ABI v9), ZERO-FILLED by the caller before the first launch that writes the tensor: the launch folds
+                               every row maximum it emits through out_absmax into max over the pixels of image n -- what
+                               bcos_image_absrange computes from out_absmax in a pass of its own -- so that a 3 x 3 launch reading `out`
+                               (bcos_operands.a_imgmax) needs no such pass.  Several launches filling disjoint pixels of one tensor
+                               accumulate.  Only for launches bcos_tapconv_fuses_image_range() answers 1 for; with out_imgmin_c.      */
+    uint32_t* out_imgmin_c; /* ... and a LOWER BOUND of the min over the NONZERO pixels of image n, stored complemented (~v; 0 = no nonzero
+                               pixel): exact when a tile owns its pixels (one column tile), the minimum over the column tiles' own maxima
+                               otherwise.  Handed on as bcos_operands.a_imgmin_c.                                                     */
     int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
     int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */
@@ -291,6 +299,10 @@ typedef struct bcos_operands {
                                    everywhere and skip the level bookkeeping; launches with >= 25 taps (7 x 7 stem) take the image
                                    maximum as the scale of such an image's rows instead of scanning every row's taps.  NULL: the
                                    range is unknown -- every tile derives its rows' levels, >= 25-tap launches scan.          */
+    const uint32_t* a_imgmin_c; /* NULL or [N] (ABI v9; read only when a_imgmin is NULL): a lower bound of a_imgmin stored complemented, as
+                                   the launch that produced A left it in bcos_epilogue.out_imgmin_c.  It can switch the level
+                                   bookkeeping of the input-patch loop on for an image that would not have needed it, never off for one
+                                   that does, and decides no bit of any result; >= 25-tap launches ignore it (they scan).              */
 } bcos_operands;
 
 /* -- contraction kernels (LDS-tiled implicit GEMM on the matrix cores) ---------------------------------------- */
@@ -298,6 +310,10 @@ typedef struct bcos_operands {
 /* The generic fused implicit GEMM every entry point below lowers to (bcos_tapconv / bcos_tapconv_presplit are the
  * same call with only `a`, `wt` [, `wt_bf16x3`] set). */
 int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geom* geom, const bcos_epilogue* epi, void* stream);
+
+/* Would bcos_tapconv_ops(ops, geom, epi, ...) fold the per-image range of its out_absmax into epi->out_imgmax / out_imgmin_c (1), or
+ * not (0: the call then rejects the two fields), or are the arguments invalid (< 0)?  Launches nothing.  (ABI v9) */
+int bcos_tapconv_fuses_image_range(const bcos_operands* ops, const bcos_tapconv_geom* geom, const bcos_epilogue* epi);
 int bcos_tapconv(const float* a, const float* wt, const bcos_tapconv_geom* geom,
                  const bcos_epilogue* epi, void* stream);
 

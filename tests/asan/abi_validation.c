@@ -149,6 +149,11 @@ int main(void) {
     EXPECT(bcos_head_rank1_grad_ex((const int64_t*)buf, buf, buf, NULL, buf, buf, NULL, 0, buf, NULL, am, NULL, 2, 4, 10, 8, 1.0f, NULL), BCOS_E_INVAL);   /* mul2 without out2 */
     EXPECT(bcos_head_rank1_grad_ex((const int64_t*)buf, buf, buf, NULL, NULL, NULL, NULL, 1, buf, buf, am, am, 2, 4, 10, 8, 1.0f, NULL), BCOS_E_INVAL);    /* gate from an absent mul */
     /* ABI v9 */
+    EXPECT(bcos_tapconv_fuses_image_range(NULL, &g, &e), BCOS_E_INVAL);
+    EXPECT(bcos_tapconv_fuses_image_range(&o, &g, &e), 0);               /* no out_absmax: nothing to fold */
+    { uint32_t* img = am + 64; e.out_imgmax = img; e.out_imgmin_c = img + 8;        /* the pair without out_absmax / outside a fusing launch */
+      EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_NOSUP); e.out_imgmin_c = NULL;
+      EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_NOSUP); e.out_imgmax = NULL; }
     EXPECT(bcos_stream_copy(NULL, buf, 16, NULL), BCOS_E_INVAL);
     EXPECT(bcos_stream_copy(buf, buf + 1, 16, NULL), BCOS_E_INVAL);      /* misaligned */
     EXPECT(bcos_stream_copy(buf, buf, 6, NULL), BCOS_E_INVAL);           /* n % 4 */

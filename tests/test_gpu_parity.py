@@ -2350,6 +2350,66 @@ def test_bench_headline_line_carries_the_contract_and_the_references(lib):
     assert h["stream_copy_gbps"] and 1000 < h["stream_copy_gbps"] < 8000 and h["frac_of_stream_copy"] > 0
 
 
+def test_image_range_folded_into_the_producing_epilogue(lib):
+    """Round 6: the per-image range of a tensor's per-pixel maxima (the operand scales of the 3 x 3 launch that reads it) comes out of the
+    producing launch's epilogue (bcos_epilogue.out_imgmax / out_imgmin_c) instead of a bcos_image_absrange pass: maxima bit-equal to that
+    pass, complemented minima equal to it where a tile owns its pixels and a lower bound otherwise; several launches filling one tensor
+    accumulate; the reader's results are bit-identical either way -- through a whole ResNet-18 / ResNet-50 explanation too."""
+    from bcos_hip import lib as blib, ops, synth
+    import bcos_hip.engine as en
+    if blib.get_contraction_mode() != "f16x2":
+        pytest.skip("operand maxima belong to the f16x2 contraction")
+    g = torch.Generator().manual_seed(3)
+    arena = ops.AbsmaxArena()
+    for (N, H, Cin, Cout, zero_img) in ((5, 14, 64, 64, None), (3, 28, 32, 256, 1), (4, 7, 128, 512, None), (9, 5, 64, 128, 4), (2, 56, 64, 64, None)):
+        x = torch.randn(N, H, H, Cin, generator=g) * torch.rand(N, 1, 1, 1, generator=g).mul(8).exp2()
+        if zero_img is not None:
+            x[zero_img] = 0.0                                   # an image without a nonzero pixel: max 0, complemented min 0
+        x = x.to(DEV)
+        w = ops.mark_static((torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).to(DEV))
+        w3 = ops.mark_static((torch.randn(64, 3, 3, Cout, generator=g) / (9 * Cout) ** 0.5).to(DEV))
+        outs = {}
+        for fused in (True, False):
+            ops.FUSE_IMAGE_RANGE = fused
+            try:
+                with ops.absmax_arena(arena, x.device):
+                    with ops.image_range_reader():              # (what the engine says around the producer of a 3 x 3 layer's input)
+                        y = ops.conv2d_fwd(ops.ensure_absmax(x), w, relu=True, want_scale=False)[0]
+                    am = ops.absmax_of(y)
+                    rec = getattr(am, "_bcos_imgmax", None)
+                    assert (rec is not None and len(rec) == 3) == (fused and H * H >= 19), (fused, H)
+                    if rec is not None:
+                        ref = torch.empty(2, N, device=DEV, dtype=torch.int32)
+                        blib.check(lib.bcos_image_absrange(am.data_ptr(), ref[0].data_ptr(), ref[1].data_ptr(), N, H * H, None), "range")
+                        torch.cuda.synchronize()
+                        assert torch.equal(rec[0][0], ref[0]), "maxima"
+                        lo = (~rec[0][1]).view(torch.int32)                              # complemented lower bound -> plain
+                        allzero = ref[1] == -1                                           # 0xffffffff: no nonzero pixel
+                        assert torch.equal(lo[allzero], ref[1][allzero])
+                        assert bool((lo[~allzero].to(torch.int64) <= ref[1][~allzero].to(torch.int64)).all())
+                        if Cout <= 64:                                                   # one column tile: the tile owns its pixels -> exact
+                            assert torch.equal(lo, ref[1]), (N, H, Cout)
+                    z = ops.conv2d_fwd(y, w3, stride=(1, 1), padding=(1, 1), relu=True, want_scale=True, want_norm=True)
+                    outs[fused] = [y] + [t for t in z if t is not None]
+            finally:
+                ops.FUSE_IMAGE_RANGE = True
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[True], outs[False])), (N, H, Cin, Cout)
+    for arch, n in (("resnet18", 6), ("resnet50", 4)):
+        net = synth.build_bcosified_resnet(arch, seed=0).to(DEV)
+        xi = synth.synthetic_images(n, seed=9).to(DEV)
+        with torch.no_grad():
+            synth.calibrate(net, xi[:4])
+        eng = en.attach(net)
+        a = eng.explain(xi)
+        ops.FUSE_IMAGE_RANGE = False
+        try:
+            b = eng.explain(xi)
+        finally:
+            ops.FUSE_IMAGE_RANGE = True
+        for k in ("logits", "dynamic_linear_weights", "contribution_map"):
+            assert torch.equal(a[k], b[k]), (arch, k)
+
+
 def test_c_abi_image_absmax(lib):
     """bcos_image_absmax (ABI v6) through the C ABI: per-image maxima of per-pixel maxima, image sizes on either side of the
     kernel's 4096-pixel stride, bit-exact (integer maxima of fp32 bit patterns)."""

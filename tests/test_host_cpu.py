@@ -871,8 +871,8 @@ def check_training_step_fixture(net, x, data, meta, path, loss_of, out_tol, tol,
     assert names == meta["param_names"]
     grads = torch.autograd.grad(loss, [x] + [p for _, p in named])
     assert rel(grads[0], data["gx"]) <= tol, ("gx", rel(grads[0], data["gx"]))
-    # (norms in fp64 on the host: torch's fp32 norm() of the 1000 x 2048 fc gradient ON THE DEVICE was measured 3.7e-4 off the norm of the
-    #  very same tensor copied to the host -- scripts/probe/fc_grad_probe2.py --, like the `var` reductions of HISTORY section 6)
+    # (norms in fp64 on the host, as the fixtures record them: torch's fp32 norm() of the 1000 x 2048 fc gradient is 3.7e-4 off the fp64
+    #  norm of the same values, on the device and on the CPU alike -- scripts/probe/fc_grad_probe3.py)
     norms = torch.stack([g.detach().cpu().double().norm() for g in grads[1:]])
     ref = torch.from_numpy(data["grad_norms"]).double()
     worst = int(((norms - ref).abs() / ref).argmax())
