@@ -92,6 +92,8 @@ SIGNATURES = {
     "bcos_patch_norm_bwd": (C.c_int, [_P, _P, _P] + [_I] * 15 + [_P]),
     "bcos_patch_norm_bwd_add": (C.c_int, [_P, _P, _P, _P] + [_I] * 15 + [_P]),
     "bcos_conv2d_wgrad": (C.c_int, [_P, _P, _P] + [_I] * 18 + [_P]),
+    "bcos_conv2d_wgrad_ws_floats": (C.c_int, [_I] * 18 + [C.POINTER(C.c_int64)]),
+    "bcos_conv2d_wgrad_ordered": (C.c_int, [_P, _P, _P, _P] + [_I] * 18 + [_P]),
     "bcos_colsum": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_colsum_ordered": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "bcos_colsum_ws_floats": (C.c_int, [_L, _I, C.POINTER(C.c_int64)]),
@@ -243,11 +245,16 @@ def reset_options():
 
 # include/bcos_hip.h: enum bcos_option
 OPTIONS = {"tail_split": 0, "d_one_wg": 1, "epi_generic": 2, "h2_loop": 3, "patch": 4, "patch_wide": 5, "h2_tile": 6, "h2_tall": 7,
-           "h2_tall_min": 8, "attention_f32": 9, "split_limit": 10, "lds_min_kb": 11, "patch_levels": 13, "h2_wide_cost": 14}
+           "h2_tall_min": 8, "attention_f32": 9, "split_limit": 10, "lds_min_kb": 11, "patch_levels": 13, "h2_wide_cost": 14, "wgrad_wgs": 15}
+
+
+OPTION_GEN = 0           # bumped by every set_option: host-side caches of values that depend on an option (ops: workspace sizes) compare it
 
 
 def set_option(name: str, value: int):
     """Process-wide development / test switch of the library (bcos_set_option); returns the previous value."""
+    global OPTION_GEN
+    OPTION_GEN += 1
     old = get_option(name)
     check(load().bcos_set_option(OPTIONS[name], int(value)), f"bcos_set_option({name}, {value})")
     return old

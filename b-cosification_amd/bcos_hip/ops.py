@@ -1139,18 +1139,56 @@ class ZeroArena:
         self.buf = None          # (the slices keep the storage alive for as long as the gradients live)
 
 
+WGRAD_ORDERED = os.environ.get("BCOS_WGRAD_ORDERED", "1") != "0"      # development A/B: 0 = the round-5 kernel (pixel chunks combined with fp32 atomics)
+_WGRAD_WS = {}                     # (device, stream) -> workspace of the ordered weight gradient (launches of one stream run in order: one buffer)
+
+
+def wgrad_is_ordered() -> bool:
+    """Does conv2d_wgrad write its result (fixed-order combine, no zeroed accumulator needed) rather than accumulate into it?"""
+    return WGRAD_ORDERED and _l.get_contraction_mode() != "f32"
+
+
+_WGRAD_NEED = {}                   # geometry -> workspace floats (one library call per distinct layer geometry and option value, not per launch)
+
+
+def _wgrad_workspace(floats: int, device, stream) -> torch.Tensor:
+    key = (device.index, stream.value)
+    buf = _WGRAD_WS.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(max(int(floats), 1 << 22), device=device, dtype=torch.float32)
+        _WGRAD_WS[key] = buf
+    return buf
+
+
 def conv2d_wgrad(glin, x, C_used, Cout, kernel, stride, padding, dilation, out=None):
-    """glin [N,P,Q,g_pitch] (first Cout channels), x [N,H,W,x_pitch] (first C_used) -> gw [Cout,kh,kw,C_used]
-    (include/bcos_hip.h: bcos_conv2d_wgrad; fp32 MFMA, pixel chunks combined with atomics).  `out`: a ZEROED [Cout,kh,kw,C_used]."""
+    """glin [N,P,Q,g_pitch] (first Cout channels), x [N,H,W,x_pitch] (first C_used) -> gw [Cout,kh,kw,C_used].
+    Default (round 6): include/bcos_hip.h: bcos_conv2d_wgrad_ordered -- both operands split into bf16 planes once at staging, the pixel
+    chunks' partial tiles added in a FIXED order through a workspace: bit-identical from call to call; `out` need not be zeroed.
+    Contraction mode f32, a gw that is not a multiple of 4 floats, or BCOS_WGRAD_ORDERED=0: bcos_conv2d_wgrad (fp32 atomics; `out`: a
+    ZEROED [Cout,kh,kw,C_used])."""
     lib = _l.load()
     N, H, W, x_pitch = x.shape
     _, P, Q, g_pitch = glin.shape
-    gw = out if out is not None else torch.zeros((Cout, kernel[0], kernel[1], C_used), device=x.device, dtype=torch.float32)
-    if tuple(gw.shape) != (Cout, kernel[0], kernel[1], C_used) or not gw.is_contiguous():
-        raise BcosHipError(f"conv2d_wgrad: out must be a contiguous {(Cout, kernel[0], kernel[1], C_used)} tensor")
-    _l.check(lib.bcos_conv2d_wgrad(_dev(glin, "glin"), _dev(x, "x"), _dev(gw, "gw"), N, H, W, C_used, x_pitch, P, Q, Cout, g_pitch,
-                                   kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
-                                   C_used, _stream()), "bcos_conv2d_wgrad")
+    shape = (Cout, kernel[0], kernel[1], C_used)
+    if out is not None and (tuple(out.shape) != shape or not out.is_contiguous()):
+        raise BcosHipError(f"conv2d_wgrad: out must be a contiguous {shape} tensor")
+    geo = (N, H, W, C_used, x_pitch, P, Q, Cout, g_pitch, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0],
+           dilation[1], C_used)
+    if WGRAD_ORDERED and _l.get_contraction_mode() != "f32" and (Cout * kernel[0] * kernel[1] * C_used) % 4 == 0:
+        gw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+        nkey = geo + (_l.OPTION_GEN,)           # (BCOS_OPT_WGRAD_WGS changes the chunking: sizes cached per generation of the option table)
+        need = _WGRAD_NEED.get(nkey)
+        if need is None:
+            out_n = C.c_int64(0)
+            _l.check(lib.bcos_conv2d_wgrad_ws_floats(*geo, C.byref(out_n)), "bcos_conv2d_wgrad_ws_floats")
+            need = _WGRAD_NEED[nkey] = out_n.value
+        st = _stream()
+        ws = _wgrad_workspace(need, x.device, st) if need else None
+        _l.check(lib.bcos_conv2d_wgrad_ordered(_dev(glin, "glin"), _dev(x, "x"), _dev(gw, "gw"), _dev(ws, "ws"), *geo, st),
+                 "bcos_conv2d_wgrad_ordered")
+        return gw
+    gw = out if out is not None else torch.zeros(shape, device=x.device, dtype=torch.float32)
+    _l.check(lib.bcos_conv2d_wgrad(_dev(glin, "glin"), _dev(x, "x"), _dev(gw, "gw"), *geo, _stream()), "bcos_conv2d_wgrad")
     return gw
 
 

@@ -265,7 +265,8 @@ class ResNetTrainPlan:
         lin = conv.linear
         gl4 = _pad4(glin).contiguous()
         if lin.weight.requires_grad:              # (on the side stream: nothing in the pass waits for a parameter gradient)
-            acc = self._zeros.take((Cout, c.k[0], c.k[1], cin), x.device)
+            # (the ordered weight gradient WRITES its result: no zeroed accumulator; the atomics kernel -- mode f32, odd sizes -- needs one)
+            acc = self._zeros.take((Cout, c.k[0], c.k[1], cin), x.device) if not (ops.wgrad_is_ordered() and (Cout * c.k[0] * c.k[1] * cin) % 4 == 0) else None
             grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4, x, cin, Cout, c.k, c.stride, c.padding, c.dilation, out=acc)
                                              .permute(0, 3, 1, 2).contiguous(), (gl4, x, acc))     # [Cout,kh,kw,Cin] -> OIHW; `acc` too: a torch.zeros of the first pass
                                                                                                    # lives in the caller's pool and is accumulated into on the side stream

@@ -152,7 +152,8 @@ class ViTTrainPlan:
         lin = st.mod.linear
         x = st.x
         if lin.weight.requires_grad:
-            acc = self._zeros.take((Cout, 1, 1, Cin), x.device)
+            # (the ordered weight gradient WRITES its result: no zeroed accumulator; the atomics kernel -- mode f32, odd sizes -- needs one)
+            acc = self._zeros.take((Cout, 1, 1, Cin), x.device) if not (ops.wgrad_is_ordered() and (Cout * 1 * 1 * Cin) % 4 == 0) else None
             grads[lin.weight] = self._pq.run(lambda: ops.conv2d_wgrad(gl4.view(1, 1, rows, gl4.shape[1]), x.view(1, 1, rows, Cin), Cin, Cout,
                                                                       (1, 1), (1, 1), (0, 0), (1, 1), out=acc).view(Cout, Cin), (gl4, x, acc))
         if lin.bias is not None and lin.bias.requires_grad:
@@ -307,7 +308,8 @@ class ViTTrainPlan:
                 rows, Cq = gq2.shape
                 h1 = rec["h1"]
                 Cin = h1.shape[1]
-                acc = self._zeros.take((Cq, 1, 1, Cin), gq2.device)
+                # (the ordered weight gradient WRITES its result: no zeroed accumulator; the atomics kernel -- mode f32, odd sizes -- needs one)
+                acc = self._zeros.take((Cq, 1, 1, Cin), gq2.device) if not (ops.wgrad_is_ordered() and (Cq * 1 * 1 * Cin) % 4 == 0) else None
                 grads[wp] = self._pq.run(lambda: ops.conv2d_wgrad(gq2.view(1, 1, rows, Cq), h1.view(1, 1, rows, Cin), Cin, Cq, (1, 1), (1, 1),
                                                                   (0, 0), (1, 1), out=acc).view(Cq, Cin), (gq2, h1, acc))
             gh1 = ops.matmul_nt(ops.ensure_absmax(gq2), ops.mark_static(rec["wq"].t().contiguous()), track_absmax=False)

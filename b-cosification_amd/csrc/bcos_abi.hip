@@ -49,11 +49,13 @@ constexpr OptSpec OPT_SPECS[BCOS_OPT_COUNT] = {
     {0, 0, 0},                       // reserved
     {1, 0, 1},                       // PATCH_LEVELS
     {7, 4, 8},                       // H2_WIDE_COST
+    {768, 64, 4096},                 // WGRAD_WGS
 };
 std::atomic<int64_t> g_opts[BCOS_OPT_COUNT] = {
     OPT_SPECS[0].def, OPT_SPECS[1].def, OPT_SPECS[2].def, OPT_SPECS[3].def, OPT_SPECS[4].def, OPT_SPECS[5].def, OPT_SPECS[6].def,
-    OPT_SPECS[7].def, OPT_SPECS[8].def, OPT_SPECS[9].def, OPT_SPECS[10].def, OPT_SPECS[11].def, OPT_SPECS[12].def, OPT_SPECS[13].def, OPT_SPECS[14].def};
-static_assert(BCOS_OPT_COUNT == 15, "one OPT_SPECS row and one initialiser per option");
+    OPT_SPECS[7].def, OPT_SPECS[8].def, OPT_SPECS[9].def, OPT_SPECS[10].def, OPT_SPECS[11].def, OPT_SPECS[12].def, OPT_SPECS[13].def, OPT_SPECS[14].def,
+    OPT_SPECS[15].def};
+static_assert(BCOS_OPT_COUNT == 16, "one OPT_SPECS row and one initialiser per option");
 }  // namespace
 
 int64_t bcos_option(int option) { return g_opts[option].load(std::memory_order_relaxed); }

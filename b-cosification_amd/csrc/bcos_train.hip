@@ -383,6 +383,243 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         }
 }
 
+// ---- weight gradient, round 6: split once at staging, fragments by ds_read_b128, fixed-order combine --------------------------------
+// The kernel above hands every wave 8 scalar LDS reads and ~60 vector instructions per fragment (each value of a stage is gathered and split
+// by the two waves that share its half tile): 17.8 M vector for 1.2 M matrix instructions, 16 % of the bf16 pipe (profiles/r05_small_probes.txt
+// (9)).  Here a 16-pixel stage of both operands is split into its three bf16 planes ONCE, by the thread that loaded it -- a thread holds a
+// 4 pixel x 4 channel block, i.e. for each of its channels four consecutive k of the contraction -- and written to LDS pixel-contiguous:
+//   plane image [k-half 0 / 1][128 channel rows][8 pixels] bf16 = 4 KB, rows permuted (see `store` below) so that the 8-byte stores of a
+//   wave spread over the banks; a fragment of v_mfma_f32_32x32x16_bf16 (row = channel, 8 consecutive pixels) is then ONE conflict-free
+//   ds_read_b128 per plane.  Waves 4 x 1: a wave owns 32 output rows and all 128 columns (a row tile beyond Cout is skipped whole), and
+//   its lanes hold four consecutive input channels per output row -- the partial tile leaves as 16-byte stores.
+// Per wave and stage: 15 fragment reads, 24 matrix instructions, ~90 vector instructions of split + 12 ds_write_b64 for its share of the
+// next stage; two LDS buffers of 24 KB, one barrier per stage; <= 168 registers: three workgroups per CU.  Same arithmetic as above (exact
+// 3-way bf16 splits by truncation, the six leading products, smallest terms first).
+// Combine: every (tile, tap, pixel chunk) workgroup STORES its partial tile into slab `chunk` of a workspace laid out like gw; a second
+// launch adds the slabs of every element in chunk order -- one fixed order whatever the dispatch: the weight gradient is reproducible bit
+// for bit from run to run (the atomics of the kernel above are not).  ws == NULL: atomics into a zeroed gw as before.
+constexpr int W3_K = 16;           // pixels per stage
+constexpr int W3_PLANE = 2 * WG_T * 16;      // bytes of one plane image of one operand: [2][128][16 B]
+constexpr int W3_BUF = 6 * W3_PLANE;         // one stage: 2 operands x 3 planes
+
+__global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradArgs p, float* __restrict__ ws, const int64_t slab) {
+    extern __shared__ __attribute__((aligned(16))) char w3sm[];       // [2 buffers][operand g | x][plane h | m | l][k-half][128 rows][16 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int tile_co = tile / p.tiles_ci, tile_ci = tile - tile_co * p.tiles_ci;
+    const int co0 = tile_co * WG_T, ci0 = tile_ci * WG_T;
+    // staging: waves 0, 1 load the gradient rows, waves 2, 3 the input rows; a thread = (16-byte channel chunk cq, pixel group pg of 4)
+    const bool is_x = wave >= 2;
+    const int cq = tid & 31, pg = (tid >> 5) & 3;
+    const int bcol = ci0 + cq * 4;
+    const int tap = p.fuse ? (bcol < p.ctot ? bcol / p.cf : 0) : (int)blockIdx.y;
+    const int bci = p.fuse ? bcol - tap * p.cf : bcol;
+    const bool bcol_ok = p.fuse ? bcol < p.ctot : true;
+    const int th = tap / p.kw, tw = tap - th * p.kw;
+    const int64_t m_lo = (int64_t)blockIdx.z * p.chunk;
+    const int64_t m_hi = m_lo + p.chunk < p.M ? m_lo + p.chunk : p.M;
+    const int PQ = p.P * p.Q;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 rv[4];                    // the thread's 4 pixels x 4 channels of its operand, one stage ahead
+    // (n, i, j) of the thread's four output pixels: divided out once, then ADVANCED by the 16 pixels of a stage (the two waves that stage
+    // the input rows would otherwise spend eight integer divisions per thread and stage); a 1 x 1 / stride-1 / unpadded layer over the
+    // whole image (P Q = H W) needs none of it: its input pixel IS the output pixel
+    const bool direct = p.kh * p.kw == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.P == p.H && p.Q == p.W;
+    int pn[4], pi[4], pj[4];
+    if (is_x && !direct) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m_lo + pg * 4 + j;
+            pn[j] = (int)(m / PQ);
+            const int rem = (int)(m - (int64_t)pn[j] * PQ);
+            pi[j] = rem / p.Q;
+            pj[j] = rem - pi[j] * p.Q;
+        }
+    }
+    auto load = [&](int64_t m0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + pg * 4 + j;
+            f32x4 v = zero4;
+            if (!is_x) {
+                if (m < m_hi) {
+                    const int co = co0 + cq * 4;
+                    if (co + 3 < p.Cout) v = *reinterpret_cast<const f32x4*>(p.glin + m * p.g_pitch + co);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (co + q < p.Cout) v[q] = p.glin[m * p.g_pitch + co + q];
+                    }
+                }
+            } else {
+                const float* src = nullptr;
+                if (direct) {
+                    if (m < m_hi && bcol_ok) src = p.x + m * p.x_pitch;
+                } else {
+                    const int ih = pi[j] * p.sh - p.ph + th * p.dh, iw = pj[j] * p.sw - p.pw + tw * p.dw;
+                    if (m < m_hi && bcol_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                        src = p.x + (((int64_t)pn[j] * p.H + ih) * p.W + iw) * p.x_pitch;
+                    pj[j] += W3_K;                         // the same thread's pixel of the next stage
+                    while (pj[j] >= p.Q) { pj[j] -= p.Q; if (++pi[j] == p.P) { pi[j] = 0; ++pn[j]; } }
+                }
+                if (src) {
+                    if (p.fuse || bci + 3 < p.C) v = *reinterpret_cast<const f32x4*>(src + bci);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (bci + q < p.C) v[q] = src[bci + q];
+                    }
+                }
+            }
+            rv[j] = v;
+        }
+    };
+    // split + store: 8 bytes (4 pixels of one channel) into k-half pg >> 1 of the channel's plane row.  Row of tile channel 4 cq + c:
+    //   gradient rows (output rows of the tile):  32 (cq / 8) + 8 c + cq % 8  -- 32-channel blocks stay together (a row tile beyond Cout is
+    //                                             skipped whole), the 8-byte stores of 16 lanes fall on 8 distinct 16-byte slots;
+    //   input rows (columns of the tile):         32 c + cq                   -- the four channels of a chunk sit at the SAME column of the
+    //                                             four column tiles: a lane of the epilogue holds 4 consecutive ci (one 16-byte store).
+    const int row0 = is_x ? cq : 32 * (cq >> 3) + (cq & 7);
+    const int rstep = is_x ? 32 : 8;
+    const int st_off = (is_x ? 3 * W3_PLANE : 0) + (pg >> 1) * (WG_T * 16) + row0 * 16 + (pg & 1) * 8;
+    auto store = [&](int buf) {
+        char* base = w3sm + buf * W3_BUF + st_off;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = rv[j][c];
+                const unsigned hu = __float_as_uint(x) & 0xffff0000u;
+                const float r1 = x - __uint_as_float(hu);
+                const unsigned mu = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(mu);
+                hh[j] = hu; mm[j] = mu; ll[j] = __float_as_uint(r2);
+            }
+            // two bf16 per word: the high halves of (odd pixel, even pixel)
+            uint2 ph, pm, pl;
+            ph.x = __builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u); ph.y = __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u);
+            pm.x = __builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u); pm.y = __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u);
+            pl.x = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u); pl.y = __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u);
+            char* row = base + c * (rstep * 16);
+            *reinterpret_cast<uint2*>(row) = ph;
+            *reinterpret_cast<uint2*>(row + W3_PLANE) = pm;
+            *reinterpret_cast<uint2*>(row + 2 * W3_PLANE) = pl;
+        }
+    };
+
+    // wave w owns output rows co0 + 32 w .. + 31 (plane rows 32 w + rho <-> channel 32 w + 4 (rho % 8) + rho / 8) and all four column tiles
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const bool rows_live = co0 + 32 * wave < p.Cout;           // (wave-uniform: a row tile beyond Cout multiplies nothing)
+
+    // fragment (row tile t of the 128 plane rows, plane): lane (row rho = lane & 31, k-half lane >> 5) reads 16 bytes
+    const int fr_off = (lane >> 5) * (WG_T * 16) + (lane & 31) * 16;
+    const int nst = (int)((m_hi - m_lo + W3_K - 1) / W3_K);
+    if (nst > 0) {
+        load(m_lo);
+        store(0);
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < nst) load(m_lo + (int64_t)(st + 1) * W3_K);
+            if (rows_live) {
+                const char* a = w3sm + cur * W3_BUF + fr_off + wave * (32 * 16);
+                const char* b = w3sm + cur * W3_BUF + fr_off + 3 * W3_PLANE;
+                wg_bf16x8 af[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) af[sp] = *reinterpret_cast<const wg_bf16x8*>(a + sp * W3_PLANE);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wg_bf16x8 bf[3];
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) bf[sp] = *reinterpret_cast<const wg_bf16x8*>(b + sp * W3_PLANE + j * (32 * 16));
+                    // smallest terms first
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[j], 0, 0, 0);
+                }
+            }
+            if (st + 1 < nst) store(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // accumulator j, register r of lane (kappa = lane & 31, half = lane >> 5): output row rho = (r & 3) + 8 (r >> 2) + 4 half of the wave's
+    // row tile, column kappa of column tile j = tile column 4 kappa + j: the lane's four accumulators are four consecutive ci
+    if (!rows_live) return;
+    float* dst = ws ? ws + (int64_t)blockIdx.z * slab : p.gw;
+    const int col = ci0 + 4 * (lane & 31);
+    const int otap = p.fuse ? (col < p.ctot ? col / p.cf : 0) : tap;
+    const int ci = p.fuse ? col - otap * p.cf : col;
+    const bool col_any = p.fuse ? (col < p.ctot && ci < p.C) : ci < p.C;
+    const bool vec = col_any && ci + 3 < p.C && (p.gw_cin & 3) == 0 && ws != nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int co = co0 + 32 * wave + 4 * (rho & 7) + (rho >> 3);
+        if (co < p.Cout && col_any) {
+            float* q = dst + ((int64_t)co * p.kh * p.kw + otap) * p.gw_cin + ci;
+            if (vec) {
+                const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                *reinterpret_cast<f32x4*>(q) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ci + e < p.C) { if (ws) q[e] = acc[e][r]; else atomicAdd(q + e, acc[e][r]); }
+            }
+        }
+    }
+}
+
+// ... for MANY slabs over a small gw (the 56^2 layers: 64 x 64 weights, several hundred pixel chunks -- one thread walking them all is a
+// chain of several hundred dependent-latency loads): 16 threads per 16-byte column, thread s adds slabs s, s + 16, ... in order, the 16
+// partial sums meet in LDS and are added in the order s = 0 .. 15.  One fixed association of the sum, whatever the dispatch.
+__global__ __launch_bounds__(256) void wgrad_combine_wide_kernel(const f32x4* __restrict__ ws, f32x4* __restrict__ gw, int64_t n4, int64_t slab4, int split) {
+    __shared__ f32x4 part[16][16];
+    const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 16 + el;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (e < n4) {
+        int z = sg;
+        for (; z + 48 < split; z += 64) {
+            const f32x4 v0 = ws[e + (int64_t)z * slab4], v1 = ws[e + (int64_t)(z + 16) * slab4];
+            const f32x4 v2 = ws[e + (int64_t)(z + 32) * slab4], v3 = ws[e + (int64_t)(z + 48) * slab4];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; z < split; z += 16) acc += ws[e + (int64_t)z * slab4];
+    }
+    part[sg][el] = acc;
+    __syncthreads();
+    if (sg == 0 && e < n4) {
+        f32x4 t = part[0][el];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][el];
+        gw[e] = t;
+    }
+}
+
+// gw[e] = sum over the pixel chunks' slabs, in chunk order (16-byte columns, four slabs in flight)
+__global__ __launch_bounds__(256) void wgrad_combine_kernel(const f32x4* __restrict__ ws, f32x4* __restrict__ gw, int64_t n4, int64_t slab4, int split) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += stride) {
+        f32x4 acc = ws[e];
+        int z = 1;
+        for (; z + 3 < split; z += 4) {
+            const f32x4 v0 = ws[e + (int64_t)z * slab4], v1 = ws[e + (int64_t)(z + 1) * slab4];
+            const f32x4 v2 = ws[e + (int64_t)(z + 2) * slab4], v3 = ws[e + (int64_t)(z + 3) * slab4];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; z < split; ++z) acc += ws[e + (int64_t)z * slab4];
+        gw[e] = acc;
+    }
+}
+
 // ---- per-channel sums over rows: out[c] += sum_r (a[r,c] - sa[c]) * (b ? b[r,c] - sb[c] : 1) -----------------------------------
 // `partial` != NULL: the workgroup's sums go to partial[blockIdx.x][C] instead (no atomics; colsum_finish_kernel adds the rows of
 // `partial` in order: every sum of the launch then has ONE fixed order -- bcos_colsum_ws)
@@ -880,6 +1117,94 @@ extern "C" int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, i
     if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
     else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("wgrad launch");
+}
+
+// ---- round 6: the same weight gradient with the split at staging and a fixed-order combine (wgrad3_kernel) ------------------------------
+namespace {
+struct Wgrad3Plan { WgradArgs p; int tiles_co, grid_y; int64_t split, slab; };
+
+int wgrad3_plan(Wgrad3Plan& pl, const float* glin, const float* x, float* gw, int N, int H, int W, int C, int x_pitch, int P, int Q, int Cout,
+                int g_pitch, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int gw_cin) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad: bad argument");
+    if (x_pitch == 0) x_pitch = C;
+    if (g_pitch == 0) g_pitch = Cout;
+    if (gw_cin == 0) gw_cin = C;
+    if (x_pitch % 4 != 0 || g_pitch % 4 != 0 || x_pitch < C || g_pitch < Cout || gw_cin < C)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad: operands must be 16-byte addressable per pixel");
+    WgradArgs& p = pl.p;
+    p.glin = glin; p.x = x; p.gw = gw;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.x_pitch = x_pitch;
+    p.P = P; p.Q = Q; p.Cout = Cout; p.g_pitch = g_pitch;
+    p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
+    p.gw_cin = gw_cin;
+    p.M = (int64_t)N * P * Q;
+    pl.tiles_co = (Cout + WG_T - 1) / WG_T;
+    p.cf = (C + 3) & ~3;
+    p.ctot = kh * kw * p.cf;
+    p.fuse = (p.cf < WG_T && kh * kw > 1 && x_pitch >= p.cf) ? 1 : 0;
+    p.tiles_ci = ((p.fuse ? p.ctot : C) + WG_T - 1) / WG_T;
+    pl.grid_y = p.fuse ? 1 : kh * kw;
+    const int64_t tiles = (int64_t)pl.tiles_co * p.tiles_ci * pl.grid_y;
+    // pixel chunks: ~3 workgroups per CU in flight (what the kernel is compiled for), chunks of at least 256 pixels; every chunk costs a
+    // slab of the workspace and a term of the combine
+    const int64_t want = bcos_option(BCOS_OPT_WGRAD_WGS);
+    int64_t split = (want + tiles - 1) / tiles;
+    const int64_t max_split = (p.M + 255) / 256;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    p.chunk = (((p.M + split - 1) / split) + W3_K - 1) / W3_K * W3_K;
+    pl.split = (p.M + p.chunk - 1) / p.chunk;
+    pl.slab = (((int64_t)Cout * kh * kw * gw_cin) + 3) & ~(int64_t)3;
+    return BCOS_OK;
+}
+}  // namespace
+
+extern "C" int bcos_conv2d_wgrad_ws_floats(int N, int H, int W, int C, int x_pitch, int P, int Q, int Cout, int g_pitch, int kh, int kw,
+                                           int sh, int sw, int ph, int pw, int dh, int dw, int gw_cin, int64_t* floats) {
+    if (!floats) return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad_ws_floats: NULL result");
+    Wgrad3Plan pl;
+    const int rc = wgrad3_plan(pl, nullptr, nullptr, nullptr, N, H, W, C, x_pitch, P, Q, Cout, g_pitch, kh, kw, sh, sw, ph, pw, dh, dw, gw_cin);
+    if (rc != BCOS_OK) return rc;
+    *floats = pl.split > 1 ? pl.split * pl.slab : 0;        // (one chunk: the kernel stores straight into gw)
+    return BCOS_OK;
+}
+
+extern "C" int bcos_conv2d_wgrad_ordered(const float* glin, const float* x, float* gw, float* ws, int N, int H, int W, int C, int x_pitch,
+                                         int P, int Q, int Cout, int g_pitch, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                         int gw_cin, void* stream) {
+    if (!glin || !x || !gw) return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad_ordered: NULL tensor");
+    if ((reinterpret_cast<uintptr_t>(glin) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gw) | reinterpret_cast<uintptr_t>(ws)) & 15)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad_ordered: tensors must be 16-byte aligned");
+    if (bcos_get_contraction_mode() == 0)
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_conv2d_wgrad_ordered: the bf16x3 weight gradient (contraction modes bf16x3 / f16x2); mode f32 uses bcos_conv2d_wgrad");
+    Wgrad3Plan pl;
+    const int rc = wgrad3_plan(pl, glin, x, gw, N, H, W, C, x_pitch, P, Q, Cout, g_pitch, kh, kw, sh, sw, ph, pw, dh, dw, gw_cin);
+    if (rc != BCOS_OK) return rc;
+    if (pl.split > 1 && !ws) return bcos_set_error(BCOS_E_INVAL, "bcos_conv2d_wgrad_ordered: this geometry needs a workspace (bcos_conv2d_wgrad_ws_floats)");
+    if ((int64_t)Cout * kh * kw * pl.p.gw_cin % 4 != 0 || pl.p.gw_cin != C)
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_conv2d_wgrad_ordered: gw must be dense (gw_cin == C) and hold a multiple of 4 floats");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)2 * W3_BUF;
+    static std::atomic<size_t> lds_hw;
+    hipError_t e = bcos_ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad3_kernel), lds, lds_hw);
+    if (e != hipSuccess) return bcos_set_hip_error("hipFuncSetAttribute", e);
+    const dim3 grid((unsigned)(pl.tiles_co * pl.p.tiles_ci), (unsigned)pl.grid_y, (unsigned)pl.split);
+    // one chunk: its slab IS gw (plain stores, every element written once: no zero fill either)
+    hipLaunchKernelGGL(wgrad3_kernel, grid, dim3(256), lds, s, pl.p, pl.split > 1 ? ws : gw, pl.slab);
+    int rc2 = check_launch("wgrad3 launch");
+    if (rc2 != BCOS_OK || pl.split == 1) return rc2;
+    const int64_t n4 = (int64_t)Cout * kh * kw * pl.p.gw_cin / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (pl.split >= 32 && n4 <= ((int64_t)1 << 20))          // many slabs, small gw: 16 threads per column (wgrad_combine_wide_kernel)
+        hipLaunchKernelGGL(wgrad_combine_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(ws),
+                           reinterpret_cast<f32x4*>(gw), n4, pl.slab / 4, (int)pl.split);
+    else
+        hipLaunchKernelGGL(wgrad_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(ws), reinterpret_cast<f32x4*>(gw),
+                           n4, pl.slab / 4, (int)pl.split);
+    return check_launch("wgrad combine launch");
 }
 
 extern "C" int bcos_colsum(const float* a, const float* b, const float* shift_a, const float* shift_b, float* out,

@@ -264,7 +264,10 @@ enum bcos_option {
                                      tests can show what the ladder is for (rows far darker than their image lose accuracy)      */
     BCOS_OPT_H2_WIDE_COST = 14,   /* cost of a 128 x 256 tile in quarters of a 128 x 128 tile in the tile-width choice of the f16x2 loop
                                      (rounds of tiles on 512 slots are compared): 8 = two narrow tiles (rounds 2-3), default 7            */
-    BCOS_OPT_COUNT = 15
+    BCOS_OPT_WGRAD_WGS = 15,      /* workgroups the ordered weight gradient (bcos_conv2d_wgrad_ordered) aims for when it cuts the pixels into
+                                     chunks (default 768 = 3 per CU; 64 .. 4096): more chunks = more parallel work, a larger workspace and
+                                     a longer combine (ABI v9)                                                                        */
+    BCOS_OPT_COUNT = 16
 };
 /* 0, or BCOS_E_INVAL for an unknown option or a value outside its range. */
 int bcos_set_option(int option, int64_t value);
@@ -588,6 +591,18 @@ int bcos_patch_norm_bwd_add(const float* x, const float* rnorm, const float* add
 int bcos_conv2d_wgrad(const float* glin, const float* x, float* gw, int N, int H, int W, int C, int x_pitch, int P, int Q,
                       int Cout, int g_pitch, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int gw_cin,
                       void* stream);
+
+/* The same weight gradient with a FIXED summation order (ABI v9): reproducible bit for bit from call to call.  Both operands of a
+ * 16-pixel stage are split into their three bf16 planes once, at staging (pixel-contiguous LDS planes, one ds_read_b128 per fragment),
+ * six v_mfma_f32_32x32x16_bf16 per product as in bcos_conv2d_wgrad; every (tile, tap, pixel chunk) workgroup stores its partial tile into
+ * slab `chunk` of the workspace `ws`, and a second launch adds the slabs of every element in chunk order.  gw need NOT be zeroed (it is
+ * written, not accumulated into); gw_cin must equal C (0 = C) and gw hold a multiple of 4 floats; contraction modes bf16x3 / f16x2 (mode
+ * f32: BCOS_E_NOSUP -- use bcos_conv2d_wgrad).  ws: bcos_conv2d_wgrad_ws_floats() floats, 16-byte aligned (0 floats: NULL is fine). */
+int bcos_conv2d_wgrad_ws_floats(int N, int H, int W, int C, int x_pitch, int P, int Q, int Cout, int g_pitch, int kh, int kw, int sh,
+                                int sw, int ph, int pw, int dh, int dw, int gw_cin, int64_t* floats);
+int bcos_conv2d_wgrad_ordered(const float* glin, const float* x, float* gw, float* ws, int N, int H, int W, int C, int x_pitch, int P,
+                              int Q, int Cout, int g_pitch, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int gw_cin,
+                              void* stream);
 
 /* out[c] += sum_r (a[r,c] - shift_a[c]) * (b ? b[r,c] - shift_b[c] : 1), C % 4 == 0, `out` zeroed by the caller: bias
  * gradients (sum of glin) and the batch statistics / parameter gradients of BatchNormUncentered2d in training mode

@@ -57,6 +57,7 @@ int main(void) {
       EXPECT(bcos_set_option(BCOS_OPT_RESERVED_12, 1), BCOS_E_INVAL);
       EXPECT(bcos_set_option(BCOS_OPT_LDS_MIN_KB, 161), BCOS_E_INVAL);
       EXPECT(bcos_set_option(BCOS_OPT_H2_WIDE_COST, 3), BCOS_E_INVAL);
+      EXPECT(bcos_set_option(BCOS_OPT_WGRAD_WGS, 32), BCOS_E_INVAL);
       EXPECT(bcos_get_option(BCOS_OPT_PATCH, NULL), BCOS_E_INVAL);
       EXPECT(bcos_get_option(BCOS_OPT_COUNT, &v), BCOS_E_INVAL);
       setenv("BCOS_PATCH", "0", 1);                         /* rounds 1-3 read this on every launch */
@@ -149,6 +150,15 @@ int main(void) {
     EXPECT(bcos_head_rank1_grad_ex((const int64_t*)buf, buf, buf, NULL, buf, buf, NULL, 0, buf, NULL, am, NULL, 2, 4, 10, 8, 1.0f, NULL), BCOS_E_INVAL);   /* mul2 without out2 */
     EXPECT(bcos_head_rank1_grad_ex((const int64_t*)buf, buf, buf, NULL, NULL, NULL, NULL, 1, buf, buf, am, am, 2, 4, 10, 8, 1.0f, NULL), BCOS_E_INVAL);    /* gate from an absent mul */
     /* ABI v9 */
+    { int64_t fl = -1;
+      EXPECT(bcos_conv2d_wgrad_ws_floats(8, 56, 56, 64, 0, 56, 56, 64, 0, 3, 3, 1, 1, 1, 1, 1, 1, 0, NULL), BCOS_E_INVAL);
+      EXPECT(bcos_conv2d_wgrad_ws_floats(8, 56, 56, 64, 0, 56, 56, 64, 0, 0, 3, 1, 1, 1, 1, 1, 1, 0, &fl), BCOS_E_INVAL);      /* kh = 0 */
+      EXPECT(bcos_conv2d_wgrad_ws_floats(8, 56, 56, 64, 0, 56, 56, 64, 0, 3, 3, 1, 1, 1, 1, 1, 1, 0, &fl), BCOS_OK);
+      if (fl <= 0 || fl % (64 * 9 * 64) != 0) { printf("FAIL wgrad workspace size %lld\n", (long long)fl); ++failures; }
+      EXPECT(bcos_conv2d_wgrad_ordered(NULL, buf, buf, buf, 8, 56, 56, 64, 0, 56, 56, 64, 0, 3, 3, 1, 1, 1, 1, 1, 1, 0, NULL), BCOS_E_INVAL);
+      EXPECT(bcos_conv2d_wgrad_ordered(buf, buf, buf, NULL, 8, 56, 56, 64, 0, 56, 56, 64, 0, 3, 3, 1, 1, 1, 1, 1, 1, 0, NULL), BCOS_E_INVAL);   /* needs a workspace */
+      EXPECT(bcos_conv2d_wgrad_ordered(buf, buf, buf + 1, buf, 8, 56, 56, 64, 0, 56, 56, 64, 0, 3, 3, 1, 1, 1, 1, 1, 1, 0, NULL), BCOS_E_INVAL); /* misaligned gw */
+      EXPECT(bcos_conv2d_wgrad_ordered(buf, buf, buf, buf, 8, 56, 56, 64, 0, 56, 56, 64, 0, 3, 3, 1, 1, 1, 1, 1, 1, 68, NULL), BCOS_E_NOSUP);   /* padded gw */ }
     EXPECT(bcos_tapconv_fuses_image_range(NULL, &g, &e), BCOS_E_INVAL);
     EXPECT(bcos_tapconv_fuses_image_range(&o, &g, &e), 0);               /* no out_absmax: nothing to fold */
     { uint32_t* img = am + 64; e.out_imgmax = img; e.out_imgmin_c = img + 8;        /* the pair without out_absmax / outside a fusing launch */

@@ -237,18 +237,39 @@ def test_training_plan_frozen_batchnorm_and_maxout_refusal_on_device(lib):
 
 
 def test_wgrad_kernel_on_resnet_shapes(lib):
-    """bcos_conv2d_wgrad at real layer sizes (several pixel chunks, atomically combined) against fp64 autograd."""
+    """The weight gradient at real layer sizes against fp64 autograd: bcos_conv2d_wgrad_ordered (round 6: bf16 planes split once at
+    staging, the pixel chunks' partial tiles added in a fixed order -- bit-identical from call to call, into a buffer that was NOT zeroed)
+    and bcos_conv2d_wgrad (fp32 atomics) on the same operands; ragged widths (Cout = 1000, 6 of 8 input channels: the fused-tap stem),
+    a single pixel chunk (stored straight into gw), dilation, 1 x 1 over many pixels."""
     from bcos_hip import ops
     g = torch.Generator().manual_seed(9)
-    for (N, Cin, H, Cout, k, s, p) in [(8, 64, 56, 64, 3, 1, 1), (8, 256, 14, 1024, 1, 1, 0), (4, 8, 64, 64, 7, 2, 3), (8, 128, 28, 128, 3, 2, 1)]:
+    cases = [(8, 64, 56, 64, 3, 1, 1, 1), (8, 256, 14, 1024, 1, 1, 0, 1), (4, 8, 64, 64, 7, 2, 3, 1), (8, 128, 28, 128, 3, 2, 1, 1),
+             (4, 2048, 2, 1000, 1, 1, 0, 1), (2, 6, 32, 64, 7, 2, 3, 1), (1, 16, 5, 12, 3, 1, 2, 2), (64, 64, 56, 256, 1, 1, 0, 1), (3, 36, 9, 20, 3, 1, 1, 1)]
+    for (N, Cin, H, Cout, k, s, p, d) in cases:
         x = torch.randn(N, Cin, H, H, generator=g)
-        Ho = (H + 2 * p - k) // s + 1
+        Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
         gl = torch.randn(N, Cout, Ho, Ho, generator=g)
         w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
-        (ref,) = torch.autograd.grad(F.conv2d(x.double(), w, None, s, p), w, gl.double())
-        gw = ops.conv2d_wgrad(gl.permute(0, 2, 3, 1).contiguous().to(DEV), x.permute(0, 2, 3, 1).contiguous().to(DEV), Cin, Cout,
-                              (k, k), (s, s), (p, p), (1, 1))
-        assert rel(gw.permute(0, 3, 1, 2), ref) <= 2e-6, (N, Cin, H, Cout, k, s, p)
+        (ref,) = torch.autograd.grad(F.conv2d(x.double(), w, None, s, p, d), w, gl.double())
+        xp = x.permute(0, 2, 3, 1).contiguous()
+        if Cin % 4:
+            xp = F.pad(xp, (0, (-Cin) % 4))                       # (the network input: 6 channels in a pitch of 8)
+        glp = gl.permute(0, 2, 3, 1).contiguous()
+        if Cout % 4:
+            glp = F.pad(glp, (0, (-Cout) % 4))
+        xd, gd = xp.to(DEV), glp.to(DEV)
+        assert ops.wgrad_is_ordered()
+        dirty = torch.full((Cout, k, k, Cin), float("nan"), device=DEV)
+        gw = ops.conv2d_wgrad(gd, xd, Cin, Cout, (k, k), (s, s), (p, p), (d, d), out=dirty)
+        assert rel(gw.permute(0, 3, 1, 2), ref) <= 2e-6, (N, Cin, H, Cout, k, s, p, d, rel(gw.permute(0, 3, 1, 2), ref))
+        again = ops.conv2d_wgrad(gd, xd, Cin, Cout, (k, k), (s, s), (p, p), (d, d))
+        assert torch.equal(gw, again), (N, Cin, H, Cout, k, s, p)
+        ops.WGRAD_ORDERED = False
+        try:
+            old = ops.conv2d_wgrad(gd, xd, Cin, Cout, (k, k), (s, s), (p, p), (d, d))
+        finally:
+            ops.WGRAD_ORDERED = True
+        assert rel(old.permute(0, 3, 1, 2), ref) <= 2e-6 and rel(gw, old) <= 2e-6
 
 
 CONV_GEOMS = [  # N, Cin, H, W, Cout, k, s, p   (the distinct R18/R50 geometry classes at reduced size + ragged edges)
@@ -946,7 +967,7 @@ def test_vit_training_plan_accumulates_over_two_forwards(lib):
         assert rel(a, b) <= 1e-4, (n, rel(a, b))
     _, gp2 = grads(net)
     for n, a, b in zip(names, gp, gp2):
-        assert rel(a, b) <= 1e-5, (n, rel(a, b))          # (atomics in the weight gradient: not bit-identical)
+        assert torch.equal(a, b), (n, rel(a, b))          # (round 6: the weight gradient combines its pixel chunks in a fixed order)
 
 
 def test_out_of_range_targets(lib):
