@@ -1929,11 +1929,11 @@ __device__ __forceinline__ void tile_body_h2(const KArgs& p, float* smem, const 
 //     WAVES_M x 1 wherever the tile allows, so every A element is still converted exactly once per tile and the conversion
 //     (~3 VALU per element with the packed f32 / cvt_pk forms) sits in the shadow of that wave's own matrix instructions;
 //   * B (pre-split weights in fragment order) is DMA'd verbatim, one 1-KB block per wave instruction;
-//   * no staging registers, no ds_write, no VALU on the load path: a ring of D_NSLOT slots, the loads of step ks + 2 are issued
-//     at the top of step ks and have two steps of matrix work to land; ONE raw s_barrier per step, counted s_waitcnt vmcnt
+//   * no staging registers, no ds_write, no VALU on the load path: a ring of three or four slots (d_nslot), the loads of step ks + 2 / ks + 3
+//     are issued at the top of step ks and have two / three steps of matrix work to land; ONE raw s_barrier per step, counted s_waitcnt vmcnt
 //     (never 0 inside the loop).  The compiler keeps ds_reads clear of the DMA queue as long as all LDS is one array.
 #ifndef D_NSLOT
-#define D_NSLOT 3
+#define D_NSLOT 0                 // 0 = per tile configuration (d_nslot), 3 / 4 = that many ring slots everywhere
 #endif
 #ifndef D_KO
 #define D_KO 0                    // development knock-outs (timing only, wrong results): 1 no DMA issue in the steady loop, 2 no split of the next A rows
@@ -1958,6 +1958,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 template <int BM, int BN>
 constexpr int d_slot_bytes() { return BM * 64 + (BN / 32) * 2048; }
+// Ring depth of a tile configuration: FOUR slots (three steps of DMA in flight behind the step being multiplied) where four slots, the row
+// scales and the largest tap table still leave room for two workgroups per CU (80 KB each) -- the <= 128-column tiles of 128 rows and the
+// 256 x 32 tile; three slots otherwise (128 x 192 / 128 x 256 / 256 x 64).  The K loops of these launches wait on DMA latency, not on a pipe
+// (a lone 128 x 128 workgroup runs a 16-k step of 12 matrix instructions in ~1 500 cycles, profiles/r04_phase_times.txt): a deeper ring is
+// more bytes in flight per workgroup.  D_NSLOT = 3 / 4 forces one depth for every configuration (development A/B).
+template <int BM, int BN>
+constexpr int d_nslot() {
+    if (D_NSLOT != 0) return D_NSLOT;
+    return 4 * d_slot_bytes<BM, BN>() + BM * 4 + 1024 + H2_MAX_TAPS * BM * 4 <= 80 * 1024 ? 4 : 3;
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NORM, int NT = NTHREADS>
 __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const int m0, const int n0, const int tile_n) {
@@ -1995,9 +2005,11 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.a_absmax), 0, p.absmax_bytes, 0x00020000);
     unsigned a_nbase[A_LD];          // byte offset of the row's image (+ this lane's 16-byte chunk)
     int a_ih0[A_LD], a_iw0[A_LD];
-    float* s_scale = reinterpret_cast<float*>(lds + D_NSLOT * SLOT);                          // [BM] row scales
-    char* s_dummy = lds + D_NSLOT * SLOT + BM * 4;                                           // 1 KB: target of the dummy B DMAs
-    unsigned* s_tapoff = reinterpret_cast<unsigned*>(lds + D_NSLOT * SLOT + BM * 4 + 1024);    // [tap][BM] byte offsets (without the lane's chunk)
+    constexpr int NS = d_nslot<BM, BN>();           // ring slots
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    float* s_scale = reinterpret_cast<float*>(lds + NS * SLOT);                          // [BM] row scales
+    char* s_dummy = lds + NS * SLOT + BM * 4;                                           // 1 KB: target of the dummy B DMAs
+    unsigned* s_tapoff = reinterpret_cast<unsigned*>(lds + NS * SLOT + BM * 4 + 1024);    // [tap][BM] byte offsets (without the lane's chunk)
     // rows of the tile this lane's DMA pieces cover: image base, first tap position (rows beyond M fail every bounds check)
     int pix0[A_LD], row_img[A_LD];
 #pragma unroll
@@ -2148,11 +2160,16 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
     // below).  Same pieces, same order, same arithmetic: bit-identical results.
     auto prologue_issue = [&](auto walk_c) {
         if constexpr (PRIV) {
+            // A(0), then the pairs [A(j + 1), B(j)] for j = 0 .. NS - 2: A runs one step ahead of B (see `run`)
             issue_a(walk_c, 0, 0);
             if (nk > 1) issue_a(walk_c, 1, SLOT);
             issue_b(0, 0);
             if (nk > 2) issue_a(walk_c, 2, 2 * SLOT);
             if (nk > 1) issue_b(1, SLOT);
+            if constexpr (NS == 4) {
+                if (nk > 3) issue_a(walk_c, 3, 3 * SLOT);
+                if (nk > 2) issue_b(2, 2 * SLOT);
+            }
         } else {
             issue_a(walk_c, 0, 0); issue_b(0, 0);
             if (nk > 1) { issue_a(walk_c, 1, SLOT); issue_b(1, SLOT); }
@@ -2391,8 +2408,8 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
         if constexpr (H2_PRIO == 1) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
     };
 
-    // Ring: step s lives in slot s % D_NSLOT (A rows and B blocks).  The loops are peeled so that the steady state has no branch.
-    auto rot = [](int o) { return o + SLOT == D_NSLOT * SLOT ? 0 : o + SLOT; };
+    // Ring: step s lives in slot s % NS (A rows and B blocks).  The loops are peeled so that the steady state has no branch.
+    auto rot = [](int o) { return o + SLOT == NS * SLOT ? 0 : o + SLOT; };
     auto barrier = []() {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");         // (the raw barrier does not order the compiler's memory operations)
@@ -2405,16 +2422,23 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
             // and ONE counted wait (everything but the last pair) covers what step ks needs: B(ks) for its matrix instructions,
             // A(ks+1) for the split that runs in their shadow.  Every piece has two steps to land.
             if constexpr (decltype(walk_c)::value == 0 || !D_EARLY) prologue_issue(walk_c);      // (the other walks: issued ahead of the scales, above)
-            if (nk > 2) wait_vmcnt<2 * LA + 2 * LB>(); else if (nk > 1) wait_vmcnt<LA + 2 * LB>(); else wait_vmcnt<LB>();
+            // The queue of a wave, oldest first, is A(0), then the PAIRS j = [A(j + 1), B(j)]; the prologue issued the pairs 0 .. NS - 2, step
+            // ks issues pair ks + NS - 1 (A(ks + NS) into the slot of step ks, whose rows were split during step ks - 1; B(ks + NS - 1) into the
+            // slot of step ks - 1, whose blocks were read during step ks - 1) and needs pair ks landed: B(ks) for its matrix instructions,
+            // A(ks + 1) for the split that runs in their shadow -- ONE counted wait that leaves the NS - 2 younger pairs in flight (those
+            // that exist near the end of the walk).  Every piece has NS - 1 steps to land.
+            // before the first split: everything behind A(0) may still be in flight
+            if constexpr (NS == 3) { if (nk > 2) wait_vmcnt<2 * LA + 2 * LB>(); else if (nk > 1) wait_vmcnt<LA + 2 * LB>(); else wait_vmcnt<LB>(); }
+            else { if (nk > 3) wait_vmcnt<3 * LA + 3 * LB>(); else if (nk > 2) wait_vmcnt<2 * LA + 3 * LB>(); else if (nk > 1) wait_vmcnt<LA + 2 * LB>(); else wait_vmcnt<LB>(); }
             {
                 f32x4 x0[TM], x1[TM];
                 read_a(0, x0, x1);
                 split_a(x0, x1);
             }
-            int off = 0, off_nx = SLOT, off_in = 2 * SLOT;      // slots of step ks, ks + 1, ks + 2 (= ks + 3 for A: that slot's rows were split in step ks - 1)
+            int off = 0, off_nx = SLOT, off_pv = (NS - 1) * SLOT;      // slots of step ks, ks + 1, ks - 1
             auto step = [&](auto ia_c, auto ib_c, auto wait_c, auto next_c, int ks) {
                 wait_vmcnt<decltype(wait_c)::value>();
-                barrier();                         // every wave's B blocks of step ks have landed; the B slot of step ks + 2 (read in step ks - 1) is free
+                barrier();                         // every wave's B blocks of step ks have landed; the slot of step ks - 1 is free
                 constexpr bool IA = decltype(ia_c)::value && !(D_KO & 1), IB = decltype(ib_c)::value && !(D_KO & 1);
 #if D_DEAL_DMA
                 // the DMA pieces dealt out one by one behind the step's matrix instructions.  Measured AGAINST issuing them
@@ -2423,31 +2447,39 @@ __device__ __forceinline__ void tile_body_d(const KArgs& p, float* smem, const i
                 // the piece's issue time saved at the top; not the default
                 unsigned va[A_LD];
                 int sa = 0;
-                if constexpr (IA) walk_a(walk_c, ks + 3, [&](int j, unsigned voff, int soff) { va[j] = voff; sa = soff; });
-                const int o_a = off, o_b = off_in;
+                if constexpr (IA) walk_a(walk_c, ks + NS, [&](int j, unsigned voff, int soff) { va[j] = voff; sa = soff; });
+                const int o_a = off, o_b = off_pv;
                 mma_step(off, next_c, off_nx, std::integral_constant<int, (IA ? LA : 0) + (IB ? LB : 0)>{}, [&](auto q_c) {
                     constexpr int q = decltype(q_c)::value;
                     if constexpr (IA && q < LA) piece_a(q, o_a, va[q < LA ? q : 0], sa);
-                    else piece_b(q - (IA ? LA : 0), ks + 2, o_b);
+                    else piece_b(q - (IA ? LA : 0), ks + NS - 1, o_b);
                 });
 #else
-                if constexpr (IA) issue_a(walk_c, ks + 3, off);
-                if constexpr (IB) issue_b(ks + 2, off_in);
+                if constexpr (IA) issue_a(walk_c, ks + NS, off);
+                if constexpr (IB) issue_b(ks + NS - 1, off_pv);
                 mma_step(off, next_c, off_nx, std::integral_constant<int, 0>{}, [](auto) {});
 #endif
-                off = off_nx; off_nx = off_in; off_in = rot(off_in);
+                off_pv = off; off = off_nx; off_nx = rot(off_nx);
             };
             using T = std::true_type; using F = std::false_type;
             int ks = 0;
-            for (; ks + 3 < nk; ++ks) step(T{}, T{}, std::integral_constant<int, LA + LB>{}, T{}, ks);
-            if (ks + 2 < nk) { step(F{}, T{}, std::integral_constant<int, LA + LB>{}, T{}, ks); ++ks; }
-            if (ks + 1 < nk) { step(F{}, F{}, std::integral_constant<int, LB>{}, T{}, ks); ++ks; }
+            if constexpr (NS == 3) {
+                for (; ks + 3 < nk; ++ks) step(T{}, T{}, std::integral_constant<int, LA + LB>{}, T{}, ks);
+                if (ks + 2 < nk) { step(F{}, T{}, std::integral_constant<int, LA + LB>{}, T{}, ks); ++ks; }
+                if (ks + 1 < nk) { step(F{}, F{}, std::integral_constant<int, LB>{}, T{}, ks); ++ks; }
+            } else {
+                // pairs in flight behind pair ks: ks + 1 and ks + 2, as far as they exist (r = nk - ks steps left)
+                for (; ks + 4 < nk; ++ks) step(T{}, T{}, std::integral_constant<int, 2 * LA + 2 * LB>{}, T{}, ks);        // r >= 5
+                if (ks + 3 < nk) { step(F{}, T{}, std::integral_constant<int, 2 * LA + 2 * LB>{}, T{}, ks); ++ks; }       // r == 4: B(ks + 3) is the last piece
+                if (ks + 2 < nk) { step(F{}, F{}, std::integral_constant<int, LA + 2 * LB>{}, T{}, ks); ++ks; }           // r == 3: pairs [A(ks+2) B(ks+1)] [B(ks+2)]
+                if (ks + 1 < nk) { step(F{}, F{}, std::integral_constant<int, LB>{}, T{}, ks); ++ks; }                    // r == 2: [B(ks+1)]
+            }
             step(F{}, F{}, std::integral_constant<int, 0>{}, F{}, ks);
         } else {
             // A rows shared by the waves of a row group (half-height tiles): A and B of step ks + 2 are issued together at the top of
             // step ks, the split happens at the top of the step behind the barrier
             if constexpr (decltype(walk_c)::value == 0 || !D_EARLY) prologue_issue(walk_c);
-            int off = 0, off_in = (2 * SLOT) % (D_NSLOT * SLOT);
+            int off = 0, off_in = (2 * SLOT) % (NS * SLOT);
             for (int ks = 0; ks < nk; ++ks) {
                 if (ks + 1 < nk) wait_vmcnt<LA + LB>(); else wait_vmcnt<0>();
                 barrier();
@@ -3207,7 +3239,7 @@ int launch_d(const KArgs& base, bool norm, hipStream_t stream) {
     plan_tiles<BM, BN, WAVES_M>(p);
     const int ntaps = p.g.TH * p.g.TW;
     const bool kmajor = ntaps > 1 && ntaps <= H2_MAX_TAPS && p.g.C % X3_BK == 0;
-    size_t lds = (size_t)D_NSLOT * d_slot_bytes<BM, BN>() + (size_t)BM * 4 + 1024 + (kmajor ? (size_t)ntaps * BM * 4 : 0);    // (the half-height body needs less)
+    size_t lds = (size_t)d_nslot<BM, BN>() * d_slot_bytes<BM, BN>() + (size_t)BM * 4 + 1024 + (kmajor ? (size_t)ntaps * BM * 4 : 0);    // (the half-height body needs less)
     const size_t lds_epi = epilogue_lds<BM, BN, WAVES_M>();
     if (lds_epi > lds) lds = lds_epi;
     if (const int64_t one = bcos_option(BCOS_OPT_D_ONE_WG)) {      // development switch: LDS request that leaves room for `one` workgroups per CU only
@@ -4027,7 +4059,13 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
         }
         return dma ? bcos_tc_d_128x32(&p, norm, s) : bcos_tc_h2_128x32(&p, norm, s);
     }
-    if (g.Cout > 64) return bcos_tc_cfg_128x128(&p, norm, s);
+    if (g.Cout > 64) {
+        // few-row launches (see the split-f16 branch above): narrower column tiles put a workgroup on more CUs; same bits
+        const int64_t tm = (M64 + 127) / 128;
+        if (G == 1 && tm * ((g.Cout + 127) / 128) < 64 && bcos_option(BCOS_OPT_H2_TILE) == 0)
+            return (tm * ((g.Cout + 63) / 64) >= 96 || g.Cout <= 128) ? bcos_tc_cfg_128x64(&p, norm, s) : bcos_tc_cfg_128x32(&p, norm, s);
+        return bcos_tc_cfg_128x128(&p, norm, s);
+    }
     if (g.Cout > 32) return bcos_tc_cfg_128x64(&p, norm, s);
     return bcos_tc_cfg_128x32(&p, norm, s);
 }
