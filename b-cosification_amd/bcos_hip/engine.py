@@ -363,7 +363,9 @@ def _pool_stride(pool: nn.AvgPool2d) -> int:
     k, s, p = _pair(pool.kernel_size), _pair(pool.stride), _pair(pool.padding)
     if k != s or k[0] != k[1] or p != (0, 0) or pool.ceil_mode or pool.divisor_override is not None:
         raise BcosHipError("engine: only AvgPool2d(stride) anti-aliasing pools are supported inside blocks")
-    return k[0]
+    # AvgPool2d(1) -- what CLIP's Bottleneck puts in front of the shortcut convolution of a block that only widens (layer1.0: stride 1) -- is
+    # the identity: no launch, no copy of the block input (it was a 205 MB read + 205 MB write per step at batch 256), forward and backward
+    return 0 if k[0] == 1 else k[0]
 
 
 class ResNetEngine:

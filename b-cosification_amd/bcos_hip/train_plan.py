@@ -22,6 +22,7 @@ convolution; its attention-pool head runs as the module it is, under autograd, o
 max_out == 1, fixed B.  Anything else -- the `attn_unpool` head, grouped / MaxOut layers, a learnable exponent, native unit-norm
 layers -- is refused by `supported()` and keeps the per-layer path.
 """
+import contextlib
 import os
 from typing import Dict, List, Optional
 
@@ -39,6 +40,7 @@ def _pad4(t: torch.Tensor) -> torch.Tensor:
 
 
 _SIDE_STREAM = os.environ.get("BCOS_TRAIN_SIDE_STREAM", "1") != "0"
+_PLAN_ARENAS = os.environ.get("BCOS_TRAIN_ARENAS", "1") != "0"        # development A/B: 0 = every operand-maxima tensor of a training pass its own zero fill (round 5)
 
 
 class ParamGradQueue:
@@ -103,6 +105,10 @@ class ResNetTrainPlan:
             raise BcosHipError(f"train plan: {why}")
         self._pq = ParamGradQueue()
         self._zeros = ops.ZeroArena()
+        # operand maxima of a pass from ONE zero fill (a forward emitted 54 fills of its own on a ResNet-50): one arena per direction -- a
+        # second forward before the first one's backward resets the forward arena only, and nothing of the backward reads forward maxima
+        self._arena_f, self._arena_b = ops.AbsmaxArena(), ops.AbsmaxArena()
+        self._nbt = []                 # num_batches_tracked buffers of the pass: advanced by ONE launch at its end (53 on a ResNet-50 before)
 
     # ------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -175,9 +181,11 @@ class ResNetTrainPlan:
         if batch_stats:
             momentum = 0.0 if bn.momentum is None else bn.momentum
             if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
-                if bn.momentum is None:
+                if bn.momentum is None:                          # cumulative average: the count is needed on the host, now
+                    bn.num_batches_tracked.add_(1)
                     momentum = 1.0 / float(bn.num_batches_tracked)
+                else:
+                    self._nbt.append(bn.num_batches_tracked)
             # ONE pass over y: mean, centred variance (x.var(unbiased=False), batchnorm_uncentered.py:36-44), 1 / std, weight / std and
             # the running_var update -- was two column-sum passes and ~10 torch launches per layer
             rv = bn.running_var if (bn.track_running_stats and bn.running_var is not None) else None
@@ -284,8 +292,14 @@ class ResNetTrainPlan:
 
     # ------------------------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
-        with ops.transient_weights():
-            return self._forward(x)
+        self._nbt = []
+        try:
+            with ops.transient_weights(), (ops.absmax_arena(self._arena_f, x.device) if _PLAN_ARENAS else contextlib.nullcontext()):
+                return self._forward(x)
+        finally:
+            if self._nbt:
+                torch._foreach_add_(self._nbt, 1)
+                self._nbt = []
 
     def _forward(self, x: torch.Tensor):
         eng = self.eng
@@ -303,7 +317,7 @@ class ResNetTrainPlan:
             st["stem"].append(u)
         st["a0_hw"] = (a0.shape[1], a0.shape[2])
         k, s, p = eng.pool
-        cur = ops.ensure_absmax(ops.avgpool2d_fwd(a0, k, s, p))
+        cur = ops.avgpool2d_fwd(a0, k, s, p, want_absmax=True)
         blocks = []
         for blk in eng.blocks:
             inp = cur
@@ -314,9 +328,9 @@ class ResNetTrainPlan:
                 rec["units"].append(u)
             if blk.pool:                               # CLIP's anti-aliasing pool between conv2 and conv3 (CLIP/clip/model.py:25,47)
                 rec["pre_pool_hw"] = (h.shape[1], h.shape[2])
-                h = ops.ensure_absmax(ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0))
+                h = ops.avgpool2d_fwd(h, blk.pool, blk.pool, 0, want_absmax=True)
             if blk.shortcut is not None:
-                sc_in = ops.ensure_absmax(ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0)) if blk.shortcut_pool else inp
+                sc_in = ops.avgpool2d_fwd(inp, blk.shortcut_pool, blk.shortcut_pool, 0, want_absmax=True) if blk.shortcut_pool else inp
                 idn, rec["shortcut"] = self._unit_fwd(blk.shortcut, sc_in, relu=False)
             else:
                 idn = inp
@@ -337,7 +351,7 @@ class ResNetTrainPlan:
         self._zeros.begin(g_logits.device)
         self._pq.begin(g_logits.device)
         try:
-            with ops.transient_weights():
+            with ops.transient_weights(), (ops.absmax_arena(self._arena_b, g_logits.device) if _PLAN_ARENAS else contextlib.nullcontext()):
                 return self._backward(st, g_logits, need_x)
         finally:
             self._pq.end()
