@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2700 -- 'bash scripts/collect_profiles.sh r05'
+#   gpurun --timeout 2700 -- 'bash scripts/collect_profiles.sh r06'
 # Writes gpurun_out/prof_<tag>/{stats,fetch,write,...}/ and gpurun_out/profiles_<tag>/ (the summaries to copy into profiles/).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -85,4 +85,13 @@ for b in blocks:
               f"waiting on a counter or barrier {100 * vals.get('SQ_WAIT_ANY', 0) / wc:.1f} %; VALU {vals.get('SQ_INSTS_VALU', 0):.0f} SALU {vals.get('SQ_INSTS_SALU', 0):.0f} "
               f"MFMA {vals.get('SQ_INSTS_MFMA', 0):.0f} LDS {vals.get('SQ_INSTS_LDS', 0):.0f} VMEM {vals.get('SQ_INSTS_VMEM', 0):.0f} instructions")
 PY
+# 6. which kernels ONE timed step launches, and for how long (difference of a 4-step and a 1-step trace): headline, CLIP forward, ViT-Ti, ResNet-50 training
+cd "$ROOT"
+bash scripts/per_step_kernels.sh ${TAG}_headline > /dev/null 2>&1; cp gpurun_out/${TAG}_headline_per_step_kernels.txt "$SUM/${TAG}_per_step_kernels.txt"
+bash scripts/per_step_kernels.sh ${TAG}_clipfwd --arch clip_rn50 --forward-only > /dev/null 2>&1; cp gpurun_out/${TAG}_clipfwd_per_step_kernels.txt "$SUM/${TAG}_per_step_kernels_clip_rn50_forwardonly.txt"
+BCOS_SUBBATCH_STREAMS=3 bash scripts/per_step_kernels.sh ${TAG}_vit --arch vit_ti --batch 512 > /dev/null 2>&1; cp gpurun_out/${TAG}_vit_per_step_kernels.txt "$SUM/${TAG}_per_step_kernels_vit_ti_batch_512.txt"
+bash scripts/per_step_kernels.sh ${TAG}_train --train --arch resnet50 > /dev/null 2>&1; cp gpurun_out/${TAG}_train_per_step_kernels.txt "$SUM/${TAG}_per_step_kernels_train_resnet50.txt"
+# 7. the weight-gradient launch on the ResNet-50 / ViT-Ti training shapes: ordered (round 6) against atomics (round 5)
+{ for f in 1 0; do echo "== BCOS_WGRAD_ORDERED=$f (ResNet-50 shapes, batch 64)"; BCOS_WGRAD_ORDERED=$f python3 scripts/probe/wgrad_probe.py 2>/dev/null
+  echo "== BCOS_WGRAD_ORDERED=$f (ViT-Ti token linears, 12 608 rows)"; BCOS_WGRAD_ORDERED=$f WGRAD_VIT=1 python3 scripts/probe/wgrad_probe.py 2>/dev/null; done; } > "$SUM/${TAG}_wgrad_probe.txt"
 ls -la "$SUM"
