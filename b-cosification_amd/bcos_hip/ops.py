@@ -1434,13 +1434,15 @@ def attention_bwd_v(qkv, stats, gout, heads, scale, want_absmax=False):
     return gv
 
 
-def finalize_explanation_patches(gp, x_nchw, std6, patch, add_inverse=False, want_weights=True, want_contrib=True):
-    """gp [N*gh*gw, patch*patch*Cpad] (patch-major input gradient) -> W(x) [N,6,H,W], contribution map [N,H,W]."""
+def finalize_explanation_patches(gp, x_nchw, std6, patch, add_inverse=False, want_weights=True, want_contrib=True, weights_out=None,
+                                 contrib_out=None):
+    """gp [N*gh*gw, patch*patch*Cpad] (patch-major input gradient) -> W(x) [N,6,H,W], contribution map [N,H,W].
+    `weights_out` / `contrib_out`: write into these tensors (slices of a larger batch) instead of new ones."""
     lib = _l.load()
     N, Cx, H, W = x_nchw.shape
     cpad = gp.shape[-1] // (patch * patch)
-    wout = torch.empty((N, 6, H, W), device=gp.device, dtype=torch.float32) if want_weights else None
-    cout = torch.empty((N, H, W), device=gp.device, dtype=torch.float32) if want_contrib else None
+    wout = (weights_out if weights_out is not None else torch.empty((N, 6, H, W), device=gp.device, dtype=torch.float32)) if want_weights else None
+    cout = (contrib_out if contrib_out is not None else torch.empty((N, H, W), device=gp.device, dtype=torch.float32)) if want_contrib else None
     _l.check(lib.bcos_finalize_explanation_patches(_dev(gp, "gp"), _dev(x_nchw, "x"), _dev(std6, "std"), _dev(wout, "w"),
                                                    _dev(cout, "c"), N, Cx, H, W, patch, cpad, int(add_inverse), _stream()),
              "bcos_finalize_explanation_patches")

@@ -418,18 +418,25 @@ class ViTEngine:
         targets = ops.check_targets(targets, self.head.cout)      # IndexError like the reference's out[0, idx]; negative indices wrap
         tg = None if targets is None else targets.to(device=x.device, dtype=torch.int64).contiguous()
 
+        # the two image-sized results of the sub-batches land in ONE pair of tensors (engine.ResNetEngine._explain_subbatches): no
+        # concatenation pass over [N, 6, H, W] behind the step (0.3 ms of a 17.4 ms ViT-Ti step at batch 512)
+        N, _, H, W = x.shape
+        wts = torch.empty((N, 6, H, W), device=x.device, dtype=torch.float32) if want_weights else None
+        contrib = torch.empty((N, H, W), device=x.device, dtype=torch.float32)
+
         def one(lo, hi):
-            return self._explain_gen(x[lo:hi], None if tg is None else tg[lo:hi], want_weights)
+            return self._explain_gen(x[lo:hi], None if tg is None else tg[lo:hi], want_weights,
+                                     outs=(wts[lo:hi] if want_weights else None, contrib[lo:hi]))
         outs = self._sub_batches(x, one)
-        if len(outs) == 1:
-            return outs[0]
-        return {k: (torch.cat([o[k] for o in outs]) if outs[0][k] is not None else None) for k in outs[0]}
+        res = {k: (outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs])) for k in ("logits", "prediction", "explained_class_idx")}
+        res.update(dynamic_linear_weights=wts, contribution_map=contrib)
+        return res
 
     def _explain(self, x, targets, want_weights):
         from .engine import _drive
         return _drive(self._explain_gen(x, targets, want_weights))
 
-    def _explain_gen(self, x, targets, want_weights):
+    def _explain_gen(self, x, targets, want_weights, outs=None):
         logits, st = yield from self._run_forward_gen(x, keep=True)
         N, T = st["N"], st["T"]
         pred, _ = ops.argmax_rows(logits)
@@ -494,10 +501,12 @@ class ViTEngine:
                 g = layer["conv"].dgrad.run(ops.ensure_absmax(g) if _F16X2 else g, hi, wi)
             gxn = g if g.shape[-1] == 8 else torch.nn.functional.pad(g, (0, 8 - g.shape[-1]))
             wts, contrib = ops.finalize_explanation(gxn.contiguous(), st["x"], std, add_inverse=st["add_inverse"],
-                                                    want_weights=want_weights, want_contrib=True)
+                                                    want_weights=want_weights, want_contrib=True,
+                                                    weights_out=outs[0] if outs else None, contrib_out=outs[1] if outs else None)
         else:
             wts, contrib = ops.finalize_explanation_patches(gp, st["x"], std, self.patch, add_inverse=st["add_inverse"],
-                                                            want_weights=want_weights, want_contrib=True)
+                                                            want_weights=want_weights, want_contrib=True,
+                                                            weights_out=outs[0] if outs else None, contrib_out=outs[1] if outs else None)
         return dict(logits=logits, prediction=pred, explained_class_idx=cls, dynamic_linear_weights=wts,
                     contribution_map=contrib)
 

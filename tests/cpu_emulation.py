@@ -609,7 +609,8 @@ def attention_bwd_v(qkv, stats, gout, heads, scale, want_absmax=False):
     return (p.transpose(-1, -2) @ g).transpose(1, 2).reshape(B, T, inner).float()
 
 
-def finalize_explanation_patches(gp, x, std6, patch, add_inverse=False, want_weights=True, want_contrib=True):
+def finalize_explanation_patches(gp, x, std6, patch, add_inverse=False, want_weights=True, want_contrib=True, weights_out=None,
+                                 contrib_out=None):
     if add_inverse:
         x = torch.cat([x, 1 - x], 1)
     N, _, H, W = x.shape
@@ -617,7 +618,9 @@ def finalize_explanation_patches(gp, x, std6, patch, add_inverse=False, want_wei
     cpad = gp.shape[-1] // (patch * patch)
     g = gp.view(N, gh, gw, patch, patch, cpad)[..., :6].permute(0, 5, 1, 3, 2, 4).reshape(N, 6, H, W)
     w = g / std6.view(1, 6, 1, 1)
-    return (w.contiguous() if want_weights else None), ((x * w).sum(1) if want_contrib else None)
+    wo = (w.contiguous() if weights_out is None else weights_out.copy_(w)) if want_weights else None
+    co = ((x * w).sum(1) if contrib_out is None else contrib_out.copy_((x * w).sum(1))) if want_contrib else None
+    return wo, co
 
 
 class _Setter:
