@@ -50,8 +50,9 @@ done
 #    M = 50176, K = 2304, N = 256; B = forward 64 -> 256 @56^2 (residual + ReLU + stored multiplier); C = forward 256 -> 1024 @14^2
 {
   echo "SQ counters of four representative contraction launches (scripts/_pmc.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass;"
-  echo "counters other than SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE are in units of 4 cycles).  derived: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES /"
-  echo "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"
+  echo "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE and the LDS-array"
+  echo "counters SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT count cycles -- 3.9 per ds_read_b128).  derived: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES /"
+  echo "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); LDS array busy = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8 XCDs)"
   echo "== A 3x3-class K=2304 (M=50176, N=256, 128x256 tiles, split-f16 loop with LDS-DMA staging)"
   MKN=50176,2304,256 bash scripts/_pmc.sh ${TAG}pmcA 2>/dev/null
   echo "== B fwd 64->256 @56^2 (residual + ReLU + stored multiplier)"
