@@ -28,13 +28,14 @@ BCOS_EPI_SCALE_GATE_LSB = 4
 BCOS_EPI_GATE2_FROM_MUL = 8
 BCOS_EPI_MUL_FROM_ACT = 16
 BCOS_EPI_UNIT_NORM_W = 32
+BCOS_E_NOSUP = -95
 ABI_VERSION = 9
 VERSION_DEV_FLAG = 0x40000000          # include/bcos_hip.h: BCOS_VERSION_DEV_FLAG
 TAPCONV_PARTS = 11
 
 
 class BcosHipError(RuntimeError):
-    pass
+    code = None                    # the library's return code where the error came from a call (check)
 
 
 class TapconvGeom(C.Structure):
@@ -48,7 +49,7 @@ class Epilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "bias", "ch_scale", "ch_shift", "addend", "mul", "mul2", "gate2", "relu_gate",
         "out", "out2", "scale_out", "norm_out", "out_absmax", "out2_absmax", "mul_norm", "mul_csc", "mul_csh", "col_scale", "row_scale", "a_sumsq",
-        "out_imgmax", "out_imgmin_c")] + [
+        "out_imgmax", "out_imgmin_c", "rowadd", "rowadd_scale")] + [
         ("bcos_mode", C.c_int32), ("relu", C.c_int32), ("b", C.c_float), ("flags", C.c_int32), ("max_out", C.c_int32), ("addend_sub", C.c_int32)]
 
 
@@ -299,4 +300,6 @@ def set_contraction_mode(mode: str):
 def check(code: int, what: str):
     if code != 0:
         msg = load().bcos_last_error_string().decode()
-        raise BcosHipError(f"{what} failed with code {code}: {msg}")
+        err = BcosHipError(f"{what} failed with code {code}: {msg}")
+        err.code = int(code)
+        raise err

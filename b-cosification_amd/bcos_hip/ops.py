@@ -59,6 +59,7 @@ def conv_out_size(size, k, s, p, d=1):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+FUSE_PATCH_NORM = os.environ.get("BCOS_FUSE_PATCH_NORM", "1") != "0"    # development A/B: 0 = the patch-norm term of pointwise layers as a pass of its own (round 5)
 _NO_PRESPLIT = bool(os.environ.get("BCOS_NO_PRESPLIT"))     # development switch: always split inside the kernel
 _NO_GROUP = bool(os.environ.get("BCOS_NO_GROUP"))           # development switch: one launch per parity class
 _NO_D2S = bool(os.environ.get("BCOS_NO_D2S"))               # development switch: narrow strided gradients on the grouped direct kernel
@@ -358,14 +359,16 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
             norm_out=None, bias=None, ch_scale=None, ch_shift=None, addend=None, mul=None, mul2=None,
             gate2=None, relu_gate=None, bcos_mode=BCOS_NONE, b=2.0, relu=False, flags=0, contraction=None,
             track_absmax=None, track_absmax2=None, max_out=1, mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0,
-            col_scale=None, row_scale=None, a_sumsq=None):
+            col_scale=None, row_scale=None, a_sumsq=None, rowadd=None, rowadd_scale=None):
     """One launch of the generic fused implicit GEMM (include/bcos_hip.h: bcos_tapconv_ops).
     `addend_sub` = s > 1: `addend` is the dense [N, ceil(OH/s), ceil(OW/s), pitch] tensor of the output pixels on the s-grid.
     `contraction`: None = the library default, or 'f32' / 'bf16x3' / 'f16x2' for this call.
     `track_absmax` / `track_absmax2`: emit the per-pixel maxima of out / out2 (default: whenever the f16x2 contraction is
     selected; a caller that knows the reader of a tensor will not use them -- K < F16X2_MIN_K -- passes False).
     `row_scale` [rows] / `a_sumsq` [rows]: a factor of every accumulator row / the squared operand norm of a B-cos launch given
-    from outside (a LayerNorm folded into the contraction, include/bcos_hip.h: bcos_epilogue.row_scale)."""
+    from outside (a LayerNorm folded into the contraction, include/bcos_hip.h: bcos_epilogue.row_scale).
+    `rowadd` (indexed like out) / `rowadd_scale` [output pixels]: out = acc + (rowadd_scale[pixel] rowadd + addend) in a plain gradient
+    launch (bcos_epilogue.rowadd; BcosHipError with code BCOS_E_NOSUP where the launch cannot take it)."""
     lib = _l.load()
     g = TapconvGeom()
     for k in ("a_pitch", "out_pitch", "norm_pitch", "out_cgroup", "groups"):
@@ -375,7 +378,8 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
     e = Epilogue()
     tensors = dict(bias=bias, ch_scale=ch_scale, ch_shift=ch_shift, addend=addend, mul=mul, mul2=mul2,
                    gate2=gate2, relu_gate=relu_gate, out=out, out2=out2, scale_out=scale_out, norm_out=norm_out,
-                   mul_norm=mul_norm, mul_csc=mul_csc, mul_csh=mul_csh, col_scale=col_scale, row_scale=row_scale, a_sumsq=a_sumsq)
+                   mul_norm=mul_norm, mul_csc=mul_csc, mul_csh=mul_csh, col_scale=col_scale, row_scale=row_scale, a_sumsq=a_sumsq,
+                   rowadd=rowadd, rowadd_scale=rowadd_scale)
     for k, t in tensors.items():
         p = _dev(t, f"tapconv.{k}", contiguous=False)
         setattr(e, k, p.value if p is not None else None)
@@ -553,9 +557,10 @@ def linear_fwd(x2d, w, *, bias=None, b=2.0, want_scale=False, want_norm=False, m
 
 
 def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None, track_absmax=None, bias=None, row_scale=None, out2=None, mul2=None,
-              track_absmax2=None):
+              track_absmax2=None, rowadd=None, rowadd_scale=None):
     """Plain fp32 GEMM on the same kernel: out[rows,N] = a2d[rows,K] @ bt[N,K]^T (no B-cos scaling).  With v = row_scale * acc + bias
-    + addend:  out = v * mul, out2 = v * mul2 (the gradient epilogue of bcos_tapconv)."""
+    + addend:  out = v * mul, out2 = v * mul2 (the gradient epilogue of bcos_tapconv).  `rowadd` [rows,N] / `rowadd_scale` [rows]:
+    + rowadd_scale[row] * rowadd (tapconv: bcos_epilogue.rowadd)."""
     rows, K = a2d.shape
     Nn = bt.shape[0]
     g = dict(N=1, H=1, W=rows, C=K, P=1, Q=rows, in_sh=1, in_sw=1, dh0=0, dw0=0, dstep_h=1, dstep_w=1,
@@ -563,8 +568,24 @@ def matmul_nt(a2d, bt, *, out=None, addend=None, mul=None, track_absmax=None, bi
     if out is None:
         out = torch.empty((rows, Nn), device=a2d.device, dtype=torch.float32)
     tapconv(a2d, bt, g, out=out, addend=addend, mul=mul, track_absmax=track_absmax, bias=bias, row_scale=row_scale, out2=out2, mul2=mul2,
-            track_absmax2=track_absmax2)
+            track_absmax2=track_absmax2, rowadd=rowadd, rowadd_scale=rowadd_scale)
     return out
+
+
+def matmul_nt_with_row_term(g2d, bt, x2d, rnorm, addend=None):
+    """g2d @ bt^T + x2d * rnorm[:, None] (+ addend): the input gradient of a B-cos LINEAR layer with the |x| term of its scale's derivative
+    (bcoslinear.py:116-142 differentiated) in the launch's epilogue -- what DgradPlan.run_with_patch_norm is for the pointwise
+    convolutions; falls back to bcos_patch_norm_bwd + a plain addend where the launch cannot take it."""
+    rows, Cin = x2d.shape
+    if FUSE_PATCH_NORM and Cin == bt.shape[0] and Cin % 4 == 0 and x2d.is_contiguous():
+        try:
+            return matmul_nt(g2d, bt, addend=addend, rowadd=x2d, rowadd_scale=rnorm.reshape(-1), track_absmax=False)
+        except BcosHipError as err:
+            if err.code != _l.BCOS_E_NOSUP:
+                raise
+    term = patch_norm_bwd(x2d.view(1, 1, rows, Cin), rnorm.view(1, 1, rows), Cin, (1, 1), (1, 1), (0, 0), (1, 1),
+                          addend=None if addend is None else addend.view(1, 1, rows, Cin)).view(rows, Cin)
+    return matmul_nt(g2d, bt, addend=term, track_absmax=False)
 
 
 def _take_taps(w, dim, idx, k):
@@ -746,6 +767,27 @@ class DgradPlan:
             if epi.get("out2") is not None:
                 ensure_absmax(epi["out2"])
         return out
+
+    @property
+    def pointwise(self) -> bool:
+        """the gradient of a 1 x 1 / stride-1 / unpadded, ungrouped convolution: every output pixel of run() is one row of ONE launch"""
+        return self.k == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1 and len(self.classes) == 1
+
+    def run_with_patch_norm(self, glin, x, rnorm, cin, H, W, addend=None):
+        """run(glin, H, W) + the patch-norm term of the B-cos scale's derivative, x * (sum of rnorm over the patches that contain the pixel)
+        (+ `addend`: a gradient that reaches the layer input by another path).  Pointwise layers (`pointwise`: patch = pixel) take the
+        term inside the launch's epilogue (bcos_epilogue.rowadd: one read of x instead of bcos_patch_norm_bwd_add's pass that writes a
+        tensor for the launch to read back); every other geometry, and a launch the library answers BCOS_E_NOSUP for, as before."""
+        N = glin.shape[0]
+        if FUSE_PATCH_NORM and self.pointwise and x.shape[-1] == self.Cin and cin == self.Cin and self.Cin % 4 == 0 and x.is_contiguous():
+            try:
+                return self.run(glin, H, W, addend=addend, rowadd=x, rowadd_scale=rnorm.reshape(-1))
+            except BcosHipError as err:
+                if err.code != _l.BCOS_E_NOSUP:
+                    raise
+        Ho, Wo = glin.shape[1], glin.shape[2]
+        return self.run(glin, H, W, addend=patch_norm_bwd(x, rnorm.view(N, Ho, Wo), cin, self.k, self.stride, self.padding, self.dilation,
+                                                          addend=addend))
 
     def _empty_class(self, out, N, H, W, rh, rw, P, Q, epi):
         sh, sw = self.stride

@@ -250,6 +250,7 @@ class ResNetTrainPlan:
         H, W = st.in_hw
         cin = c.cin
         addend = extra if (extra is None or extra.is_contiguous()) else extra.contiguous()
+        pn_rnorm = None                                   # the patch-norm term's per-patch factor: the input-gradient launch below adds the term
         if st.b != 1.0 and not conv.detach:
             if Cout % 4 == 0:          # (+ the per-pixel maxima of glin for the input-gradient launches)
                 gl2, rnorm, _ = ops.train_scale_bwd((ga if fuse_bn else gy).reshape(-1, Cout).contiguous(), y2, st.scale.view(-1, Cout),
@@ -264,8 +265,7 @@ class ResNetTrainPlan:
                 glin, rnorm, _ = _scale_bwd_cols(gy.reshape(-1, Cout), y2, st.scale.view(-1, Cout), st.norm.view(-1), BCOS_CONV_EPS,
                                                  dict(b=st.b, force_pow=st.force_pow), False)
                 glin = glin.view(N, Ho, Wo, Cout)
-            if need_x:
-                addend = ops.patch_norm_bwd(x, rnorm.view(N, Ho, Wo), cin, c.k, c.stride, c.padding, c.dilation, addend=addend)
+            pn_rnorm = rnorm
         elif st.b != 1.0:
             glin = ops.mul(gy, st.scale)
         else:
@@ -287,7 +287,11 @@ class ResNetTrainPlan:
             if r:
                 wq = torch.cat([wq, wq.new_zeros((r,) + tuple(wq.shape[1:]))], 0)
             plan = ops.DgradPlan(wq, c.stride, c.padding, c.dilation)
-            gx = plan.run(gl4 if (r or Cout % 4) else glin.contiguous(), H, W, addend=addend)
+            g_in = gl4 if (r or Cout % 4) else glin.contiguous()
+            if pn_rnorm is not None:
+                gx = plan.run_with_patch_norm(g_in, x, pn_rnorm, cin, H, W, addend=addend)
+            else:
+                gx = plan.run(g_in, H, W, addend=addend)
         return gx, g_addend
 
     # ------------------------------------------------------------------------------------------------------------------

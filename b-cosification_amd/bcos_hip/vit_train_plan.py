@@ -160,11 +160,10 @@ class ViTTrainPlan:
             grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4)[:Cout].contiguous(), (gl4,))
         if not need_x:
             return None
-        addend = None
-        if rnorm is not None:
-            addend = ops.patch_norm_bwd(st.x.view(1, 1, rows, Cin), rnorm.view(1, 1, rows), Cin, (1, 1), (1, 1), (0, 0), (1, 1)).view(rows, Cin)
         wt = ops.mark_static(_pad4(st.w.t()).contiguous())               # [Cin, Cout (+ pad)]
-        return ops.matmul_nt(gl4, wt, addend=addend, track_absmax=False)
+        if rnorm is not None:             # (the |x| term of the scale's derivative: added by the launch's epilogue)
+            return ops.matmul_nt_with_row_term(gl4, wt, st.x.view(rows, Cin), rnorm)
+        return ops.matmul_nt(gl4, wt, track_absmax=False)
 
     @staticmethod
     def _ln_fwd(ln, x2, want_absmax=True):

@@ -583,16 +583,24 @@ __device__ __forceinline__ void epi_part_generic(float* smem, const int pm, cons
 //     loads, so the loop body has no predicates,
 //   * keeps the per-row values (output offset, 1 / norm, inverse operand scale, pixel index) as one 16-byte LDS record.
 // Anything else (MaxOut, B != 2, GELU, replayed gates, ragged Cout, tensors >= 2 GiB, ...) takes the general epilogue.
-enum : int { EF_ADDEND = 1, EF_RELU = 2, EF_SCALE_OUT = 4, EF_MUL = 8, EF_OUT2 = 16, EF_MUL2 = 32, EF_GELU = 64, EF_MULACT = 128, EF_NONE = -1 };
+enum : int { EF_ADDEND = 1, EF_RELU = 2, EF_SCALE_OUT = 4, EF_MUL = 8, EF_OUT2 = 16, EF_MUL2 = 32, EF_GELU = 64, EF_MULACT = 128, EF_ROWADD = 256, EF_NONE = -1 };
 // forward kinds (NORM kernels): B = 2 scale, optional bias / channel affine;  backward kinds (no norm): gradient multipliers
 // (the GELU kinds are the linear1 layers of the B-cosified ViTs: MyGELU with its gate folded into the stored multiplier)
 constexpr int EPI_KINDS_FWD[] = {EF_RELU | EF_SCALE_OUT, EF_RELU | EF_SCALE_OUT | EF_ADDEND, EF_SCALE_OUT, EF_RELU, EF_RELU | EF_ADDEND, 0,
                                  EF_GELU | EF_SCALE_OUT, EF_GELU};
 constexpr int EPI_KINDS_BWD[] = {EF_MUL, EF_MUL | EF_ADDEND | EF_OUT2, EF_MUL | EF_ADDEND | EF_OUT2 | EF_MUL2, 0, EF_ADDEND, EF_MUL | EF_OUT2,
-                                 EF_MUL | EF_MULACT, EF_NONE};       // MULACT: the multiplier is rebuilt from the kept activation (BCOS_EPI_MUL_FROM_ACT)
+                                 EF_MUL | EF_MULACT, EF_ADDEND | EF_ROWADD};       // MULACT: the multiplier is rebuilt from the kept activation (BCOS_EPI_MUL_FROM_ACT);
+                                                                                   // ROWADD: out = acc + (rowadd_scale[pixel] rowadd + addend), the addend optional (bcos_epilogue.rowadd)
 constexpr int N_EPI_KINDS = 8;
 
 struct __attribute__((aligned(16))) EpiRow { unsigned off; float rinv; float ainv; int pix; };
+
+// a * b rounded, THEN + c rounded (no fused multiply-add: the two passes this stands in for round twice)
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float prod = a * b;
+    return prod + c;
+}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -633,6 +641,7 @@ __device__ __forceinline__ void epi_rows_fast(float* smem, const float* ss, cons
             }
             sRow[r].rinv = __uint_as_float(aoff);
         }
+        if (!NORM && e.rowadd != nullptr) sRow[r].rinv = pix >= 0 ? e.rowadd_scale[pix] : 0.f;      // (host: rowadd excludes addend_sub > 1)
     }
     // output pixel of tile row r (bcos_epilogue.row_scale / a_sumsq are indexed by it), or -1
     auto row_pix = [&](int r) -> int {
@@ -695,6 +704,8 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     static_assert(!(RELU && GELU), "one activation");
     constexpr bool MULACT = (EF & EF_MULACT) != 0;
     static_assert(!MULACT || (MUL && !OUT2), "rebuilt multipliers: plain gradient launches");
+    constexpr bool ROWADD = (EF & EF_ROWADD) != 0;
+    static_assert(!ROWADD || (!NORM && ADDEND && !MUL && !OUT2), "row-scaled addend: plain gradient launches");
     float* sC = smem;
     EpiRow* sRow = reinterpret_cast<EpiRow*>(smem + SBM * LDC);    // [BM]
     float* sNorm = reinterpret_cast<float*>(sRow + BM);            // [BM] patch norm (for norm_out)
@@ -704,7 +715,10 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     const unsigned tbytes = p.out_bytes;
     auto rsrc = [&](const void* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q), 0, tbytes, 0x00020000); };
     const __amdgpu_buffer_rsrc_t r_out = rsrc(e.out);
-    const __amdgpu_buffer_rsrc_t r_ad = rsrc(ADDEND ? e.addend : e.out);
+    // (ROWADD: the addend is optional -- a descriptor of zero records answers every load with zeros)
+    const __amdgpu_buffer_rsrc_t r_ad = (ROWADD && e.addend == nullptr)
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.out), 0, 0, 0x00020000) : rsrc(ADDEND ? e.addend : e.out);
+    const __amdgpu_buffer_rsrc_t r_radd = rsrc(ROWADD ? e.rowadd : e.out);
     const __amdgpu_buffer_rsrc_t r_mul = rsrc(MUL ? e.mul : e.out);
     const __amdgpu_buffer_rsrc_t r_mul2 = rsrc(MUL2 ? e.mul2 : e.out);
     const __amdgpu_buffer_rsrc_t r_out2 = rsrc(OUT2 ? e.out2 : e.out);
@@ -732,7 +746,7 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     constexpr int CPR = SBN / 4;
     constexpr int RPP = NT / CPR;
     constexpr int PASSES = SBM / RPP;
-    constexpr int NIN = (ADDEND ? 1 : 0) + (MUL ? 1 : 0) + (MUL2 ? 1 : 0);
+    constexpr int NIN = (ADDEND ? 1 : 0) + (MUL ? 1 : 0) + (MUL2 ? 1 : 0) + (ROWADD ? 1 : 0);
     // (the narrow split-f16 forward kernels are compiled for three workgroups per CU -- 168 registers: 4 chunks there)
     constexpr int G = (NIN <= 1 && PASSES % 8 == 0 && NT <= 256 && PM * PN == 1 && !(SCALED && NORM && BN <= 64)) ? 8 : (PASSES % 4 == 0 ? 4 : 2);
     static_assert(PASSES % G == 0, "epilogue grouping");
@@ -772,12 +786,13 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
     for (int p0 = 0; p0 < PASSES; p0 += G) {
         EpiRow rw[G];
         unsigned voff[G];
-        f32x4 ad[G], m1[G], m2[G];
+        f32x4 ad[G], m1[G], m2[G], xr[G];
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             const int lrow = rbase + (p0 + u) * RPP;
             rw[u] = sRow[(lrow / HM) * WM + pm * HM + lrow % HM];
             voff[u] = (rw[u].off + coloff) | ((rw[u].off | coloff) & OOB);
+            if (ROWADD) xr[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_radd, (int)voff[u], 0, 0));      // (x is read again by the weight gradient: default cache policy)
             if (ADDEND && !NORM && asub) {
                 const unsigned aoff = __float_as_uint(rw[u].rinv);
                 ad[u] = ldq(r_ad, (aoff + coloff) | ((aoff | coloff) & OOB));
@@ -800,7 +815,12 @@ __device__ __forceinline__ void epi_part_fast(float* smem, const int pm, const i
             }
             val = val * csc4 + csh4;
             s *= csc4;
-            if (ADDEND) val += ad[u];
+            if (ROWADD) {
+                // (the roundings of bcos_patch_norm_bwd_add followed by a plain addend -- acc + ((x r) + addend), product and sum rounded
+                //  separately as that kernel does: the fused launch gives the bits of the two passes it replaces)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) val[q] += mul_then_add(xr[u][q], rw[u].rinv, ad[u][q]);
+            } else if (ADDEND) val += ad[u];
             if (RELU) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -924,18 +944,12 @@ __device__ __forceinline__ void tile_epilogue(const auto& p, float* smem, f32x16
         epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, (NORM ? EPI_KINDS_FWD[I] : EPI_KINDS_BWD[I])>(smem, pm, pn, part, \
                                                                                                                 n0, tile_n, kpin); \
         break;
-#define BCOS_EPI_CASE_FWD(I)                                                                                                 \
-    case I + 1:                                                                                                              \
-        if constexpr (NORM)                                                                                                  \
-            epi_part_fast<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT, EPI_KINDS_FWD[I]>(smem, pm, pn, part, n0, tile_n, kpin); \
-        break;
         switch (kind) {
             BCOS_EPI_CASE(0) BCOS_EPI_CASE(1) BCOS_EPI_CASE(2) BCOS_EPI_CASE(3) BCOS_EPI_CASE(4) BCOS_EPI_CASE(5)
-            BCOS_EPI_CASE(6) BCOS_EPI_CASE_FWD(7)
+            BCOS_EPI_CASE(6) BCOS_EPI_CASE(7)
             default: epi_part_generic<BM, BN, WAVES_M, WAVES_N, NORM, SCALED, NT>(smem, pm, pn, part, n0, tile_n, kpin);
         }
 #undef BCOS_EPI_CASE
-#undef BCOS_EPI_CASE_FWD
 #if BCOS_PHASE_TIMING
         if constexpr (part == 0) {
             if (threadIdx.x == 0) {
@@ -3884,6 +3898,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 if (e2.out2_absmax) e2.out2_absmax += opix;
                 if (e2.out_imgmax) e2.out_imgmax += n0;
                 if (e2.out_imgmin_c) e2.out_imgmin_c += n0;
+                if (e2.rowadd) e2.rowadd += opix * p.g.out_pitch;
+                if (e2.rowadd_scale) e2.rowadd_scale += opix;
                 bcos_operands o2 = *ops;
                 o2.a = a + (int64_t)n0 * g.H * g.W * p.g.a_pitch;
                 if (o2.a_absmax) o2.a_absmax += (int64_t)n0 * g.H * g.W;
@@ -3951,7 +3967,8 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                  (!e.out2 || e.mul) && (!e.out2_absmax || e.out2);
             // out2 is either ungated or gated by the low bit of mul (BCOS_EPI_GATE2_FROM_MUL): both are what the kinds compute
             ef = (e.addend ? EF_ADDEND : 0) | (e.mul ? EF_MUL : 0) | (e.out2 ? EF_OUT2 : 0) | (e.mul2 ? EF_MUL2 : 0) |
-                 ((e.flags & BCOS_EPI_MUL_FROM_ACT) ? EF_MULACT : 0);
+                 ((e.flags & BCOS_EPI_MUL_FROM_ACT) ? EF_MULACT : 0) | (e.rowadd ? (EF_ROWADD | EF_ADDEND) : 0);
+            if (e.rowadd) ok = ok && e.rowadd_scale && e.addend_sub <= 1 && !(reinterpret_cast<uintptr_t>(e.rowadd) & 15) && g.out_cgroup == 0;
             if (e.flags & BCOS_EPI_MUL_FROM_ACT)
                 ok = ok && ((reinterpret_cast<uintptr_t>(e.mul_csc) | reinterpret_cast<uintptr_t>(e.mul_csh)) & 15) == 0;
         }
@@ -3961,6 +3978,9 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
                 if (kinds[k] == ef) { p.epi_kind = k + 1; p.out_bytes = (unsigned)obytes; break; }
         }
     }
+    if (epi->rowadd && (p.epi_kind == 0 || (epi->bcos_mode != BCOS_NONE)))
+        return bcos_set_error(BCOS_E_NOSUP, "bcos_tapconv: rowadd / rowadd_scale belong to a plain gradient launch that takes a specialised epilogue "
+                                            "(16-byte addressable tensors < 2 GiB, Cout % 4 == 0, no mul / out2 / addend_sub): use bcos_patch_norm_bwd_add");
     {   // per-image range of the emitted maxima (bcos_epilogue.out_imgmax / out_imgmin_c): folded into the specialised epilogues only, for
         // launches whose tiles span at most 16 images (256 rows at >= 19 rows per image), plain output mapping, one group
         const bool fuses = p.epi_kind > 0 && epi->out_absmax && g.out_cgroup == 0 && G == 1 && (int64_t)g.P * g.Q >= 19;
@@ -3973,7 +3993,7 @@ extern "C" int bcos_tapconv_ops(const bcos_operands* ops, const bcos_tapconv_geo
     }
     const bool norm = epi->bcos_mode != BCOS_NONE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1 && epi->addend_sub <= 1 && !epi->row_scale && !epi->a_sumsq) {
+    if (g.Cout <= 8 && G == 1 && !epi->out_absmax && !epi->out2_absmax && epi->max_out <= 1 && epi->addend_sub <= 1 && !epi->row_scale && !epi->a_sumsq && !epi->rowadd) {
         const int handled = bcos_try_skinny(a, wt, p.g, p.e, p.M, s);
         if (handled != 0) return handled < 0 ? handled : BCOS_OK;
     }

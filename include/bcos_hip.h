@@ -157,6 +157,13 @@ typedef struct bcos_epilogue {
     uint32_t* out_imgmin_c; /* ... and a LOWER BOUND of the min over the NONZERO pixels of image n, stored complemented (~v; 0 = no nonzero
                                pixel): exact when a tile owns its pixels (one column tile), the minimum over the column tiles' own maxima
                                otherwise.  Handed on as bcos_operands.a_imgmin_c.                                                     */
+    const float* rowadd;    /* NULL or a tensor indexed like `out` (ABI v9), with rowadd_scale [output pixels]: a plain gradient launch
+                               (bcos_mode BCOS_NONE, no mul / out2, addend_sub <= 1) writes out = acc + (rowadd_scale[pixel] * rowadd + addend)
+                               -- the patch-norm term of a 1 x 1 / stride-1 B-cos layer's input gradient, x * (sum over the patches that
+                               contain the pixel of r) = x[pixel] * r[pixel], which bcos_patch_norm_bwd_add otherwise writes as a tensor of
+                               its own for this launch to read back as `addend`.  Specialised epilogues only: BCOS_E_NOSUP otherwise
+                               (the caller falls back to bcos_patch_norm_bwd_add).                                                    */
+    const float* rowadd_scale;
     int32_t bcos_mode;      /* BCOS_NONE / BCOS_CONV_EPS / BCOS_LINEAR_EPS */
     int32_t relu;           /* 0 none, 1 ReLU, 2 GELU with constant gate  */
     float b;                /* the B-cos exponent B (2 = fast path)       */

@@ -164,6 +164,8 @@ int main(void) {
     { uint32_t* img = am + 64; e.out_imgmax = img; e.out_imgmin_c = img + 8;        /* the pair without out_absmax / outside a fusing launch */
       EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_NOSUP); e.out_imgmin_c = NULL;
       EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_NOSUP); e.out_imgmax = NULL; }
+    { e.rowadd = buf;                                                               /* a row-scaled addend without its scales */
+      EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_NOSUP); e.rowadd = NULL; }
     EXPECT(bcos_stream_copy(NULL, buf, 16, NULL), BCOS_E_INVAL);
     EXPECT(bcos_stream_copy(buf, buf + 1, 16, NULL), BCOS_E_INVAL);      /* misaligned */
     EXPECT(bcos_stream_copy(buf, buf, 6, NULL), BCOS_E_INVAL);           /* n % 4 */

@@ -15,7 +15,8 @@ from bcos_hip.lib import (BCOS_CONV_EPS, BCOS_EPI_FORCE_POW, BCOS_EPI_GATE2_FROM
 def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, bias=None, ch_scale=None,
             ch_shift=None, addend=None, mul=None, mul2=None, gate2=None, relu_gate=None, bcos_mode=BCOS_NONE,
             b=2.0, relu=False, flags=0, contraction=None, track_absmax=None, track_absmax2=None, max_out=1,
-            mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0, col_scale=None, row_scale=None, a_sumsq=None):
+            mul_norm=None, mul_csc=None, mul_csh=None, addend_sub=0, col_scale=None, row_scale=None, a_sumsq=None, rowadd=None,
+            rowadd_scale=None):
     # contraction / track_absmax*: how the device evaluates the products and which side tensors it emits for the next
     # launch's operand scaling -- no effect on the documented result
     g = dict(a_pitch=0, out_pitch=0, norm_pitch=0, out_cgroup=0, groups=0)
@@ -133,6 +134,10 @@ def tapconv(a, wt, geom, *, out=None, out2=None, scale_out=None, norm_out=None, 
         v = v + rd(full)
     elif addend is not None:
         v = v + rd(addend)
+    if rowadd is not None:        # include/bcos_hip.h: bcos_epilogue.rowadd -- a plain gradient launch: + rowadd_scale[output pixel] * rowadd
+        assert bcos_mode == BCOS_NONE and mul is None and out2 is None and addend_sub <= 1 and not cg and rowadd_scale is not None
+        rs = rowadd_scale.view(N, g["OH"], g["OW"], 1)
+        v = v + rd(rowadd) * rs[:, oh][:, :, ow].double()
     if relu == 2:
         gate = 0.5 * (1 + torch.erf(v / 2 ** 0.5))
         s = s * gate

@@ -236,6 +236,58 @@ def test_training_plan_frozen_batchnorm_and_maxout_refusal_on_device(lib):
     H.check_frozen_batchnorm_and_maxout("cuda", tol_out=1e-4, tol=2e-3)
 
 
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_patch_norm_term_in_the_input_gradient_epilogue(lib, with_addend):
+    """bcos_epilogue.rowadd (ABI v9): the input-gradient launch of a pointwise layer adds x[pixel] * r[pixel] (+ the shortcut's gradient)
+    itself.  Same bits as bcos_patch_norm_bwd_add followed by a plain addend (acc + (x r + addend) in both), on a launch with ragged row
+    tiles; a strided layer and a launch the library cannot specialise keep the separate pass through the same entry point."""
+    from bcos_hip import ops
+    torch.manual_seed(3)
+    dev = "cuda"
+    for (N, H, Cin, Cout) in [(3, 14, 256, 64), (2, 9, 64, 256), (2, 7, 512, 128)]:
+        w = (torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5).to(dev)
+        x = torch.randn(N, H, H, Cin, device=dev)
+        glin = ops.ensure_absmax(torch.randn(N, H, H, Cout, device=dev))
+        rnorm = torch.randn(N * H * H, device=dev) * 0.1
+        extra = torch.randn(N, H, H, Cin, device=dev) if with_addend else None
+        plan = ops.DgradPlan(w, (1, 1), (0, 0))
+        assert plan.pointwise
+        fused = plan.run_with_patch_norm(glin, x, rnorm, Cin, H, H, addend=extra)
+        apart = plan.run(glin, H, H, addend=ops.patch_norm_bwd(x, rnorm.view(N, H, H), Cin, (1, 1), (1, 1), (0, 0), (1, 1), addend=extra))
+        want = torch.einsum("nhwo,oc->nhwc", glin.double(), w.view(Cout, Cin).double()) + x.double() * rnorm.view(N, H, H, 1).double()
+        if extra is not None:
+            want = want + extra.double()
+        assert rel(apart, want) <= 1e-5
+        assert torch.equal(fused, apart), float((fused - apart).abs().max())
+    # a strided layer: the entry point takes the separate pass (same result as before)
+    w = (torch.randn(64, 32, 3, 3) / 17.0).to(dev)
+    x = torch.randn(2, 12, 12, 32, device=dev)
+    glin = ops.ensure_absmax(torch.randn(2, 6, 6, 64, device=dev))
+    rnorm = torch.randn(2 * 6 * 6, device=dev) * 0.1
+    plan = ops.DgradPlan(w, (2, 2), (1, 1))
+    assert not plan.pointwise
+    a = plan.run_with_patch_norm(glin, x, rnorm, 32, 12, 12)
+    b = plan.run(glin, 12, 12, addend=ops.patch_norm_bwd(x, rnorm.view(2, 6, 6), 32, (3, 3), (2, 2), (1, 1), (1, 1)))
+    assert torch.equal(a, b)
+    # the library refuses what it cannot fuse, with BCOS_E_NOSUP (the general epilogue: forced here by the test switch)
+    from bcos_hip import lib as L
+    w = (torch.randn(64, 64, 1, 1) / 8.0).to(dev)
+    x = torch.randn(2, 8, 8, 64, device=dev)
+    glin = ops.ensure_absmax(torch.randn(2, 8, 8, 64, device=dev))
+    rnorm = torch.randn(128, device=dev)
+    plan = ops.DgradPlan(w, (1, 1), (0, 0))
+    L.set_option("epi_generic", 1)
+    try:
+        with pytest.raises(L.BcosHipError) as ei:
+            plan.run(glin, 8, 8, rowadd=x, rowadd_scale=rnorm)
+        assert ei.value.code == L.BCOS_E_NOSUP
+        c = plan.run_with_patch_norm(glin, x, rnorm, 64, 8, 8)        # ... and the entry point falls back
+    finally:
+        L.set_option("epi_generic", 0)
+    d = plan.run_with_patch_norm(glin, x, rnorm, 64, 8, 8)
+    assert rel(c, d) <= 1e-6
+
+
 def test_wgrad_kernel_on_resnet_shapes(lib):
     """The weight gradient at real layer sizes against fp64 autograd: bcos_conv2d_wgrad_ordered (round 6: bf16 planes split once at
     staging, the pixel chunks' partial tiles added in a fixed order -- bit-identical from call to call, into a buffer that was NOT zeroed)
