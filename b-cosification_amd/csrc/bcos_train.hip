@@ -185,6 +185,43 @@ __global__ __launch_bounds__(256) void patch_norm_bwd_kernel(const float* __rest
     }
 }
 
+// The same for C = 64 / 128 channels (the 3 x 3 layers at 56^2 / 28^2, where one wave per pixel left 48 / 32 of its lanes without a
+// float4): LPP = C / 4 lanes per pixel, 64 / LPP pixels per wave; the taps go to the first lanes of the pixel's group and meet by a
+// butterfly over the group -- for kh kw <= LPP the very additions of the kernel above (its upper butterfly steps add zeros), so the bits
+// do not change.
+template <int LPP>
+__global__ __launch_bounds__(256) void patch_norm_bwd_group_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ add,
+                                                                   float* __restrict__ out, int N, int H, int W, int C, int x_pitch,
+                                                                   int P, int Q, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                                                                   int dw) {
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPP;
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t pix = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;
+    const bool live = pix < total;                 // (whole groups: the shuffles below stay inside a group)
+    float t = 0.f;
+    if (live) {
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const int n = (int)(pix / ((int64_t)W * H));
+        if (sub < kh * kw) {
+            const int th = sub / kw, tw = sub - th * kw;
+            const int hn = h + ph - th * dh, wn = w + pw - tw * dw;
+            if (hn >= 0 && wn >= 0 && hn % sh == 0 && wn % sw == 0) {
+                const int i = hn / sh, j = wn / sw;
+                if (i < P && j < Q) t = r[((int64_t)n * P + i) * Q + j];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (!live) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * x_pitch + sub * 4) * t;
+    if (add) v += *reinterpret_cast<const f32x4*>(add + pix * C + sub * 4);
+    *reinterpret_cast<f32x4*>(out + pix * C + sub * 4) = v;
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------------------------
 // gw[co][th][tw][ci] += sum_m glin[m, co] * x[pix(m, th, tw), ci]: per (128 co x 128 ci tile, tap, pixel chunk) one workgroup;
 // operands staged pixel-major through LDS ([32 pixels][128 channels], the memory order), fragments of v_mfma_f32_32x32x2_f32
@@ -1062,7 +1099,19 @@ extern "C" int bcos_patch_norm_bwd_add(const float* x, const float* rnorm, const
     const int vec = (C % 4 == 0 && x_pitch % 4 == 0 &&
                      !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(addend)) & 15)) ? 1 : 0;
     const int64_t total = (int64_t)N * H * W;
-    hipLaunchKernelGGL(patch_norm_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (vec && (C == 64 || C == 128) && kh * kw <= C / 4) {
+        const int ppb = 4 * (256 / C);             // pixels per workgroup
+        const dim3 grid((unsigned)((total + ppb - 1) / ppb));
+        if (C == 64)
+            hipLaunchKernelGGL(patch_norm_bwd_group_kernel<16>, grid, dim3(256), 0, s, x, rnorm, addend, out, N, H, W, C, x_pitch, P, Q, kh, kw,
+                               sh, sw, ph, pw, dh, dw);
+        else
+            hipLaunchKernelGGL(patch_norm_bwd_group_kernel<32>, grid, dim3(256), 0, s, x, rnorm, addend, out, N, H, W, C, x_pitch, P, Q, kh, kw,
+                               sh, sw, ph, pw, dh, dw);
+        return check_launch("patch_norm_bwd launch");
+    }
+    hipLaunchKernelGGL(patch_norm_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s,
                        x, rnorm, addend, out, N, H, W, C, x_pitch, P, Q, kh, kw, sh, sw, ph, pw, dh, dw, vec);
     return check_launch("patch_norm_bwd launch");
 }

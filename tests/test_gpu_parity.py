@@ -288,6 +288,27 @@ def test_patch_norm_term_in_the_input_gradient_epilogue(lib, with_addend):
     assert rel(c, d) <= 1e-6
 
 
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_patch_norm_term_of_a_3x3_layer_has_one_summation_order(lib, C):
+    """bcos_patch_norm_bwd(_add): out = x * (sum of r over the patches that contain the pixel) + addend.  The one-wave-per-pixel kernel and the
+    4 / 2-pixels-per-wave kernel of the 64- / 128-channel layers (round 6) add the nine taps in ONE order -- the butterfly
+    [((r0 + r8) + r4) + (r2 + r6)] + [(r1 + r5) + (r3 + r7)], tap t = 3 th + tw -- so a layer's bits do not depend on its width."""
+    from bcos_hip import ops
+    torch.manual_seed(C)
+    N, H, W = 2, 13, 11
+    x = torch.randn(N, H, W, C, device="cuda")
+    r = torch.randn(N, H, W, device="cuda")
+    add = torch.randn(N, H, W, C, device="cuda")
+    got = ops.patch_norm_bwd(x, r, C, (3, 3), (1, 1), (1, 1), (1, 1), addend=add)
+    rp = F.pad(r, (1, 1, 1, 1))                                      # tap (th, tw) of pixel (h, w) reads r[h + 1 - th, w + 1 - tw]
+    tap = [rp[:, 2 - th:2 - th + H, 2 - tw:2 - tw + W] for th in range(3) for tw in range(3)]
+    t = (((tap[0] + tap[8]) + tap[4]) + (tap[2] + tap[6])) + ((tap[1] + tap[5]) + (tap[3] + tap[7]))
+    want = x * t[..., None] + add
+    assert torch.equal(got, want), float((got - want).abs().max())
+    want64 = x.double() * sum(tp.double() for tp in tap)[..., None] + add.double()
+    assert rel(got, want64) <= 1e-6
+
+
 def test_wgrad_kernel_on_resnet_shapes(lib):
     """The weight gradient at real layer sizes against fp64 autograd: bcos_conv2d_wgrad_ordered (round 6: bf16 planes split once at
     staging, the pixel chunks' partial tiles added in a fixed order -- bit-identical from call to call, into a buffer that was NOT zeroed)
