@@ -624,24 +624,54 @@ class DgradPlan:
         self.stride, self.padding, self.dilation = (sh, sw), (ph, pw), tuple(dilation)
         self.Cin, self.Cout, self.k, self.groups = Cin, Cout, (kh, kw), G
         self.classes = []     # (rho_h, rho_w, TH, TW, dh0, dw0, weight [Cin,TH,TW,Cout] or None)
-        for rh in range(sh):
-            rs_h, dh0, step_h = self._taps(rh, sh, ph, kh, dilation[0])
-            for rw in range(sw):
-                rs_w, dw0, step_w = self._taps(rw, sw, pw, kw, dilation[1])
-                if len(rs_h) == 0 or len(rs_w) == 0:
-                    self.classes.append((rh, rw, 0, 0, 0, 0, 1, 1, None))
-                    continue
-                sub = _take_taps(_take_taps(w_oihw, 2, rs_h, kh), 3, rs_w, kw)      # [Cout,Cin/G,TH,TW]
-                if G == 1:
-                    wt = sub.permute(1, 2, 3, 0).contiguous()               # [Cin,TH,TW,Cout]
-                else:                                                       # [G Cin/G, TH, TW, Cout/G]: the groups' transposed filters, stacked
-                    cg = Cout // G
-                    wt = torch.cat([sub[k * cg:(k + 1) * cg].permute(1, 2, 3, 0) for k in range(G)], 0).contiguous()
-                mark_static(wt, transient)     # a DgradPlan is built once per weight version (engine plan / WeightCache)
-                self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
+        for (rh, rw, rs_h, rs_w, dh0, dw0, step_h, step_w) in self.class_taps((kh, kw), (sh, sw), (ph, pw), dilation):
+            if len(rs_h) == 0 or len(rs_w) == 0:
+                self.classes.append((rh, rw, 0, 0, 0, 0, 1, 1, None))
+                continue
+            sub = _take_taps(_take_taps(w_oihw, 2, rs_h, kh), 3, rs_w, kw)      # [Cout,Cin/G,TH,TW]
+            if G == 1:
+                wt = sub.permute(1, 2, 3, 0).contiguous()               # [Cin,TH,TW,Cout]
+            else:                                                       # [G Cin/G, TH, TW, Cout/G]: the groups' transposed filters, stacked
+                cg = Cout // G
+                wt = torch.cat([sub[k * cg:(k + 1) * cg].permute(1, 2, 3, 0) for k in range(G)], 0).contiguous()
+            mark_static(wt, transient)     # a DgradPlan is built once per weight version (engine plan / WeightCache)
+            self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
         self.has_empty = any(c[8] is None for c in self.classes)
         self.transient = bool(transient)
         self._d2s = {}        # channel pitch -> (weights [sh*sw*pitch, TH, TW, Cout], TH, TW, dh0, dw0), see _depth_to_space
+
+    @classmethod
+    def class_taps(cls, k, stride, padding, dilation=(1, 1)):
+        """The parity classes of the input gradient of a k / stride / padding convolution, in the order of `classes`:
+        [(rho_h, rho_w, rs_h, rs_w, dh0, dw0, step_h, step_w)] -- rs_h / rs_w: the filter taps of the class in the order its launch walks them
+        (empty: no tap reaches the class)."""
+        out = []
+        for rh in range(stride[0]):
+            rs_h, dh0, step_h = cls._taps(rh, stride[0], padding[0], k[0], dilation[0])
+            for rw in range(stride[1]):
+                rs_w, dw0, step_w = cls._taps(rw, stride[1], padding[1], k[1], dilation[1])
+                out.append((rh, rw, rs_h, rs_w, dh0, dw0, step_h, step_w))
+        return out
+
+    @classmethod
+    def from_banks(cls, Cin, Cout, k, stride, padding, dilation, banks):
+        """A plan over weight banks made elsewhere (WeightPrepBatch: the training plans rebuild every bank of a step by ONE launch): `banks`
+        [i] = the [Cin, TH, TW, Cout] bank of class i of class_taps(...), None where the class has no tap.  groups = 1."""
+        if (dilation[0] != 1 or dilation[1] != 1) and (stride[0] != 1 or stride[1] != 1):
+            raise BcosHipError("dgrad with dilation > 1 and stride > 1 is not supported")
+        self = cls.__new__(cls)
+        self.stride, self.padding, self.dilation = tuple(stride), tuple(padding), tuple(dilation)
+        self.Cin, self.Cout, self.k, self.groups = int(Cin), int(Cout), tuple(k), 1
+        self.classes = []
+        for (rh, rw, rs_h, rs_w, dh0, dw0, step_h, step_w), wt in zip(cls.class_taps(k, stride, padding, dilation), banks):
+            if len(rs_h) == 0 or len(rs_w) == 0:
+                self.classes.append((rh, rw, 0, 0, 0, 0, 1, 1, None))
+            else:
+                self.classes.append((rh, rw, len(rs_h), len(rs_w), dh0, dw0, step_h, step_w, wt))
+        self.has_empty = any(c[8] is None for c in self.classes)
+        self.transient = False
+        self._d2s = {}
+        return self
 
     def _depth_to_space(self, pitch: int):
         """All parity classes of a narrow strided input gradient as ONE contraction (bcos_tapconv_geom.out_cgroup): rows =
@@ -804,6 +834,90 @@ class DgradPlan:
                 raise BcosHipError(f"dgrad parity class without taps does not support epilogue field {k}")
         if epi.get("relu"):
             raise BcosHipError("dgrad parity class without taps does not support relu")
+
+
+class WeightPrepBatch:
+    """Weight banks and f16x2 images of MANY layers, kept in buffers of their own and rebuilt from the layers' parameters by ONE launch
+    (include/bcos_hip.h: bcos_weight_prep_batch).  A training step changes every weight once; per layer, the forward bank (NHWC filters) and
+    its image, the transposed / tap-reversed banks of the input-gradient classes and theirs, each made by two to five small launches
+    (layout copy, flip, row scale, split), were ~350 launches of a ResNet-50 step.  add_*() registers a job and hands out the bank tensor
+    -- marked static, with its image attached where tapconv looks for it -- and run() refreshes all of them on the current stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._jobs, self._srcs, self._banks, self._keep = [], [], [], []
+        self._table = None
+        self._max_rows = 0
+
+    def _add(self, src, bank_shape, rows, channels, Cp, taps, row_stride, ch_stride, tap_offsets):
+        if taps > _l.PREP_MAX_TAPS or src.dtype != torch.float32 or not src.is_contiguous():
+            return None
+        lib = _l.load()
+        nbytes = C.c_int64(0)
+        _l.check(lib.bcos_split_weights_f16x2_bytes(rows, taps * Cp, C.byref(nbytes)), "bcos_split_weights_f16x2_bytes")
+        bank = torch.empty(bank_shape, device=self.device, dtype=torch.float32)
+        image = torch.empty(nbytes.value, device=self.device, dtype=torch.uint8)
+        j = _l.WeightPrepJob()
+        j.src, j.bank, j.image = src.data_ptr(), bank.data_ptr(), image.data_ptr()
+        j.rows, j.channels, j.Cp, j.taps, j.row_stride, j.ch_stride = rows, channels, Cp, taps, row_stride, ch_stride
+        for t, o in enumerate(tap_offsets):
+            j.tap_offset[t] = int(o)
+        mark_static(bank)
+        setattr(bank, f"_bcos_wt2_t{taps}", (bank._version, image))      # (where _image_of looks; the bank is never written through torch: its version stays)
+        self._jobs.append(j)
+        self._srcs.append(src)
+        self._banks.append(bank)
+        self._keep.append(image)
+        self._max_rows = max(self._max_rows, rows)
+        self._table = None
+        return bank
+
+    def add_forward(self, w_oihw):
+        """-> the [Cout, kh, kw, Cp] bank of OIHW weights (Cp = Cin rounded up to 4), or None where the batch cannot make it"""
+        Cout, Cin, kh, kw = w_oihw.shape
+        Cp = (Cin + 3) & ~3
+        return self._add(w_oihw, (Cout, kh, kw, Cp), Cout, Cin, Cp, kh * kw, Cin * kh * kw, kh * kw, range(kh * kw))
+
+    def add_linear(self, w2d):
+        """-> (the [Cout, Cp] bank of a linear layer's [Cout, Cin] weight, the [Cin, Coutp] bank of its transpose: what the forward launch
+        and the input-gradient launch of the layer read), or None"""
+        Cout, Cin = w2d.shape
+        Cp, Coutp = (Cin + 3) & ~3, (Cout + 3) & ~3
+        fwd = self._add(w2d, (Cout, Cp), Cout, Cin, Cp, 1, Cin, 1, (0,))
+        tr = self._add(w2d, (Cin, Coutp), Cin, Cout, Coutp, 1, 1, Cin, (0,))
+        return None if (fwd is None or tr is None) else (fwd, tr)
+
+    def add_dgrad(self, w_oihw, stride, padding, dilation=(1, 1)):
+        """-> DgradPlan over banks of this batch (its K dimension = Cout rounded up to 4 with zero filters), or None"""
+        Cout, Cin, kh, kw = w_oihw.shape
+        Cp = (Cout + 3) & ~3
+        banks = []
+        for (rh, rw, rs_h, rs_w, *_rest) in DgradPlan.class_taps((kh, kw), stride, padding, dilation):
+            if len(rs_h) == 0 or len(rs_w) == 0:
+                banks.append(None)
+                continue
+            offs = [a * kw + b for a in rs_h for b in rs_w]
+            bank = self._add(w_oihw, (Cin, len(rs_h), len(rs_w), Cp), Cin, Cout, Cp, len(offs), kh * kw, Cin * kh * kw, offs)
+            if bank is None:
+                return None
+            banks.append(bank)
+        return DgradPlan.from_banks(Cin, Cp, (kh, kw), stride, padding, dilation, banks)
+
+    def run(self):
+        """refresh every bank and image from the current values of the parameters (one launch on the current stream)"""
+        if not self._jobs:
+            return
+        moved = any(j.src != s.data_ptr() for j, s in zip(self._jobs, self._srcs))
+        if self._table is None or moved:
+            for j, s in zip(self._jobs, self._srcs):
+                j.src = s.data_ptr()
+            raw = b"".join(bytes(j) for j in self._jobs)
+            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        for b in self._banks:               # (an image tapconv made lazily of an earlier version of a bank -- the bf16x3 one -- is stale now)
+            if hasattr(b, "_bcos_wt3"):
+                del b._bcos_wt3
+        _l.check(_l.load().bcos_weight_prep_batch(C.c_void_p(self._table.data_ptr()), len(self._jobs), self._max_rows, _stream()),
+                 "bcos_weight_prep_batch")
 
 
 def weight_rownorm_scale(w2d, gain=None):

@@ -41,6 +41,7 @@ def _pad4(t: torch.Tensor) -> torch.Tensor:
 
 _SIDE_STREAM = os.environ.get("BCOS_TRAIN_SIDE_STREAM", "1") != "0"
 _PLAN_ARENAS = os.environ.get("BCOS_TRAIN_ARENAS", "1") != "0"        # development A/B: 0 = every operand-maxima tensor of a training pass its own zero fill (round 5)
+_WEIGHT_BATCH = os.environ.get("BCOS_TRAIN_WEIGHT_BATCH", "1") != "0"  # development A/B: 0 = every layer's banks and images from launches of its own, in front of the launch that reads them (round 5)
 
 
 class ParamGradQueue:
@@ -93,7 +94,7 @@ class ParamGradQueue:
 
 class _UnitState:
     __slots__ = ("x", "y", "scale", "norm", "w", "bias", "b", "force_pow", "mean", "rstd", "g", "act", "relu", "bn", "conv",
-                 "has_addend", "in_hw", "batch_stats")
+                 "has_addend", "in_hw", "batch_stats", "dplan")
 
 
 class ResNetTrainPlan:
@@ -109,6 +110,8 @@ class ResNetTrainPlan:
         # second forward before the first one's backward resets the forward arena only, and nothing of the backward reads forward maxima
         self._arena_f, self._arena_b = ops.AbsmaxArena(), ops.AbsmaxArena()
         self._nbt = []                 # num_batches_tracked buffers of the pass: advanced by ONE launch at its end (53 on a ResNet-50 before)
+        self._wbatch = None            # ops.WeightPrepBatch of the plan's layers (None: not built yet / not applicable), see _weights
+        self._wunits = {}              # id(conv) -> (weight parameter, forward bank or None, input-gradient plan or None)
 
     # ------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -132,6 +135,31 @@ class ResNetTrainPlan:
                 return False, "MaxOut layers keep the per-layer path"
         return True, ""
 
+    def _weights(self, device):
+        """Every weight bank and split image of the step from ONE launch (ops.WeightPrepBatch) at the top of the forward pass: the forward
+        banks, and the input-gradient plans the backward pass will run (kept across steps: only their contents change).  A layer whose
+        effective weight is not its parameter itself (or a contraction mode without f16x2 images) keeps the per-layer preparation."""
+        if not _WEIGHT_BATCH or torch.device(device).type != "cuda" or ops._l.get_contraction_mode() != "f16x2":
+            self._wunits = {}
+            return
+        if self._wbatch is None or self._wbatch.device != torch.device(device):
+            batch, units = ops.WeightPrepBatch(device), {}
+            first = next(iter(self.eng._all_convs()))
+            for c in self.eng._all_convs():
+                conv = c.module
+                w, _ = conv._effective_weight_and_bias()
+                p = conv.linear.weight
+                if not (isinstance(p, nn.Parameter) and w.data_ptr() == p.data_ptr() and tuple(w.shape) == tuple(p.shape) and p.is_contiguous()
+                        and p.dim() == 4 and getattr(c, "groups", 1) == 1):
+                    continue
+                wk = batch.add_forward(p)          # (the Parameter itself: the batch follows a replaced .data)
+                dplan = None
+                if c is not first and c.cin > 8:          # (the narrow stem gradient runs its one-launch forms over banks of their own)
+                    dplan = batch.add_dgrad(p, c.stride, c.padding, c.dilation)
+                units[id(c)] = (p, wk, dplan)
+            self._wbatch, self._wunits = batch, units
+        self._wbatch.run()
+
     def parameters(self) -> List[nn.Parameter]:
         """every parameter the plan reads, in a fixed order (the autograd Function's inputs)"""
         ps, seen = [], set()
@@ -151,7 +179,12 @@ class ResNetTrainPlan:
         batch_stats = bn is not None and (bn.training or (bn.running_mean is None and bn.running_var is None))
         w, bias = conv._effective_weight_and_bias()
         wd = w.detach()
-        wk = ops.mark_static(_pad4(wd.permute(0, 2, 3, 1)).contiguous())
+        pre = self._wunits.get(id(c))
+        if pre is not None and pre[1] is not None and pre[0] is conv.linear.weight and w.data_ptr() == pre[0].data_ptr():
+            wk = pre[1]                    # made by the step's one weight launch (_weights)
+        else:
+            pre = None
+            wk = ops.mark_static(_pad4(wd.permute(0, 2, 3, 1)).contiguous())
         N, H, W, Cp = x.shape
         Cout = wd.shape[0]
         kh, kw = c.k
@@ -168,6 +201,7 @@ class ResNetTrainPlan:
         st = _UnitState()
         st.conv, st.bn, st.x, st.y, st.scale, st.norm, st.w, st.bias, st.b, st.force_pow = c, bn, x, y, scale, norm, wd, bias, b, force_pow
         st.relu, st.has_addend, st.in_hw, st.batch_stats = relu, addend is not None, (H, W), batch_stats
+        st.dplan = pre[2] if pre is not None else None
         st.mean = st.rstd = st.g = None
         if bn is None:
             out = y
@@ -282,12 +316,14 @@ class ResNetTrainPlan:
             grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4.view(-1, gl4.shape[3]))[:Cout].contiguous(), (gl4,))
         gx = None
         if need_x:
-            wq = st.w
-            r = (-wq.shape[0]) % 4                                # the dgrad K dimension (Cout) padded with zero filters
-            if r:
-                wq = torch.cat([wq, wq.new_zeros((r,) + tuple(wq.shape[1:]))], 0)
-            plan = ops.DgradPlan(wq, c.stride, c.padding, c.dilation)
-            g_in = gl4 if (r or Cout % 4) else glin.contiguous()
+            plan = st.dplan
+            if plan is None:
+                wq = st.w
+                r = (-wq.shape[0]) % 4                            # the dgrad K dimension (Cout) padded with zero filters
+                if r:
+                    wq = torch.cat([wq, wq.new_zeros((r,) + tuple(wq.shape[1:]))], 0)
+                plan = ops.DgradPlan(wq, c.stride, c.padding, c.dilation)
+            g_in = gl4 if Cout % 4 else glin.contiguous()
             if pn_rnorm is not None:
                 gx = plan.run_with_patch_norm(g_in, x, pn_rnorm, cin, H, W, addend=addend)
             else:
@@ -299,6 +335,7 @@ class ResNetTrainPlan:
         self._nbt = []
         try:
             with ops.transient_weights(), (ops.absmax_arena(self._arena_f, x.device) if _PLAN_ARENAS else contextlib.nullcontext()):
+                self._weights(x.device)
                 return self._forward(x)
         finally:
             if self._nbt:

@@ -53,6 +53,7 @@ class ViTTrainPlan:
         self._arena_f, self._arena_b = ops.AbsmaxArena(), ops.AbsmaxArena()
         from .train_plan import ParamGradQueue
         self._pq = ParamGradQueue()           # weight gradients and column sums on a second stream
+        self._wbatch, self._wbanks = None, {}  # ops.WeightPrepBatch of the linear layers; id(parameter) -> (parameter, forward bank, transposed bank)
         self._zeros = ops.ZeroArena()         # their accumulators from one zero fill per pass
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -110,6 +111,31 @@ class ViTTrainPlan:
         return ps
 
     # ------------------------------------------------------------------------------------------------------------------
+    def _weights(self, device):
+        """every linear layer's forward and transposed weight bank, with their split images, from ONE launch at the top of the forward pass
+        (ops.WeightPrepBatch; train_plan.ResNetTrainPlan._weights) -- a ViT-Ti step made ~100 banks by ~250 small launches"""
+        from .train_plan import _WEIGHT_BATCH
+        if not _WEIGHT_BATCH or torch.device(device).type != "cuda" or ops._l.get_contraction_mode() != "f16x2":
+            self._wbanks = {}
+            return
+        if self._wbatch is None or self._wbatch.device != torch.device(device):
+            batch, banks = ops.WeightPrepBatch(device), {}
+            ws = [m.linear.weight for m in self._linears(self.eng) if m is not self.eng.embed_mod] + [blk["qkv"].weight for blk in self.eng.blocks]
+            for p in ws:
+                if isinstance(p, nn.Parameter) and p.dim() == 2 and p.is_contiguous() and id(p) not in banks:
+                    pair = batch.add_linear(p)
+                    if pair is not None:
+                        banks[id(p)] = (p,) + pair
+            self._wbatch, self._wbanks = batch, banks
+        self._wbatch.run()
+
+    def _bank(self, param, w, transposed: bool):
+        """the step's bank of `param` (forward or transposed) when `w` -- the weight a launch is about to read -- is that parameter"""
+        hit = self._wbanks.get(id(param))
+        if hit is None or hit[0] is not param or w.data_ptr() != param.data_ptr() or tuple(w.shape) != tuple(param.shape):
+            return None
+        return hit[2] if transposed else hit[1]
+
     @staticmethod
     def _lin_setup(mod, st):
         w, bias = mod._effective_weight_and_bias()
@@ -122,7 +148,9 @@ class ViTTrainPlan:
         """B-cos linear on [rows, Cin] with the scale differentiated: keeps x, y, s and |x| (+ eps) for the backward"""
         st = _LinState()
         bias = self._lin_setup(mod, st)
-        wk = ops.mark_static(st.w if st.w.is_contiguous() else st.w.contiguous())
+        wk = self._bank(mod.linear.weight, st.w, False)
+        if wk is None:
+            wk = ops.mark_static(st.w if st.w.is_contiguous() else st.w.contiguous())
         bcos = st.b != 1.0
         y, scale, norm = ops.linear_fwd(x2, wk, bias=bias, b=st.b, want_scale=bcos, want_norm=bcos,
                                         flags=BCOS_EPI_FORCE_POW if st.force_pow else 0)
@@ -160,7 +188,9 @@ class ViTTrainPlan:
             grads[lin.bias] = self._pq.run(lambda: ops.colsum(gl4)[:Cout].contiguous(), (gl4,))
         if not need_x:
             return None
-        wt = ops.mark_static(_pad4(st.w.t()).contiguous())               # [Cin, Cout (+ pad)]
+        wt = self._bank(st.mod.linear.weight, st.w, True)
+        if wt is None:
+            wt = ops.mark_static(_pad4(st.w.t()).contiguous())           # [Cin, Cout (+ pad)]
         if rnorm is not None:             # (the |x| term of the scale's derivative: added by the launch's epilogue)
             return ops.matmul_nt_with_row_term(gl4, wt, st.x.view(rows, Cin), rnorm)
         return ops.matmul_nt(gl4, wt, track_absmax=False)
@@ -196,6 +226,7 @@ class ViTTrainPlan:
         xd = x.detach()
         xd = xd if xd.is_contiguous() else xd.contiguous()
         with ops.transient_weights(), ops.no_absmax(), ops.absmax_arena(self._arena_f, xd.device):
+            self._weights(xd.device)
             return self._forward(xd)
 
     def _forward(self, xd):
@@ -233,7 +264,8 @@ class ViTTrainPlan:
             h1, rec["ln1"] = self._ln_fwd(blk["ln1"], cur)
             wq = blk["qkv"].weight.detach()
             rec["wq"] = wq
-            qkv = ops.matmul_nt(h1, ops.mark_static(wq if wq.is_contiguous() else wq.contiguous()), track_absmax=False)
+            wq_f = self._bank(blk["qkv"].weight, wq, False)
+            qkv = ops.matmul_nt(h1, wq_f if wq_f is not None else ops.mark_static(wq if wq.is_contiguous() else wq.contiguous()), track_absmax=False)
             rec["h1"] = h1
             a, stats = ops.attention_fwd(qkv.view(N, T, -1), blk["heads"], blk["scale"], want_stats=True, want_absmax=True)
             rec["qkv"], rec["stats"], rec["a"] = qkv, stats, a
@@ -311,7 +343,8 @@ class ViTTrainPlan:
                 acc = self._zeros.take((Cq, 1, 1, Cin), gq2.device) if not (ops.wgrad_is_ordered() and (Cq * 1 * 1 * Cin) % 4 == 0) else None
                 grads[wp] = self._pq.run(lambda: ops.conv2d_wgrad(gq2.view(1, 1, rows, Cq), h1.view(1, 1, rows, Cin), Cin, Cq, (1, 1), (1, 1),
                                                                   (0, 0), (1, 1), out=acc).view(Cq, Cin), (gq2, h1, acc))
-            gh1 = ops.matmul_nt(ops.ensure_absmax(gq2), ops.mark_static(rec["wq"].t().contiguous()), track_absmax=False)
+            wq_t = self._bank(wp, rec["wq"], True)
+            gh1 = ops.matmul_nt(ops.ensure_absmax(gq2), wq_t if wq_t is not None else ops.mark_static(rec["wq"].t().contiguous()), track_absmax=False)
             g = self._ln_bwd(rec["ln1"], gh1, grads, addend=g_x1)
             st["blocks"][bi] = None
         # patch embedding (the positional table is a constant): a p x p / stride p convolution over the NHWC input

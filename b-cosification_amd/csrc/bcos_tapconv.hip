@@ -3605,8 +3605,8 @@ __global__ __launch_bounds__(256) void split_weights_h2_fused_kernel(const float
     }
 }
 
-inline int64_t h2_tiles(int rows) { return (((int64_t)rows + 127) / 128) * 4; }
-inline int64_t h2_image_bytes(int rows, int Ktot) { return h2_tiles(rows) * (((int64_t)Ktot + 15) / 16) * 2 * 1024; }
+__host__ __device__ inline int64_t h2_tiles(int rows) { return (((int64_t)rows + 127) / 128) * 4; }
+__host__ __device__ inline int64_t h2_image_bytes(int rows, int Ktot) { return h2_tiles(rows) * (((int64_t)Ktot + 15) / 16) * 2 * 1024; }
 
 }  // namespace
 
@@ -3646,6 +3646,83 @@ extern "C" int bcos_split_weights_f16x2_conv(const float* wt, void* wt2, int row
     }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("split_weights_f16x2 launch", err);
+    return BCOS_OK;
+}
+
+// ---- banks + images of many layers in one launch (bcos_weight_prep_batch) ---------------------------------------------------------------
+namespace {
+// grid (32-row tiles, jobs): a workgroup gathers its tile's rows of the job's bank from the strided source (writing them out where the job
+// wants the fp32 bank), takes the row maxima, and writes the tile's fragments -- the arithmetic of weight_rowscale_kernel +
+// split_weights_h2_kernel on the gathered values (gathered twice: the weights are L2-sized), so the image is that pair's bit for bit.
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const bcos_weight_prep_job* __restrict__ jobs) {
+    __shared__ unsigned s_max[32];
+    __shared__ float s_scale[32];
+    const bcos_weight_prep_job& jb = jobs[blockIdx.y];
+    const int rows = jb.rows, taps = jb.taps, Cp = jb.Cp, channels = jb.channels;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tiles = (int)h2_tiles(rows);                       // (the image is padded to a multiple of 128 rows: empty tiles hold zeros)
+    if (tile >= tiles) return;
+    const int Ktot = taps * Cp;
+    const int row0 = tile * 32;
+    const int live = rows - row0 < 32 ? (rows - row0 < 0 ? 0 : rows - row0) : 32;
+    const float* __restrict__ src = jb.src;
+    auto gather = [&](int row, int k) -> float {                  // bank[row][k], k = t Cp + c
+        const int t = k / Cp, c = k - t * Cp;
+        return c < channels ? src[(int64_t)row * jb.row_stride + (int64_t)c * jb.ch_stride + jb.tap_offset[t]] : 0.f;
+    };
+    if (tid < 32) s_max[tid] = 0u;
+    __syncthreads();
+    {
+        const int n = live * Ktot;
+        float* bank = jb.bank;
+        for (int i = tid; i < n; i += 256) {
+            const int r = i / Ktot, k = i - r * Ktot;
+            const float v = gather(row0 + r, k);
+            if (bank) bank[(int64_t)(row0 + r) * Ktot + k] = v;
+            atomicMax(&s_max[r], __float_as_uint(v) & 0x7fffffffu);
+        }
+    }
+    __syncthreads();
+    if (jb.image == nullptr) return;
+    const int nk = (Ktot + 15) / 16;
+    uint4* wt2 = reinterpret_cast<uint4*>(jb.image);
+    float* cinv = reinterpret_cast<float*>(static_cast<char*>(jb.image) + h2_image_bytes(rows, Ktot));
+    if (tid < 32) {
+        unsigned E = s_max[tid] >> 23;
+        E = E < 15u ? 15u : E;
+        const float ci = __uint_as_float((E - 14u) << 23);
+        cinv[row0 + tid] = ci;
+        s_scale[tid] = 1.0f / ci;                                     // exact: a power of two
+    }
+    __syncthreads();
+    const int ktaps = (taps > 1 && taps <= H2_MAX_TAPS && Cp % 16 == 0) ? taps : 1;      // (bcos_split_weights_f16x2_conv: channel-chunk-major K)
+    const int lane = tid & 63;
+    const int row = row0 + (lane & 31);
+    const float scale = s_scale[lane & 31];
+    for (int ks = tid >> 6; ks < nk; ks += 4) {
+        const int k0 = ktaps > 1 ? (ks % ktaps) * Cp + (ks / ktaps) * 16 + 8 * (lane >> 5) : ks * 16 + 8 * (lane >> 5);
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (row < rows && k0 + e < Ktot) ? gather(row, k0 + e) * scale : 0.f;
+            const _Float16 hh = (_Float16)x;
+            h[e] = hh;
+            l[e] = (_Float16)(x - (float)hh);
+        }
+        uint4* dst = wt2 + ((int64_t)tile * nk + ks) * 2 * 64 + lane;
+        dst[0] = __builtin_bit_cast(uint4, h);
+        dst[64] = __builtin_bit_cast(uint4, l);
+    }
+}
+}  // namespace
+
+extern "C" int bcos_weight_prep_batch(const bcos_weight_prep_job* jobs, int njobs, int max_rows, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > 65535 || max_rows <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_weight_prep_batch: bad argument");
+    if (reinterpret_cast<uintptr_t>(jobs) & 7) return bcos_set_error(BCOS_E_INVAL, "bcos_weight_prep_batch: job table must be 8-byte aligned");
+    hipLaunchKernelGGL(weight_prep_batch_kernel, dim3((unsigned)h2_tiles(max_rows), (unsigned)njobs), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), jobs);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("weight_prep_batch launch", err);
     return BCOS_OK;
 }
 

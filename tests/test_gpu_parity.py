@@ -309,6 +309,60 @@ def test_patch_norm_term_of_a_3x3_layer_has_one_summation_order(lib, C):
     assert rel(got, want64) <= 1e-6
 
 
+def test_weight_banks_and_images_of_many_layers_from_one_launch(lib):
+    """bcos_weight_prep_batch (ABI v9; ops.WeightPrepBatch): the forward bank and the input-gradient banks of a set of layers, and their
+    f16x2 images, are what the per-layer preparation makes -- layout copy / flip / tap selection, bcos_split_weights_f16x2_conv -- bit
+    for bit; a second run() follows updated parameters; the plan over the banks gives the input gradient of the plan built per layer."""
+    from bcos_hip import ops
+    torch.manual_seed(11)
+    dev = "cuda"
+    shapes = [((64, 64, 1, 1), (1, 1), (0, 0)), ((64, 64, 3, 3), (1, 1), (1, 1)), ((128, 64, 3, 3), (2, 2), (1, 1)), ((256, 128, 1, 1), (2, 2), (0, 0)),
+              ((1000, 512, 1, 1), (1, 1), (0, 0)), ((64, 6, 7, 7), (2, 2), (3, 3)), ((30, 20, 3, 3), (1, 1), (1, 1))]
+    params = [torch.nn.Parameter((torch.randn(s) * (0.5 + i)).to(dev)) for i, (s, _, _) in enumerate(shapes)]
+    batch = ops.WeightPrepBatch(dev)
+    made = []
+    for p, (s, stride, padding) in zip(params, shapes):
+        made.append((batch.add_forward(p), batch.add_dgrad(p, stride, padding) if s[1] > 8 else None))
+
+    def check():
+        for p, (s, stride, padding), (wk, dplan) in zip(params, shapes, made):
+            Cout, Cin, kh, kw = s
+            w = p.detach()
+            ref_bank = F.pad(w.permute(0, 2, 3, 1), (0, (-Cin) % 4)).contiguous()
+            assert torch.equal(wk, ref_bank)
+            taps = kh * kw
+            img = getattr(wk, f"_bcos_wt2_t{taps}")[1]
+            assert torch.equal(img, ops.split_weights_f16x2(ref_bank, taps)), (s, "forward image")
+            if dplan is None:
+                continue
+            r = (-Cout) % 4
+            wq = w if not r else torch.cat([w, w.new_zeros((r,) + tuple(w.shape[1:]))], 0)
+            ref = ops.DgradPlan(wq, stride, padding)
+            assert len(ref.classes) == len(dplan.classes) and ref.has_empty == dplan.has_empty and ref.Cout == dplan.Cout and ref.Cin == dplan.Cin
+            for a, b in zip(ref.classes, dplan.classes):
+                assert a[:8] == b[:8]
+                if a[8] is None:
+                    assert b[8] is None
+                    continue
+                assert torch.equal(a[8], b[8]), (s, "class bank")
+                t = a[2] * a[3]
+                assert torch.equal(getattr(b[8], f"_bcos_wt2_t{t}")[1], ops.split_weights_f16x2(a[8], t)), (s, "class image")
+            Ho = (16 + 2 * padding[0] - kh) // stride[0] + 1
+            g = ops.ensure_absmax(torch.randn(2, Ho, Ho, wq.shape[0], device=dev))
+            assert torch.equal(ref.run(g, 16, 16), dplan.run(g, 16, 16))
+    batch.run()
+    check()
+    with torch.no_grad():
+        for p in params:
+            p.mul_(1.7).add_(0.01)
+    batch.run()
+    check()
+    with torch.no_grad():                                     # a parameter whose storage is replaced: the batch follows it
+        params[1].data = torch.randn_like(params[1]) * 3.0
+    batch.run()
+    check()
+
+
 def test_wgrad_kernel_on_resnet_shapes(lib):
     """The weight gradient at real layer sizes against fp64 autograd: bcos_conv2d_wgrad_ordered (round 6: bf16 planes split once at
     staging, the pixel chunks' partial tiles added in a fixed order -- bit-identical from call to call, into a buffer that was NOT zeroed)
