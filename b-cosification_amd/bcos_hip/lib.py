@@ -60,7 +60,7 @@ class WeightPrepJob(C.Structure):
     """include/bcos_hip.h: bcos_weight_prep_job"""
     _fields_ = [("src", C.c_void_p), ("bank", C.c_void_p), ("image", C.c_void_p),
                 ("rows", C.c_int32), ("channels", C.c_int32), ("Cp", C.c_int32), ("taps", C.c_int32),
-                ("row_stride", C.c_int32), ("ch_stride", C.c_int32), ("tap_offset", C.c_int32 * PREP_MAX_TAPS), ("reserved", C.c_int32)]
+                ("row_stride", C.c_int32), ("ch_stride", C.c_int32), ("tap_offset", C.c_int32 * PREP_MAX_TAPS), ("row_offset", C.c_int32)]
 
 
 class Operands(C.Structure):
@@ -88,7 +88,7 @@ SIGNATURES = {
     "bcos_split_weights_f16x2_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights_f16x2": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_conv": (C.c_int, [_P, _P, _I, _I, _I, _P]),
-    "bcos_weight_prep_batch": (C.c_int, [_P, _I, _I, _P]),
+    "bcos_weight_prep_batch": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "bcos_rows_absmax": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "bcos_split_weights_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights": (C.c_int, [_P, _P, _I, _I, _P]),

@@ -837,7 +837,7 @@ class DgradPlan:
 
 
 class WeightPrepBatch:
-    """Weight banks and f16x2 images of MANY layers, kept in buffers of their own and rebuilt from the layers' parameters by ONE launch
+    """Weight banks and f16x2 images of MANY layers, kept in buffers of their own and rebuilt from the layers' parameters by ONE call
     (include/bcos_hip.h: bcos_weight_prep_batch).  A training step changes every weight once; per layer, the forward bank (NHWC filters) and
     its image, the transposed / tap-reversed banks of the input-gradient classes and theirs, each made by two to five small launches
     (layout copy, flip, row scale, split), were ~350 launches of a ResNet-50 step.  add_*() registers a job and hands out the bank tensor
@@ -846,8 +846,8 @@ class WeightPrepBatch:
     def __init__(self, device):
         self.device = torch.device(device)
         self._jobs, self._srcs, self._banks, self._keep = [], [], [], []
-        self._table = None
-        self._max_rows = 0
+        self._table = self._row_max = None
+        self._max_rows = self._max_ktot = self._rows_total = 0
 
     def _add(self, src, bank_shape, rows, channels, Cp, taps, row_stride, ch_stride, tap_offsets):
         if taps > _l.PREP_MAX_TAPS or src.dtype != torch.float32 or not src.is_contiguous():
@@ -862,6 +862,9 @@ class WeightPrepBatch:
         j.rows, j.channels, j.Cp, j.taps, j.row_stride, j.ch_stride = rows, channels, Cp, taps, row_stride, ch_stride
         for t, o in enumerate(tap_offsets):
             j.tap_offset[t] = int(o)
+        j.row_offset = self._rows_total
+        self._rows_total += (rows + 127) & ~127
+        self._max_ktot = max(self._max_ktot, taps * Cp)
         mark_static(bank)
         setattr(bank, f"_bcos_wt2_t{taps}", (bank._version, image))      # (where _image_of looks; the bank is never written through torch: its version stays)
         self._jobs.append(j)
@@ -916,8 +919,11 @@ class WeightPrepBatch:
         for b in self._banks:               # (an image tapconv made lazily of an earlier version of a bank -- the bf16x3 one -- is stale now)
             if hasattr(b, "_bcos_wt3"):
                 del b._bcos_wt3
-        _l.check(_l.load().bcos_weight_prep_batch(C.c_void_p(self._table.data_ptr()), len(self._jobs), self._max_rows, _stream()),
-                 "bcos_weight_prep_batch")
+        if self._row_max is None or self._row_max.numel() != self._rows_total:
+            self._row_max = torch.empty(self._rows_total, device=self.device, dtype=torch.int32)
+        self._row_max.zero_()               # (the rows' maxima meet there by atomicMax)
+        _l.check(_l.load().bcos_weight_prep_batch(C.c_void_p(self._table.data_ptr()), len(self._jobs), self._max_rows, self._max_ktot,
+                                                  C.c_void_p(self._row_max.data_ptr()), _stream()), "bcos_weight_prep_batch")
 
 
 def weight_rownorm_scale(w2d, gain=None):

@@ -3649,62 +3649,89 @@ extern "C" int bcos_split_weights_f16x2_conv(const float* wt, void* wt2, int row
     return BCOS_OK;
 }
 
-// ---- banks + images of many layers in one launch (bcos_weight_prep_batch) ---------------------------------------------------------------
+// ---- banks + images of many layers from one call (bcos_weight_prep_batch) ---------------------------------------------------------------
 namespace {
-// grid (32-row tiles, jobs): a workgroup gathers its tile's rows of the job's bank from the strided source (writing them out where the job
-// wants the fp32 bank), takes the row maxima, and writes the tile's fragments -- the arithmetic of weight_rowscale_kernel +
-// split_weights_h2_kernel on the gathered values (gathered twice: the weights are L2-sized), so the image is that pair's bit for bit.
-__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const bcos_weight_prep_job* __restrict__ jobs) {
-    __shared__ unsigned s_max[32];
-    __shared__ float s_scale[32];
+constexpr int PREP_KCH = 1024;          // bank elements of a row per workgroup of the gather
+// (1) grid (32-row tile x K part, jobs): gather the part's elements of the tile's rows from the strided source into the bank (coalesced
+//     along K) and fold their maxima into row_max[job.row_offset + row] (zero-filled by the caller): per thread, per wave, then ONE atomic per
+//     row and workgroup.
+__global__ __launch_bounds__(256) void weight_prep_gather_kernel(const bcos_weight_prep_job* __restrict__ jobs, unsigned* __restrict__ row_max) {
     const bcos_weight_prep_job& jb = jobs[blockIdx.y];
-    const int rows = jb.rows, taps = jb.taps, Cp = jb.Cp, channels = jb.channels;
-    const int tile = blockIdx.x, tid = threadIdx.x;
-    const int tiles = (int)h2_tiles(rows);                       // (the image is padded to a multiple of 128 rows: empty tiles hold zeros)
-    if (tile >= tiles) return;
-    const int Ktot = taps * Cp;
+    const int rows = jb.rows, Cp = jb.Cp, channels = jb.channels;
+    const int Ktot = jb.taps * Cp;
+    const int kparts = (Ktot + PREP_KCH - 1) / PREP_KCH;
+    const int tile = (int)blockIdx.x / kparts, kpart = (int)blockIdx.x - tile * kparts;
     const int row0 = tile * 32;
-    const int live = rows - row0 < 32 ? (rows - row0 < 0 ? 0 : rows - row0) : 32;
+    if (row0 >= rows) return;
+    const int live = rows - row0 < 32 ? rows - row0 : 32;
+    const int k_lo = kpart * PREP_KCH, k_hi = k_lo + PREP_KCH < Ktot ? k_lo + PREP_KCH : Ktot;
     const float* __restrict__ src = jb.src;
-    auto gather = [&](int row, int k) -> float {                  // bank[row][k], k = t Cp + c
+    float* __restrict__ bank = jb.bank;
+    const int tid = threadIdx.x;
+    // (t, c) of this thread's elements do not depend on the row: decoded once
+    int off[PREP_KCH / 256];
+    bool in[PREP_KCH / 256];
+#pragma unroll
+    for (int q = 0; q < PREP_KCH / 256; ++q) {
+        const int k = k_lo + q * 256 + tid;
         const int t = k / Cp, c = k - t * Cp;
-        return c < channels ? src[(int64_t)row * jb.row_stride + (int64_t)c * jb.ch_stride + jb.tap_offset[t]] : 0.f;
-    };
-    if (tid < 32) s_max[tid] = 0u;
-    __syncthreads();
-    {
-        const int n = live * Ktot;
-        float* bank = jb.bank;
-        for (int i = tid; i < n; i += 256) {
-            const int r = i / Ktot, k = i - r * Ktot;
-            const float v = gather(row0 + r, k);
-            if (bank) bank[(int64_t)(row0 + r) * Ktot + k] = v;
-            atomicMax(&s_max[r], __float_as_uint(v) & 0x7fffffffu);
+        in[q] = k < k_hi && c < channels && t < jb.taps;
+        off[q] = in[q] ? c * jb.ch_stride + jb.tap_offset[t] : 0;
+    }
+    // rows in groups of eight: eight independent loads in flight per thread and K part, then the stores and the rows' maxima
+#pragma unroll
+    for (int q = 0; q < PREP_KCH / 256; ++q) {
+        const int k = k_lo + q * 256 + tid;
+        if (k_lo + q * 256 >= k_hi) break;
+        for (int r0 = 0; r0 < live; r0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (in[q] && r0 + u < live) ? src[(int64_t)(row0 + r0 + u) * jb.row_stride + off[q]] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (r0 + u < live) {            // (uniform over the workgroup)
+                    if (k < k_hi) bank[(int64_t)(row0 + r0 + u) * Ktot + k] = v[u];
+                    unsigned m = k < k_hi ? __float_as_uint(v[u]) & 0x7fffffffu : 0u;
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+                    if ((tid & 63) == 0 && m) atomicMax(row_max + jb.row_offset + row0 + r0 + u, m);
+                }
+            }
         }
     }
-    __syncthreads();
+}
+
+// (2) grid (32-row tile x group of 16-k steps, jobs): the image of the bank -- the arithmetic of weight_rowscale_kernel + split_weights_h2_kernel
+//     on the bank's values and the rows' maxima: that pair's image bit for bit.
+__global__ __launch_bounds__(256) void weight_prep_split_kernel(const bcos_weight_prep_job* __restrict__ jobs, const unsigned* __restrict__ row_max) {
+    const bcos_weight_prep_job& jb = jobs[blockIdx.y];
     if (jb.image == nullptr) return;
+    const int rows = jb.rows, taps = jb.taps, Cp = jb.Cp;
+    const int Ktot = taps * Cp;
     const int nk = (Ktot + 15) / 16;
+    constexpr int KS_PER_WG = PREP_KCH / 16;                    // 64 steps (16 per wave)
+    const int kgroups = (nk + KS_PER_WG - 1) / KS_PER_WG;
+    const int tiles = (int)h2_tiles(rows);                       // (the image is padded to a multiple of 128 rows: empty tiles hold zeros)
+    const int tile = (int)blockIdx.x / kgroups, kgroup = (int)blockIdx.x - tile * kgroups;
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int row = tile * 32 + (lane & 31);
+    unsigned E = (row < rows ? row_max[jb.row_offset + row] : 0u) >> 23;
+    E = E < 15u ? 15u : E;
+    const float ci = __uint_as_float((E - 14u) << 23);
+    const float scale = 1.0f / ci;                                // exact: a power of two
     uint4* wt2 = reinterpret_cast<uint4*>(jb.image);
-    float* cinv = reinterpret_cast<float*>(static_cast<char*>(jb.image) + h2_image_bytes(rows, Ktot));
-    if (tid < 32) {
-        unsigned E = s_max[tid] >> 23;
-        E = E < 15u ? 15u : E;
-        const float ci = __uint_as_float((E - 14u) << 23);
-        cinv[row0 + tid] = ci;
-        s_scale[tid] = 1.0f / ci;                                     // exact: a power of two
-    }
-    __syncthreads();
+    if (kgroup == 0 && tid < 32) reinterpret_cast<float*>(static_cast<char*>(jb.image) + h2_image_bytes(rows, Ktot))[tile * 32 + tid] = ci;
+    const float* __restrict__ bank = jb.bank;
     const int ktaps = (taps > 1 && taps <= H2_MAX_TAPS && Cp % 16 == 0) ? taps : 1;      // (bcos_split_weights_f16x2_conv: channel-chunk-major K)
-    const int lane = tid & 63;
-    const int row = row0 + (lane & 31);
-    const float scale = s_scale[lane & 31];
-    for (int ks = tid >> 6; ks < nk; ks += 4) {
+    const int ks_hi = (kgroup + 1) * KS_PER_WG < nk ? (kgroup + 1) * KS_PER_WG : nk;
+    for (int ks = kgroup * KS_PER_WG + (tid >> 6); ks < ks_hi; ks += 4) {
         const int k0 = ktaps > 1 ? (ks % ktaps) * Cp + (ks / ktaps) * 16 + 8 * (lane >> 5) : ks * 16 + 8 * (lane >> 5);
         f16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float x = (row < rows && k0 + e < Ktot) ? gather(row, k0 + e) * scale : 0.f;
+            const float x = (row < rows && k0 + e < Ktot) ? bank[(int64_t)row * Ktot + k0 + e] * scale : 0.f;
             const _Float16 hh = (_Float16)x;
             h[e] = hh;
             l[e] = (_Float16)(x - (float)hh);
@@ -3716,11 +3743,16 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const bcos_weigh
 }
 }  // namespace
 
-extern "C" int bcos_weight_prep_batch(const bcos_weight_prep_job* jobs, int njobs, int max_rows, void* stream) {
-    if (!jobs || njobs <= 0 || njobs > 65535 || max_rows <= 0) return bcos_set_error(BCOS_E_INVAL, "bcos_weight_prep_batch: bad argument");
+extern "C" int bcos_weight_prep_batch(const bcos_weight_prep_job* jobs, int njobs, int max_rows, int max_ktot, uint32_t* row_max, void* stream) {
+    if (!jobs || !row_max || njobs <= 0 || njobs > 65535 || max_rows <= 0 || max_ktot <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_weight_prep_batch: bad argument");
     if (reinterpret_cast<uintptr_t>(jobs) & 7) return bcos_set_error(BCOS_E_INVAL, "bcos_weight_prep_batch: job table must be 8-byte aligned");
-    hipLaunchKernelGGL(weight_prep_batch_kernel, dim3((unsigned)h2_tiles(max_rows), (unsigned)njobs), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), jobs);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t tiles = h2_tiles(max_rows);
+    const int64_t kparts = ((int64_t)max_ktot + PREP_KCH - 1) / PREP_KCH;
+    if (tiles * kparts > 0x7fffffff) return bcos_set_error(BCOS_E_NOSUP, "bcos_weight_prep_batch: too large");
+    hipLaunchKernelGGL(weight_prep_gather_kernel, dim3((unsigned)(tiles * kparts), (unsigned)njobs), dim3(256), 0, s, jobs, row_max);
+    hipLaunchKernelGGL(weight_prep_split_kernel, dim3((unsigned)(tiles * kparts), (unsigned)njobs), dim3(256), 0, s, jobs, row_max);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return bcos_set_hip_error("weight_prep_batch launch", err);
     return BCOS_OK;

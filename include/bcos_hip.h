@@ -338,16 +338,18 @@ int bcos_split_weights_f16x2(const float* wt, void* image, int rows, int Ktot, v
  * made with ITS tap count and C (bcos_tapconv_geom.TH * TW, C). */
 int bcos_split_weights_f16x2_conv(const float* wt, void* image, int rows, int taps, int C, void* stream);
 
-/* The weight banks and f16x2 images of MANY layers from ONE launch (ABI v9; a training step rebuilds every layer's forward bank, its
- * transposed / tap-reversed input-gradient banks and their images from the updated weights: ~350 small launches per ResNet-50 step).
- * Job j gathers bank[r][t][c] = c < channels ? src[r * row_stride + c * ch_stride + tap_offset[t]] : 0 (r < rows, t < taps, c < Cp),
- * writes it to `bank` ([rows][taps][Cp] fp32; NULL: not written) and writes `image` = what
- * bcos_split_weights_f16x2_conv(bank, image, rows, taps, Cp) would make of it, bit for bit (image: bcos_split_weights_f16x2_bytes(rows,
- * taps * Cp) bytes, 16-byte aligned; NULL: not written).  `jobs` is a DEVICE array of `njobs` descriptors -- the caller uploads it once
- * and reuses it while the pointers in it stay valid; `max_rows` >= every job's rows (the launch's grid).
+/* The weight banks and f16x2 images of MANY layers from ONE call -- two launches (ABI v9; a training step rebuilds every layer's forward
+ * bank, its transposed / tap-reversed input-gradient banks and their images from the updated weights: ~350 small launches per ResNet-50 step).
+ * Job j gathers bank[r][t][c] = c < channels ? src[r * row_stride + c * ch_stride + tap_offset[t]] : 0 (r < rows, t < taps, c < Cp) into
+ * `bank` ([rows][taps][Cp] fp32) and writes `image` = what bcos_split_weights_f16x2_conv(bank, image, rows, taps, Cp) would make of it, bit
+ * for bit (bcos_split_weights_f16x2_bytes(rows, taps * Cp) bytes, 16-byte aligned; NULL: the bank only).  `jobs` is a DEVICE array of
+ * `njobs` descriptors -- the caller uploads it once and reuses it while the pointers in it stay valid; `max_rows` / `max_ktot` >= every
+ * job's rows / taps * Cp (they size the grids); `row_max`: DEVICE scratch, ZERO-FILLED by the caller before every call, in which job j
+ * owns the words [row_offset, row_offset + rows).
  *   forward bank of OIHW weights [Cout][Cin][kh][kw]:   rows = Cout, channels = Cin, row_stride = Cin kh kw, ch_stride = kh kw, tap_offset[t] = t
  *   a parity class of the input gradient:               rows = Cin, channels = Cout, row_stride = kh kw, ch_stride = Cin kh kw,
- *                                                        tap_offset[a TW + b] = rs_h[a] kw + rs_w[b] (the class's tap lists, bcos_hip/ops.py: DgradPlan) */
+ *                                                        tap_offset[a TW + b] = rs_h[a] kw + rs_w[b] (the class's tap lists, bcos_hip/ops.py: DgradPlan)
+ *   a linear layer [Cout][Cin] / its transpose:         rows = Cout / Cin, channels = Cin / Cout, strides (Cin, 1) / (1, Cin), one tap at offset 0 */
 #define BCOS_PREP_MAX_TAPS 49
 typedef struct bcos_weight_prep_job {
     const float* src;
@@ -356,9 +358,9 @@ typedef struct bcos_weight_prep_job {
     int32_t rows, channels, Cp, taps;
     int32_t row_stride, ch_stride;
     int32_t tap_offset[BCOS_PREP_MAX_TAPS];
-    int32_t reserved;            /* (keeps the size a multiple of 8) */
+    int32_t row_offset;          /* the job's first word in row_max */
 } bcos_weight_prep_job;
-int bcos_weight_prep_batch(const bcos_weight_prep_job* jobs, int njobs, int max_rows, void* stream);
+int bcos_weight_prep_batch(const bcos_weight_prep_job* jobs, int njobs, int max_rows, int max_ktot, uint32_t* row_max, void* stream);
 
 /* out[r] = fp32 bit pattern of max_c |x[r*pitch + c]|, c < C (C % 4 == 0; pitch 0 = C): the `a_absmax` of a tensor whose
  * producer is not a bcos_tapconv epilogue (network input, pooling, attention ...).  One pass over x. */
