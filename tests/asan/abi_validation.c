@@ -166,6 +166,11 @@ int main(void) {
       EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_NOSUP); e.out_imgmax = NULL; }
     { e.rowadd = buf;                                                               /* a row-scaled addend without its scales */
       EXPECT(bcos_tapconv_ops(&o, &g, &e, NULL), BCOS_E_NOSUP); e.rowadd = NULL; }
+    EXPECT(bcos_weight_prep_batch(NULL, 1, 64, 64, am, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_weight_prep_batch((const bcos_weight_prep_job*)buf, 1, 64, 64, NULL, NULL), BCOS_E_INVAL);     /* no scratch for the rows' maxima */
+    EXPECT(bcos_weight_prep_batch((const bcos_weight_prep_job*)buf, 0, 64, 64, am, NULL), BCOS_E_INVAL);
+    EXPECT(bcos_weight_prep_batch((const bcos_weight_prep_job*)buf, 1, 0, 64, am, NULL), BCOS_E_INVAL);
+    if (sizeof(bcos_weight_prep_job) != 248) { printf("FAIL sizeof(bcos_weight_prep_job) = %zu\n", sizeof(bcos_weight_prep_job)); ++failures; }
     EXPECT(bcos_stream_copy(NULL, buf, 16, NULL), BCOS_E_INVAL);
     EXPECT(bcos_stream_copy(buf, buf + 1, 16, NULL), BCOS_E_INVAL);      /* misaligned */
     EXPECT(bcos_stream_copy(buf, buf, 6, NULL), BCOS_E_INVAL);           /* n % 4 */
