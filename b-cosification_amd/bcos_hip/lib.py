@@ -85,6 +85,7 @@ SIGNATURES = {
     "bcos_tapconv_fuses_image_range": (C.c_int, [C.POINTER(Operands), C.POINTER(TapconvGeom), C.POINTER(Epilogue)]),
     "bcos_image_absmax": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_image_absrange": (C.c_int, [_P, _P, _P, _I, _I, _P]),
+    "bcos_image_absrange_c": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_bytes": (C.c_int, [_I, _I, C.POINTER(C.c_int64)]),
     "bcos_split_weights_f16x2": (C.c_int, [_P, _P, _I, _I, _P]),
     "bcos_split_weights_f16x2_conv": (C.c_int, [_P, _P, _I, _I, _I, _P]),

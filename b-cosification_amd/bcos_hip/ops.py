@@ -59,6 +59,7 @@ def conv_out_size(size, k, s, p, d=1):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+IMAGE_RANGE_PARTS = os.environ.get("BCOS_IMAGE_RANGE_PARTS", "1") != "0"    # development A/B: 0 = per-image ranges by one workgroup per image (round 5)
 FUSE_PATCH_NORM = os.environ.get("BCOS_FUSE_PATCH_NORM", "1") != "0"    # development A/B: 0 = the patch-norm term of pointwise layers as a pass of its own (round 5)
 _NO_PRESPLIT = bool(os.environ.get("BCOS_NO_PRESPLIT"))     # development switch: always split inside the kernel
 _NO_GROUP = bool(os.environ.get("BCOS_NO_GROUP"))           # development switch: one launch per parity class
@@ -314,6 +315,14 @@ def image_absmax(am: torch.Tensor, n_images: int, pixels_per_image: int):
     rec = getattr(am, "_bcos_imgmax", None)
     if rec is not None and rec[1] == (n_images, pixels_per_image):
         return rec[0], len(rec) > 2
+    if IMAGE_RANGE_PARTS and _ARENA is not None and pixels_per_image >= 2048:
+        # several workgroups per image, meeting by atomics in zero-filled words of the pass's arena (the form the fused epilogues leave:
+        # complemented minima): the one-workgroup-per-image kernel is a chain of dependent loads, 30 us per call beside another stream's launch
+        out = _new_absmax(2 * n_images, am.device).view(2, n_images)
+        _l.check(_l.load().bcos_image_absrange_c(am.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), n_images, pixels_per_image, _stream()),
+                 "bcos_image_absrange_c")
+        am._bcos_imgmax = (out, (n_images, pixels_per_image), "parts")
+        return out, True
     out = torch.empty(2, n_images, device=am.device, dtype=torch.int32)
     _l.check(_l.load().bcos_image_absrange(am.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), n_images, pixels_per_image, _stream()),
              "bcos_image_absrange")
@@ -350,7 +359,7 @@ def _out_absmax(t: Optional[torch.Tensor], pixels: int):
     if am is None or am.numel() != pixels:
         am = _new_absmax(pixels, t.device)
         _attach_absmax(t, am)
-    elif hasattr(am, "_bcos_imgmax") and len(am._bcos_imgmax) < 3:
+    elif hasattr(am, "_bcos_imgmax") and am._bcos_imgmax[2:] != ("fused",):
         del am._bcos_imgmax            # the maxima are about to grow: per-image values cached from an earlier fill are stale
     return am                          # (a range the producing launches fold in themselves grows with them: tapconv keeps or drops it)
 
@@ -441,7 +450,7 @@ def tapconv(a: torch.Tensor, wt: torch.Tensor, geom: dict, *, out=None, out2=Non
         fuses = (FUSE_IMAGE_RANGE and _IMAGE_RANGE_READER and _ARENA is not None and int(g.P) * int(g.Q) >= 19
                  and lib.bcos_tapconv_fuses_image_range(C.byref(o), C.byref(g), C.byref(e)) == 1)
         if fuses:
-            if rec is not None and len(rec) > 2 and rec[1] == key:
+            if rec is not None and rec[2:] == ("fused",) and rec[1] == key:
                 img = rec[0]               # another launch of the same tensor (parity classes of a strided gradient): the range accumulates
             else:
                 img = _new_absmax(2 * key[0], out.device).view(2, key[0])

@@ -3826,6 +3826,60 @@ __global__ __launch_bounds__(1024) void image_absmax_kernel(const unsigned* __re
 }
 }  // namespace
 
+namespace {
+// the same range from SEVERAL workgroups per image (grid: image x part), for images of many pixels or a device that is busy with
+// another stream's launch: the parts meet by atomicMax in ZERO-FILLED words -- the minimum over the nonzero pixels as its complement
+// (~v; 0 = no nonzero pixel), the form the producing epilogues leave (bcos_epilogue.out_imgmin_c)
+__global__ __launch_bounds__(256) void image_absrange_c_kernel(const unsigned* __restrict__ absmax, unsigned* __restrict__ out_max,
+                                                               unsigned* __restrict__ out_min_c, int hw, int per_part) {
+    __shared__ unsigned s_max[4], s_min[4];
+    const unsigned* src = absmax + (size_t)blockIdx.x * hw;
+    const int lo = (int)blockIdx.y * per_part, hi = lo + per_part < hw ? lo + per_part : hw;
+    unsigned v = 0u, w = 0xffffffffu;
+    for (int i0 = lo; i0 < hi; i0 += 1024) {
+        unsigned u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * 256 + (int)threadIdx.x;
+            u[q] = i < hi ? src[i] : 0u;
+        }
+        v = max(max(v, u[0]), max(max(u[1], u[2]), u[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w = min(w, u[q] - 1u);      // (0 - 1 wraps to the top: zero pixels never win)
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        v = max(v, (unsigned)__shfl_xor((int)v, o));
+        w = min(w, (unsigned)__shfl_xor((int)w, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = v; s_min[threadIdx.x >> 6] = w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        const unsigned mn = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        if (m) atomicMax(out_max + blockIdx.x, m);
+        if (mn != 0xffffffffu) atomicMax(out_min_c + blockIdx.x, ~(mn + 1u));
+    }
+}
+}  // namespace
+
+extern "C" int bcos_image_absrange_c(const uint32_t* absmax, uint32_t* out_max, uint32_t* out_min_c, int n_images, int pixels_per_image,
+                                     void* stream) {
+    if (!absmax || !out_max || !out_min_c || n_images <= 0 || pixels_per_image <= 0)
+        return bcos_set_error(BCOS_E_INVAL, "bcos_image_absrange_c: bad argument");
+    // parts of >= 2 048 pixels, as many as put ~1 024 workgroups on the device
+    int parts = (pixels_per_image + 2047) / 2048;
+    const int want = (1024 + n_images - 1) / n_images;
+    parts = parts < 1 ? 1 : (parts > want ? want : parts);
+    const int per_part = (((pixels_per_image + parts - 1) / parts) + 255) & ~255;
+    parts = (pixels_per_image + per_part - 1) / per_part;
+    hipLaunchKernelGGL(image_absrange_c_kernel, dim3((unsigned)n_images, (unsigned)parts), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       absmax, out_max, out_min_c, pixels_per_image, per_part);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return bcos_set_hip_error("image_absrange_c launch", err);
+    return BCOS_OK;
+}
+
 extern "C" int bcos_image_absmax(const uint32_t* absmax, uint32_t* out, int n_images, int pixels_per_image, void* stream) {
     return bcos_image_absrange(absmax, out, nullptr, n_images, pixels_per_image, stream);
 }

@@ -370,6 +370,10 @@ int bcos_image_absmax(const uint32_t* absmax, uint32_t* out, int n_images, int p
 /* ... and out_min[n] = the smallest NONZERO absmax of image n, 0xffffffff if every pixel is zero (bcos_operands.a_imgmin; ABI v7;
  * out_min may be NULL). */
 int bcos_image_absrange(const uint32_t* absmax, uint32_t* out_max, uint32_t* out_min, int n_images, int pixels_per_image, void* stream);
+/* The same range by several workgroups per image (ABI v9): out_max [N] and out_min_c [N] are ZERO-FILLED by the caller; out_min_c[n] receives
+ * the COMPLEMENT of the minimum over the nonzero pixels (~v; 0 = no nonzero pixel) -- the form of bcos_epilogue.out_imgmin_c, handed to the
+ * reading launch as bcos_operands.a_imgmin_c. */
+int bcos_image_absrange_c(const uint32_t* absmax, uint32_t* out_max, uint32_t* out_min_c, int n_images, int pixels_per_image, void* stream);
 
 /* Pre-split weights for the bf16x3 contraction.  Weights are constant at inference (NormedConv2d / BcosifyConv2d
  * weights only change in training, bcosconv2d.py:26-35), so their exact 3-way bf16 split is done once:

@@ -363,6 +363,26 @@ def test_weight_banks_and_images_of_many_layers_from_one_launch(lib):
     check()
 
 
+def test_image_range_by_several_workgroups_per_image(lib):
+    """bcos_image_absrange_c (ABI v9): the per-image range of a per-pixel maxima tensor from several workgroups per image -- maxima as
+    bcos_image_absrange gives them, minima over the nonzero pixels complemented (the form of bcos_epilogue.out_imgmin_c); images without a
+    nonzero pixel keep 0 / 0."""
+    from bcos_hip import lib as L
+    torch.manual_seed(5)
+    for (n, hw) in [(3, 5000), (64, 12544), (2, 50176), (5, 100)]:
+        am = torch.randint(1, 2 ** 30, (n, hw), dtype=torch.int32, device="cuda")
+        am[:, ::7] = 0
+        am[0] = 0                                              # an all-zero image
+        ref = torch.empty(2, n, dtype=torch.int32, device="cuda")
+        L.check(lib.bcos_image_absrange(am.data_ptr(), ref[0].data_ptr(), ref[1].data_ptr(), n, hw, None), "bcos_image_absrange")
+        got = torch.zeros(2, n, dtype=torch.int32, device="cuda")
+        L.check(lib.bcos_image_absrange_c(am.data_ptr(), got[0].data_ptr(), got[1].data_ptr(), n, hw, None), "bcos_image_absrange_c")
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0])
+        want_c = torch.where(ref[1] == -1, torch.zeros_like(ref[1]), ~ref[1])      # (0xffffffff: no nonzero pixel)
+        assert torch.equal(got[1], want_c)
+
+
 def test_wgrad_kernel_on_resnet_shapes(lib):
     """The weight gradient at real layer sizes against fp64 autograd: bcos_conv2d_wgrad_ordered (round 6: bf16 planes split once at
     staging, the pixel chunks' partial tiles added in a fixed order -- bit-identical from call to call, into a buffer that was NOT zeroed)
