@@ -309,6 +309,67 @@ def test_patch_norm_term_of_a_3x3_layer_has_one_summation_order(lib, C):
     assert rel(got, want64) <= 1e-6
 
 
+def test_training_plan_with_batched_weights_follows_every_parameter_change(lib, golden_dir):
+    """The training plan keeps its weight banks, their images and its input-gradient plans across steps and refreshes them from the
+    parameters by one call per step (train_plan.ResNetTrainPlan._weights).  Whatever happens to a parameter between two steps -- an
+    in-place update, an optimizer step, a replaced .data -- the step's loss and every gradient equal, bit for bit, those of the same
+    network prepared per layer (BCOS_TRAIN_WEIGHT_BATCH=0: fresh banks in front of every launch)."""
+    import copy
+    from bcos_hip import engine, synth, train_plan
+    net, _, _ = _golden_net(golden_dir, "resnet18_e2e")
+    ref = copy.deepcopy(net)
+    engine.attach(net); engine.attach(ref)
+    net.train(); ref.train()
+    x = synth.synthetic_images(4, seed=7, size=64).to(DEV)
+    target = F.one_hot(torch.tensor([1, 5, 9, 700]), 1000).float().to(DEV)
+
+    def step(model, batched):
+        prev = train_plan._WEIGHT_BATCH
+        train_plan._WEIGHT_BATCH = batched
+        try:
+            xs = x.clone().requires_grad_(True)
+            loss = F.binary_cross_entropy_with_logits(model(xs), target)
+            ps = [p for p in model.parameters() if p.requires_grad]
+            return loss.detach(), torch.autograd.grad(loss, [xs] + ps)
+        finally:
+            train_plan._WEIGHT_BATCH = prev
+
+    def same():
+        la, ga = step(net, True)
+        lb, gb = step(ref, False)
+        assert net._bcos_engine._train_plan._wbatch is not None and ref._bcos_engine._train_plan._wbatch is None
+        assert torch.equal(la, lb)
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+
+    same()
+    convs_a = [m for m in net.modules() if isinstance(m, nn.Conv2d)]
+    convs_b = [m for m in ref.modules() if isinstance(m, nn.Conv2d)]
+    with torch.no_grad():                                  # in-place updates (what an optimizer step is)
+        for ma, mb in zip(convs_a, convs_b):
+            ma.weight.mul_(0.97).add_(1e-3); mb.weight.mul_(0.97).add_(1e-3)
+    same()
+    with torch.no_grad():                                  # a parameter whose storage is replaced (load of a checkpoint by assignment)
+        for ma, mb in zip(convs_a[3:6], convs_b[3:6]):
+            new = torch.randn_like(ma.weight) * ma.weight.std()
+            ma.weight.data = new.clone(); mb.weight.data = new.clone()
+    same()
+    opt_a = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9); opt_b = torch.optim.SGD(ref.parameters(), lr=1e-3, momentum=0.9)
+    for opt, model, batched in ((opt_a, net, True), (opt_b, ref, False)):
+        prev = train_plan._WEIGHT_BATCH
+        train_plan._WEIGHT_BATCH = batched
+        try:
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                F.binary_cross_entropy_with_logits(model(x), target).backward()
+                opt.step()
+        finally:
+            train_plan._WEIGHT_BATCH = prev
+    for pa, pb in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(pa, pb)
+    same()
+
+
 def test_weight_banks_and_images_of_many_layers_from_one_launch(lib):
     """bcos_weight_prep_batch (ABI v9; ops.WeightPrepBatch): the forward bank and the input-gradient banks of a set of layers, and their
     f16x2 images, are what the per-layer preparation makes -- layout copy / flip / tap selection, bcos_split_weights_f16x2_conv -- bit
